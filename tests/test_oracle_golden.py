@@ -1,0 +1,143 @@
+"""The oracle (oracle/) against outputs of the reference itself (tests/golden/, made by
+tools/make_golden.py).  CPU only.  Bars: token indices exact; fp32 tensors max|d|/max|ref| <= 1e-4."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr, synth_model_sd
+from oracle import artv, bert, tower, vqgan
+from oracle.synth import synth_input, synth_state_dict, synth_tensor, synth_tokens
+from oracle.vq import vq_argmin
+
+TOL = 1e-4
+
+
+@pytest.mark.parametrize('tag,n', [('sep', 1024), ('stress', 1024), ('small', 256)])
+def test_vq_argmin_c_oracle_matches_reference(golden, tag, n):
+    g = golden('vq')
+    cb = (synth_input('cb_' + tag, (n, 256), 7, 'uniform') * 2 - 1) / n if tag == 'stress' else \
+        synth_tensor('quantize.embedding.weight', (n, 256), 7)
+    z = synth_input('z_' + tag, (512, 256), 7)
+    idx, dmin = vq_argmin(z, cb)
+    ref = g[tag + '_idx']
+    mism = (idx != ref).nonzero().view(-1)
+    # any disagreement must be a near-tie of the reference's own distances (<= 4 ulp at |d|)
+    top2 = g[tag + '_top2_d']
+    gap = top2[:, 1] - top2[:, 0]
+    ulp = torch.tensor(np.spacing(top2[:, 0].abs().numpy()))
+    assert (gap[mism] <= 4 * ulp[mism]).all()
+    if tag != 'stress':
+        assert len(mism) == 0
+    assert torch.allclose(dmin, top2[:, 0], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['vqgan_tiny', 'vqgan_full'])
+def test_vqgan_encode_decode(golden, name):
+    g = golden(name)
+    meta = g.meta
+    sd = synth_state_dict(g.manifest, 11)
+    s = meta['image_size']
+    img = synth_input('img', (meta['n'], 3, s, s), 11, 'uniform')
+    with torch.no_grad():
+        z = vqgan.encode_z(sd, img, s)
+        idx = vqgan.get_codebook_indices(sd, img, s)
+        dec = vqgan.decode(sd, g['indices'], s)
+    assert relerr(z, g['z_e']) <= TOL
+    assert torch.equal(idx, g['indices'])
+    assert relerr(dec, g['decoded']) <= TOL
+
+
+@pytest.mark.parametrize('tag,L,mt,idx', [('L51', 51, 'mask_prev', [17, 18]), ('L579', 579, 'mask_prev', [65, 66]),
+                                          ('causal40', 40, 'causal', [])])
+def test_tower_forward_backward(golden, tag, L, mt, idx):
+    g = golden('tower')
+    sd = synth_state_dict(g.manifest, 13)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = synth_input('x_' + tag, (2, L, 768), 13).requires_grad_(True)
+    gy = synth_input('g_' + tag, (2, L, 768), 13)
+    y = tower.tower(sd, x, tower.build_attention_mask(L, mt, idx), 'transformer.')
+    y.backward(gy)
+    if L <= 64:
+        assert relerr(y, g[tag + '_y']) <= TOL and relerr(x.grad, g[tag + '_dx']) <= TOL
+    else:
+        assert relerr(y[:, ::37, ::13], g[tag + '_y_s']) <= TOL
+        assert relerr(x.grad[:, ::37, ::13], g[tag + '_dx_s']) <= TOL
+    assert abs(y.double().norm().item() / g[tag + '_y_norm'].item() - 1) < 1e-5
+    p = 'transformer.resblocks.'
+    for nm, k in (('inw', p + '0.attn.in_proj_weight'), ('outw', p + '1.attn.out_proj.weight'),
+                  ('fcw', p + '0.mlp.c_fc.weight'), ('pjw', p + '1.mlp.c_proj.weight')):
+        assert relerr(sd[k].grad[::61, ::29], g[f'{tag}_d{nm}_s']) <= TOL
+    for nm, k in (('inb', p + '0.attn.in_proj_bias'), ('ln1w', p + '0.ln_1.weight'), ('ln2b', p + '1.ln_2.bias'),
+                  ('fcb', p + '1.mlp.c_fc.bias')):
+        assert relerr(sd[k].grad, g[f'{tag}_d{nm}']) <= TOL
+
+
+@pytest.mark.parametrize('name,nv', [('bert_tiny', 0), ('bert_tiny_visual', 1)])
+def test_bert_losses_and_grads(golden, name, nv):
+    g = golden(name)
+    sd = synth_model_sd(g, 17)
+    for k in sd:
+        sd[k].requires_grad_(not k.startswith(('vae.', 'cvae.')))
+    cfg = bert.Cfg(sd, 16, nv, 2, 64, use_cvae=nv > 0)
+    text, frames = g['text'], g['frames']
+    with torch.no_grad():
+        tt = bert.get_image_tokens(sd, cfg, frames)
+        wt = bert.get_image_tokens(sd, cfg, g['warped_frames'])
+        vt = bert.get_image_tokens(sd, cfg, g['visual'], 'cvae') if nv else None
+    assert torch.equal(tt, g['target_tok']) and torch.equal(wt, g['warp_tok'])
+    if nv:
+        assert torch.equal(vt, g['visual_tok'])
+    r = bert.forward_losses(sd, cfg, text, tt, g['mask1'], wt, vt)
+    assert relerr(r['control_emb'], g['control_emb']) <= TOL
+    assert relerr(r['tokens_msm'], g['tokens_msm']) <= TOL
+    assert relerr(r['out_msm'], g['out_msm']) <= TOL
+    assert relerr(r['logits_msm'], g['logits_msm']) <= TOL
+    losses = torch.stack([r['loss_msm'], r['loss_rel'], r['loss_vid']])
+    assert torch.allclose(losses, g['losses'], rtol=1e-5)
+    (7 * r['loss_msm'] + .5 * r['loss_rel'] + .5 * r['loss_vid']).backward()
+    G = {k: v.grad for k, v in sd.items() if v.grad is not None}
+    assert relerr(G['image_emb.weight'][::3, ::5], g['g_image_emb']) <= TOL
+    assert relerr(G['to_logits.1.weight'][::4, ::6], g['g_to_logits_w']) <= TOL
+    assert relerr(G['special_emb.weight'], g['g_special_emb']) <= TOL
+    assert relerr(G['target_pos_emb.weights_0'].reshape(-1, 768), g['g_tpos0']) <= TOL
+    assert relerr(G['transformer.transformer.resblocks.0.ln_1.weight'], g['g_ln1w']) <= TOL
+    assert relerr(G['text_emb.weight'][g['g_text_emb_row_ids']][:, ::11], g['g_text_emb_rows']) <= TOL
+    tn = torch.sqrt(sum((v.double()**2).sum() for v in G.values()))
+    assert abs(tn.item() / g['g_total_norm'].item() - 1) < 1e-5
+
+
+def test_mask_predict_trajectory(golden):
+    g, gb = golden('mask_predict'), golden('bert_tiny')
+    sd = synth_model_sd(gb, 17)
+    cfg = bert.Cfg(sd, 16, 0, 2, 64)
+    text = synth_tokens('text', (2, 16), 49408, 17, low=1)
+    text[0, 11:] = 0
+    text[1, 5:] = 0
+    for tag, steps, dyn, B in (('s4', 4, False, 1), ('s8dynB2', 8, True, 2)):
+        random.seed(31), np.random.seed(31), torch.manual_seed(31)
+        imgs, seq = bert.generate_images(sd, cfg, text, steps, dict(g.meta['mp_config'], B=B), dyn)
+        assert torch.equal(seq, g[tag + '_img_seq'])
+        assert relerr(imgs[:, :, :, ::8, ::8], g[tag + '_images_s']) <= TOL
+
+
+def test_artv_logits_loss_and_sampling(golden):
+    g = golden('artv_tiny')
+    sd = synth_model_sd(g, 19)
+    cfg = artv.Cfg(sd, 16, 1, 2, 64)
+    text = g['text']
+    with torch.no_grad():
+        tt = vqgan.get_codebook_indices(sd, g['frames'].reshape(-1, 3, 64, 64), 64, 'vae.model.').view(2, -1)
+        vt = vqgan.get_codebook_indices(sd, g['visual'].reshape(-1, 3, 64, 64), 64, 'vae.model.').view(2, -1)
+        assert torch.equal(tt, g['target_tok'])
+        assert abs(artv.forward(sd, cfg, text, vt, tt, True).item() - g['loss'].item()) < 1e-5
+        assert abs(artv.forward(sd, cfg, text, None, tt, True).item() - g['loss_novisual'].item()) < 1e-5
+        for k in (0, 5, 31):
+            last = artv.forward(sd, cfg, text, vt, tt[:, :k])[:, -1]
+            assert relerr(last[:, cfg.num_control_tokens:], g[f'logits_k{k}_img']) <= TOL
+            assert torch.equal(last.argmax(-1), g[f'logits_k{k}_argmax'])
+        random.seed(5), np.random.seed(5), torch.manual_seed(5)
+        imgs, _ = artv.generate_images(sd, cfg, text[:1], vt[:1])
+        assert relerr(imgs[:, :, :, ::8, ::8], g['gen_images_s']) <= TOL
