@@ -1,0 +1,88 @@
+"""ctypes binding of libmmvid_hip.so (declared in include/mmvid_hip.h).
+
+The product path has NO fallback: importing works anywhere (so host logic is testable on CPU), but the
+first kernel call without the library or without a GPU raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libmmvid_hip.so')
+
+P = c_void_p
+I, I64, F = c_int, c_int64, c_float
+
+
+class TowerLayer(Structure):
+    _fields_ = [(n, P) for n in (
+        'ln1_w', 'ln1_b', 'ln2_w', 'ln2_b', 'in_w', 'in_b', 'out_w', 'out_b', 'fc_w', 'fc_b', 'pj_w', 'pj_b',
+        'g_ln1_w', 'g_ln1_b', 'g_ln2_w', 'g_ln2_b', 'g_in_w', 'g_in_b', 'g_out_w', 'g_out_b', 'g_fc_w', 'g_fc_b',
+        'g_pj_w', 'g_pj_b')]
+
+
+class TowerCfg(Structure):
+    _fields_ = [('B', I), ('L', I), ('E', I), ('H', I), ('F', I), ('layers', I), ('mask_mode', I), ('r0', I),
+                ('c0', I), ('r1', I), ('c1', I), ('ln_eps', F)]
+
+
+# name -> argtypes (all return int unless noted)
+SIGNATURES = {
+    'mmvid_vq_sqnorm': [P, I, I, P, P],
+    'mmvid_vq_argmin_l2': [P, P, P, I64, I, I, P, P, P],
+    'mmvid_gather_rows': [P, I64, P, I64, I, P, P, P],
+    'mmvid_gemm_bf16': [I, I, I, I, I, P, I64, P, I64, I, I64, I64, I64, I, F, P, P, I64, P, P, I64, I, I, P, P, I64, P],
+    'mmvid_layernorm_fwd': [P, I64, I64, I, P, P, F, P, P, I64, P, P, P],
+    'mmvid_layernorm_bwd': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P],
+    'mmvid_groupnorm_swish_nhwc': [P, I, I, I64, I, P, P, F, I, P, P, P, P],
+    'mmvid_head_transpose': [P, I64, I, I, I, I, I, P, P],
+    'mmvid_attention_fwd': [P, I64, P, I, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
+    'mmvid_attention_bwd': [P, I64, P, P, P, I64, P, I64, P, P, P, I, I, I, I, I, F, I, I, I, I, I, P, I64, P],
+    'mmvid_assemble_sequence': [POINTER(P), POINTER(I64), I, P, P, P, I64, I, I, P, P],
+    'mmvid_assemble_sequence_bwd': [POINTER(P), POINTER(I64), I, P, P, P, I64, I, I, P, I, P],
+    'mmvid_cross_entropy_fwd': [P, I64, P, P, I64, I, P, P, P],
+    'mmvid_cross_entropy_bwd': [P, I64, P, P, P, P, I64, I, P, I64, P],
+    'mmvid_colsum_bf16': [P, I64, I64, I, P, P],
+    'mmvid_grad_sqnorm': [P, I64, P, P],
+    'mmvid_adam_step': [P, P, P, P, P, I64, F, F, F, F, F, I, F, P, F, P],
+    'mmvid_cast_f32_to_bf16': [P, P, I64, P],
+    'mmvid_tower_workspace': [POINTER(TowerCfg), POINTER(I64), POINTER(I64)],
+    'mmvid_tower_forward': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, P, P],
+    'mmvid_tower_backward': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, P],
+    'mmvid_conv2d_nhwc': [I, P, I, I, I, I, P, P, I, P, P, I, P, P, P],
+    'mmvid_image_to_nhwc8': [P, I, I, I, P, P],
+    'mmvid_nhwc_to_nchw_f32': [P, I, I, I, I, I, P, P],
+    'mmvid_spatial_attention': [P, P, P, I, I, I, F, P, P, P],
+}
+OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I)}
+
+_lib = None
+
+
+class MMVIDError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed for loading).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMVIDError(f'{LIB_PATH} is missing: run `python -m mmvid_amd.build` (hipcc, gfx950). '
+                             'There is no CPU/PyTorch fallback for the kernels.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, I
+        for name, (args, res) in OTHER.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MMVIDError(f'{name} failed (rc={rc}): {lib.mmvid_last_error().decode()}')

@@ -1,0 +1,248 @@
+"""Host-side mirror of mmvid_pytorch/transformers/clip_model.py::OpenAICLIPTransformer (520-584) over the
+native tower of csrc/tower.hip.  Same constructor meaning, same state_dict keys
+(`transformer.resblocks.{i}.{attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.*, ln_1.*, mlp.c_fc.*,
+mlp.c_proj.*, ln_2.*}`), same forward contract ([B, L, E] fp32 in/out).  The attention mask is kept as the
+predicate the reference's build_attention_mask (561-578) encodes, not as an L x L tensor."""
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+TOWER_SHAPES = {  # which_model -> (width, layers, heads), clip_model.py:538-541 with ViT-B/32
+    'openai_clip_visual': (768, 12, 12),
+    'openai_clip_text': (512, 12, 8),
+}
+MATRIX_KEYS = ('attn.in_proj_weight', 'attn.out_proj.weight', 'mlp.c_fc.weight', 'mlp.c_proj.weight')
+
+
+class _Holder(nn.Module):
+    """Parameter container (no forward): gives parameters their reference names."""
+
+
+def _linear_params(out_f, in_f, std):
+    h = _Holder()
+    h.weight = nn.Parameter(torch.randn(out_f, in_f) * std)
+    h.bias = nn.Parameter(torch.zeros(out_f))
+    return h
+
+
+def _ln_params(e):
+    h = _Holder()
+    h.weight = nn.Parameter(torch.ones(e))
+    h.bias = nn.Parameter(torch.zeros(e))
+    return h
+
+
+class ResidualAttentionBlockParams(_Holder):
+    def __init__(self, width, layers):
+        super().__init__()
+        # CLIP.initialize_parameters (clip_model.py:348-378) scales
+        proj_std = (width**-0.5) * ((2 * layers)**-0.5)
+        attn_std = width**-0.5
+        fc_std = (2 * width)**-0.5
+        self.attn = _Holder()
+        self.attn.in_proj_weight = nn.Parameter(torch.randn(3 * width, width) * attn_std)
+        self.attn.in_proj_bias = nn.Parameter(torch.zeros(3 * width))
+        self.attn.out_proj = _linear_params(width, width, proj_std)
+        self.ln_1 = _ln_params(width)
+        self.mlp = _Holder()
+        self.mlp.c_fc = _linear_params(4 * width, width, fc_std)
+        self.mlp.c_proj = _linear_params(width, 4 * width, proj_std)
+        self.ln_2 = _ln_params(width)
+
+
+class _TowerParams(_Holder):
+    def __init__(self, width, layers):
+        super().__init__()
+        self.resblocks = nn.ModuleList([ResidualAttentionBlockParams(width, layers) for _ in range(layers)])
+
+
+class _TowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tower, *params):
+        ctx.tower = tower
+        y, saved = tower._run_forward(x, keep=torch.is_grad_enabled() and (x.requires_grad or tower._any_trainable()))
+        ctx.saved_arena = saved
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        g = gy.contiguous().clone()  # updated in place into dL/dx
+        ctx.tower._run_backward(g, ctx.saved_arena, ctx.shape)
+        ctx.saved_arena = None
+        return (g.view(ctx.shape), None) + (None, ) * (len(ctx.needs_input_grad) - 2)
+
+
+class OpenAICLIPTransformer(nn.Module):
+    def __init__(self, seq_len=0, which_model='openai_clip_text', model_path=None, causal=True, mask_type='causal',
+                 mask_kwargs=None, layers=None, width=None, heads=None):
+        super().__init__()
+        if not which_model.startswith('openai_clip'):
+            raise NotImplementedError(which_model)  # as dalle_bert.py:406-407
+        w, l, h = TOWER_SHAPES[which_model]
+        self.width, self.layers, self.heads = width or w, layers or l, heads or h
+        assert self.width == 64 * self.heads, 'head_dim must be 64 (CLIP towers)'
+        self.context_length = seq_len
+        self.causal = causal
+        self.transformer = _TowerParams(self.width, self.layers)
+        self.mask_spec = self.build_attention_mask(seq_len, mask_type, **(mask_kwargs or {})) if causal else None
+        if model_path is not None:
+            self.load_clip_checkpoint(model_path, which_model)
+        self._shadow = None  # flat bf16 copy of the matrix weights
+        self._shadow_key = None
+        self._scratch = None
+        self._scratch_key = None
+        self.backward_chunk_layers = 3  # the backward returns to the host every N layers ...
+        self.on_layers_done = None      # ... and calls this (first_layer) so gradient exchange can overlap
+
+    # ---- reference API -----------------------------------------------------------------------------
+    @staticmethod
+    def build_attention_mask(context_length, mask_type='causal', **kwargs):
+        """clip_model.py:561-578 as a predicate: 'causal' or ('rows', [(i, i) for i in index])."""
+        if mask_type == 'causal':
+            return 'causal'
+        if mask_type == 'mask_prev':
+            idx = list(kwargs['index'])
+            assert len(idx) <= 2, 'the kernels carry at most two restricted rows (BERT uses [ST1],[VID])'
+            return ('rows', [(int(i), int(i)) for i in idx])
+        raise NotImplementedError(mask_type)
+
+    def dense_attention_mask(self, L=None):
+        """The additive [L, L] float mask the reference would have built (for tests / inspection)."""
+        L = L or self.context_length
+        if self.mask_spec is None:
+            return None
+        if self.mask_spec == 'causal':
+            return torch.full((L, L), float('-inf')).triu_(1)
+        m = torch.zeros(L, L)
+        for r, c in self.mask_spec[1]:
+            m[r, :c] = float('-inf')
+        return m
+
+    def load_clip_checkpoint(self, path, which_model):
+        """clip_model.py:535-559: pull one tower out of OpenAI's TorchScript archive (fp16 weights -> fp32)."""
+        sd = torch.jit.load(path, map_location='cpu').state_dict()
+        prefix = 'transformer.' if which_model == 'openai_clip_text' else 'visual.transformer.'
+        own = {k[len(prefix):]: v.float() for k, v in sd.items() if k.startswith(prefix + 'resblocks.')}
+        self.transformer.load_state_dict(own)
+
+    def forward(self, x, **kwargs):
+        assert x.dim() == 3 and x.shape[-1] == self.width
+        return _TowerFn.apply(x, self, *self.parameters())
+
+    # ---- native plumbing ---------------------------------------------------------------------------
+    def _any_trainable(self):
+        return any(p.requires_grad for p in self.parameters())
+
+    def _matrix_params(self):
+        for blk in self.transformer.resblocks:
+            yield blk.attn.in_proj_weight
+            yield blk.attn.out_proj.weight
+            yield blk.mlp.c_fc.weight
+            yield blk.mlp.c_proj.weight
+
+    def attach_shadow(self, views):
+        """Engine hook: `views` = list of bf16 tensors (one per matrix param, in _matrix_params order) that an
+        external fused optimiser keeps equal to bf16(param)."""
+        self._shadow = list(views)
+        self.mark_shadow_fresh()
+
+    def mark_shadow_fresh(self):
+        self._shadow_key = tuple((p._version, p.data_ptr()) for p in self._matrix_params())
+
+    def _sync_shadow(self):
+        ps = list(self._matrix_params())
+        key = tuple((p._version, p.data_ptr()) for p in ps)
+        if self._shadow is None or self._shadow[0].device != ps[0].device:
+            self._shadow = [torch.empty(p.shape, device=p.device, dtype=torch.bfloat16) for p in ps]
+            self._shadow_key = None
+        if key != self._shadow_key:
+            for p, s in zip(ps, self._shadow):
+                ops.cast_bf16(p.detach().contiguous(), s)
+            self._shadow_key = key
+        return self._shadow
+
+    def _cfg(self, B, L):
+        c = _lib.TowerCfg()
+        c.B, c.L, c.E, c.H, c.F, c.layers = B, L, self.width, self.heads, 4 * self.width, self.layers
+        c.mask_mode, c.r0, c.c0, c.r1, c.c1 = ops._mask_args(self.mask_spec)
+        c.ln_eps = 1e-5
+        return c
+
+    def _layer_structs(self, with_grads):
+        sh = self._sync_shadow()
+        arr = (_lib.TowerLayer * self.layers)()
+        keep = []
+
+        def ptr(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        def gptr(p):
+            if not with_grads or not p.requires_grad:
+                return None
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            return p.grad.data_ptr()
+
+        for i, blk in enumerate(self.transformer.resblocks):
+            a = arr[i]
+            a.ln1_w, a.ln1_b = ptr(blk.ln_1.weight), ptr(blk.ln_1.bias)
+            a.ln2_w, a.ln2_b = ptr(blk.ln_2.weight), ptr(blk.ln_2.bias)
+            a.in_w, a.in_b = ptr(sh[4 * i]), ptr(blk.attn.in_proj_bias)
+            a.out_w, a.out_b = ptr(sh[4 * i + 1]), ptr(blk.attn.out_proj.bias)
+            a.fc_w, a.fc_b = ptr(sh[4 * i + 2]), ptr(blk.mlp.c_fc.bias)
+            a.pj_w, a.pj_b = ptr(sh[4 * i + 3]), ptr(blk.mlp.c_proj.bias)
+            a.g_ln1_w, a.g_ln1_b = gptr(blk.ln_1.weight), gptr(blk.ln_1.bias)
+            a.g_ln2_w, a.g_ln2_b = gptr(blk.ln_2.weight), gptr(blk.ln_2.bias)
+            a.g_in_w, a.g_in_b = gptr(blk.attn.in_proj_weight), gptr(blk.attn.in_proj_bias)
+            a.g_out_w, a.g_out_b = gptr(blk.attn.out_proj.weight), gptr(blk.attn.out_proj.bias)
+            a.g_fc_w, a.g_fc_b = gptr(blk.mlp.c_fc.weight), gptr(blk.mlp.c_fc.bias)
+            a.g_pj_w, a.g_pj_b = gptr(blk.mlp.c_proj.weight), gptr(blk.mlp.c_proj.bias)
+        return arr, keep
+
+    def _workspace(self, cfg, device, keep):
+        sb, cb = ctypes.c_int64(), ctypes.c_int64()
+        _lib.call('mmvid_tower_workspace', ctypes.byref(cfg), ctypes.byref(sb), ctypes.byref(cb))
+        key = (cfg.B, cfg.L, str(device))
+        if self._scratch_key != key:
+            self._scratch = torch.empty(cb.value, device=device, dtype=torch.uint8)
+            self._scratch_key = key
+        saved = torch.empty(sb.value, device=device, dtype=torch.uint8) if keep else None
+        return saved, self._scratch
+
+    def _run_forward(self, x, keep):
+        x = ops._chk(x.contiguous(), torch.float32, 'tower input')
+        B, L, _ = x.shape
+        cfg = self._cfg(B, L)
+        layers, _keep = self._layer_structs(False)
+        saved, scratch = self._workspace(cfg, x.device, keep)
+        y = torch.empty_like(x)
+        _lib.call('mmvid_tower_forward', ctypes.byref(cfg), layers, ops._p(x), ops._p(y), ops._p(saved), ops._p(scratch),
+                  ops._stream())
+        return y, saved
+
+    def _run_backward(self, g, saved, shape):
+        if saved is None:
+            raise _lib.MMVIDError('tower backward without saved activations (forward ran under no_grad)')
+        B, L, _ = shape
+        cfg = self._cfg(B, L)
+        layers, _keep = self._layer_structs(True)
+        _, scratch = self._workspace(cfg, g.device, False)
+        per_layer = saved.numel() // self.layers
+        step = self.backward_chunk_layers if self.on_layers_done is not None else self.layers
+        hi = self.layers
+        while hi > 0:
+            lo = max(0, hi - step)
+            sub = self._cfg(B, L)
+            sub.layers = hi - lo
+            lp = ctypes.cast(ctypes.byref(layers, lo * ctypes.sizeof(_lib.TowerLayer)), ctypes.POINTER(_lib.TowerLayer))
+            _lib.call('mmvid_tower_backward', ctypes.byref(sub), lp, ops._p(g),
+                      ctypes.c_void_p(saved.data_ptr() + lo * per_layer), ops._p(scratch), ops._stream())
+            if self.on_layers_done is not None:
+                self.on_layers_done(lo)
+            hi = lo

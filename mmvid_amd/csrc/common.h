@@ -1,0 +1,66 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the MMVID hot path.
+// wave = 64 lanes everywhere in this tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MMVID_OK 0
+#define MMVID_ERR_ARG 1
+#define MMVID_ERR_HIP 2
+
+// ---- error reporting (thread-local message, read through mmvid_last_error()) ----
+extern "C" const char* mmvid_last_error();
+void mmvid_set_error(const char* fmt, ...);
+
+#define MMVID_REQUIRE(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            mmvid_set_error(__VA_ARGS__); \
+            return MMVID_ERR_ARG;         \
+        }                                 \
+    } while (0)
+
+#define MMVID_LAUNCH_CHECK(name)                                               \
+    do {                                                                       \
+        hipError_t e__ = hipGetLastError();                                    \
+        if (e__ != hipSuccess) {                                               \
+            mmvid_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return MMVID_ERR_HIP;                                              \
+        }                                                                      \
+    } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, same as torch) ----
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,295 @@
+// VQGAN convolutions as implicit GEMM on NHWC bf16, for gfx950.
+//   M = N*Hout*Wout output pixels, N_gemm = Cout, K = taps*Cin with k = (ky*3+kx)*Cin + ci.
+// The A tile is gathered straight from the NHWC activation (each 16-B chunk = 8 input channels of one
+// tap of one pixel: contiguous), zero-filled at the padding; the weight [Cout][taps][Cin] is the
+// row-major B operand.  Same 128x128x64 tile / swizzled LDS / 32x32x16 MFMA core as gemm.hip.
+//   mode 0: 3x3 s1 p1                     (model.py:102-115 ResnetBlock convs, conv_in/out)
+//   mode 1: 3x3 s2, zero pad right/bottom (model.py:77-81 Downsample)
+//   mode 2: nearest x2 upsample + 3x3 p1  (model.py:56-62 Upsample; the upsampled image is never materialised)
+//   mode 3: 1x1                           (nin_shortcut, AttnBlock q/k/v/proj_out, quant_conv, post_quant_conv)
+// Epilogue: + bias, + residual (ResnetBlock/AttnBlock skip), optional (clamp(x,-1,1)+1)/2 (vae.py:55).
+// Roofline: bf16 MFMA; algorithmic FLOPs = 2 * M * Cout * taps * Cin.
+#include "../../include/mmvid_hip.h"
+#include "gemm_core.h"
+
+namespace {
+using namespace mmvid_core;
+
+struct ConvParams {
+    const bf16_t* x;
+    const bf16_t* w;
+    int N, Hin, Win, Cin, cin_log2, Hout, Wout, Cout, mode, taps;
+    long M;
+    int K;
+    const float* bias;
+    const bf16_t* res_bf16;
+    const float* res_f32;
+    int clamp01;
+    bf16_t* out_bf16;
+    float* out_f32;
+};
+
+// A-operand gather: thread t owns chunk c = t&7 of rows (t>>3)+32i.
+struct ConvAStage {
+    uint4 v[4];
+    int oy[4], ox[4];
+    long nbase[4];  // n*Hin*Win, or -1 when the row is out of range
+    __device__ __forceinline__ void init(const ConvParams& p, long m0, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = m0 + (tid >> 3) + 32 * i;
+            if (m < p.M) {
+                const long hw = (long)p.Hout * p.Wout;
+                const long n = m / hw;
+                const int rem = (int)(m - n * hw);
+                oy[i] = rem / p.Wout;
+                ox[i] = rem - oy[i] * p.Wout;
+                nbase[i] = n * p.Hin * p.Win;
+            } else {
+                nbase[i] = -1, oy[i] = ox[i] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const ConvParams& p, int k0, int tid) {
+        const int k = k0 + (tid & 7) * 8;
+        const int tap = k >> p.cin_log2;
+        const int ci = k & (p.Cin - 1);
+        const int ky = (p.mode == 3) ? 0 : tap / 3;
+        const int kx = (p.mode == 3) ? 0 : tap - ky * 3;
+        const bool kvalid = k < p.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int iy, ix;
+            bool ok = kvalid && nbase[i] >= 0;
+            if (p.mode == 0) {
+                iy = oy[i] + ky - 1, ix = ox[i] + kx - 1;
+                ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            } else if (p.mode == 1) {
+                iy = 2 * oy[i] + ky, ix = 2 * ox[i] + kx;
+                ok = ok && iy < p.Hin && ix < p.Win;
+            } else if (p.mode == 2) {
+                const int uy = oy[i] + ky - 1, ux = ox[i] + kx - 1;
+                ok = ok && uy >= 0 && uy < 2 * p.Hin && ux >= 0 && ux < 2 * p.Win;
+                iy = uy >> 1, ix = ux >> 1;
+            } else {
+                iy = oy[i], ix = ox[i];
+            }
+            v[i] = ok ? *reinterpret_cast<const uint4*>(p.x + ((nbase[i] + (long)iy * p.Win + ix) << p.cin_log2) + ci)
+                      : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+        const int c = tid & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + lds_off((tid >> 3) + 32 * i, c)) = v[i];
+    }
+};
+
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bn0 = blockIdx.x * BN;
+    const long bm0 = (long)blockIdx.y * BM;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    ConvAStage sa;
+    RowMajorStage sb;
+    sa.init(p, bm0, tid);
+    const int nt = (p.K + BK - 1) / BK;
+    sa.load(p, 0, tid);
+    sb.load(p.w, p.K, p.Cout, p.K, bn0, 0, tid);
+    sa.store(smem, tid);
+    sb.store(smem + TILE_BYTES, tid);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * (2 * TILE_BYTES);
+        char* nxt = smem + ((t + 1) & 1) * (2 * TILE_BYTES);
+        const bool more = t + 1 < nt;
+        if (more) {
+            sa.load(p, (t + 1) * BK, tid);
+            sb.load(p.w, p.K, p.Cout, p.K, bn0, (t + 1) * BK, tid);
+        }
+        mma_tile(cur, cur + TILE_BYTES, acc, wm, wn, lane);
+        if (more) {
+            sa.store(nxt, tid);
+            sb.store(nxt + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+    const int frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long m = bm0 + wm * 64 + i * 32 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = bn0 + wn * 64 + j * 32 + 8 * q + 4 * fh;
+                if (n >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                if (p.bias) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += b4.x, v[1] += b4.y, v[2] += b4.z, v[3] += b4.w;
+                }
+                const long o = m * p.Cout + n;
+                if (p.res_bf16) {
+                    const uint2 r = *reinterpret_cast<const uint2*>(p.res_bf16 + o);
+                    v[0] += bf_lo(r.x), v[1] += bf_hi(r.x), v[2] += bf_lo(r.y), v[3] += bf_hi(r.y);
+                }
+                if (p.res_f32) {
+                    const float4 r = *reinterpret_cast<const float4*>(p.res_f32 + o);
+                    v[0] += r.x, v[1] += r.y, v[2] += r.z, v[3] += r.w;
+                }
+                if (p.clamp01) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (fminf(fmaxf(v[e], -1.f), 1.f) + 1.f) * 0.5f;
+                }
+                if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.out_bf16)
+                    *reinterpret_cast<uint2*>(p.out_bf16 + o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
+    }
+}
+
+// img NCHW f32 [N,3,H,W] in [0,1] -> NHWC bf16 [N,H,W,8] holding 2x-1 (vae.py:41), channels 3..7 = 0
+__global__ __launch_bounds__(256) void image_to_nhwc8_kernel(const float* __restrict__ img, long npix, long hw,
+                                                             bf16_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const long n = i / hw, p = i - n * hw;
+    const float* s = img + n * 3 * hw + p;
+    const float r = 2.f * s[0] - 1.f, g = 2.f * s[hw] - 1.f, b = 2.f * s[2 * hw] - 1.f;
+    *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(pack_bf2(r, g), pack_bf2(b, 0.f), 0u, 0u);
+}
+
+// NHWC f32 -> NCHW f32 (first Cuse channels); small tensors only (decoder output, z)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, long total, long hw, int C,
+                                                           int Cuse, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over N*Cuse*hw (output order)
+    if (i >= total) return;
+    const long n = i / (Cuse * hw);
+    const long r = i - n * Cuse * hw;
+    const int c = (int)(r / hw);
+    const long p = r - (long)c * hw;
+    out[i] = x[(n * hw + p) * C + c];
+}
+
+// row softmax: P[r, :] = softmax(S[r, :] * scale) -> bf16 ; one wave per row, cols % 4 == 0
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, long rows, int cols,
+                                                           float scale, bf16_t* __restrict__ p) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4* src = reinterpret_cast<const float4*>(s + r * cols);
+    float mx = -INFINITY;
+    for (int c = lane; c < (cols >> 2); c += 64) {
+        const float4 v = src[c];
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    mx = wave_max(mx) * scale;
+    float sum = 0.f;
+    for (int c = lane; c < (cols >> 2); c += 64) {
+        const float4 v = src[c];
+        sum += (__expf(v.x * scale - mx) + __expf(v.y * scale - mx)) + (__expf(v.z * scale - mx) + __expf(v.w * scale - mx));
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    uint2* dst = reinterpret_cast<uint2*>(p + r * cols);
+    for (int c = lane; c < (cols >> 2); c += 64) {
+        const float4 v = src[c];
+        dst[c] = make_uint2(pack_bf2(__expf(v.x * scale - mx) * inv, __expf(v.y * scale - mx) * inv),
+                            pack_bf2(__expf(v.z * scale - mx) * inv, __expf(v.w * scale - mx) * inv));
+    }
+}
+
+int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+}  // namespace
+
+extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w,
+                                 const float* bias, int Cout, const void* residual_bf16, const float* residual_f32,
+                                 int clamp01, void* out_bf16, float* out_f32, void* stream) {
+    MMVID_REQUIRE(x && w && (out_bf16 || out_f32), "conv2d_nhwc: null pointer");
+    MMVID_REQUIRE(mode >= 0 && mode <= 3, "conv2d_nhwc: mode %d", mode);
+    const int l2 = ilog2_exact(Cin);
+    MMVID_REQUIRE(l2 >= 3, "conv2d_nhwc: Cin=%d must be a power of two >= 8", Cin);
+    MMVID_REQUIRE(Cout % 8 == 0, "conv2d_nhwc: Cout=%d must be a multiple of 8", Cout);
+    ConvParams p;
+    p.x = (const bf16_t*)x, p.w = (const bf16_t*)w;
+    p.N = N, p.Hin = Hin, p.Win = Win, p.Cin = Cin, p.cin_log2 = l2, p.Cout = Cout, p.mode = mode;
+    p.taps = mode == 3 ? 1 : 9;
+    if (mode == 1) {
+        p.Hout = Hin / 2, p.Wout = Win / 2;  // pad (0,1,0,1) then 3x3 stride 2: floor((H+1-3)/2)+1 = H/2 for even H
+        MMVID_REQUIRE(Hin % 2 == 0 && Win % 2 == 0, "conv2d_nhwc: downsample needs even H, W");
+    } else if (mode == 2) {
+        p.Hout = 2 * Hin, p.Wout = 2 * Win;
+    } else {
+        p.Hout = Hin, p.Wout = Win;
+    }
+    p.M = (long)N * p.Hout * p.Wout;
+    p.K = p.taps * Cin;
+    p.bias = bias, p.res_bf16 = (const bf16_t*)residual_bf16, p.res_f32 = residual_f32, p.clamp01 = clamp01;
+    p.out_bf16 = (bf16_t*)out_bf16, p.out_f32 = out_f32;
+    if (p.M == 0) return MMVID_OK;
+    static bool attr = false;
+    const int lds = 4 * TILE_BYTES;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv_igemm_kernel, dim3(cdiv(Cout, BN), cdiv(p.M, BM)), dim3(256), lds, (hipStream_t)stream, p);
+    MMVID_LAUNCH_CHECK("conv2d_nhwc");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_image_to_nhwc8(const float* img, int N, int H, int W, void* out_bf16, void* stream) {
+    MMVID_REQUIRE(img && out_bf16, "image_to_nhwc8: null pointer");
+    const long npix = (long)N * H * W;
+    if (npix == 0) return MMVID_OK;
+    hipLaunchKernelGGL(image_to_nhwc8_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, img, npix,
+                       (long)H * W, (bf16_t*)out_bf16);
+    MMVID_LAUNCH_CHECK("image_to_nhwc8");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int Cuse, float* out, void* stream) {
+    MMVID_REQUIRE(x && out && Cuse <= C, "nhwc_to_nchw_f32: bad arguments");
+    const long total = (long)N * Cuse * H * W;
+    if (total == 0) return MMVID_OK;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, total,
+                       (long)H * W, C, Cuse, out);
+    MMVID_LAUNCH_CHECK("nhwc_to_nchw_f32");
+    return MMVID_OK;
+}
+
+// AttnBlock core (model.py:188-201): w = softmax(q k^T * C^-0.5) over keys; o = w v.   q,k,v,o: [N, HW, C] bf16.
+// scores_scratch: N*HW*HW fp32 followed by N*HW*HW bf16.
+extern "C" int mmvid_spatial_attention(const void* q, const void* k, const void* v, int N, int HW, int C, float scale,
+                                       float* scores_scratch, void* out_bf16, void* stream) {
+    MMVID_REQUIRE(q && k && v && scores_scratch && out_bf16, "spatial_attention: null pointer");
+    MMVID_REQUIRE(HW % 8 == 0 && C % 8 == 0, "spatial_attention: HW=%d and C=%d must be multiples of 8", HW, C);
+    const long hw2 = (long)HW * HW;
+    void* P = (void*)(scores_scratch + (long)N * hw2);
+    int rc = mmvid_gemm_bf16(0, 0, HW, HW, C, q, C, k, C, N, (long)HW * C, (long)HW * C, hw2, 1, 1.0f, nullptr, nullptr, 0,
+                             nullptr, nullptr, 0, 0, 0, scores_scratch, nullptr, HW, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv((long)N * HW, 4)), dim3(256), 0, (hipStream_t)stream,
+                       scores_scratch, (long)N * HW, HW, scale, (bf16_t*)P);
+    MMVID_LAUNCH_CHECK("spatial_attention.softmax");
+    // o[q][c] = sum_key P[q][key] v[key][c] : A = P row-major [HW, HW], B = v k-major [HW(red)][C]
+    return mmvid_gemm_bf16(0, 1, HW, C, HW, P, HW, v, C, N, hw2, (long)HW * C, (long)HW * C, 1, 1.0f, nullptr, nullptr, 0,
+                           nullptr, nullptr, 0, 0, 0, nullptr, out_bf16, C, stream);
+}

@@ -1,0 +1,236 @@
+// Sequence assembly and losses around the tower -- HBM-bound gathers/scatters.
+//   assemble_sequence      dalle_bert.py:899-973,1030-1035 : x[b,l,:] = table[seg[l]][ids[b,l], :] + pos[l, :]
+//   assemble_sequence_bwd  scatter-add of dx rows into the table gradients (fp32 atomics) + dpos = sum_b dx
+//   cross_entropy fwd/bwd  dalle_bert.py:1040 F.cross_entropy(logits[~mask1], target[~mask1]) (mean over selected rows)
+//   colsum                 bias gradients: db[n] += sum_m dY[m][n]
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_TABLES = 4;
+struct Tables {
+    const float* t[MAX_TABLES];
+    long rows[MAX_TABLES];
+};
+struct GradTables {
+    float* t[MAX_TABLES];
+    long rows[MAX_TABLES];
+};
+
+// one wave per (b,l) row; E % 4 == 0
+__global__ __launch_bounds__(256) void assemble_fwd_kernel(Tables tb, const long long* __restrict__ ids,
+                                                           const int* __restrict__ seg,
+                                                           const float* __restrict__ pos, long nrows, int L, int E,
+                                                           float* __restrict__ out) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int l = (int)(row % L);
+    const int s = seg[l];
+    long id = ids[row];
+    if (id < 0 || id >= tb.rows[s]) id = 0;  // host validates; never fault
+    const float4* src = reinterpret_cast<const float4*>(tb.t[s] + id * E);
+    const float4* pp = reinterpret_cast<const float4*>(pos + (long)l * E);
+    float4* dst = reinterpret_cast<float4*>(out + row * E);
+    for (int c = lane; c < (E >> 2); c += 64) {
+        const float4 a = src[c], p = pp[c];
+        dst[c] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void assemble_bwd_scatter_kernel(GradTables tb, const long long* __restrict__ ids,
+                                                                   const int* __restrict__ seg,
+                                                                   const float* __restrict__ dx, long nrows, int L,
+                                                                   int E) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int l = (int)(row % L);
+    const int s = seg[l];
+    float* g = tb.t[s];
+    if (!g) return;
+    long id = ids[row];
+    if (id < 0 || id >= tb.rows[s]) return;
+    const float* src = dx + row * E;
+    float* dst = g + id * E;
+    for (int c = lane; c < E; c += 64) unsafeAtomicAdd(dst + c, src[c]);
+}
+
+// dpos[l, e] (+)= sum_b dx[b, l, e]
+__global__ __launch_bounds__(256) void batch_reduce_kernel(const float* __restrict__ dx, int B, long LE,
+                                                           float* __restrict__ dpos, int accumulate) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= LE) return;
+    float4 a = make_float4(0, 0, 0, 0);
+    for (int b = 0; b < B; ++b) {
+        const float4 v = *reinterpret_cast<const float4*>(dx + (long)b * LE + i);
+        a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+    }
+    float4* d = reinterpret_cast<float4*>(dpos + i);
+    if (accumulate) {
+        const float4 p = *d;
+        a.x += p.x, a.y += p.y, a.z += p.z, a.w += p.w;
+    }
+    *d = a;
+}
+
+// ---- cross entropy over selected rows.  One wave per row, V % 4 == 0.
+// fwd: lse[row] saved; loss_sum += (lse - logit[target]) for selected rows (select[row] != 0).
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long ldl,
+                                                     const long long* __restrict__ target,
+                                                     const unsigned char* __restrict__ select, long rows, int V,
+                                                     float* __restrict__ lse, float* __restrict__ loss_sum) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    if (select && !select[row]) {
+        if (lane == 0) lse[row] = 0.f;
+        return;
+    }
+    const float4* p = reinterpret_cast<const float4*>(logits + row * ldl);
+    float mx = -INFINITY;
+    for (int c = lane; c < (V >> 2); c += 64) {
+        const float4 v = p[c];
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < (V >> 2); c += 64) {
+        const float4 v = p[c];
+        s += (__expf(v.x - mx) + __expf(v.y - mx)) + (__expf(v.z - mx) + __expf(v.w - mx));
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float l = mx + __logf(s);
+        lse[row] = l;
+        long t = target[row];
+        if (t < 0 || t >= V) t = 0;
+        unsafeAtomicAdd(loss_sum, l - logits[row * ldl + t]);
+    }
+}
+
+// bwd: dlogits[row] = (softmax - onehot) * (*gscale) for selected rows, 0 otherwise; bf16 output.
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long ldl,
+                                                     const long long* __restrict__ target,
+                                                     const unsigned char* __restrict__ select,
+                                                     const float* __restrict__ lse,
+                                                     const float* __restrict__ gscale, long rows, int V,
+                                                     bf16_t* __restrict__ dlogits, long ldd) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    uint2* d = reinterpret_cast<uint2*>(dlogits + row * ldd);
+    if (select && !select[row]) {
+        for (int c = lane; c < (V >> 2); c += 64) d[c] = make_uint2(0, 0);
+        return;
+    }
+    const float gs = *gscale;
+    const float l = lse[row];
+    long t = target[row];
+    if (t < 0 || t >= V) t = 0;
+    const float4* p = reinterpret_cast<const float4*>(logits + row * ldl);
+    for (int c = lane; c < (V >> 2); c += 64) {
+        const float4 v = p[c];
+        float o[4] = {__expf(v.x - l), __expf(v.y - l), __expf(v.z - l), __expf(v.w - l)};
+        const long base = (long)c * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (base + e == t) o[e] -= 1.0f;
+        d[c] = make_uint2(pack_bf2(o[0] * gs, o[1] * gs), pack_bf2(o[2] * gs, o[3] * gs));
+    }
+}
+
+// db[n] += sum_m dY[m][n] (bf16 in, fp32 atomic out); block = 64 rows x 256 columns (2 per thread)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ dy, long ld, long M, int N,
+                                                          float* __restrict__ db) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (n >= N) return;
+    const long m0 = (long)blockIdx.y * 64;
+    long m1 = m0 + 64;
+    if (m1 > M) m1 = M;
+    float a = 0.f, b = 0.f;
+    for (long m = m0; m < m1; ++m) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(dy + m * ld + n);
+        a += bf_lo(w), b += bf_hi(w);
+    }
+    unsafeAtomicAdd(db + n, a);
+    unsafeAtomicAdd(db + n + 1, b);
+}
+
+}  // namespace
+
+extern "C" int mmvid_assemble_sequence(const float* const* tables, const int64_t* table_rows, int ntables,
+                                       const int64_t* ids, const int32_t* seg, const float* pos, int64_t B, int L,
+                                       int E, float* out, void* stream) {
+    MMVID_REQUIRE(tables && table_rows && ids && seg && pos && out, "assemble_sequence: null pointer");
+    MMVID_REQUIRE(ntables >= 1 && ntables <= MAX_TABLES && E % 4 == 0, "assemble_sequence: ntables=%d E=%d", ntables, E);
+    Tables tb;
+    for (int i = 0; i < MAX_TABLES; ++i) {
+        tb.t[i] = i < ntables ? tables[i] : tables[0];
+        tb.rows[i] = i < ntables ? table_rows[i] : table_rows[0];
+    }
+    const long nrows = (long)B * L;
+    if (nrows == 0) return MMVID_OK;
+    hipLaunchKernelGGL(assemble_fwd_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, tb,
+                       (const long long*)ids, seg, pos, nrows, L, E, out);
+    MMVID_LAUNCH_CHECK("assemble_sequence");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_assemble_sequence_bwd(float* const* grad_tables, const int64_t* table_rows, int ntables,
+                                           const int64_t* ids, const int32_t* seg, const float* dx, int64_t B, int L,
+                                           int E, float* dpos, int accumulate_dpos, void* stream) {
+    MMVID_REQUIRE(grad_tables && table_rows && ids && seg && dx, "assemble_sequence_bwd: null pointer");
+    MMVID_REQUIRE(ntables >= 1 && ntables <= MAX_TABLES && E % 4 == 0, "assemble_sequence_bwd: ntables=%d E=%d", ntables, E);
+    GradTables tb;
+    for (int i = 0; i < MAX_TABLES; ++i) {
+        tb.t[i] = i < ntables ? grad_tables[i] : nullptr;
+        tb.rows[i] = i < ntables ? table_rows[i] : 0;
+    }
+    const long nrows = (long)B * L;
+    if (nrows == 0) return MMVID_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(assemble_bwd_scatter_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, s, tb, (const long long*)ids,
+                       seg, dx, nrows, L, E);
+    if (dpos) {
+        const long LE = (long)L * E;
+        hipLaunchKernelGGL(batch_reduce_kernel, dim3(cdiv(LE / 4, 256)), dim3(256), 0, s, dx, (int)B, LE, dpos,
+                           accumulate_dpos);
+    }
+    MMVID_LAUNCH_CHECK("assemble_sequence_bwd");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_cross_entropy_fwd(const float* logits, int64_t ldl, const int64_t* target,
+                                       const uint8_t* select, int64_t rows, int V, float* lse, float* loss_sum,
+                                       void* stream) {
+    MMVID_REQUIRE(logits && target && lse && loss_sum, "cross_entropy_fwd: null pointer");
+    MMVID_REQUIRE(V % 4 == 0 && ldl % 4 == 0, "cross_entropy_fwd: V and ldl must be multiples of 4");
+    if (rows == 0) return MMVID_OK;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl,
+                       (const long long*)target, select, (long)rows, V, lse, loss_sum);
+    MMVID_LAUNCH_CHECK("cross_entropy_fwd");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_cross_entropy_bwd(const float* logits, int64_t ldl, const int64_t* target,
+                                       const uint8_t* select, const float* lse, const float* gscale, int64_t rows,
+                                       int V, void* dlogits_bf16, int64_t ldd, void* stream) {
+    MMVID_REQUIRE(logits && target && lse && gscale && dlogits_bf16, "cross_entropy_bwd: null pointer");
+    MMVID_REQUIRE(V % 4 == 0 && ldl % 4 == 0 && ldd % 4 == 0, "cross_entropy_bwd: V/ld must be multiples of 4");
+    if (rows == 0) return MMVID_OK;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, (long)ldl,
+                       (const long long*)target, select, lse, gscale, (long)rows, V, (bf16_t*)dlogits_bf16, (long)ldd);
+    MMVID_LAUNCH_CHECK("cross_entropy_bwd");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_colsum_bf16(const void* dy, int64_t ld, int64_t M, int N, float* db, void* stream) {
+    MMVID_REQUIRE(dy && db, "colsum_bf16: null pointer");
+    MMVID_REQUIRE(N % 2 == 0 && ld % 2 == 0, "colsum_bf16: N and ld must be even");
+    if (M == 0) return MMVID_OK;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N / 2, 256), cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, (long)ld, (long)M, N, db);
+    MMVID_LAUNCH_CHECK("colsum_bf16");
+    return MMVID_OK;
+}

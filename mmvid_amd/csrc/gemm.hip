@@ -1,0 +1,229 @@
+// bf16 MFMA GEMM with fused epilogues for the transformer tower (SURVEY K2, K4-K7 and their
+// backward GEMMs).  One kernel template, three operand layouts:
+//
+//   C[m][n] = sum_k A(m,k) * B(n,k)
+//     A row-major  [M][K] (lda)  or k-major [K][M]   (AKM)
+//     B row-major  [N][K] (ldb)  or k-major [K][N]   (BKM)
+//
+//   forward  Y = X W^T          : A = X [M,K] row-major, B = W [N,K] row-major      (AKM=0,BKM=0)
+//   dX = dY W                   : A = dY [M,N'] row-major, B = W [N'(red)][K(out)] k-major (AKM=0,BKM=1)
+//   dW = dY^T X                 : A = dY [M(red)][N(out)] k-major, B = X [M(red)][K(out)] k-major (AKM=1,BKM=1)
+//
+// so neither weights nor activations ever need a transposed copy in HBM: k-major tiles are
+// transposed in registers (8x4 bf16 blocks, v_perm-class ops) on their way into LDS.
+//
+// Tiling for gfx950: 128x128x64 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 as
+// 2x2 v_mfma_f32_32x32x16_bf16 tiles (fp32 accumulate).  LDS holds A and B tiles as rows of
+// 64 bf16 (128 B) with 16-B chunks XOR-swizzled by ((row>>1)&7): conflict-free for the
+// ds_read_b128 lane groups of the 32x32 fragment read and for the 8-lane ds_write_b128 /
+// 16-lane ds_write_b64 groups of the staging writes.  Double-buffered LDS + register
+// prefetch: one barrier per K tile.  MFMA operands are swapped (a=B-frag, b=A-frag) so that
+// each lane ends up with 4 consecutive n for one m: 16-B epilogue loads/stores.
+// Roofline: bf16 MFMA (2.5 PFLOP/s dense); algorithmic FLOPs = 2*M*N*K.
+#include "gemm_core.h"
+
+namespace {
+using namespace mmvid_core;
+
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    int M, N, K;
+    long lda, ldb;
+    long strideA, strideB, strideC;  // batch strides in elements (0 = shared)
+    int splitk;                       // >1: K split over blockIdx.z % splitk, fp32 atomic accumulate
+    // epilogue
+    const float* bias;      // [N] or null
+    const float* residual;  // [M][ldr] fp32 or null  (added after activation)
+    long ldr;
+    const bf16_t* dact_pre;  // [M][ldp] bf16: multiply by QuickGELU'(pre) (backward) or null
+    bf16_t* save_pre;        // [M][ldp] bf16: store pre-activation (forward) or null
+    long ldp;
+    int act;         // 0 none, 1 QuickGELU
+    int accumulate;  // out_f32 += result (non-atomic) when splitk == 1
+    float alpha;     // scale applied to the accumulator first
+    float* out_f32;  // [M][ldc] or null
+    bf16_t* out_bf16;
+    long ldc;
+};
+
+__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+    float s = sigmoidf_(1.702f * x);
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A tile | B tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bn0 = blockIdx.x * BN, bm0 = blockIdx.y * BM;
+    const int batch = blockIdx.z / p.splitk, ks = blockIdx.z % p.splitk;
+    const bf16_t* A = p.A + (long)batch * p.strideA;
+    const bf16_t* B = p.B + (long)batch * p.strideB;
+
+    // K range of this split (multiples of BK)
+    const int ktiles_total = (p.K + BK - 1) / BK;
+    const int per = (ktiles_total + p.splitk - 1) / p.splitk;
+    const int kt0 = ks * per;
+    int kt1 = kt0 + per;
+    if (kt1 > ktiles_total) kt1 = ktiles_total;
+    const int nt = kt1 - kt0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    typename StageSel<AKM>::type sa;
+    typename StageSel<BKM>::type sb;
+
+    if (nt > 0) {
+        sa.load(A, p.lda, p.M, p.K, bm0, kt0 * BK, tid);
+        sb.load(B, p.ldb, p.N, p.K, bn0, kt0 * BK, tid);
+        sa.store(smem, tid);
+        sb.store(smem + TILE_BYTES, tid);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * (2 * TILE_BYTES);
+        char* nxt = smem + ((t + 1) & 1) * (2 * TILE_BYTES);
+        const bool more = (t + 1 < nt);
+        if (more) {
+            sa.load(A, p.lda, p.M, p.K, bm0, (kt0 + t + 1) * BK, tid);
+            sb.load(B, p.ldb, p.N, p.K, bn0, (kt0 + t + 1) * BK, tid);
+        }
+        mma_tile(cur, cur + TILE_BYTES, acc, wm, wn, lane);
+        if (more) {
+            sa.store(nxt, tid);
+            sb.store(nxt + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    const int frow = lane & 31, fh = lane >> 5;
+    // ---- epilogue: lane holds, for m = l&31, n = 8q + 4*(l>>5) + (0..3), q = 0..3 ----
+    const long cb = (long)batch * p.strideC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = bm0 + wm * 64 + i * 32 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = bn0 + wn * 64 + j * 32 + 8 * q + 4 * fh;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                if (p.splitk > 1) {
+                    float* o = p.out_f32 + cb + (long)m * p.ldc + n;
+                    if (p.bias && ks == 0) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+                        v[0] += b4.x, v[1] += b4.y, v[2] += b4.z, v[3] += b4.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, v[e]);
+                    continue;
+                }
+                if (p.bias) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += b4.x, v[1] += b4.y, v[2] += b4.z, v[3] += b4.w;
+                }
+                if (p.save_pre) {
+                    *reinterpret_cast<uint2*>(p.save_pre + cb + (long)m * p.ldp + n) =
+                        make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+                }
+                if (p.dact_pre) {
+                    const uint2 pr = *reinterpret_cast<const uint2*>(p.dact_pre + cb + (long)m * p.ldp + n);
+                    v[0] *= quick_gelu_grad(bf_lo(pr.x));
+                    v[1] *= quick_gelu_grad(bf_hi(pr.x));
+                    v[2] *= quick_gelu_grad(bf_lo(pr.y));
+                    v[3] *= quick_gelu_grad(bf_hi(pr.y));
+                }
+                if (p.residual) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(p.residual + cb + (long)m * p.ldr + n);
+                    v[0] += r4.x, v[1] += r4.y, v[2] += r4.z, v[3] += r4.w;
+                }
+                if (p.out_f32) {
+                    float4* o = reinterpret_cast<float4*>(p.out_f32 + cb + (long)m * p.ldc + n);
+                    if (p.accumulate) {
+                        const float4 o4 = *o;
+                        v[0] += o4.x, v[1] += o4.y, v[2] += o4.z, v[3] += o4.w;
+                    }
+                    *o = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                if (p.out_bf16) {
+                    *reinterpret_cast<uint2*>(p.out_bf16 + cb + (long)m * p.ldc + n) =
+                        make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
+            }
+        }
+    }
+}
+
+template <bool AKM, bool BKM>
+int launch(const GemmParams& p, int batch, hipStream_t stream) {
+    static bool attr = false;
+    const int lds = 4 * TILE_BYTES;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), batch * p.splitk);
+    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM>), grid, dim3(256), lds, stream, p);
+    return 0;
+}
+
+}  // namespace
+
+// See include/mmvid_hip.h for the contract.
+extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int64_t lda,
+                               const void* B, int64_t ldb, int batch, int64_t strideA, int64_t strideB,
+                               int64_t strideC, int splitk, float alpha, const float* bias, const float* residual,
+                               int64_t ldr, const void* dact_pre, void* save_pre, int64_t ldp, int act,
+                               int accumulate, float* out_f32, void* out_bf16, int64_t ldc, void* stream) {
+    MMVID_REQUIRE(A && B && (out_f32 || out_bf16), "gemm_bf16: null pointer");
+    MMVID_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_bf16: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    MMVID_REQUIRE(N % 8 == 0 && ldc % 4 == 0, "gemm_bf16: N (%d) must be a multiple of 8 and ldc of 4", N);
+    MMVID_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16: lda/ldb must be multiples of 8 elements (16-B rows)");
+    if (!a_kmajor) MMVID_REQUIRE(K % 8 == 0, "gemm_bf16: K (%d) must be a multiple of 8 for a row-major A", K);
+    if (!b_kmajor) MMVID_REQUIRE(K % 8 == 0, "gemm_bf16: K (%d) must be a multiple of 8 for a row-major B", K);
+    if (a_kmajor) MMVID_REQUIRE(M % 8 == 0, "gemm_bf16: M (%d) must be a multiple of 8 for a k-major A", M);
+    MMVID_REQUIRE(!(a_kmajor && !b_kmajor), "gemm_bf16: layout (A k-major, B row-major) is not used on this path");
+    MMVID_REQUIRE(splitk >= 1, "gemm_bf16: splitk must be >= 1");
+    if (splitk > 1)
+        MMVID_REQUIRE(out_f32 && !out_bf16 && !act && !dact_pre && !save_pre && !residual,
+                      "gemm_bf16: split-K supports only fp32 atomic accumulation (+bias)");
+    if (dact_pre || save_pre) MMVID_REQUIRE(ldp % 4 == 0, "gemm_bf16: ldp must be a multiple of 4");
+    if (residual) MMVID_REQUIRE(ldr % 4 == 0, "gemm_bf16: ldr must be a multiple of 4");
+    GemmParams p;
+    p.A = (const bf16_t*)A, p.B = (const bf16_t*)B;
+    p.M = M, p.N = N, p.K = K, p.lda = lda, p.ldb = ldb;
+    p.strideA = strideA, p.strideB = strideB, p.strideC = strideC, p.splitk = splitk;
+    p.bias = bias, p.residual = residual, p.ldr = ldr;
+    p.dact_pre = (const bf16_t*)dact_pre, p.save_pre = (bf16_t*)save_pre, p.ldp = ldp;
+    p.act = act, p.accumulate = accumulate, p.alpha = alpha;
+    p.out_f32 = out_f32, p.out_bf16 = (bf16_t*)out_bf16, p.ldc = ldc;
+    hipStream_t s = (hipStream_t)stream;
+    if (!a_kmajor && !b_kmajor)
+        launch<false, false>(p, batch, s);
+    else if (!a_kmajor && b_kmajor)
+        launch<false, true>(p, batch, s);
+    else
+        launch<true, true>(p, batch, s);
+    MMVID_LAUNCH_CHECK("gemm_bf16");
+    return MMVID_OK;
+}

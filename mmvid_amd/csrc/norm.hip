@@ -1,0 +1,300 @@
+// Row normalisations on the path (HBM-bound, fp32 statistics):
+//   LayerNorm forward/backward     clip_model.py:188-193 (eps 1e-5, fp32 math), dalle_bert.py:414-425 heads
+//   GroupNorm(32, eps 1e-6)+swish  taming/modules/diffusionmodules/model.py:38-42, 33-35 (NHWC here)
+// One wave per row for LayerNorm (E <= 64*4*MAXV lanes*float4), 16-B accesses.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;  // float4 per lane -> E <= 1024
+
+// y = (x - mean) * rstd * w + b ; writes bf16 and/or f32; saves mean/rstd.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx, long rows, int E,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ b, float eps,
+                                                            bf16_t* __restrict__ y_bf16, float* __restrict__ y_f32,
+                                                            long ldy, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int nv = E >> 2;  // float4 count
+    const float4* xr = reinterpret_cast<const float4*>(x + r * ldx);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = xr[c];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0, 0, 0, 0);
+        }
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float a = v[i].x - mean, b2 = v[i].y - mean, c2 = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b2 * b2) + (c2 * c2 + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[r] = mean;
+        if (rstd_out) rstd_out[r] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 w4 = reinterpret_cast<const float4*>(w)[c];
+            const float4 b4 = reinterpret_cast<const float4*>(b)[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * w4.x + b4.x;
+            o.y = (v[i].y - mean) * rstd * w4.y + b4.y;
+            o.z = (v[i].z - mean) * rstd * w4.z + b4.z;
+            o.w = (v[i].w - mean) * rstd * w4.w + b4.w;
+            if (y_f32) reinterpret_cast<float4*>(y_f32 + r * ldy)[c] = o;
+            if (y_bf16) reinterpret_cast<uint2*>(y_bf16 + r * ldy)[c] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*w ;  dx is ADDED into dx_accum (residual-stream
+// gradient) when add != 0, else stored.  dw += sum dy*xhat, db += sum dy  (fp32 atomics, one per block/column).
+// Each block walks rows blockIdx.x, +gridDim.x, ... with 4 waves; per-lane partial dw/db stay in registers.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, long lddy,
+                                                            const float* __restrict__ x, long ldx,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ w, long rows, int E,
+                                                            float* __restrict__ dx, long lddx, int add,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[2][4][LN_MAXV * 64 * 4];  // [dw|db][wave][E]  = 32 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = E >> 2;
+    float4 pw[LN_MAXV], pb[LN_MAXV], w4[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        pw[i] = pb[i] = make_float4(0, 0, 0, 0);
+        const int c = lane + 64 * i;
+        w4[i] = (c < nv) ? reinterpret_cast<const float4*>(w)[c] : make_float4(0, 0, 0, 0);
+    }
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        const float mu = mean[r], rs = rstd[r];
+        float4 g[LN_MAXV], xh[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 d4 = reinterpret_cast<const float4*>(dy + r * lddy)[c];
+                const float4 x4 = reinterpret_cast<const float4*>(x + r * ldx)[c];
+                xh[i] = make_float4((x4.x - mu) * rs, (x4.y - mu) * rs, (x4.z - mu) * rs, (x4.w - mu) * rs);
+                g[i] = make_float4(d4.x * w4[i].x, d4.y * w4[i].y, d4.z * w4[i].z, d4.w * w4[i].w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                pw[i].x += d4.x * xh[i].x, pw[i].y += d4.y * xh[i].y, pw[i].z += d4.z * xh[i].z, pw[i].w += d4.w * xh[i].w;
+                pb[i].x += d4.x, pb[i].y += d4.y, pb[i].z += d4.z, pb[i].w += d4.w;
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)E, m2 = wave_sum(s2) / (float)E;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float4 o;
+                o.x = rs * (g[i].x - m1 - xh[i].x * m2);
+                o.y = rs * (g[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (g[i].z - m1 - xh[i].z * m2);
+                o.w = rs * (g[i].w - m1 - xh[i].w * m2);
+                float4* d = reinterpret_cast<float4*>(dx + r * lddx) + c;
+                if (add) {
+                    const float4 p = *d;
+                    o.x += p.x, o.y += p.y, o.z += p.z, o.w += p.w;
+                }
+                *d = o;
+            }
+        }
+    }
+    if (!dw && !db) return;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            reinterpret_cast<float4*>(red[0][wave])[c] = pw[i];
+            reinterpret_cast<float4*>(red[1][wave])[c] = pb[i];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) {
+        const float sw = (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]);
+        const float sb = (red[1][0][e] + red[1][1][e]) + (red[1][2][e] + red[1][3][e]);
+        if (dw) unsafeAtomicAdd(dw + e, sw);
+        if (db) unsafeAtomicAdd(db + e, sb);
+    }
+}
+
+// ---------------------------------------------------------------- GroupNorm(32) on NHWC
+// stats pass: one block per (image n, pixel chunk); accumulates per-group sum / sumsq with fp32 atomics
+// into stats[n][32][2].  C = 32*cpg channels, cpg in {1,4,8,16}.
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&f)[8]);
+template <>
+__device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&f)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    f[0] = bf_lo(u.x), f[1] = bf_hi(u.x), f[2] = bf_lo(u.y), f[3] = bf_hi(u.y);
+    f[4] = bf_lo(u.z), f[5] = bf_hi(u.z), f[6] = bf_lo(u.w), f[7] = bf_hi(u.w);
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&f)[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    f[0] = a.x, f[1] = a.y, f[2] = a.z, f[3] = a.w, f[4] = b.x, f[5] = b.y, f[6] = b.z, f[7] = b.w;
+}
+
+// Thread t handles channel chunk (t % (C/8)) for pixels t / (C/8) + k * (256 / (C/8)).  Requires C%8==0,
+// C/8 <= 256 and 256 % (C/8) == 0  (C in {32, 64, 128, 256, 512}).
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, long hw, int C,
+                                                              int pix_per_block, float* __restrict__ stats) {
+    __shared__ float sh[2][512];  // per-channel partials
+    const int n = blockIdx.y;
+    const int cchunks = C >> 3;
+    const int cc = threadIdx.x % cchunks, prow = threadIdx.x / cchunks, pstep = 256 / cchunks;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    long p1 = p0 + pix_per_block;
+    if (p1 > hw) p1 = hw;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    const T* base = x + ((long)n * hw) * C + cc * 8;
+    for (long p = p0 + prow; p < p1; p += pstep) {
+        float f[8];
+        load8<T>(base + p * C, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += f[e], q[e] += f[e] * f[e];
+    }
+    for (int i = threadIdx.x; i < 2 * 512; i += 256) (&sh[0][0])[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sh[0][cc * 8 + e], s[e]);
+        atomicAdd(&sh[1][cc * 8 + e], q[e]);
+    }
+    __syncthreads();
+    const int cpg = C / 32;
+    if (threadIdx.x < 64) {
+        const int grp = threadIdx.x & 31, which = threadIdx.x >> 5;
+        float a = 0.f;
+        for (int e = 0; e < cpg; ++e) a += sh[which][grp * cpg + e];
+        unsafeAtomicAdd(stats + ((long)n * 32 + grp) * 2 + which, a);
+    }
+}
+
+// apply: y = swish?( (x-mean)*rstd*w + b ) -> bf16 NHWC (and/or f32).  8 channels per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, long hw, int C,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ b, float eps, int swish,
+                                                              bf16_t* __restrict__ y_bf16,
+                                                              float* __restrict__ y_f32, long total_chunks) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total_chunks) return;
+    const int cchunks = C >> 3;
+    const int cc = (int)(t % cchunks);
+    const long pix = t / cchunks;  // n*hw + p
+    const int n = (int)(pix / hw);
+    const int cpg = C / 32;
+    const float cnt = (float)hw * (float)cpg;
+    float f[8];
+    load8<T>(x + pix * C + cc * 8, f);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = cc * 8 + e;
+        const int grp = ch / cpg;
+        const float sm = stats[((long)n * 32 + grp) * 2], sq = stats[((long)n * 32 + grp) * 2 + 1];
+        const float mu = sm / cnt;
+        float var = sq / cnt - mu * mu;
+        var = var < 0.f ? 0.f : var;
+        const float rs = rsqrtf(var + eps);
+        float v = (f[e] - mu) * rs * w[ch] + b[ch];
+        if (swish) v = v * sigmoidf_(v);
+        o[e] = v;
+    }
+    if (y_bf16)
+        *reinterpret_cast<uint4*>(y_bf16 + pix * C + cc * 8) =
+            make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+    if (y_f32) {
+        float4* d = reinterpret_cast<float4*>(y_f32 + pix * C + cc * 8);
+        d[0] = make_float4(o[0], o[1], o[2], o[3]);
+        d[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+}  // namespace
+
+extern "C" int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const float* w, const float* b,
+                                   float eps, void* y_bf16, float* y_f32, int64_t ldy, float* mean, float* rstd,
+                                   void* stream) {
+    MMVID_REQUIRE(x && w && b && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
+    MMVID_REQUIRE(E % 4 == 0 && E <= 64 * 4 * LN_MAXV && ldx % 4 == 0 && ldy % 4 == 0,
+                  "layernorm_fwd: E=%d must be a multiple of 4 and <= %d; row strides multiples of 4", E,
+                  64 * 4 * LN_MAXV);
+    if (rows == 0) return MMVID_OK;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                       (long)rows, E, w, b, eps, (bf16_t*)y_bf16, y_f32, (long)ldy, mean, rstd);
+    MMVID_LAUNCH_CHECK("layernorm_fwd");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                   const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
+                                   int add_into_dx, float* dw, float* db, void* stream) {
+    MMVID_REQUIRE(dy && x && mean && rstd && w && dx, "layernorm_bwd: null pointer");
+    MMVID_REQUIRE(E % 4 == 0 && E <= 64 * 4 * LN_MAXV && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0,
+                  "layernorm_bwd: bad E/strides");
+    if (rows == 0) return MMVID_OK;
+    int blocks = cdiv(rows, 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x,
+                       (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, dw, db);
+    MMVID_LAUNCH_CHECK("layernorm_bwd");
+    return MMVID_OK;
+}
+
+// x NHWC [N, hw, C] (bf16 when x_is_bf16 else f32); stats scratch [N,32,2] fp32 is zeroed here.
+extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, int C, const float* w,
+                                          const float* b, float eps, int swish, float* stats_scratch, void* y_bf16,
+                                          float* y_f32, void* stream) {
+    MMVID_REQUIRE(x && w && b && stats_scratch && (y_bf16 || y_f32), "groupnorm: null pointer");
+    MMVID_REQUIRE(C % 32 == 0 && C <= 512 && 256 % (C / 8) == 0, "groupnorm: C=%d unsupported", C);
+    if (N == 0 || hw == 0) return MMVID_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats_scratch, 0, sizeof(float) * 64 * (size_t)N, s) != hipSuccess) {
+        mmvid_set_error("groupnorm: memset failed");
+        return MMVID_ERR_HIP;
+    }
+    const int pix_per_block = 256;
+    dim3 g1(cdiv(hw, pix_per_block), N);
+    const long chunks = (long)N * hw * (C / 8);
+    if (x_is_bf16) {
+        hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)x, (long)hw, C,
+                           pix_per_block, stats_scratch);
+        hipLaunchKernelGGL(groupnorm_apply_kernel<bf16_t>, dim3(cdiv(chunks, 256)), dim3(256), 0, s,
+                           (const bf16_t*)x, (long)hw, C, stats_scratch, w, b, eps, swish, (bf16_t*)y_bf16, y_f32,
+                           chunks);
+    } else {
+        hipLaunchKernelGGL(groupnorm_stats_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (long)hw, C,
+                           pix_per_block, stats_scratch);
+        hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3(cdiv(chunks, 256)), dim3(256), 0, s, (const float*)x,
+                           (long)hw, C, stats_scratch, w, b, eps, swish, (bf16_t*)y_bf16, y_f32, chunks);
+    }
+    MMVID_LAUNCH_CHECK("groupnorm");
+    return MMVID_OK;
+}

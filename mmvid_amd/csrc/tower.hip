@@ -1,0 +1,219 @@
+// Native layer loop of the CLIP ViT-B/32-shaped tower (clip_model.py:580-584 -> 230-247 -> 224-227):
+//   x += out_proj(MHA(LN1 x)) ; x += c_proj(QuickGELU(c_fc(LN2 x)))
+// forward and hand-written backward, launching the kernels of gemm/norm/attn/embed/optim.hip on one
+// stream.  Activations needed by the backward live in a caller-allocated "saved" arena (per layer:
+// x_in f32, x_mid f32, LN stats, h1/h2/O bf16, qkv bf16, fc pre-activation + GELU output bf16, lse2);
+// transient buffers live in a "scratch" arena.  No allocation, no host sync: graph-capturable.
+#include "../../include/mmvid_hip.h"
+#include "common.h"
+
+namespace {
+
+inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct Dims {
+    int B, L, Lp, E, H, F, layers;
+    int64_t M;
+};
+Dims dims_of(const mmvid_tower_cfg_t& c) {
+    Dims d;
+    d.B = c.B, d.L = c.L, d.E = c.E, d.H = c.H, d.F = c.F, d.layers = c.layers;
+    d.Lp = (c.L + 63) / 64 * 64;
+    d.M = (int64_t)c.B * c.L;
+    return d;
+}
+
+struct SavedLayer {  // byte offsets inside one layer's slice of the saved arena
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1, qkv, o, lse2, h2, pre, act, total;
+};
+SavedLayer saved_layout(const Dims& d) {
+    SavedLayer s;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    s.x_in = take(d.M * d.E * 4);
+    s.x_mid = take(d.M * d.E * 4);
+    s.mean1 = take(d.M * 4), s.rstd1 = take(d.M * 4), s.mean2 = take(d.M * 4), s.rstd2 = take(d.M * 4);
+    s.h1 = take(d.M * d.E * 2);
+    s.qkv = take(d.M * 3 * d.E * 2);
+    s.o = take(d.M * d.E * 2);
+    s.lse2 = take((int64_t)d.B * d.H * d.L * 4);
+    s.h2 = take(d.M * d.E * 2);
+    s.pre = take(d.M * d.F * 2);
+    s.act = take(d.M * d.F * 2);
+    s.total = off;
+    return s;
+}
+
+struct Scratch {  // byte offsets inside the scratch arena
+    int64_t xt0, xt1, xt2, delta, dqkv, d_h, d_o, d_pre, g_bf16, infer, total;
+};
+Scratch scratch_layout(const Dims& d) {
+    Scratch s;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    const int64_t xt = (int64_t)d.B * d.H * 64 * d.Lp * 2;
+    s.xt0 = take(xt), s.xt1 = take(xt), s.xt2 = take(xt);
+    s.delta = take((int64_t)d.B * d.H * d.L * 4);
+    s.dqkv = take(d.M * 3 * d.E * 2);
+    s.d_h = take(d.M * d.E * 4);
+    s.d_o = take(d.M * d.E * 2);
+    s.d_pre = take(d.M * d.F * 2);
+    s.g_bf16 = take(d.M * d.E * 2);
+    s.infer = take(saved_layout(d).total);  // one layer's worth of activations for inference mode
+    s.total = off;
+    return s;
+}
+
+#define TRY(call)                   \
+    do {                            \
+        int rc__ = (call);          \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+int check_cfg(const mmvid_tower_cfg_t* c) {
+    MMVID_REQUIRE(c, "tower: null config");
+    MMVID_REQUIRE(c->B > 0 && c->L > 0 && c->layers > 0, "tower: bad B/L/layers");
+    MMVID_REQUIRE(c->E == c->H * 64 && c->E % 8 == 0 && c->F % 8 == 0 && c->E <= 1024,
+                  "tower: need E == 64*H <= 1024 and F %% 8 == 0 (E=%d H=%d F=%d)", c->E, c->H, c->F);
+    return 0;
+}
+
+int pick_splitk(int Mout, int Nout, int64_t K) {
+    const int tiles = cdiv(Mout, 128) * cdiv(Nout, 128);
+    int sk = 1024 / (tiles > 0 ? tiles : 1);
+    const int ktiles = cdiv(K, 64);
+    if (sk > ktiles / 4) sk = ktiles / 4;
+    if (sk > 32) sk = 32;
+    if (sk < 1) sk = 1;
+    return sk;
+}
+
+// Y = X W^T + b with epilogue options (A row-major [M,K], B row-major [N,K])
+int linear_fwd(int64_t M, int N, int K, const void* X, const void* W, const float* bias, const float* residual,
+               void* save_pre, int act, float* out_f32, void* out_bf16, void* st) {
+    return mmvid_gemm_bf16(0, 0, (int)M, N, K, X, K, W, K, 1, 0, 0, 0, 1, 1.0f, bias, residual, N, nullptr, save_pre, N,
+                           act, 0, out_f32, out_bf16, N, st);
+}
+// dX = dY W (A = dY [M,N] row-major, B = W [N(red)][K(out)] k-major)
+int linear_dx(int64_t M, int N, int K, const void* dY, const void* W, const void* dact_pre, float* out_f32,
+              void* out_bf16, void* st) {
+    return mmvid_gemm_bf16(0, 1, (int)M, K, N, dY, N, W, K, 1, 0, 0, 0, 1, 1.0f, nullptr, nullptr, 0, dact_pre, nullptr, K,
+                           0, 0, out_f32, out_bf16, K, st);
+}
+// dW[N,K] += dY^T X (both k-major over the token dimension), db[N] += colsum(dY)
+int linear_dw(int64_t M, int N, int K, const void* dY, const void* X, float* dW, float* db, void* st) {
+    const int sk = pick_splitk(N, K, M);
+    TRY(mmvid_gemm_bf16(1, 1, N, K, (int)M, dY, N, X, K, 1, 0, 0, 0, sk, 1.0f, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                        0, /*accumulate=*/1, dW, nullptr, K, st));
+    if (db) TRY(mmvid_colsum_bf16(dY, N, M, N, db, st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mmvid_tower_workspace(const mmvid_tower_cfg_t* cfg, int64_t* saved_bytes, int64_t* scratch_bytes) {
+    TRY(check_cfg(cfg));
+    const Dims d = dims_of(*cfg);
+    if (saved_bytes) *saved_bytes = saved_layout(d).total * d.layers;
+    if (scratch_bytes) *scratch_bytes = scratch_layout(d).total;
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_tower_forward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers,
+                                   const float* x_in, float* x_out, void* saved, void* scratch, void* stream) {
+    TRY(check_cfg(cfg));
+    MMVID_REQUIRE(layers && x_in && x_out && scratch, "tower_forward: null pointer");
+    const Dims d = dims_of(*cfg);
+    const SavedLayer sl = saved_layout(d);
+    const Scratch sc = scratch_layout(d);
+    char* scr = (char*)scratch;
+    const float scale = 0.125f;  // head_dim^-0.5, head_dim = 64
+    const float* x = x_in;
+    for (int i = 0; i < d.layers; ++i) {
+        const mmvid_tower_layer_t& ly = layers[i];
+        char* sv = saved ? (char*)saved + (int64_t)i * sl.total : scr + sc.infer;
+        float* xin_s = (float*)(sv + sl.x_in);
+        float* xmid = (float*)(sv + sl.x_mid);
+        // the layer's input must survive for the backward: copy it into the arena (first layer) or it already
+        // lives there (previous layer wrote its output into this layer's x_in slot).
+        if (saved && i == 0) {
+            if (hipMemcpyAsync(xin_s, x_in, d.M * d.E * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+                mmvid_set_error("tower_forward: memcpy failed");
+                return MMVID_ERR_HIP;
+            }
+            x = xin_s;
+        }
+        float* xnext;
+        if (i == d.layers - 1)
+            xnext = x_out;
+        else if (saved)
+            xnext = (float*)((char*)saved + (int64_t)(i + 1) * sl.total + sl.x_in);
+        else
+            xnext = x_out;  // inference: ping through x_out (x_mid holds the intermediate)
+        TRY(mmvid_layernorm_fwd(x, d.E, d.M, d.E, ly.ln1_w, ly.ln1_b, cfg->ln_eps, sv + sl.h1, nullptr, d.E,
+                                (float*)(sv + sl.mean1), (float*)(sv + sl.rstd1), stream));
+        TRY(linear_fwd(d.M, 3 * d.E, d.E, sv + sl.h1, ly.in_w, ly.in_b, nullptr, nullptr, 0, nullptr, sv + sl.qkv, stream));
+        TRY(mmvid_head_transpose(sv + sl.qkv, 3 * d.E, 2 * d.E, d.B, d.L, d.Lp, d.H, scr + sc.xt0, stream));
+        TRY(mmvid_attention_fwd(sv + sl.qkv, 3 * d.E, scr + sc.xt0, d.B, d.L, d.Lp, d.H, d.E, scale, cfg->mask_mode,
+                                cfg->r0, cfg->c0, cfg->r1, cfg->c1, sv + sl.o, d.E, (float*)(sv + sl.lse2), stream));
+        TRY(linear_fwd(d.M, d.E, d.E, sv + sl.o, ly.out_w, ly.out_b, x, nullptr, 0, xmid, nullptr, stream));
+        TRY(mmvid_layernorm_fwd(xmid, d.E, d.M, d.E, ly.ln2_w, ly.ln2_b, cfg->ln_eps, sv + sl.h2, nullptr, d.E,
+                                (float*)(sv + sl.mean2), (float*)(sv + sl.rstd2), stream));
+        TRY(linear_fwd(d.M, d.F, d.E, sv + sl.h2, ly.fc_w, ly.fc_b, nullptr, saved ? sv + sl.pre : nullptr, 1, nullptr,
+                       sv + sl.act, stream));
+        TRY(linear_fwd(d.M, d.E, d.F, sv + sl.act, ly.pj_w, ly.pj_b, xmid, nullptr, 0, xnext, nullptr, stream));
+        x = xnext;
+    }
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
+                                    const void* saved, void* scratch, void* stream) {
+    TRY(check_cfg(cfg));
+    MMVID_REQUIRE(layers && g && saved && scratch, "tower_backward: null pointer");
+    const Dims d = dims_of(*cfg);
+    const SavedLayer sl = saved_layout(d);
+    const Scratch sc = scratch_layout(d);
+    char* scr = (char*)scratch;
+    const float scale = 0.125f;
+    void* gb = scr + sc.g_bf16;
+    float* d_h = (float*)(scr + sc.d_h);
+    for (int i = d.layers - 1; i >= 0; --i) {
+        const mmvid_tower_layer_t& ly = layers[i];
+        const char* sv = (const char*)saved + (int64_t)i * sl.total;
+        // ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(LN2 x_mid)))
+        TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
+        TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, ly.g_pj_b, stream));
+        TRY(linear_dx(d.M, d.E, d.F, gb, ly.pj_w, sv + sl.pre, nullptr, scr + sc.d_pre, stream));
+        TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, ly.g_fc_b, stream));
+        TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, d_h, nullptr, stream));
+        TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
+                                (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, ly.g_ln2_w, ly.g_ln2_b,
+                                stream));
+        // ---- attention branch: x_mid = x_in + out_proj(MHA(LN1 x_in))
+        TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
+        TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, ly.g_out_b, stream));
+        TRY(linear_dx(d.M, d.E, d.E, gb, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
+        TRY(mmvid_head_transpose(sv + sl.qkv, 3 * d.E, 0, d.B, d.L, d.Lp, d.H, scr + sc.xt0, stream));        // Q^T
+        TRY(mmvid_head_transpose(sv + sl.qkv, 3 * d.E, d.E, d.B, d.L, d.Lp, d.H, scr + sc.xt1, stream));      // K^T
+        TRY(mmvid_head_transpose(scr + sc.d_o, d.E, 0, d.B, d.L, d.Lp, d.H, scr + sc.xt2, stream));           // dO^T
+        TRY(mmvid_attention_bwd(sv + sl.qkv, 3 * d.E, scr + sc.xt0, scr + sc.xt1, sv + sl.o, d.E, scr + sc.d_o, d.E,
+                                scr + sc.xt2, (const float*)(sv + sl.lse2), (float*)(scr + sc.delta), d.B, d.L, d.Lp,
+                                d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0, cfg->r1, cfg->c1, scr + sc.dqkv,
+                                3 * d.E, stream));
+        TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, ly.g_in_b, stream));
+        TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, d_h, nullptr, stream));
+        TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
+                                (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, ly.g_ln1_w, ly.g_ln1_b,
+                                stream));
+    }
+    return MMVID_OK;
+}

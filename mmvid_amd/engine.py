@@ -1,0 +1,161 @@
+"""Training engine for the data-parallel hot path (train.py:28-35, 298-325 of the reference: DDP + clip_grad_norm_
++ Adam), MI355X-first:
+
+  * every trainable parameter, its gradient and its Adam moments are slices of FLAT fp32 buffers (plus one flat
+    bf16 shadow the MFMA kernels read), so the optimiser is one HIP launch over 125 M elements and the gradient
+    exchange is a handful of large RCCL collectives instead of hundreds of per-tensor ones;
+  * gradients are all-reduced (SUM; the 1/world factor is folded into the Adam kernel) in buckets on a side
+    stream.  Buckets follow the order in which the hand-written backward FINISHES gradients -- heads and tower
+    layers first, embedding tables last -- so the exchange of the big early buckets overlaps the rest of the
+    backward.  xGMI is point-to-point: few, large messages keep every link busy.
+
+One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+ALIGN = 128  # elements: keeps every slice 16-B aligned for the vector kernels (fp32 and bf16)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class FlatTrainer:
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
+                 process_group=None, bucket_mb=64, order=None):
+        self.model = model
+        params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if order is not None:
+            params = order(params)
+        self.names = [n for n, _ in params]
+        self.params = [p for _, p in params]
+        dev = self.params[0].device
+        offs, tot = [], 0
+        for p in self.params:
+            offs.append(tot)
+            tot += _round_up(p.numel(), ALIGN)
+        self.offsets, self.numel = offs, tot
+        self.P = torch.zeros(tot, device=dev, dtype=torch.float32)
+        self.G = torch.zeros(tot, device=dev, dtype=torch.float32)
+        self.M = torch.zeros(tot, device=dev, dtype=torch.float32)
+        self.V = torch.zeros(tot, device=dev, dtype=torch.float32)
+        self.S = torch.zeros(tot, device=dev, dtype=torch.bfloat16) if dev.type == 'cuda' else None
+        for p, o in zip(self.params, offs):
+            n = p.numel()
+            self.P[o:o + n].copy_(p.detach().reshape(-1))
+            p.data = self.P[o:o + n].view(p.shape)
+            p.grad = self.G[o:o + n].view(p.shape)
+        if self.S is not None:
+            ops.cast_bf16(self.P, self.S)
+            self._attach_shadows()
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.step_count = 0
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.bucket_elems = max(ALIGN, int(bucket_mb * (1 << 20) / 4) // ALIGN * ALIGN)
+        self._sq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        self._works = []
+        self._sent_from = tot  # gradients at flat offsets >= this are already on the wire this step
+        # first flat offset of each tower layer (the flat order puts layers ascending, heads after, tables before)
+        self._layer_start = {}
+        for n, o in zip(self.names, offs):
+            if n.startswith('transformer.transformer.resblocks.'):
+                i = int(n.split('.')[3])
+                self._layer_start[i] = min(o, self._layer_start.get(i, tot))
+        tw = getattr(model, 'transformer', None)
+        if tw is not None and hasattr(tw, 'on_layers_done') and self._layer_start:
+            tw.on_layers_done = self.layers_done
+
+    def _shadow_view(self, p):
+        i = next(k for k, q in enumerate(self.params) if q is p)
+        o = self.offsets[i]
+        return self.S[o:o + p.numel()].view(p.shape)
+
+    def _attach_shadows(self):
+        m = self.model
+        tw = getattr(m, 'transformer', None)
+        if tw is not None and hasattr(tw, 'attach_shadow') and all(p.requires_grad for p in tw._matrix_params()):
+            tw.attach_shadow([self._shadow_view(p) for p in tw._matrix_params()])
+        if hasattr(m, 'attach_head_shadow') and m.to_logits[1].weight.requires_grad:
+            m.attach_head_shadow(m.to_logits[1], self._shadow_view(m.to_logits[1].weight))
+
+    # ---------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        self.G.zero_()
+
+    def _send(self, lo, hi):
+        """All-reduce G[lo:hi] (SUM) on the side stream, in messages of at most bucket_elems."""
+        if self.world == 1 or hi <= lo:
+            return
+        if self._comm_stream is not None:
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+        for s in range(lo, hi, self.bucket_elems):
+            e = min(s + self.bucket_elems, hi)
+            if self._comm_stream is not None:
+                with torch.cuda.stream(self._comm_stream):
+                    self._works.append(dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            else:
+                self._works.append(dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def layers_done(self, first_layer):
+        """Tower backward callback: gradients of layers >= first_layer (and everything after them in the flat
+        buffer: later layers, heads) are final -> put them on the wire while the backward continues."""
+        lo = self._layer_start.get(first_layer)
+        if lo is None or lo >= self._sent_from:
+            return
+        self._send(lo, self._sent_from)
+        self._sent_from = lo
+
+    def allreduce_grads(self):
+        """Send whatever is still local (embedding tables, or everything when no callback fired) and wait."""
+        if self.world > 1:
+            self._send(0, self._sent_from)
+            for w in self._works:
+                w.wait()
+            self._works = []
+            if self._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._sent_from = self.numel
+
+    def step(self):
+        """clip_grad_norm_(max_norm) + Adam (train.py:324-325) on the averaged gradients."""
+        self.allreduce_grads()
+        self.step_count += 1
+        gscale = 1.0 / self.world
+        # the update itself is the HIP kernel; on a host tensor ops.adam_step raises (there is no CPU path)
+        self._sq.zero_()
+        ops.grad_sqnorm(self.G, self._sq)
+        ops.adam_step(self.P, self.G, self.M, self.V, self.S, self.step_count, self.lr, self.betas, self.eps, self.wd,
+                      self.max_norm, self._sq, gscale)
+        tw = getattr(self.model, 'transformer', None)
+        if tw is not None and hasattr(tw, 'mark_shadow_fresh'):
+            tw.mark_shadow_fresh()
+
+    def grad_norm(self):
+        return float(self.G.norm()) / self.world
+
+
+def backward_order(params):
+    """Flat-buffer order = REVERSE of the order gradients become final in the backward, so that reversed buckets
+    (heads + last layers first) can be sent while earlier layers are still being differentiated."""
+    def key(item):
+        n = item[0]
+        if n.startswith('transformer.transformer.resblocks.'):
+            return (1, int(n.split('.')[3]))
+        if n.startswith('to_logits'):
+            return (2, 0)
+        return (0, 0)  # embeddings / positional tables: final only when the whole backward is done
+
+    return sorted(params, key=key)
+
+
+def broadcast_parameters(model, src=0, group=None):
+    """DDP construction broadcast (train.py:32): parameters and buffers from rank 0."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

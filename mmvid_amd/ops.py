@@ -1,0 +1,298 @@
+"""Tensor-level wrappers over the C-ABI (mmvid_amd/_lib.py).  PyTorch here is plumbing only: it owns the
+device memory and the stream; every computation below runs in the hand-written HIP kernels.
+
+All tensors must live on a HIP device and be contiguous (strided views are passed through explicit ld
+arguments where a kernel supports them)."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call
+
+bf16, f32, i64 = torch.bfloat16, torch.float32, torch.int64
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.MMVIDError(f'{name}: tensor is on {t.device}; the MMVID kernels run on an MI355X only (no CPU path)')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: tensor must be contiguous')
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ VQ
+def vq_sqnorm(codebook):
+    _chk(codebook, f32, 'codebook')
+    ee = torch.empty(codebook.shape[0], device=codebook.device, dtype=f32)
+    call('mmvid_vq_sqnorm', _p(codebook), codebook.shape[0], codebook.shape[1], _p(ee), _stream())
+    return ee
+
+
+def vq_argmin(z, codebook, ee=None, return_dmin=False):
+    """z [rows, 256] f32, codebook [n, 256] f32 -> idx int64 [rows] (first argmin of the reference expression)."""
+    _chk(z, f32, 'z'), _chk(codebook, f32, 'codebook')
+    if ee is None:
+        ee = vq_sqnorm(codebook)
+    rows = z.shape[0]
+    idx = torch.empty(rows, device=z.device, dtype=i64)
+    dmin = torch.empty(rows, device=z.device, dtype=f32) if return_dmin else None
+    call('mmvid_vq_argmin_l2', _p(z), _p(codebook), _p(ee), rows, codebook.shape[0], codebook.shape[1], _p(idx),
+         _p(dmin), _stream())
+    return (idx, dmin) if return_dmin else idx
+
+
+def gather_rows(table, idx, out_dtype=f32):
+    _chk(table, f32, 'table'), _chk(idx, i64, 'idx')
+    rows, dim = idx.numel(), table.shape[1]
+    out = torch.empty(*idx.shape, dim, device=table.device, dtype=out_dtype)
+    call('mmvid_gather_rows', _p(table), table.shape[0], _p(idx), rows, dim, _p(out) if out_dtype == f32 else None,
+         _p(out) if out_dtype == bf16 else None, _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, residual=None, dact_pre=None, save_pre=None, act=0,
+         out_dtype=bf16, out=None, accumulate=False, splitk=1, alpha=1.0):
+    """C[m,n] = sum_k A(m,k) B(n,k).  A: [M,K] (or [K,M] when a_kmajor), B: [N,K] (or [K,N] when b_kmajor), 2-D
+    bf16; or 3-D batched with identical leading batch size."""
+    _chk(A, bf16, 'A'), _chk(B, bf16, 'B')
+    batch = 1
+    sA = sB = 0
+    if A.dim() == 3:
+        batch = A.shape[0]
+        sA, sB = A.stride(0), B.stride(0)
+        A2, B2 = A[0], B[0]
+    else:
+        A2, B2 = A, B
+    K, M = (A2.shape if a_kmajor else A2.shape[::-1])
+    Kb, N = (B2.shape if b_kmajor else B2.shape[::-1])
+    assert K == Kb, (A.shape, B.shape)
+    if out is None:
+        shape = (batch, M, N) if A.dim() == 3 else (M, N)
+        out = torch.empty(shape, device=A.device, dtype=out_dtype)
+    sC = M * N if batch > 1 else 0
+    is32 = out.dtype == f32
+    for t, n in ((bias, 'bias'), (residual, 'residual')):
+        if t is not None:
+            _chk(t, f32, n)
+    call('mmvid_gemm_bf16', int(a_kmajor), int(b_kmajor), M, N, K, _p(A), A2.stride(0), _p(B), B2.stride(0), batch,
+         sA, sB, sC, splitk, float(alpha), _p(bias), _p(residual), N, _p(dact_pre), _p(save_pre), N, act,
+         int(accumulate), _p(out) if is32 else None, None if is32 else _p(out), N, _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- norms
+def layernorm_fwd(x, w, b, eps=1e-5, out_dtype=bf16, save_stats=True):
+    _chk(x, f32, 'x')
+    rows, E = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    mean = torch.empty(rows, device=x.device, dtype=f32) if save_stats else None
+    rstd = torch.empty(rows, device=x.device, dtype=f32) if save_stats else None
+    call('mmvid_layernorm_fwd', _p(x), E, rows, E, _p(w), _p(b), float(eps), _p(y) if out_dtype == bf16 else None,
+         _p(y) if out_dtype == f32 else None, E, _p(mean), _p(rstd), _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, w, dx=None, add=False, dw=None, db=None):
+    _chk(dy, f32, 'dy'), _chk(x, f32, 'x')
+    rows, E = x.numel() // x.shape[-1], x.shape[-1]
+    if dx is None:
+        dx = torch.empty_like(x)
+        add = False
+    call('mmvid_layernorm_bwd', _p(dy), E, _p(x), E, _p(mean), _p(rstd), _p(w), rows, E, _p(dx), E, int(add), _p(dw),
+         _p(db), _stream())
+    return dx
+
+
+def groupnorm_swish(x, w, b, eps=1e-6, swish=True, out_dtype=bf16):
+    """x NHWC [N,H,W,C] bf16 or f32 -> same shape."""
+    N, H, W, C = x.shape
+    assert x.is_contiguous() and x.dtype in (bf16, f32)
+    stats = torch.empty(N * 64, device=x.device, dtype=f32)
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    call('mmvid_groupnorm_swish_nhwc', _p(x), int(x.dtype == bf16), N, H * W, C, _p(w), _p(b), float(eps), int(swish),
+         _p(stats), _p(y) if out_dtype == bf16 else None, _p(y) if out_dtype == f32 else None, _stream())
+    return y
+
+
+# ------------------------------------------------------------------------------------------ attention
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def head_transpose(src, col0, B, L, H):
+    """src token-major [B*L, ld] bf16 -> [B, H, 64, Lp] bf16 (zero padded)."""
+    _chk(src, bf16, 'src')
+    Lp = round_up(L, 64)
+    dst = torch.empty(B, H, 64, Lp, device=src.device, dtype=bf16)
+    call('mmvid_head_transpose', _p(src), src.shape[-1], col0, B, L, Lp, H, _p(dst), _stream())
+    return dst
+
+
+def _mask_args(mask):
+    """mask: None | 'causal' | ('rows', [(row, first_allowed_col), ...])."""
+    if mask is None:
+        return 0, -1, 0, -1, 0
+    if mask == 'causal':
+        return 1, -1, 0, -1, 0
+    kind, rows = mask
+    assert kind == 'rows' and len(rows) <= 2
+    rows = list(rows) + [(-1, 0)] * (2 - len(rows))
+    return 2, rows[0][0], rows[0][1], rows[1][0], rows[1][1]
+
+
+def attention_fwd(qkv, B, L, H, mask=None, scale=0.125):
+    """qkv [B*L, 3E] bf16 -> (out [B*L, E] bf16, lse2 [B,H,L] f32)."""
+    _chk(qkv, bf16, 'qkv')
+    E = H * 64
+    VT = head_transpose(qkv, 2 * E, B, L, H)
+    out = torch.empty(B * L, E, device=qkv.device, dtype=bf16)
+    lse2 = torch.empty(B, H, L, device=qkv.device, dtype=f32)
+    call('mmvid_attention_fwd', _p(qkv), 3 * E, _p(VT), B, L, VT.shape[-1], H, E, float(scale), *_mask_args(mask),
+         _p(out), E, _p(lse2), _stream())
+    return out, lse2
+
+
+def attention_bwd(qkv, out, dout, lse2, B, L, H, mask=None, scale=0.125):
+    """-> dqkv [B*L, 3E] bf16."""
+    E = H * 64
+    QT = head_transpose(qkv, 0, B, L, H)
+    KT = head_transpose(qkv, E, B, L, H)
+    dOT = head_transpose(dout, 0, B, L, H)
+    delta = torch.empty(B, H, L, device=qkv.device, dtype=f32)
+    dqkv = torch.empty_like(qkv)
+    call('mmvid_attention_bwd', _p(qkv), 3 * E, _p(QT), _p(KT), _p(out), E, _p(dout), E, _p(dOT), _p(lse2), _p(delta),
+         B, L, QT.shape[-1], H, E, float(scale), *_mask_args(mask), _p(dqkv), 3 * E, _stream())
+    return dqkv
+
+
+# --------------------------------------------------------------------------------- sequence / losses
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else 0 for t in tensors])
+    return ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p)), arr
+
+
+def assemble_sequence(tables, ids, seg, pos):
+    """x[b,l,:] = tables[seg[l]][ids[b,l]] + pos[l].  tables: list of [V_i, E] f32; ids [B,L] i64; seg [L] i32."""
+    B, L = ids.shape
+    E = pos.shape[-1]
+    for t in tables:
+        _chk(t, f32, 'table')
+    _chk(ids, i64, 'ids'), _chk(pos, f32, 'pos')
+    assert seg.dtype == torch.int32 and seg.is_cuda
+    out = torch.empty(B, L, E, device=ids.device, dtype=f32)
+    tp, keep = _ptr_array(tables)
+    rows = (ctypes.c_int64 * len(tables))(*[t.shape[0] for t in tables])
+    call('mmvid_assemble_sequence', tp, rows, len(tables), _p(ids), _p(seg), _p(pos), B, L, E, _p(out), _stream())
+    return out
+
+
+def assemble_sequence_bwd(grad_tables, table_rows, ids, seg, dx, dpos=None, accumulate_dpos=False):
+    B, L = ids.shape
+    E = dx.shape[-1]
+    _chk(dx, f32, 'dx')
+    tp, keep = _ptr_array(grad_tables)
+    rows = (ctypes.c_int64 * len(grad_tables))(*table_rows)
+    call('mmvid_assemble_sequence_bwd', tp, rows, len(grad_tables), _p(ids), _p(seg), _p(dx), B, L, E, _p(dpos),
+         int(accumulate_dpos), _stream())
+
+
+def cross_entropy_fwd(logits, target, select):
+    """Returns (lse [rows], loss_sum [1]) over rows with select != 0 (select uint8 or None)."""
+    _chk(logits, f32, 'logits'), _chk(target, i64, 'target')
+    rows, V = logits.shape
+    lse = torch.empty(rows, device=logits.device, dtype=f32)
+    loss = torch.zeros(1, device=logits.device, dtype=f32)
+    call('mmvid_cross_entropy_fwd', _p(logits), V, _p(target), _p(select), rows, V, _p(lse), _p(loss), _stream())
+    return lse, loss
+
+
+def cross_entropy_bwd(logits, target, select, lse, gscale):
+    rows, V = logits.shape
+    d = torch.empty(rows, V, device=logits.device, dtype=bf16)
+    call('mmvid_cross_entropy_bwd', _p(logits), V, _p(target), _p(select), _p(lse), _p(gscale), rows, V, _p(d), V,
+         _stream())
+    return d
+
+
+def colsum_bf16(dy, db):
+    M, N = dy.shape
+    call('mmvid_colsum_bf16', _p(dy), N, M, N, _p(db), _stream())
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def grad_sqnorm(g, out):
+    _chk(g, f32, 'g'), _chk(out, f32, 'out')
+    call('mmvid_grad_sqnorm', _p(g), g.numel(), _p(out), _stream())
+
+
+def adam_step(p, g, m, v, shadow, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0,
+              sqnorm=None, grad_scale=1.0):
+    for t, n in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
+        _chk(t, f32, n)
+    call('mmvid_adam_step', _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(betas[0]),
+         float(betas[1]), float(eps), float(weight_decay), int(step), float(max_norm), _p(sqnorm), float(grad_scale),
+         _stream())
+
+
+def cast_bf16(x, out=None):
+    _chk(x, f32, 'x')
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=bf16)
+    call('mmvid_cast_f32_to_bf16', _p(x), _p(out), x.numel(), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- VQGAN
+def conv2d_nhwc(x, w, bias, mode, residual=None, clamp01=False, out_dtype=bf16):
+    """x [N,H,W,Cin] bf16; w [Cout,taps,Cin] bf16 (taps 9 or 1); mode 0 3x3 | 1 down | 2 up | 3 1x1."""
+    _chk(x, bf16, 'x'), _chk(w, bf16, 'w')
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (H // 2, W // 2) if mode == 1 else ((2 * H, 2 * W) if mode == 2 else (H, W))
+    out = torch.empty(N, Ho, Wo, Cout, device=x.device, dtype=out_dtype)
+    rb = residual if (residual is not None and residual.dtype == bf16) else None
+    rf = residual if (residual is not None and residual.dtype == f32) else None
+    call('mmvid_conv2d_nhwc', mode, _p(x), N, H, W, Cin, _p(w), _p(bias), Cout, _p(rb), _p(rf), int(clamp01),
+         _p(out) if out_dtype == bf16 else None, _p(out) if out_dtype == f32 else None, _stream())
+    return out
+
+
+def image_to_nhwc8(img):
+    _chk(img, f32, 'img')
+    N, C, H, W = img.shape
+    assert C == 3
+    out = torch.empty(N, H, W, 8, device=img.device, dtype=bf16)
+    call('mmvid_image_to_nhwc8', _p(img), N, H, W, _p(out), _stream())
+    return out
+
+
+def nhwc_to_nchw(x, c_use=None):
+    _chk(x, f32, 'x')
+    N, H, W, C = x.shape
+    c_use = c_use or C
+    out = torch.empty(N, c_use, H, W, device=x.device, dtype=f32)
+    call('mmvid_nhwc_to_nchw_f32', _p(x), N, H, W, C, c_use, _p(out), _stream())
+    return out
+
+
+def spatial_attention(q, k, v):
+    """q,k,v [N,HW,C] bf16 -> softmax(q k^T C^-0.5) v, bf16."""
+    N, HW, C = q.shape
+    scratch = torch.empty(N * HW * HW * 3 // 2 + 16, device=q.device, dtype=f32)
+    out = torch.empty_like(q)
+    call('mmvid_spatial_attention', _p(q), _p(k), _p(v), N, HW, C, float(C)**-0.5, _p(scratch), _p(out), _stream())
+    return out

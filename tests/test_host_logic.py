@@ -1,0 +1,143 @@
+"""CPU-side checks of the product package: checkpoint layout (state_dict keys/shapes) against the manifests
+captured from the reference, mask predicates, C-ABI library exports, and that nothing silently falls back to
+the CPU.  No kernel runs here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def tiny_vae():
+    from mmvid_amd.vae import VQGanVAE1024
+    v = VQGanVAE1024(None, 64, ddconfig={'ch': 32}, n_embed=256)
+    v.image_size, v.num_tokens = 64, 256
+    return v
+
+
+def tiny_bert(num_visuals=0, use_cvae=False, **kw):
+    from mmvid_amd.dalle_bert import BERT
+    return BERT(dim=768, vae=tiny_vae(), cvae=tiny_vae() if use_cvae else None, num_text_tokens=49408, text_seq_len=16,
+                which_transformer='openai_clip_visual', num_visuals=num_visuals, num_targets=2, transformer_layers=2, **kw)
+
+
+def manifest(m):
+    return [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+
+
+@pytest.mark.parametrize('name,tiny', [('vqgan_tiny', True), ('vqgan_full', False)])
+def test_vae_state_dict_layout_matches_reference(golden, name, tiny):
+    from mmvid_amd.vae import VQGanVAE1024
+    v = tiny_vae() if tiny else VQGanVAE1024(None, 128)
+    assert manifest(v) == golden(name).manifest
+
+
+def test_tower_state_dict_layout_matches_reference(golden):
+    from mmvid_amd.clip_tower import OpenAICLIPTransformer
+    t = OpenAICLIPTransformer(51, 'openai_clip_visual', causal=True, mask_type='mask_prev', mask_kwargs={'index': [17, 18]}, layers=2)
+    assert manifest(t) == golden('tower').manifest
+    assert t.mask_spec == ('rows', [(17, 17), (18, 18)])
+    from oracle.tower import build_attention_mask
+    assert torch.equal(t.dense_attention_mask(), build_attention_mask(51, 'mask_prev', [17, 18]))
+    c = OpenAICLIPTransformer(40, 'openai_clip_visual', layers=2)
+    assert c.mask_spec == 'causal' and torch.equal(c.dense_attention_mask(), build_attention_mask(40, 'causal'))
+
+
+@pytest.mark.parametrize('name,nv,cvae', [('bert_tiny', 0, False), ('bert_tiny_visual', 1, True)])
+def test_bert_state_dict_layout_and_indices(golden, name, nv, cvae):
+    m = tiny_bert(nv, cvae)
+    assert manifest(m) == golden(name).manifest
+    assert m.total_seq_len == 1 + 16 + nv * 16 + 2 + 32
+    assert m.st1_tok_index == 17 + nv * 16 and m.vid_tok_index == 18 + nv * 16
+    assert m.image_token_lut == {'[MASK]': 256, '[SEP]': 257}
+    assert m.transformer.mask_spec == ('rows', [(m.st1_tok_index, m.st1_tok_index), (m.vid_tok_index, m.vid_tok_index)])
+    assert all(not p.requires_grad for p in m.vae.parameters())
+    seg = m._seg.tolist()
+    assert seg[0] == 0 and seg[1:17] == [1] * 16 and seg[-32:] == [3] * 32 and len(seg) == m.total_seq_len
+
+
+def test_bert_full_config_sizes():
+    """Config 2 of BASELINE.json: L = 579, 124.7 M trainable parameters."""
+    from mmvid_amd.dalle_bert import BERT
+    from mmvid_amd.vae import VQGanVAE1024
+    with torch.device('meta'):
+        vae = VQGanVAE1024(None, 128)
+        vae.image_size = 128
+        m = BERT(dim=768, vae=vae, num_text_tokens=49408, text_seq_len=64, which_transformer='openai_clip_visual',
+                 num_visuals=0, num_targets=8)
+    assert m.total_seq_len == 579 and (m.st1_tok_index, m.vid_tok_index) == (65, 66)
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 124705794
+    assert sum(p.numel() for p in vae.parameters()) == 68201859
+
+
+def test_artv_state_dict_layout(golden):
+    from mmvid_amd.dalle_artv import DALLE
+    m = DALLE(dim=768, vae=tiny_vae(), cvae=None, num_text_tokens=49408, text_seq_len=16,
+              which_transformer='openai_clip_visual', num_visuals=1, num_targets=2, transformer_layers=2)
+    assert manifest(m) == golden('artv_tiny').manifest
+    assert m.total_tokens == 49952 and m.total_seq_len == 64
+    from oracle.artv import Cfg
+    sd = {k: torch.empty(s) for k, s in golden('artv_tiny').manifest if 'emb.weight' in k or 'quantize' in k}
+    assert torch.equal(m.logits_mask, Cfg(sd, 16, 1, 2, 64).logits_mask)
+    assert m._allowed_range(0) == (0, 49424) and m._allowed_range(16) == (49424, 49424 + 272) and m._allowed_range(32)[1] == 49952
+
+
+def test_random_erasing_box_statistics():
+    from mmvid_amd.random_erasing import RandomErasing
+    torch.manual_seed(0)
+    er = RandomErasing(p=1, scale=(0.2, 0.8), ratio=(0.5, 2), value=0)
+    fr = []
+    for _ in range(200):
+        m = er(torch.ones(8, 1, 8, 8))
+        assert (m[0] == m[3]).all()  # same box on every frame
+        z = (m[0, 0] == 0)
+        if z.any():
+            rows, cols = z.any(1).nonzero(), z.any(0).nonzero()
+            assert z.sum() == (rows.max() - rows.min() + 1) * (cols.max() - cols.min() + 1)  # a rectangle
+        fr.append(z.float().mean().item())
+    assert 0.15 < np.mean(fr) < 0.7
+
+
+def test_msm_mask_strategies_cpu():
+    m = tiny_bert()
+    np.random.seed(0), torch.manual_seed(0)
+    mask, nfm = m._msm_mask(64, torch.device('cpu'), [0.7, 0.1, 0.1, 0.1], [0.2, 0.5], 0)
+    assert mask.shape == (64, 32) and mask.dtype == torch.bool
+    assert ((nfm == 0) == (~mask).all(1)).all() or (nfm == 0).sum() <= (~mask).all(1).sum()
+
+
+def test_library_exports_every_declared_symbol():
+    from mmvid_amd import _lib
+    from mmvid_amd.build import build
+    build()
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, 'include', 'mmvid_hip.h')).read()
+    declared = set(re.findall(r'\b(mmvid_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'mmvid_tower_layer_t', 'mmvid_tower_cfg_t'}
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/mmvid_hip.h but not exported'
+    assert set(_lib.SIGNATURES) | set(_lib.OTHER) == declared
+    assert lib.mmvid_abi_version() == 1
+    assert ctypes.sizeof(_lib.TowerLayer) == 24 * 8 and ctypes.sizeof(_lib.TowerCfg) == 12 * 4
+
+
+def test_no_cpu_fallback():
+    """Host tensors must be refused loudly: the kernels are the only implementation."""
+    from mmvid_amd import ops
+    from mmvid_amd._lib import MMVIDError
+    with pytest.raises(MMVIDError):
+        ops.vq_argmin(torch.zeros(4, 256), torch.zeros(32, 256))
+    with pytest.raises(MMVIDError):
+        ops.layernorm_fwd(torch.zeros(4, 768), torch.ones(768), torch.zeros(768))
+    m = tiny_bert()
+    with pytest.raises(MMVIDError):
+        m(torch.ones(2, 16, dtype=torch.long), return_loss=False)
+    # the product package never imports the oracle
+    import subprocess
+    out = subprocess.run(['grep', '-rlE', r'^\s*(from|import)\s+oracle', os.path.join(ROOT, 'mmvid_amd')], capture_output=True, text=True)
+    assert out.stdout.strip() == ''

@@ -1,0 +1,334 @@
+"""Per-kernel parity of the HIP path (through the C-ABI) on a real MI355X.
+
+Bars: integer / index outputs bit-exact against the oracle; bf16-MFMA kernels within a relative
+max-error of 2e-2 (bf16 operands, fp32 accumulate; stated per test) of an fp32 evaluation of the same
+op on the same bf16-rounded inputs; fp32-in/fp32-out kernels within 1e-5..1e-4."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from mmvid_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device='cpu').manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def close(a, b, tol, what=''):
+    e = relerr(a.float().cpu(), b.float().cpu())
+    print(f'{what}: relerr {e:.3e} (tol {tol})')
+    assert e <= tol, f'{what}: relerr {e} > {tol}'
+
+
+# ------------------------------------------------------------------------------------------------ VQ
+@pytest.mark.parametrize('tag,n', [('sep', 1024), ('stress', 1024), ('small', 256)])
+def test_vq_argmin_bit_exact_vs_oracle(ops, golden, tag, n):
+    from oracle.synth import synth_input, synth_tensor
+    from oracle.vq import vq_argmin
+    cb = (synth_input('cb_' + tag, (n, 256), 7, 'uniform') * 2 - 1) / n if tag == 'stress' else \
+        synth_tensor('quantize.embedding.weight', (n, 256), 7)
+    z = synth_input('z_' + tag, (512, 256), 7)
+    idx_o, dmin_o = vq_argmin(z, cb)
+    idx, dmin = ops.vq_argmin(z.to(DEV), cb.to(DEV), return_dmin=True)
+    assert torch.equal(idx.cpu(), idx_o)
+    assert torch.equal(dmin.cpu(), dmin_o)  # bit-exact distances, not just indices
+    if tag != 'stress':
+        assert torch.equal(idx.cpu(), golden('vq')[tag + '_idx'])  # and the reference itself
+
+
+def test_vq_argmin_ragged_rows_and_ties(ops):
+    from oracle.vq import vq_argmin
+    g = torch.Generator().manual_seed(3)
+    for rows in (1, 31, 33, 4097):
+        z = torch.randn(rows, 256, generator=g)
+        cb = torch.randn(1024, 256, generator=g) * 0.5
+        cb[700] = cb[5]  # exact duplicate rows: first index must win
+        cb[900] = cb[5]
+        idx_o, dmin_o = vq_argmin(z, cb)
+        idx, dmin = ops.vq_argmin(z.to(DEV), cb.to(DEV), return_dmin=True)
+        assert torch.equal(idx.cpu(), idx_o) and torch.equal(dmin.cpu(), dmin_o)
+    z = cb[[5, 700, 900, 17]].clone()  # rows equal to a codebook entry
+    assert ops.vq_argmin(z.to(DEV), cb.to(DEV)).cpu().tolist() == [5, 5, 5, 17]
+    assert ops.vq_argmin(torch.empty(0, 256, device=DEV), cb.to(DEV)).numel() == 0
+
+
+def test_gather_rows(ops):
+    t = rnd(1024, 256)
+    idx = torch.randint(0, 1024, (7, 64), device=DEV)
+    assert torch.equal(ops.gather_rows(t, idx), t[idx])
+    assert torch.equal(ops.gather_rows(t, idx, torch.bfloat16), t[idx].bfloat16())
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def _ref_mm(A, B, a_km, b_km):
+    A32, B32 = A.float(), B.float()
+    if a_km:
+        A32 = A32.transpose(-1, -2)
+    if not b_km:
+        B32 = B32.transpose(-1, -2)
+    return A32 @ B32
+
+
+@pytest.mark.parametrize('a_km,b_km', [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (300, 136, 200), (1000, 768, 768), (579, 2304, 768)])
+def test_gemm_layouts(ops, a_km, b_km, M, N, K):
+    if a_km and M % 8:
+        M = M // 8 * 8 + 8
+    if (a_km or b_km) and K % 8:
+        pass
+    A = rnd(*((K, M) if a_km else (M, K)), seed=1, dtype=torch.bfloat16)
+    B = rnd(*((K, N) if b_km else (N, K)), seed=2, dtype=torch.bfloat16)
+    ref = _ref_mm(A, B, a_km, b_km)
+    out = ops.gemm(A, B, a_kmajor=a_km, b_kmajor=b_km, out_dtype=torch.float32)
+    close(out, ref, 1e-5 * math.sqrt(K) + 1e-4, f'gemm f32 {a_km}{b_km} {M}x{N}x{K}')
+    out16 = ops.gemm(A, B, a_kmajor=a_km, b_kmajor=b_km)
+    close(out16, ref, 1e-2, 'gemm bf16 out')
+
+
+def test_gemm_k_reduction_not_multiple_of_tile_and_splitk(ops):
+    # dW-shaped: reduce over 10422 tokens (not a multiple of 64), split-K with atomics into an existing buffer
+    M, N, K = 776, 264, 1043
+    A = rnd(K, M, seed=3, dtype=torch.bfloat16)
+    B = rnd(K, N, seed=4, dtype=torch.bfloat16)
+    base = rnd(M, N, seed=5)
+    ref = base + _ref_mm(A, B, True, True)
+    for sk in (1, 3, 8):
+        out = base.clone()
+        ops.gemm(A, B, a_kmajor=True, b_kmajor=True, out=out, accumulate=True, splitk=sk)
+        close(out, ref, 2e-4, f'splitk={sk}')
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 333, 3072, 768
+    A, W = rnd(M, K, seed=6, dtype=torch.bfloat16), rnd(N, K, seed=7, scale=0.05, dtype=torch.bfloat16)
+    bias, res = rnd(N, seed=8), rnd(M, N, seed=9)
+    pre = A.float() @ W.float().t() + bias
+    # forward c_fc: save pre-activation, QuickGELU
+    save = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    out = ops.gemm(A, W, bias=bias, act=1, save_pre=save)
+    close(save, pre, 1e-2, 'save_pre')
+    close(out, pre * torch.sigmoid(1.702 * pre), 1e-2, 'quickgelu')
+    # residual + fp32 out
+    out = ops.gemm(A, W, bias=bias, residual=res, out_dtype=torch.float32)
+    close(out, pre + res, 1e-4, 'bias+residual f32')
+    # backward through QuickGELU: dX-shaped NN gemm with dact
+    dY = rnd(M, 768, seed=10, dtype=torch.bfloat16)
+    Wp = rnd(768, N, seed=11, scale=0.05, dtype=torch.bfloat16)  # c_proj weight [E, F]
+    x = save.float()
+    s = torch.sigmoid(1.702 * x)
+    ref = (dY.float() @ Wp.float()) * (s * (1 + 1.702 * x * (1 - s)))
+    out = ops.gemm(dY, Wp, b_kmajor=True, dact_pre=save)
+    close(out, ref, 1e-2, 'dgelu')
+    # batched
+    Ab, Bb = rnd(3, 256, 64, seed=12, dtype=torch.bfloat16), rnd(3, 256, 64, seed=13, dtype=torch.bfloat16)
+    close(ops.gemm(Ab, Bb, out_dtype=torch.float32), Ab.float() @ Bb.float().transpose(1, 2), 1e-4, 'batched')
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from mmvid_amd._lib import MMVIDError
+    with pytest.raises(MMVIDError):
+        ops.gemm(rnd(16, 12, dtype=torch.bfloat16), rnd(16, 12, dtype=torch.bfloat16))  # K % 8 != 0
+    with pytest.raises(MMVIDError):
+        ops.gemm(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))  # CPU tensors
+
+
+# ---------------------------------------------------------------------------------------------- norms
+def test_layernorm_fwd_bwd(ops):
+    for rows, E in ((10, 768), (1158, 768), (77, 512)):
+        x = rnd(rows, E, seed=1) * 2 + 0.5
+        w, b = rnd(E, seed=2) * 0.1 + 1, rnd(E, seed=3) * 0.1
+        y, mean, rstd = ops.layernorm_fwd(x, w, b, out_dtype=torch.float32)
+        xr = x.clone().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = F.layer_norm(xr, (E, ), wr, br, 1e-5)
+        close(y, yr, 1e-5, 'ln fwd')
+        y16, _, _ = ops.layernorm_fwd(x, w, b)
+        assert torch.equal(y16, y.bfloat16())
+        dy = rnd(rows, E, seed=4)
+        yr.backward(dy)
+        base = rnd(rows, E, seed=5)
+        dx = base.clone()
+        dw, db = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+        ops.layernorm_bwd(dy, x, mean, rstd, w, dx=dx, add=True, dw=dw, db=db)
+        close(dx, base + xr.grad, 1e-5, 'ln dx')
+        close(dw, wr.grad, 1e-4, 'ln dw')
+        close(db, br.grad, 1e-4, 'ln db')
+
+
+def test_groupnorm_swish(ops):
+    for N, H, C in ((2, 16, 128), (1, 8, 512), (3, 4, 32), (1, 32, 256)):
+        x = rnd(N, H, H, C, seed=1) * 1.5 + 0.3
+        w, b = rnd(C, seed=2) * 0.1 + 1, rnd(C, seed=3) * 0.1
+        ref = F.group_norm(x.permute(0, 3, 1, 2), 32, w, b, 1e-6)
+        ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1)
+        close(ops.groupnorm_swish(x, w, b, out_dtype=torch.float32), ref, 2e-5, f'gn f32 C={C}')
+        x16 = x.bfloat16()
+        ref16 = F.group_norm(x16.float().permute(0, 3, 1, 2), 32, w, b, 1e-6).permute(0, 2, 3, 1)
+        close(ops.groupnorm_swish(x16, w, b, swish=False), ref16, 1e-2, 'gn bf16 noswish')
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, B, L, H, mask):
+    E = H * 64
+    q, k, v = qkv.float().view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * 0.125
+    if mask is not None:
+        s = s + mask
+    p = torch.softmax(s, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * L, E), p
+
+
+def _mask_tensor(L, spec):
+    if spec is None:
+        return None
+    if spec == 'causal':
+        return torch.full((L, L), float('-inf'), device=DEV).triu_(1)
+    m = torch.zeros(L, L, device=DEV)
+    for r, c in spec[1]:
+        m[r, :c] = float('-inf')
+    return m
+
+
+@pytest.mark.parametrize('B,L,H,spec', [(2, 51, 12, ('rows', [(17, 17), (18, 18)])), (2, 579, 12, ('rows', [(65, 65), (66, 66)])),
+                                        (1, 130, 8, 'causal'), (3, 64, 2, None), (1, 1152, 12, 'causal')])
+def test_attention_fwd_bwd(ops, B, L, H, spec):
+    E = H * 64
+    qkv = rnd(B * L, 3 * E, seed=L, dtype=torch.bfloat16)
+    qkv_r = qkv.float().requires_grad_(True)
+    ref, _ = _attn_ref(qkv_r, B, L, H, _mask_tensor(L, spec))
+    out, lse2 = ops.attention_fwd(qkv, B, L, H, spec)
+    close(out, ref, 1e-2, f'attn fwd L={L}')
+    dout = rnd(B * L, E, seed=L + 1, dtype=torch.bfloat16)
+    ref.backward(dout.float())
+    dqkv = ops.attention_bwd(qkv, out, dout, lse2, B, L, H, spec)
+    g = qkv_r.grad
+    close(dqkv[:, :E], g[:, :E], 2e-2, 'dQ')
+    close(dqkv[:, E:2 * E], g[:, E:2 * E], 2e-2, 'dK')
+    close(dqkv[:, 2 * E:], g[:, 2 * E:], 2e-2, 'dV')
+
+
+def test_attention_softmax_spike(ops):
+    # one key dominates late in the sequence: exercises the online-softmax rescale path
+    B, L, H = 1, 200, 1
+    qkv = rnd(B * L, 192, seed=9, dtype=torch.bfloat16)
+    q = qkv[:, :64].float()
+    qkv[150, 64:128] = (q[3] * 6).bfloat16()
+    ref, _ = _attn_ref(qkv.float(), B, L, H, None)
+    out, _ = ops.attention_fwd(qkv, B, L, H, None)
+    close(out, ref, 1e-2, 'spike')
+
+
+# ------------------------------------------------------------------------------------- embed / losses
+def test_assemble_sequence_and_backward(ops):
+    B, L, E = 3, 37, 768
+    tabs = [rnd(5, E, seed=1), rnd(200, E, seed=2), rnd(258, E, seed=3)]
+    seg = torch.tensor([0] + [1] * 10 + [0, 0] + [2] * 24, dtype=torch.int32, device=DEV)
+    ids = torch.stack([torch.randint(0, tabs[s].shape[0], (B, ), device=DEV) for s in seg.tolist()], 1)
+    pos = rnd(L, E, seed=4)
+    x = ops.assemble_sequence(tabs, ids, seg, pos)
+    ref = torch.stack([torch.stack([tabs[seg[l]][ids[b, l]] + pos[l] for l in range(L)]) for b in range(B)])
+    assert torch.equal(x, ref)
+    dx = rnd(B, L, E, seed=5)
+    gts = [torch.zeros_like(t) for t in tabs]
+    dpos = torch.empty(L, E, device=DEV)
+    ops.assemble_sequence_bwd(gts, [t.shape[0] for t in tabs], ids, seg, dx, dpos)
+    close(dpos, dx.sum(0), 1e-6, 'dpos')
+    for s, gt in enumerate(gts):
+        r = torch.zeros_like(gt)
+        for l in range(L):
+            if seg[l] == s:
+                r.index_add_(0, ids[:, l], dx[:, l])
+        close(gt, r, 1e-6, f'dtable{s}')
+
+
+def test_cross_entropy(ops):
+    rows, V = 1000, 1024
+    logits = rnd(rows, V, seed=1) * 3
+    target = torch.randint(0, V, (rows, ), device=DEV)
+    sel = (torch.rand(rows, device=DEV) < 0.7)
+    lr = logits.clone().requires_grad_(True)
+    loss_ref = F.cross_entropy(lr[sel], target[sel])
+    lse, loss_sum = ops.cross_entropy_fwd(logits, target, sel.to(torch.uint8))
+    cnt = sel.sum()
+    close(loss_sum / cnt, loss_ref.detach().view(1), 1e-5, 'ce loss')
+    loss_ref.backward()
+    gs = (1.0 / cnt).float().view(1)
+    d = ops.cross_entropy_bwd(logits, target, sel.to(torch.uint8), lse, gs)
+    close(d, lr.grad, 1e-2, 'ce grad')
+    assert (d[~sel] == 0).all()
+
+
+def test_adam_and_grad_norm(ops):
+    n = 100003
+    p, g = rnd(n, seed=1), rnd(n, seed=2) * 3
+    p = torch.cat([p, torch.zeros(1, device=DEV)])[:n].contiguous()
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    for step in (1, 2, 3):
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        sq = torch.zeros(1, device=DEV)
+        ops.grad_sqnorm(g, sq)
+        close(sq, (g.double()**2).sum().float().view(1), 1e-5, 'sqnorm')
+        ops.adam_step(p, g, m, v, shadow, step, 1e-3, max_norm=1.0, sqnorm=sq)
+        close(p, pr.detach(), 1e-6, f'adam step {step}')
+        assert torch.equal(shadow, p.bfloat16())
+
+
+# ---------------------------------------------------------------------------------------------- VQGAN
+@pytest.mark.parametrize('mode', [0, 1, 2, 3])
+@pytest.mark.parametrize('N,H,Cin,Cout', [(2, 16, 128, 128), (1, 8, 256, 512), (3, 4, 32, 64), (1, 32, 8, 128), (1, 16, 128, 8)])
+def test_conv_modes(ops, mode, N, H, Cin, Cout):
+    taps = 1 if mode == 3 else 9
+    x = rnd(N, H, H, Cin, seed=1, dtype=torch.bfloat16)
+    w = rnd(Cout, taps, Cin, seed=2, scale=1 / math.sqrt(taps * Cin), dtype=torch.bfloat16)
+    b = rnd(Cout, seed=3) * 0.1
+    xn = x.float().permute(0, 3, 1, 2)
+    wn = w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2) if mode != 3 else w.float().view(Cout, Cin, 1, 1)
+    if mode == 0:
+        ref = F.conv2d(xn, wn, b, padding=1)
+    elif mode == 1:
+        ref = F.conv2d(F.pad(xn, (0, 1, 0, 1)), wn, b, stride=2)
+    elif mode == 2:
+        ref = F.conv2d(F.interpolate(xn, scale_factor=2.0, mode='nearest'), wn, b, padding=1)
+    else:
+        ref = F.conv2d(xn, wn, b)
+    ref = ref.permute(0, 2, 3, 1)
+    out = ops.conv2d_nhwc(x, w, b, mode, out_dtype=torch.float32)
+    close(out, ref, 2e-4, f'conv mode {mode}')
+    res = rnd(*ref.shape, seed=4, dtype=torch.bfloat16)
+    out = ops.conv2d_nhwc(x, w, b, mode, residual=res)
+    close(out, ref + res.float(), 1e-2, 'conv + residual bf16')
+    out = ops.conv2d_nhwc(x, w, b, mode, clamp01=True, out_dtype=torch.float32)
+    close(out, (ref.clamp(-1, 1) + 1) * 0.5, 2e-4, 'conv clamp01')
+
+
+def test_image_layout_kernels(ops):
+    img = torch.rand(2, 3, 16, 16, device=DEV)
+    o = ops.image_to_nhwc8(img)
+    assert torch.equal(o[..., :3], (2 * img - 1).permute(0, 2, 3, 1).bfloat16()) and (o[..., 3:] == 0).all()
+    x = rnd(2, 8, 8, 8)
+    assert torch.equal(ops.nhwc_to_nchw(x, 3), x.permute(0, 3, 1, 2)[:, :3].contiguous())
+
+
+@pytest.mark.parametrize('N,HW,C', [(2, 256, 256), (1, 64, 512), (3, 16, 128)])
+def test_spatial_attention(ops, N, HW, C):
+    q, k, v = (rnd(N, HW, C, seed=s, dtype=torch.bfloat16) for s in (1, 2, 3))
+    p = torch.softmax(q.float() @ k.float().transpose(1, 2) * C**-0.5, -1)
+    close(ops.spatial_attention(q, k, v), p @ v.float(), 1.5e-2, 'spatial attn')
