@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: video-tokens/sec of one full MMVID training step on MI355X.
+
+Workload (BASELINE.json configs[1]): text_to_video, 8 frames of 128x128, 64 text tokens
+(L = 579), full BERT (CLIP ViT-B/32-shaped tower, 12 layers) + full VQGAN (encoder runs inside the step: 16
+frames per sample), bf16 MFMA compute with fp32 accumulation / fp32 master weights, losses 7*MSM + 0.5*REL +
+0.5*VID (three transformer passes), backward, clip_grad_norm_(1.0) and Adam -- i.e. everything train.py:298-325
+of the reference does per iteration.  Synthetic inputs, random-init weights, per-GPU batch 6 (= the recipe's 48/8).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1 via `python -m torch.distributed.run ...`)
+
+Prints ONE JSON line on rank 0: value = whole-job video tokens / second (512 per sample), a `roofline` object for
+the dominant kernel (HIP-event timed inside the timed region) and, at N = 1, a `cpu_baseline` object (the fp32
+CPU oracle timed on the host cores on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TEXT_LEN, FRAMES, SIZE, TOK_PER_SAMPLE = 64, 8, 128, 512
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+CLASS_NAMES = ['gemm_bf16_kernel<A.B^T> (forward)', 'gemm_bf16_kernel<dX>', 'gemm_bf16_kernel<dW>',
+               'conv_igemm_kernel (VQGAN)', 'attn_fwd_kernel', 'attn_bwd (dq+dkv)']
+
+
+def build_model(device, layers=12):
+    from mmvid_amd.dalle_bert import BERT
+    from mmvid_amd.vae import VQGanVAE1024
+    vae = VQGanVAE1024(None, SIZE)
+    vae.image_size = SIZE
+    model = BERT(dim=768, vae=vae, cvae=None, num_text_tokens=49408, text_seq_len=TEXT_LEN,
+                 which_transformer='openai_clip_visual', num_visuals=0, num_targets=FRAMES, transformer_layers=layers)
+    return model.to(device)
+
+
+def synth_batch(B, device, gen):
+    text = torch.randint(1, 49408, (B, TEXT_LEN), generator=gen)
+    lens = torch.randint(8, TEXT_LEN + 1, (B, ), generator=gen)
+    text[torch.arange(TEXT_LEN)[None, :] >= lens[:, None]] = 0  # padded tail
+    frames = torch.rand(B, FRAMES, 3, SIZE, SIZE, generator=gen)
+    return text.to(device), frames.to(device)
+
+
+def train_step(model, trainer, text, frames):
+    trainer.zero_grad()
+    lm, lr, lv = model(text, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
+                       msm_strategy_prob=np.array([0.7, 0.1, 0.1, 0.1]), msm_bernoulli_prob=[0.2, 0.2],
+                       vid_strategy_prob=np.array([0.25, 0.25, 0.25, 0.25]))
+    loss = 7.0 * lm + 0.5 * lr + 0.5 * lv
+    loss.backward()
+    trainer.step()
+    return loss
+
+
+def cpu_baseline(model, B=2, iters=2):
+    """The fp32 CPU oracle (oracle/bert.py, parity-pinned against the reference) on the host cores: same step
+    (3 passes fwd+bwd, 16 VQGAN encodes per sample, Adam) at batch B -> video tokens / s.  Checker code, timed
+    here only as the reported baseline."""
+    from oracle import bert as ob
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    train_keys = [k for k in sd if not k.startswith(('vae.', 'cvae.'))]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    cfg = ob.Cfg(sd, TEXT_LEN, 0, FRAMES, SIZE)
+    opt = torch.optim.Adam([sd[k] for k in train_keys], lr=1e-4)
+    gen = torch.Generator().manual_seed(1)
+    text, frames = synth_batch(B, 'cpu', gen)
+    times = []
+    for it in range(iters + 1):
+        t0 = time.time()
+        with torch.no_grad():
+            tt = ob.get_image_tokens(sd, cfg, frames)
+            wt = ob.get_image_tokens(sd, cfg, frames.flip(1))  # VID negative: second encode of 8 frames
+        mask1 = torch.rand(B, cfg.target_seq_len, generator=gen) < 0.2
+        r = ob.forward_losses(sd, cfg, text, tt, mask1, wt)
+        opt.zero_grad()
+        (7 * r['loss_msm'] + 0.5 * r['loss_rel'] + 0.5 * r['loss_vid']).backward()
+        torch.nn.utils.clip_grad_norm_([sd[k] for k in train_keys], 1.0)
+        opt.step()
+        times.append(time.time() - t0)
+    t = float(np.mean(times[1:]))
+    return {'value': B * TOK_PER_SAMPLE / t, 'unit': 'video-tokens/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{iters} full training steps at batch {B} (config 2 shapes, fp32 torch-CPU oracle), {t:.2f} s/step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=6, help='per-GPU batch (even; the recipe is 48 / 8 GPUs)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--layers', type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the model
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    from mmvid_amd import _lib
+    from mmvid_amd.build import build
+    from mmvid_amd.engine import FlatTrainer, backward_order, broadcast_parameters
+    build()
+    # seed_everything(seed + rank) as train.py:87; identical initial weights come from the rank-0 broadcast
+    seed = 42 + rank
+    random.seed(seed), np.random.seed(seed), torch.manual_seed(seed)
+    model = build_model(device, args.layers)
+    broadcast_parameters(model)
+    model.train()
+    trainer = FlatTrainer(model, lr=1e-4, max_grad_norm=1.0, order=backward_order)
+    gen = torch.Generator().manual_seed(seed)
+    B = args.batch
+    text, frames = synth_batch(B, device, gen)
+
+    for _ in range(args.warmup):
+        train_step(model, trainer, text, frames)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lib = _lib.load()
+    fence()
+    lib.mmvid_prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(model, trainer, text, frames)
+    fence()
+    dt = time.perf_counter() - t0
+    nc = len(CLASS_NAMES)
+    ms, cnt, fl = (ctypes.c_double * nc)(), (ctypes.c_int64 * nc)(), (ctypes.c_double * nc)()
+    lib.mmvid_prof_end(ms, cnt, fl, nc)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * B * TOK_PER_SAMPLE / (dt / args.steps)
+        kernels = []
+        for i in range(nc):
+            if cnt[i]:
+                kernels.append({'kernel': CLASS_NAMES[i], 'launches': int(cnt[i]), 'avg_ms': ms[i] / cnt[i],
+                                'ms_per_step': ms[i] / args.steps, 'tflops': fl[i] / (ms[i] * 1e-3) / 1e12})
+        dom = max(kernels, key=lambda k: k['ms_per_step']) if kernels else None
+        roofline = None
+        if dom:
+            roofline = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS, 'traffic': None,
+                        'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches'] / args.steps}
+        out = {
+            'metric': 'video-tokens/sec training step, 8-frame 128px text-to-video', 'value': value,
+            'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'text_to_video 8-frame 128x128, 64 text tokens (L=579), full dalle_bert (12-layer '
+                                   'CLIP ViT-B/32 tower) + VQGAN encode in-step, MSM+REL+VID, backward, clip+Adam',
+                       'per_gpu_batch': B, 'global_batch': world * B, 'seq_len': 579, 'parallelism': f'dp{world}',
+                       'layers': args.layers},
+            'loss': float(loss), 'roofline': roofline, 'kernels': kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(model)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -51,7 +51,8 @@ int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const 
 int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                         const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
                         int add_into_dx, float* dw, float* db, void* stream);
-/* GroupNorm(32, eps) [+ swish] on NHWC: taming/modules/diffusionmodules/model.py:38-42, 33-35. */
+/* GroupNorm(32, eps) [+ swish] on NHWC: taming/modules/diffusionmodules/model.py:38-42, 33-35.
+ * stats_scratch: fp32 [N * 64 * (1 + ceil(hw / 256))]; deterministic (fixed-order reductions, no atomics). */
 int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, int C, const float* w,
                                const float* b, float eps, int swish, float* stats_scratch, void* y_bf16,
                                float* y_f32, void* stream);
@@ -138,6 +139,11 @@ int mmvid_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int Cuse,
 /* single-head spatial attention of AttnBlock (model.py:180-205): q,k,v NHWC bf16 [N, HW, C] -> o bf16. */
 int mmvid_spatial_attention(const void* q, const void* k, const void* v, int N, int HW, int C, float scale,
                             float* scores_scratch, void* out_bf16, void* stream);
+
+/* ---- optional per-launch HIP-event timing of the MFMA kernel families (bench.py roofline line).
+ * classes: 0 gemm A.B^T (forward) | 1 gemm dX | 2 gemm dW | 3 conv implicit GEMM | 4 attention fwd | 5 attention bwd */
+int mmvid_prof_begin(void);
+int mmvid_prof_end(double* ms, int64_t* launches, double* flops, int nclass);
 
 #ifdef __cplusplus
 }

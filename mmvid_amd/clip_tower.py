@@ -62,9 +62,9 @@ class _TowerParams(_Holder):
 
 class _TowerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, tower, *params):
+    def forward(ctx, x, tower, keep, *params):
         ctx.tower = tower
-        y, saved = tower._run_forward(x, keep=torch.is_grad_enabled() and (x.requires_grad or tower._any_trainable()))
+        y, saved = tower._run_forward(x, keep=keep)  # NB: grad mode is always off inside Function.forward
         ctx.saved_arena = saved
         ctx.shape = x.shape
         return y
@@ -74,7 +74,7 @@ class _TowerFn(torch.autograd.Function):
         g = gy.contiguous().clone()  # updated in place into dL/dx
         ctx.tower._run_backward(g, ctx.saved_arena, ctx.shape)
         ctx.saved_arena = None
-        return (g.view(ctx.shape), None) + (None, ) * (len(ctx.needs_input_grad) - 2)
+        return (g.view(ctx.shape), None, None) + (None, ) * (len(ctx.needs_input_grad) - 3)
 
 
 class OpenAICLIPTransformer(nn.Module):
@@ -132,7 +132,8 @@ class OpenAICLIPTransformer(nn.Module):
 
     def forward(self, x, **kwargs):
         assert x.dim() == 3 and x.shape[-1] == self.width
-        return _TowerFn.apply(x, self, *self.parameters())
+        keep = torch.is_grad_enabled() and (x.requires_grad or self._any_trainable())
+        return _TowerFn.apply(x, self, keep, *self.parameters())
 
     # ---- native plumbing ---------------------------------------------------------------------------
     def _any_trainable(self):

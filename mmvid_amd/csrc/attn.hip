@@ -14,6 +14,7 @@
 // use 136-byte rows.  Probabilities are exp2 with the 1/sqrt(d)*log2(e) scale folded in; the row
 // statistic saved for backward is lse2 = m + log2(sum).
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -487,6 +488,7 @@ extern "C" int mmvid_attention_fwd(const void* qkv, int64_t ld, const void* VT, 
     MMVID_REQUIRE(qkv && VT && out && lse2, "attention_fwd: null pointer");
     ATTN_COMMON_CHECKS("attention_fwd");
     MMVID_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, "attention_fwd: bad leading dims");
+    MmvidProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * 64, (hipStream_t)stream);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((L + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)qkv, (long)ld, (const bf16_t*)VT, L, Lp, H, E, scale * 1.4426950408889634f,
                        make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out, (long)ldo, lse2);
@@ -507,6 +509,7 @@ extern "C" int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* QT, 
     const long items = (long)B * L * H * 8;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(items, 256)), dim3(256), 0, s, (const bf16_t*)O, (long)ldo,
                        (const bf16_t*)dO, (long)lddo, B, L, H, delta);
+    MmvidProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)L * L * 64, s);  // 5 GEMM-equivalents (recompute counted once)
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((L + 63) / 64, H, B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
                        (const bf16_t*)KT, (const bf16_t*)dO, (long)lddo, lse2, delta, L, Lp, H, E, scale, sl2, m,
                        (bf16_t*)dqkv, (long)ldg);

@@ -11,6 +11,7 @@
 // Roofline: bf16 MFMA; algorithmic FLOPs = 2 * M * Cout * taps * Cin.
 #include "../../include/mmvid_hip.h"
 #include "gemm_core.h"
+#include "prof.h"
 
 namespace {
 using namespace mmvid_core;
@@ -250,6 +251,7 @@ extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Wi
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
+    MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * p.K, (hipStream_t)stream);
     hipLaunchKernelGGL(conv_igemm_kernel, dim3(cdiv(Cout, BN), cdiv(p.M, BM)), dim3(256), lds, (hipStream_t)stream, p);
     MMVID_LAUNCH_CHECK("conv2d_nhwc");
     return MMVID_OK;

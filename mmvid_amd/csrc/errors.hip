@@ -23,3 +23,70 @@ extern "C" int mmvid_device_count() {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+// ---------------------------------------------------------------------------------------------- profiler
+#include <mutex>
+#include <vector>
+
+#include "prof.h"
+
+namespace {
+struct Rec {
+    hipEvent_t a, b;
+    int cls;
+    double flops;
+};
+bool g_prof_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+size_t g_pool_next = 0;
+std::mutex g_prof_mu;
+
+hipEvent_t pool_get() {
+    if (g_pool_next == g_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        g_pool.push_back(e);
+    }
+    return g_pool[g_pool_next++];
+}
+}  // namespace
+
+MmvidProfScope::MmvidProfScope(int cls, double flops, hipStream_t stream) : slot(-1), s(stream) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    Rec r;
+    r.a = pool_get(), r.b = pool_get(), r.cls = cls, r.flops = flops;
+    (void)hipEventRecord(r.a, s);
+    slot = (int)g_recs.size();
+    g_recs.push_back(r);
+}
+MmvidProfScope::~MmvidProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_recs[slot].b, s);
+}
+
+extern "C" int mmvid_prof_begin() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_recs.clear();
+    g_pool_next = 0;
+    g_prof_on = true;
+    return 0;
+}
+
+// Stops recording, waits for the device, and returns per class: total ms, launches, total algorithmic flops.
+extern "C" int mmvid_prof_end(double* ms, int64_t* launches, double* flops, int nclass) {
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = false;
+    for (int c = 0; c < nclass; ++c) ms[c] = 0, launches[c] = 0, flops[c] = 0;
+    for (const Rec& r : g_recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+        if (r.cls < nclass) ms[r.cls] += t, launches[r.cls] += 1, flops[r.cls] += r.flops;
+    }
+    g_recs.clear();
+    g_pool_next = 0;
+    return 0;
+}

@@ -21,6 +21,7 @@
 // each lane ends up with 4 consecutive n for one m: 16-B epilogue loads/stores.
 // Roofline: bf16 MFMA (2.5 PFLOP/s dense); algorithmic FLOPs = 2*M*N*K.
 #include "gemm_core.h"
+#include "prof.h"
 
 namespace {
 using namespace mmvid_core;
@@ -183,6 +184,7 @@ int launch(const GemmParams& p, int batch, hipStream_t stream) {
         attr = true;
     }
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), batch * p.splitk);
+    MmvidProfScope prof(AKM ? PROF_GEMM_TN : (BKM ? PROF_GEMM_NN : PROF_GEMM_NT), 2.0 * p.M * p.N * (double)p.K * batch, stream);
     hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM>), grid, dim3(256), lds, stream, p);
     return 0;
 }

@@ -160,8 +160,11 @@ __device__ __forceinline__ void load8<float>(const float* p, float (&f)[8]) {
 // C/8 <= 256 and 256 % (C/8) == 0  (C in {32, 64, 128, 256, 512}).
 template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, long hw, int C,
-                                                              int pix_per_block, float* __restrict__ stats) {
-    __shared__ float sh[2][512];  // per-channel partials
+                                                              int pix_per_block, float* __restrict__ partial) {
+    // Deterministic (no atomics): per-thread partials -> LDS [pixel row][channel] -> fixed-order column sums
+    // -> per-group sums -> partial[n][block][32][2]; groupnorm_finalize_kernel adds the blocks in order.
+    __shared__ float red[2][2048];  // [sum|sumsq][prow * C + channel], pstep * C == 2048
+    __shared__ float sh[2][512];    // per-channel sums
     const int n = blockIdx.y;
     const int cchunks = C >> 3;
     const int cc = threadIdx.x % cchunks, prow = threadIdx.x / cchunks, pstep = 256 / cchunks;
@@ -178,12 +181,17 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] += f[e], q[e] += f[e] * f[e];
     }
-    for (int i = threadIdx.x; i < 2 * 512; i += 256) (&sh[0][0])[i] = 0.f;
-    __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        atomicAdd(&sh[0][cc * 8 + e], s[e]);
-        atomicAdd(&sh[1][cc * 8 + e], q[e]);
+        red[0][prow * C + cc * 8 + e] = s[e];
+        red[1][prow * C + cc * 8 + e] = q[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const int which = c / C, ch = c - which * C;
+        float a = 0.f;
+        for (int r = 0; r < pstep; ++r) a += red[which][r * C + ch];
+        sh[which][ch] = a;
     }
     __syncthreads();
     const int cpg = C / 32;
@@ -191,8 +199,19 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
         const int grp = threadIdx.x & 31, which = threadIdx.x >> 5;
         float a = 0.f;
         for (int e = 0; e < cpg; ++e) a += sh[which][grp * cpg + e];
-        unsafeAtomicAdd(stats + ((long)n * 32 + grp) * 2 + which, a);
+        partial[(((long)n * gridDim.x + blockIdx.x) * 32 + grp) * 2 + which] = a;
     }
+}
+
+// stats[n][grp][which] = sum over blocks (fixed order) of partial[n][blk][grp][which]
+__global__ void groupnorm_finalize_kernel(const float* __restrict__ partial, int nblk, int total,
+                                          float* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N*64
+    if (i >= total) return;
+    const int n = i >> 6, r = i & 63;
+    float a = 0.f;
+    for (int b = 0; b < nblk; ++b) a += partial[((long)n * nblk + b) * 64 + r];
+    stats[i] = a;
 }
 
 // apply: y = swish?( (x-mean)*rstd*w + b ) -> bf16 NHWC (and/or f32).  8 channels per thread.
@@ -268,7 +287,8 @@ extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x
     return MMVID_OK;
 }
 
-// x NHWC [N, hw, C] (bf16 when x_is_bf16 else f32); stats scratch [N,32,2] fp32 is zeroed here.
+// x NHWC [N, hw, C] (bf16 when x_is_bf16 else f32).  stats_scratch: fp32 [N*64*(1 + ceil(hw/256))]
+// (final sums first, then the per-block partials).  Deterministic: no atomics anywhere.
 extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, int C, const float* w,
                                           const float* b, float eps, int swish, float* stats_scratch, void* y_bf16,
                                           float* y_f32, void* stream) {
@@ -276,25 +296,26 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
     MMVID_REQUIRE(C % 32 == 0 && C <= 512 && 256 % (C / 8) == 0, "groupnorm: C=%d unsupported", C);
     if (N == 0 || hw == 0) return MMVID_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats_scratch, 0, sizeof(float) * 64 * (size_t)N, s) != hipSuccess) {
-        mmvid_set_error("groupnorm: memset failed");
-        return MMVID_ERR_HIP;
-    }
     const int pix_per_block = 256;
-    dim3 g1(cdiv(hw, pix_per_block), N);
+    const int nblk = cdiv(hw, pix_per_block);
+    dim3 g1(nblk, N);
+    float* partial = stats_scratch + (long)N * 64;
     const long chunks = (long)N * hw * (C / 8);
-    if (x_is_bf16) {
+    if (x_is_bf16)
         hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)x, (long)hw, C,
-                           pix_per_block, stats_scratch);
+                           pix_per_block, partial);
+    else
+        hipLaunchKernelGGL(groupnorm_stats_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (long)hw, C,
+                           pix_per_block, partial);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv((long)N * 64, 256)), dim3(256), 0, s, partial, nblk, N * 64,
+                       stats_scratch);
+    if (x_is_bf16)
         hipLaunchKernelGGL(groupnorm_apply_kernel<bf16_t>, dim3(cdiv(chunks, 256)), dim3(256), 0, s,
                            (const bf16_t*)x, (long)hw, C, stats_scratch, w, b, eps, swish, (bf16_t*)y_bf16, y_f32,
                            chunks);
-    } else {
-        hipLaunchKernelGGL(groupnorm_stats_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (long)hw, C,
-                           pix_per_block, stats_scratch);
+    else
         hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3(cdiv(chunks, 256)), dim3(256), 0, s, (const float*)x,
                            (long)hw, C, stats_scratch, w, b, eps, swish, (bf16_t*)y_bf16, y_f32, chunks);
-    }
     MMVID_LAUNCH_CHECK("groupnorm");
     return MMVID_OK;
 }
