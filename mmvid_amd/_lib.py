@@ -69,6 +69,10 @@ def load():
     """Load the shared library (no GPU needed for loading).  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        # torch's ROCm wheel bundles its own libamdhip64; it must be in the process first so that our library
+        # binds to the SAME HIP runtime that owns torch's device pointers and streams (loading ours first gives
+        # two runtimes and "no ROCm-capable device" at the first launch).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise MMVIDError(f'{LIB_PATH} is missing: run `python -m mmvid_amd.build` (hipcc, gfx950). '
                              'There is no CPU/PyTorch fallback for the kernels.')

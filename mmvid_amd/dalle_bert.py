@@ -477,7 +477,7 @@ class BERT(nn.Module):
             if rel_no_fully_masked:
                 a = F.binary_cross_entropy_with_logits(lp, ones, reduction='none')
                 b_ = F.binary_cross_entropy_with_logits(ln, zeros, reduction='none')
-                loss_rel = (a * not_fully_masked + b_ * not_fully_masked).sum() / max(1., not_fully_masked.sum())
+                loss_rel = (a * not_fully_masked + b_ * not_fully_masked).sum() / not_fully_masked.sum().clamp(min=1.)  # max(1., .) without a host sync
             else:
                 loss_rel = F.binary_cross_entropy_with_logits(lp, ones) + F.binary_cross_entropy_with_logits(ln, zeros)
         else:
@@ -488,7 +488,7 @@ class BERT(nn.Module):
             ln = self._small_head(self.to_logits_vid, out_neg[:, self.vid_tok_index, :])
             ones, zeros = torch.ones(B, 1, device=device), torch.zeros(B, 1, device=device)
             if rel_no_fully_masked:  # NB: the reference does not weight by not_fully_masked here (1107-1116)
-                den = max(1., not_fully_masked.sum())
+                den = not_fully_masked.sum().clamp(min=1.)
                 loss_vid = F.binary_cross_entropy_with_logits(lp, ones, reduction='none').sum() / den + \
                     F.binary_cross_entropy_with_logits(ln, zeros, reduction='none').sum() / den
             else:
