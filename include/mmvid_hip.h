@@ -44,6 +44,11 @@ int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void*
                     void* save_pre, int64_t ldp, int act, int accumulate, float* out_f32, void* out_bf16,
                     int64_t ldc, void* stream);
 
+/* Weight gradient dW[N][K] (+)= dY^T X over M tokens (autograd of nn.Linear); split-K through `workspace`
+ * ([splitk][N][K] fp32) with a fixed-order reduction: deterministic. */
+int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64_t ldy, const void* X, int64_t ldx, int splitk,
+                       float* workspace, float* dW, int accumulate, void* stream);
+
 /* ---- LayerNorm: clip_model.py:188-193 (fp32 statistics, eps 1e-5) and the nn.LayerNorm of the heads. */
 int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const float* w, const float* b, float eps,
                         void* y_bf16, float* y_f32, int64_t ldy, float* mean, float* rstd, void* stream);
@@ -139,6 +144,9 @@ int mmvid_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int Cuse,
 /* single-head spatial attention of AttnBlock (model.py:180-205): q,k,v NHWC bf16 [N, HW, C] -> o bf16. */
 int mmvid_spatial_attention(const void* q, const void* k, const void* v, int N, int HW, int C, float scale,
                             float* scores_scratch, void* out_bf16, void* stream);
+
+/* hardware probe (tools/gpu_probe.py): which = 0 -> ds_read_b64_tr_b16 lane layout. */
+int mmvid_probe(int which, const void* in, void* out, void* stream);
 
 /* ---- optional per-launch HIP-event timing of the MFMA kernel families (bench.py roofline line).
  * classes: 0 gemm A.B^T (forward) | 1 gemm dX | 2 gemm dW | 3 conv implicit GEMM | 4 attention fwd | 5 attention bwd */

@@ -32,6 +32,7 @@ SIGNATURES = {
     'mmvid_vq_argmin_l2': [P, P, P, I64, I, I, P, P, P],
     'mmvid_gather_rows': [P, I64, P, I64, I, P, P, P],
     'mmvid_gemm_bf16': [I, I, I, I, I, P, I64, P, I64, I, I64, I64, I64, I, F, P, P, I64, P, P, I64, I, I, P, P, I64, P],
+    'mmvid_gemm_bf16_dw': [I64, I, I, P, I64, P, I64, I, P, P, I, P],
     'mmvid_layernorm_fwd': [P, I64, I64, I, P, P, F, P, P, I64, P, P, P],
     'mmvid_layernorm_bwd': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P],
     'mmvid_groupnorm_swish_nhwc': [P, I, I, I64, I, P, P, F, I, P, P, P, P],
@@ -53,6 +54,7 @@ SIGNATURES = {
     'mmvid_image_to_nhwc8': [P, I, I, I, P, P],
     'mmvid_nhwc_to_nchw_f32': [P, I, I, I, I, I, P, P],
     'mmvid_spatial_attention': [P, P, P, I, I, I, F, P, P, P],
+    'mmvid_probe': [I, P, P, P],
     'mmvid_prof_begin': [],
     'mmvid_prof_end': [P, P, P, I],
 }

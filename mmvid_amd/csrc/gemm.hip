@@ -47,6 +47,7 @@ struct GemmParams {
     float* out_f32;  // [M][ldc] or null
     bf16_t* out_bf16;
     long ldc;
+    float* partial;  // split-K workspace [splitk][M][N] (plain stores, reduced by splitk_reduce_kernel) or null
 };
 
 __device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
@@ -125,6 +126,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                if (p.partial) {
+                    *reinterpret_cast<float4*>(p.partial + ((long)ks * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
+                }
                 if (p.splitk > 1) {
                     float* o = p.out_f32 + cb + (long)m * p.ldc + n;
                     if (p.bias && ks == 0) {
@@ -175,6 +180,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
+// out[i] = (accumulate ? out[i] : 0) + sum_s partial[s][i]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splitk, long mn,
+                                                            float* __restrict__ out, int accumulate) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= mn) return;
+    float4 a = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
+    for (int s = 0; s < splitk; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + (long)s * mn + i);
+        a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = a;
+}
+
 template <bool AKM, bool BKM>
 int launch(const GemmParams& p, int batch, hipStream_t stream) {
     static bool attr = false;
@@ -219,6 +237,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.dact_pre = (const bf16_t*)dact_pre, p.save_pre = (bf16_t*)save_pre, p.ldp = ldp;
     p.act = act, p.accumulate = accumulate, p.alpha = alpha;
     p.out_f32 = out_f32, p.out_bf16 = (bf16_t*)out_bf16, p.ldc = ldc;
+    p.partial = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor)
         launch<false, false>(p, batch, s);
@@ -227,5 +246,30 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     else
         launch<true, true>(p, batch, s);
     MMVID_LAUNCH_CHECK("gemm_bf16");
+    return MMVID_OK;
+}
+
+// dW[N][K] (+)= dY^T X reduced over M tokens: both operands k-major.  Split-K goes through `workspace`
+// ([splitk][N][K] fp32) and a fixed-order reduction: deterministic, no atomics.  dY [M][ldy>=N], X [M][ldx>=K].
+extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64_t ldy, const void* X, int64_t ldx,
+                                  int splitk, float* workspace, float* dW, int accumulate, void* stream) {
+    MMVID_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "gemm_bf16_dw: bad arguments");
+    MMVID_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "gemm_bf16_dw: N, K, ldy, ldx must be multiples of 8");
+    MMVID_REQUIRE(splitk >= 1 && (splitk == 1 || workspace), "gemm_bf16_dw: split-K needs a workspace");
+    GemmParams p;
+    p.A = (const bf16_t*)dY, p.B = (const bf16_t*)X;
+    p.M = N, p.N = K, p.K = (int)M, p.lda = ldy, p.ldb = ldx;
+    p.strideA = p.strideB = p.strideC = 0, p.splitk = splitk;
+    p.bias = nullptr, p.residual = nullptr, p.ldr = 0, p.dact_pre = nullptr, p.save_pre = nullptr, p.ldp = 0;
+    p.act = 0, p.accumulate = accumulate, p.alpha = 1.0f;
+    p.out_f32 = dW, p.out_bf16 = nullptr, p.ldc = K;
+    p.partial = splitk > 1 ? workspace : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    launch<true, true>(p, 1, s);
+    if (splitk > 1) {
+        const long mn = (long)N * K;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(mn / 4, 256)), dim3(256), 0, s, workspace, splitk, mn, dW, accumulate);
+    }
+    MMVID_LAUNCH_CHECK("gemm_bf16_dw");
     return MMVID_OK;
 }

@@ -10,6 +10,7 @@
 namespace {
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+constexpr int kMaxSplitK = 8;
 
 struct Dims {
     int B, L, Lp, E, H, F, layers;
@@ -49,7 +50,7 @@ SavedLayer saved_layout(const Dims& d) {
 }
 
 struct Scratch {  // byte offsets inside the scratch arena
-    int64_t xt0, xt1, xt2, delta, dqkv, d_h, d_o, d_pre, g_bf16, infer, total;
+    int64_t xt0, xt1, xt2, delta, dqkv, d_h, d_o, d_pre, g_bf16, splitk_ws, infer, total;
 };
 Scratch scratch_layout(const Dims& d) {
     Scratch s;
@@ -67,6 +68,7 @@ Scratch scratch_layout(const Dims& d) {
     s.d_o = take(d.M * d.E * 2);
     s.d_pre = take(d.M * d.F * 2);
     s.g_bf16 = take(d.M * d.E * 2);
+    s.splitk_ws = take((int64_t)kMaxSplitK * d.F * d.E * 4);  // largest weight ([F,E] >= [3E,E]) x splits
     s.infer = take(saved_layout(d).total);  // one layer's worth of activations for inference mode
     s.total = off;
     return s;
@@ -86,12 +88,13 @@ int check_cfg(const mmvid_tower_cfg_t* c) {
     return 0;
 }
 
+// dW GEMMs have few output tiles (<= 144) and a long reduction (tokens): split K so that ~2 blocks per CU exist.
 int pick_splitk(int Mout, int Nout, int64_t K) {
     const int tiles = cdiv(Mout, 128) * cdiv(Nout, 128);
-    int sk = 1024 / (tiles > 0 ? tiles : 1);
+    int sk = (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
     const int ktiles = cdiv(K, 64);
     if (sk > ktiles / 4) sk = ktiles / 4;
-    if (sk > 32) sk = 32;
+    if (sk > kMaxSplitK) sk = kMaxSplitK;
     if (sk < 1) sk = 1;
     return sk;
 }
@@ -109,10 +112,9 @@ int linear_dx(int64_t M, int N, int K, const void* dY, const void* W, const void
                            0, 0, out_f32, out_bf16, K, st);
 }
 // dW[N,K] += dY^T X (both k-major over the token dimension), db[N] += colsum(dY)
-int linear_dw(int64_t M, int N, int K, const void* dY, const void* X, float* dW, float* db, void* st) {
+int linear_dw(int64_t M, int N, int K, const void* dY, const void* X, float* dW, float* db, float* ws, void* st) {
     const int sk = pick_splitk(N, K, M);
-    TRY(mmvid_gemm_bf16(1, 1, N, K, (int)M, dY, N, X, K, 1, 0, 0, 0, sk, 1.0f, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                        0, /*accumulate=*/1, dW, nullptr, K, st));
+    TRY(mmvid_gemm_bf16_dw(M, N, K, dY, N, X, K, sk, ws, dW, /*accumulate=*/1, st));
     if (db) TRY(mmvid_colsum_bf16(dY, N, M, N, db, st));
     return 0;
 }
@@ -186,21 +188,22 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
     const float scale = 0.125f;
     void* gb = scr + sc.g_bf16;
     float* d_h = (float*)(scr + sc.d_h);
+    float* ws = (float*)(scr + sc.splitk_ws);
     for (int i = d.layers - 1; i >= 0; --i) {
         const mmvid_tower_layer_t& ly = layers[i];
         const char* sv = (const char*)saved + (int64_t)i * sl.total;
         // ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(LN2 x_mid)))
         TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
-        TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, ly.g_pj_b, stream));
+        TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, ly.g_pj_b, ws, stream));
         TRY(linear_dx(d.M, d.E, d.F, gb, ly.pj_w, sv + sl.pre, nullptr, scr + sc.d_pre, stream));
-        TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, ly.g_fc_b, stream));
+        TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, ly.g_fc_b, ws, stream));
         TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, d_h, nullptr, stream));
         TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
                                 (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, ly.g_ln2_w, ly.g_ln2_b,
                                 stream));
         // ---- attention branch: x_mid = x_in + out_proj(MHA(LN1 x_in))
         TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
-        TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, ly.g_out_b, stream));
+        TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, ly.g_out_b, ws, stream));
         TRY(linear_dx(d.M, d.E, d.E, gb, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
         TRY(mmvid_head_transpose(sv + sl.qkv, 3 * d.E, 0, d.B, d.L, d.Lp, d.H, scr + sc.xt0, stream));        // Q^T
         TRY(mmvid_head_transpose(sv + sl.qkv, 3 * d.E, d.E, d.B, d.L, d.Lp, d.H, scr + sc.xt1, stream));      // K^T
@@ -209,7 +212,7 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
                                 scr + sc.xt2, (const float*)(sv + sl.lse2), (float*)(scr + sc.delta), d.B, d.L, d.Lp,
                                 d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0, cfg->r1, cfg->c1, scr + sc.dqkv,
                                 3 * d.E, stream));
-        TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, ly.g_in_b, stream));
+        TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, ly.g_in_b, ws, stream));
         TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, d_h, nullptr, stream));
         TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
                                 (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, ly.g_ln1_w, ly.g_ln1_b,

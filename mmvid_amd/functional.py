@@ -59,8 +59,7 @@ class LNLinear(torch.autograd.Function):
         R, N = d16.shape
         E = x.shape[1]
         if w.requires_grad:
-            sk = max(1, min(16, R // 512))
-            ops.gemm(d16, h, a_kmajor=True, b_kmajor=True, out=_grad_buf(w), accumulate=True, splitk=sk)
+            ops.gemm_dw(d16, h, _grad_buf(w), accumulate=True)
         if b.requires_grad:
             ops.colsum_bf16(d16, _grad_buf(b))
         dh = ops.gemm(d16, w_bf16, b_kmajor=True, out_dtype=f32)  # [R, E]

@@ -96,6 +96,19 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, residual=None, dact
     return out
 
 
+def gemm_dw(dY, X, dW, accumulate=True, splitk=None):
+    """dW[N,K] (+)= dY[M,N]^T X[M,K] (weight gradient), deterministic split-K through a scratch workspace."""
+    _chk(dY, bf16, 'dY'), _chk(X, bf16, 'X'), _chk(dW, f32, 'dW')
+    M, N = dY.shape
+    K = X.shape[1]
+    if splitk is None:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splitk = max(1, min(8, (512 + tiles - 1) // tiles, ((M + 63) // 64) // 4))
+    ws = torch.empty(splitk * N * K, device=dY.device, dtype=f32) if splitk > 1 else None
+    call('mmvid_gemm_bf16_dw', M, N, K, _p(dY), N, _p(X), K, splitk, _p(ws), _p(dW), int(accumulate), _stream())
+    return dW
+
+
 # ---------------------------------------------------------------------------------------------- norms
 def layernorm_fwd(x, w, b, eps=1e-5, out_dtype=bf16, save_stats=True):
     _chk(x, f32, 'x')
