@@ -1,7 +1,7 @@
 // VQGAN convolutions as implicit GEMM on NHWC bf16, for gfx950.
 //   M = N*Hout*Wout output pixels, N_gemm = Cout, K = taps*Cin with k = (ky*3+kx)*Cin + ci.
-// The A tile is gathered straight from the NHWC activation (each 16-B chunk = 8 input channels of one
-// tap of one pixel: contiguous), zero-filled at the padding; the weight [Cout][taps][Cin] is the
+// The A tile is gathered straight from the NHWC activation by LDS-DMA (each 16-B chunk = 8 input channels of
+// one tap of one pixel: contiguous; padding taps read a zero block); the weight [Cout][taps][Cin] is the
 // row-major B operand.  Same 128x128x64 tile / swizzled LDS / 32x32x16 MFMA core as gemm.hip.
 //   mode 0: 3x3 s1 p1                     (model.py:102-115 ResnetBlock convs, conv_in/out)
 //   mode 1: 3x3 s2, zero pad right/bottom (model.py:77-81 Downsample)
@@ -30,59 +30,56 @@ struct ConvParams {
     float* out_f32;
 };
 
-// A-operand gather: thread t owns chunk c = t&7 of rows (t>>3)+32i.
+// A-operand gather by LDS-DMA: this lane owns, in each of its wave's 4 DMA pieces, LDS slot (lane&7) of tile row
+// (wave*4+jj)*8 + (lane>>3); the logical k chunk that belongs in that slot follows the row swizzle of gemm_core.h.
 struct ConvAStage {
-    uint4 v[4];
-    int oy[4], ox[4];
-    long nbase[4];  // n*Hin*Win, or -1 when the row is out of range
-    __device__ __forceinline__ void init(const ConvParams& p, long m0, int tid) {
+    int oy[4], ox[4], chunk[4];
+    long nbase[4];  // n*Hin*Win, or -1 when the output pixel is out of range
+    __device__ __forceinline__ void init(const ConvParams& p, long m0, int wave, int lane) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long m = m0 + (tid >> 3) + 32 * i;
+        for (int jj = 0; jj < 4; ++jj) {
+            const int row = (wave * 4 + jj) * 8 + (lane >> 3);
+            chunk[jj] = (lane & 7) ^ ((row >> 1) & 7);
+            const long m = m0 + row;
             if (m < p.M) {
                 const long hw = (long)p.Hout * p.Wout;
                 const long n = m / hw;
                 const int rem = (int)(m - n * hw);
-                oy[i] = rem / p.Wout;
-                ox[i] = rem - oy[i] * p.Wout;
-                nbase[i] = n * p.Hin * p.Win;
+                oy[jj] = rem / p.Wout;
+                ox[jj] = rem - oy[jj] * p.Wout;
+                nbase[jj] = n * p.Hin * p.Win;
             } else {
-                nbase[i] = -1, oy[i] = ox[i] = 0;
+                nbase[jj] = -1, oy[jj] = ox[jj] = 0;
             }
         }
     }
-    __device__ __forceinline__ void load(const ConvParams& p, int k0, int tid) {
-        const int k = k0 + (tid & 7) * 8;
-        const int tap = k >> p.cin_log2;
-        const int ci = k & (p.Cin - 1);
-        const int ky = (p.mode == 3) ? 0 : tap / 3;
-        const int kx = (p.mode == 3) ? 0 : tap - ky * 3;
-        const bool kvalid = k < p.K;
+    __device__ __forceinline__ void issue(const ConvParams& p, int k0, char* tile, int wave) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int jj = 0; jj < 4; ++jj) {
+            const int k = k0 + chunk[jj] * 8;
+            const int tap = k >> p.cin_log2;
+            const int ci = k & (p.Cin - 1);
+            const int ky = (p.mode == 3) ? 0 : tap / 3;
+            const int kx = (p.mode == 3) ? 0 : tap - ky * 3;
             int iy, ix;
-            bool ok = kvalid && nbase[i] >= 0;
+            bool ok = k < p.K && nbase[jj] >= 0;
             if (p.mode == 0) {
-                iy = oy[i] + ky - 1, ix = ox[i] + kx - 1;
+                iy = oy[jj] + ky - 1, ix = ox[jj] + kx - 1;
                 ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
             } else if (p.mode == 1) {
-                iy = 2 * oy[i] + ky, ix = 2 * ox[i] + kx;
+                iy = 2 * oy[jj] + ky, ix = 2 * ox[jj] + kx;
                 ok = ok && iy < p.Hin && ix < p.Win;
             } else if (p.mode == 2) {
-                const int uy = oy[i] + ky - 1, ux = ox[i] + kx - 1;
+                const int uy = oy[jj] + ky - 1, ux = ox[jj] + kx - 1;
                 ok = ok && uy >= 0 && uy < 2 * p.Hin && ux >= 0 && ux < 2 * p.Win;
                 iy = uy >> 1, ix = ux >> 1;
             } else {
-                iy = oy[i], ix = ox[i];
+                iy = oy[jj], ix = ox[jj];
             }
-            v[i] = ok ? *reinterpret_cast<const uint4*>(p.x + ((nbase[i] + (long)iy * p.Win + ix) << p.cin_log2) + ci)
-                      : make_uint4(0, 0, 0, 0);
+            const void* src = ok ? (const void*)(p.x + ((nbase[jj] + (long)iy * p.Win + ix) << p.cin_log2) + ci)
+                                 : (const void*)g_zero16;
+            glds16(src, tile + (wave * 4 + jj) * 1024);
         }
-    }
-    __device__ __forceinline__ void store(char* tile, int tid) const {
-        const int c = tid & 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + lds_off((tid >> 3) + 32 * i, c)) = v[i];
     }
 };
 
@@ -101,28 +98,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     ConvAStage sa;
-    RowMajorStage sb;
-    sa.init(p, bm0, tid);
+    sa.init(p, bm0, wave, lane);
     const int nt = (p.K + BK - 1) / BK;
-    sa.load(p, 0, tid);
-    sb.load(p.w, p.K, p.Cout, p.K, bn0, 0, tid);
-    sa.store(smem, tid);
-    sb.store(smem + TILE_BYTES, tid);
-    __syncthreads();
+    sa.issue(p, 0, smem, wave);
+    stage<false>(p.w, p.K, p.Cout, p.K, bn0, 0, smem + TILE_BYTES, wave, lane);
     for (int t = 0; t < nt; ++t) {
         char* cur = smem + (t & 1) * (2 * TILE_BYTES);
         char* nxt = smem + ((t + 1) & 1) * (2 * TILE_BYTES);
-        const bool more = t + 1 < nt;
-        if (more) {
-            sa.load(p, (t + 1) * BK, tid);
-            sb.load(p.w, p.K, p.Cout, p.K, bn0, (t + 1) * BK, tid);
-        }
-        mma_tile(cur, cur + TILE_BYTES, acc, wm, wn, lane);
-        if (more) {
-            sa.store(nxt, tid);
-            sb.store(nxt + TILE_BYTES, tid);
-        }
         __syncthreads();
+        if (t + 1 < nt) {
+            sa.issue(p, (t + 1) * BK, nxt, wave);
+            stage<false>(p.w, p.K, p.Cout, p.K, bn0, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+        }
+        mma_tile<false, false>(cur, cur + TILE_BYTES, acc, wm, wn, lane);
     }
     const int frow = lane & 31, fh = lane >> 5;
 #pragma unroll

@@ -9,15 +9,14 @@
 //   dX = dY W                   : A = dY [M,N'] row-major, B = W [N'(red)][K(out)] k-major (AKM=0,BKM=1)
 //   dW = dY^T X                 : A = dY [M(red)][N(out)] k-major, B = X [M(red)][K(out)] k-major (AKM=1,BKM=1)
 //
-// so neither weights nor activations ever need a transposed copy in HBM: k-major tiles are
-// transposed in registers (8x4 bf16 blocks, v_perm-class ops) on their way into LDS.
+// so neither weights nor activations ever need a transposed copy in HBM: k-major tiles are copied as they
+// are and transposed by the LDS transpose read (ds_read_b64_tr_b16) when fragments are formed (gemm_core.h).
 //
 // Tiling for gfx950: 128x128x64 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 as
 // 2x2 v_mfma_f32_32x32x16_bf16 tiles (fp32 accumulate).  LDS holds A and B tiles as rows of
 // 64 bf16 (128 B) with 16-B chunks XOR-swizzled by ((row>>1)&7): conflict-free for the
-// ds_read_b128 lane groups of the 32x32 fragment read and for the 8-lane ds_write_b128 /
-// 16-lane ds_write_b64 groups of the staging writes.  Double-buffered LDS + register
-// prefetch: one barrier per K tile.  MFMA operands are swapped (a=B-frag, b=A-frag) so that
+// ds_read_b128 lane groups of the 32x32 fragment read.  Tiles are filled by LDS-DMA
+// (global_load_lds_dwordx4), double buffered: one barrier per K tile.  MFMA operands are swapped (a=B-frag, b=A-frag) so that
 // each lane ends up with 4 consecutive n for one m: 16-B epilogue loads/stores.
 // Roofline: bf16 MFMA (2.5 PFLOP/s dense); algorithmic FLOPs = 2*M*N*K.
 #include "gemm_core.h"
@@ -83,31 +82,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    typename StageSel<AKM>::type sa;
-    typename StageSel<BKM>::type sb;
-
+    // LDS-DMA pipeline, one barrier per K tile: the barrier (with the compiler's vmcnt(0) in front of it) makes
+    // tile t visible to every wave and proves everyone is done reading the buffer tile t+1 is about to overwrite.
     if (nt > 0) {
-        sa.load(A, p.lda, p.M, p.K, bm0, kt0 * BK, tid);
-        sb.load(B, p.ldb, p.N, p.K, bn0, kt0 * BK, tid);
-        sa.store(smem, tid);
-        sb.store(smem + TILE_BYTES, tid);
+        stage<AKM>(A, p.lda, p.M, p.K, bm0, kt0 * BK, smem, wave, lane);
+        stage<BKM>(B, p.ldb, p.N, p.K, bn0, kt0 * BK, smem + TILE_BYTES, wave, lane);
     }
-    __syncthreads();
-
     for (int t = 0; t < nt; ++t) {
         char* cur = smem + (t & 1) * (2 * TILE_BYTES);
         char* nxt = smem + ((t + 1) & 1) * (2 * TILE_BYTES);
-        const bool more = (t + 1 < nt);
-        if (more) {
-            sa.load(A, p.lda, p.M, p.K, bm0, (kt0 + t + 1) * BK, tid);
-            sb.load(B, p.ldb, p.N, p.K, bn0, (kt0 + t + 1) * BK, tid);
-        }
-        mma_tile(cur, cur + TILE_BYTES, acc, wm, wn, lane);
-        if (more) {
-            sa.store(nxt, tid);
-            sb.store(nxt + TILE_BYTES, tid);
-        }
         __syncthreads();
+        if (t + 1 < nt) {
+            stage<AKM>(A, p.lda, p.M, p.K, bm0, (kt0 + t + 1) * BK, nxt, wave, lane);
+            stage<BKM>(B, p.ldb, p.N, p.K, bn0, (kt0 + t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+        }
+        mma_tile<AKM, BKM>(cur, cur + TILE_BYTES, acc, wm, wn, lane);
     }
 
     const int frow = lane & 31, fh = lane >> 5;

@@ -1,5 +1,21 @@
-// Shared tile machinery of the bf16 MFMA kernels (gemm.hip, conv.hip): 128x128x64 block tile, LDS tiles of
-// 128 rows x 64 bf16 with 16-B chunks XOR-swizzled by ((row>>1)&7), 2x2 waves each 2x2 v_mfma_f32_32x32x16_bf16.
+// Shared tile machinery of the bf16 MFMA kernels (gemm.hip, conv.hip) for gfx950.
+//
+// Block tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves in 2x2, each wave 64x64 as 2x2
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Both operand tiles are 16 KiB in LDS and are filled by
+// LDS-DMA (global_load_lds_dwordx4: 16 B per lane, no VGPR round trip, no ds_write).  The DMA destination is
+// lane-linear (1 KiB per wave-instruction), so the bank-conflict swizzle is applied to the per-lane SOURCE
+// address and again on the fragment read (guide rule 21):
+//
+//   row-major operand  [rows][K]  -> LDS [128 rows][64 k] (128-B rows), 16-B chunk ^= (row>>1)&7,
+//                                    fragment = one ds_read_b128 (8 consecutive k of one row);
+//   k-major operand    [K][rows]  -> LDS [64 k][128 rows] (256-B rows, i.e. the global layout as is),
+//                                    64-B block ^= (k&3), fragment = two ds_read_b64_tr_b16 (the hardware
+//                                    transpose read: lane t of a 16-lane group receives src[4j+(t>>2)][t&3],
+//                                    j=0..3 -- verified on hardware by tools/gpu_probe.py), so dX / dW GEMMs need
+//                                    neither transposed copies in HBM nor register transposes.
+//
+// Out-of-range chunks (row >= rows, k >= K) read a 16-byte zero block instead: the DMA cannot be predicated per
+// lane without leaving stale LDS bytes.
 #pragma once
 #include "common.h"
 
@@ -8,94 +24,88 @@ namespace mmvid_core {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
 
-__device__ __forceinline__ int lds_off(int row, int chunk) {  // byte offset inside a tile
-    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+static __device__ uint4 g_zero16[1];  // source of out-of-range chunks (zero-initialised)
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)lds_dst_wave_uniform, 16, 0, 0);
 }
 
-// Row-major operand: tile rows [r0, r0+128) x k [k0, k0+64).  Thread t owns chunk c = t&7 of rows
-// (t>>3) + 32*i, i = 0..3.
-struct RowMajorStage {
-    uint4 v[4];
-    __device__ __forceinline__ void load(const bf16_t* base, long ld, int rows, int K, int r0, int k0, int tid) {
-        const int c = tid & 7;
-        const int k = k0 + c * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + (tid >> 3) + 32 * i;
-            if (r < rows && k < K)
-                v[i] = *reinterpret_cast<const uint4*>(base + (long)r * ld + k);
-            else
-                v[i] = make_uint4(0, 0, 0, 0);
-        }
-    }
-    __device__ __forceinline__ void store(char* tile, int tid) const {
-        const int c = tid & 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (tid >> 3) + 32 * i;
-            *reinterpret_cast<uint4*>(tile + lds_off(r, c)) = v[i];
-        }
-    }
-};
+// ---- row-major operand -------------------------------------------------------------------------------------
+__device__ __forceinline__ int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// k-major operand stored [K][rows]: tile k [k0,k0+64) x rows [r0,r0+128).  Thread t owns the 4(k) x 8(row)
-// block  half = t&1 (k sub-block), kc = (t>>1)&7 (k chunk), nb = t>>4 (row block of 8).
-struct KMajorStage {
-    uint4 v[4];
-    __device__ __forceinline__ void load(const bf16_t* base, long ld, int rows, int K, int r0, int k0, int tid) {
-        const int half = tid & 1, kc = (tid >> 1) & 7, nb = tid >> 4;
-        const int r = r0 + nb * 8;
+// Issue the 4 DMA pieces this wave owns of a row-major tile: rows [r0, r0+128) x k [k0, k0+64) of base[rows][ld].
+__device__ __forceinline__ void stage_rowmajor(const bf16_t* base, long ld, int rows, int K, int r0, int k0, char* tile,
+                                               int wave, int lane) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + kc * 8 + half * 4 + q;
-            if (k < K && r < rows)
-                v[q] = *reinterpret_cast<const uint4*>(base + (long)k * ld + r);
-            else
-                v[q] = make_uint4(0, 0, 0, 0);
-        }
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = wave * 4 + jj;
+        const int row = j * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int gr = r0 + row, k = k0 + c * 8;
+        const void* src = (gr < rows && k < K) ? (const void*)(base + (long)gr * ld + k) : (const void*)g_zero16;
+        glds16(src, tile + j * 1024);
     }
-    __device__ __forceinline__ void store(char* tile, int tid) const {
-        const int half = tid & 1, kc = (tid >> 1) & 7, nb = tid >> 4;
-        const uint32_t w[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w},
-                                  {v[1].x, v[1].y, v[1].z, v[1].w},
-                                  {v[2].x, v[2].y, v[2].z, v[2].w},
-                                  {v[3].x, v[3].y, v[3].z, v[3].w}};
+}
+__device__ __forceinline__ bf16x8_t frag_rowmajor(const char* tile, int row, int s, int fh) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + rm_off(row, 2 * s + fh));
+}
+
+// ---- k-major operand ---------------------------------------------------------------------------------------
+// tile k [k0, k0+64) x rows [r0, r0+128) of base[K][ld]
+__device__ __forceinline__ void stage_kmajor(const bf16_t* base, long ld, int rows, int K, int r0, int k0, char* tile,
+                                             int wave, int lane) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {  // row pair (2p, 2p+1) of the 8-row block
-            uint2 ev, od;
-            ev.x = (w[0][p] & 0xffffu) | (w[1][p] << 16);
-            ev.y = (w[2][p] & 0xffffu) | (w[3][p] << 16);
-            od.x = (w[0][p] >> 16) | (w[1][p] & 0xffff0000u);
-            od.y = (w[2][p] >> 16) | (w[3][p] & 0xffff0000u);
-            const int re = nb * 8 + 2 * p;
-            *reinterpret_cast<uint2*>(tile + lds_off(re, kc) + half * 8) = ev;
-            *reinterpret_cast<uint2*>(tile + lds_off(re + 1, kc) + half * 8) = od;
-        }
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = wave * 4 + jj;
+        const int kr = j * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((kr & 3) << 2);  // logical 16-B chunk (8 rows) that lands in slot lane&15
+        const int k = k0 + kr, r = r0 + c * 8;
+        const void* src = (k < K && r < rows) ? (const void*)(base + (long)k * ld + r) : (const void*)g_zero16;
+        glds16(src, tile + j * 1024);
     }
-};
+}
+// 8 consecutive k (k-step s of 16, half fh) for row `rowbase + (lane&31)`: two transpose reads 4 k-rows apart.
+__device__ __forceinline__ bf16x8_t frag_kmajor(const char* tile, int rowbase, int s, int lane) {
+    const int G = lane >> 4, si = lane & 15;
+    const int kk = 16 * s + 8 * (G >> 1) + (si >> 2);
+    const int mbyte = (rowbase + 16 * (G & 1) + 4 * (si & 3)) * 2;
+    const char* p = tile + kk * 256 + (mbyte ^ ((kk & 3) << 6));
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)p);
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(p + 1024));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 template <bool KM>
-struct StageSel {
-    using type = RowMajorStage;
-};
-template <>
-struct StageSel<true> {
-    using type = KMajorStage;
-};
+__device__ __forceinline__ void stage(const bf16_t* base, long ld, int rows, int K, int r0, int k0, char* tile, int wave,
+                                      int lane) {
+    if constexpr (KM)
+        stage_kmajor(base, ld, rows, K, r0, k0, tile, wave, lane);
+    else
+        stage_rowmajor(base, ld, rows, K, r0, k0, tile, wave, lane);
+}
+template <bool KM>
+__device__ __forceinline__ bf16x8_t frag(const char* tile, int rowbase, int s, int lane) {
+    if constexpr (KM)
+        return frag_kmajor(tile, rowbase, s, lane);
+    else
+        return frag_rowmajor(tile, rowbase + (lane & 31), s, lane >> 5);
+}
 
-
-// One 64-deep K tile: acc[i][j] (+)= B-frag(j) x A-frag(i)  (operands swapped: lane gets 4 consecutive n).
+// One 64-deep K tile: acc[i][j] (+)= B-frag(j) x A-frag(i)  (operands swapped: a lane gets 4 consecutive n).
+template <bool AKM, bool BKM>
 __device__ __forceinline__ void mma_tile(const char* At, const char* Bt, f32x16 (&acc)[2][2], int wm, int wn, int lane) {
-    const int frow = lane & 31, fh = lane >> 5;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int chunk = 2 * s + fh;
         bf16x8_t af[2], bfr[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            af[i] = *reinterpret_cast<const bf16x8_t*>(At + lds_off(wm * 64 + i * 32 + frow, chunk));
-            bfr[i] = *reinterpret_cast<const bf16x8_t*>(Bt + lds_off(wn * 64 + i * 32 + frow, chunk));
+            af[i] = frag<AKM>(At, wm * 64 + i * 32, s, lane);
+            bfr[i] = frag<BKM>(Bt, wn * 64 + i * 32, s, lane);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
