@@ -57,7 +57,7 @@ int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t l
                         const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
                         int add_into_dx, float* dw, float* db, void* stream);
 /* GroupNorm(32, eps) [+ swish] on NHWC: taming/modules/diffusionmodules/model.py:38-42, 33-35.
- * stats_scratch: fp32 [N * 64 * (1 + ceil(hw / 256))]; deterministic (fixed-order reductions, no atomics). */
+ * stats_scratch: fp32 [N * (2*C + 64 * ceil(hw / 256))]; deterministic (fixed-order reductions, no atomics). */
 int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, int C, const float* w,
                                const float* b, float eps, int swish, float* stats_scratch, void* y_bf16,
                                float* y_f32, void* stream);
@@ -144,6 +144,34 @@ int mmvid_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int Cuse,
 /* single-head spatial attention of AttnBlock (model.py:180-205): q,k,v NHWC bf16 [N, HW, C] -> o bf16. */
 int mmvid_spatial_attention(const void* q, const void* k, const void* v, int N, int HW, int C, float scale,
                             float* scores_scratch, void* out_bf16, void* stream);
+
+/* ---- native op-list executor for the VQGAN encoder / decoder (model.py:439-466, 551-582; vae.py:38-56): the host
+ * plans the op sequence once per input shape, every call is then one host->native transition.  Offsets are bytes
+ * into `arena` (-1 = unused); w/b/ext_* are device pointers. */
+enum {
+    MMVID_VQOP_IMG2NHWC8 = 0, /* ext_in img [N,3,H,W] f32 -> out_bf16 [N,H,W,8]                                  */
+    MMVID_VQOP_CONV = 1,      /* in0 x [N,H,W,C] bf16, w, b, Cout, mode; in1 residual (flags&1: f32); flags&2 clamp01 */
+    MMVID_VQOP_GROUPNORM = 2, /* in0 [N,H,W,C] (flags&1: f32), w, b, eps, mode = swish, scratch = stats           */
+    MMVID_VQOP_CAST = 3,      /* in0 f32 -> out_bf16, N*H*W*C elements                                           */
+    MMVID_VQOP_SPATIAL_ATTN = 4, /* in0,in1,in2 = q,k,v [N,H*W,C] bf16, eps = scale, scratch                        */
+    MMVID_VQOP_VQ_ARGMIN = 5, /* in0 z [N*H*W, C] f32, w = codebook [Cout, C], b = ee -> ext_out int64            */
+    MMVID_VQOP_GATHER = 6,    /* ext_in idx int64 [N*H*W], w = table [Cout, C] f32 -> out_bf16 [N,H,W,C]           */
+    MMVID_VQOP_NHWC2NCHW = 7  /* in0 [N,H,W,C] f32 -> ext_out [N,Cout,H,W] f32                                    */
+};
+typedef struct {
+    int32_t op, mode;
+    int32_t N, H, W, C;
+    int32_t Cout, flags;
+    int64_t in0, in1, in2;
+    int64_t out_bf16, out_f32, scratch;
+    const void* w;
+    const float* b;
+    const void* ext_in;
+    void* ext_out;
+    float eps;
+    int32_t pad;
+} mmvid_vqgan_op_t;
+int mmvid_vqgan_run(const mmvid_vqgan_op_t* ops, int nops, void* arena, void* stream);
 
 /* hardware probe (tools/gpu_probe.py): which = 0 -> ds_read_b64_tr_b16 lane layout. */
 int mmvid_probe(int which, const void* in, void* out, void* stream);

@@ -26,6 +26,13 @@ class TowerCfg(Structure):
                 ('c0', I), ('r1', I), ('c1', I), ('ln_eps', F)]
 
 
+class VqganOp(Structure):
+    _fields_ = [('op', c_int32), ('mode', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32), ('C', c_int32),
+                ('Cout', c_int32), ('flags', c_int32), ('in0', I64), ('in1', I64), ('in2', I64), ('out_bf16', I64),
+                ('out_f32', I64), ('scratch', I64), ('w', P), ('b', P), ('ext_in', P), ('ext_out', P), ('eps', F),
+                ('pad', c_int32)]
+
+
 # name -> argtypes (all return int unless noted)
 SIGNATURES = {
     'mmvid_vq_sqnorm': [P, I, I, P, P],
@@ -54,6 +61,7 @@ SIGNATURES = {
     'mmvid_image_to_nhwc8': [P, I, I, I, P, P],
     'mmvid_nhwc_to_nchw_f32': [P, I, I, I, I, I, P, P],
     'mmvid_spatial_attention': [P, P, P, I, I, I, F, P, P, P],
+    'mmvid_vqgan_run': [POINTER(VqganOp), I, P, P],
     'mmvid_probe': [I, P, P, P],
     'mmvid_prof_begin': [],
     'mmvid_prof_end': [P, P, P, I],

@@ -203,23 +203,32 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
     }
 }
 
-// stats[n][grp][which] = sum over blocks (fixed order) of partial[n][blk][grp][which]
-__global__ void groupnorm_finalize_kernel(const float* __restrict__ partial, int nblk, int total,
-                                          float* __restrict__ stats) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N*64
-    if (i >= total) return;
-    const int n = i >> 6, r = i & 63;
-    float a = 0.f;
-    for (int b = 0; b < nblk; ++b) a += partial[((long)n * nblk + b) * 64 + r];
-    stats[i] = a;
+// Per (image, channel) affine of the normalisation: y = x*a + b with a = rstd*w, b = bias - mean*a.  Group sums are
+// the fixed-order sums over blocks of partial[n][blk][grp][which].  ab[n][C][2].
+__global__ void groupnorm_finalize_kernel(const float* __restrict__ partial, int nblk, int N, int C, float cnt,
+                                          float eps, const float* __restrict__ w, const float* __restrict__ b,
+                                          float* __restrict__ ab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N*C
+    if (i >= N * C) return;
+    const int n = i / C, ch = i - n * C;
+    const int grp = ch / (C / 32);
+    float sm = 0.f, sq = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        const float* p = partial + ((long)n * nblk + k) * 64 + grp * 2;
+        sm += p[0], sq += p[1];
+    }
+    const float mu = sm / cnt;
+    float var = sq / cnt - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    const float a = rsqrtf(var + eps) * w[ch];
+    ab[2 * (long)i] = a;
+    ab[2 * (long)i + 1] = b[ch] - mu * a;
 }
 
-// apply: y = swish?( (x-mean)*rstd*w + b ) -> bf16 NHWC (and/or f32).  8 channels per thread.
+// apply: y = swish?(x*a + b) -> bf16 NHWC (and/or f32).  8 channels per thread, 16-B accesses.
 template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restrict__ x, long hw, int C,
-                                                              const float* __restrict__ stats,
-                                                              const float* __restrict__ w,
-                                                              const float* __restrict__ b, float eps, int swish,
+                                                              const float* __restrict__ ab, int swish,
                                                               bf16_t* __restrict__ y_bf16,
                                                               float* __restrict__ y_f32, long total_chunks) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -228,21 +237,16 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
     const int cc = (int)(t % cchunks);
     const long pix = t / cchunks;  // n*hw + p
     const int n = (int)(pix / hw);
-    const int cpg = C / 32;
-    const float cnt = (float)hw * (float)cpg;
     float f[8];
     load8<T>(x + pix * C + cc * 8, f);
+    const float4* q = reinterpret_cast<const float4*>(ab + ((long)n * C + cc * 8) * 2);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const float av[8] = {q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.z};
+    const float bv[8] = {q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.y, q3.w};
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int ch = cc * 8 + e;
-        const int grp = ch / cpg;
-        const float sm = stats[((long)n * 32 + grp) * 2], sq = stats[((long)n * 32 + grp) * 2 + 1];
-        const float mu = sm / cnt;
-        float var = sq / cnt - mu * mu;
-        var = var < 0.f ? 0.f : var;
-        const float rs = rsqrtf(var + eps);
-        float v = (f[e] - mu) * rs * w[ch] + b[ch];
+        float v = f[e] * av[e] + bv[e];
         if (swish) v = v * sigmoidf_(v);
         o[e] = v;
     }
@@ -287,8 +291,8 @@ extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x
     return MMVID_OK;
 }
 
-// x NHWC [N, hw, C] (bf16 when x_is_bf16 else f32).  stats_scratch: fp32 [N*64*(1 + ceil(hw/256))]
-// (final sums first, then the per-block partials).  Deterministic: no atomics anywhere.
+// x NHWC [N, hw, C] (bf16 when x_is_bf16 else f32).  stats_scratch: fp32 [N*(2*C + 64*ceil(hw/256))]
+// (per-channel affine first, then the per-block partial sums).  Deterministic: no atomics anywhere.
 extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, int C, const float* w,
                                           const float* b, float eps, int swish, float* stats_scratch, void* y_bf16,
                                           float* y_f32, void* stream) {
@@ -299,7 +303,8 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
     const int pix_per_block = 256;
     const int nblk = cdiv(hw, pix_per_block);
     dim3 g1(nblk, N);
-    float* partial = stats_scratch + (long)N * 64;
+    float* ab = stats_scratch;                       // [N][C][2]
+    float* partial = stats_scratch + (long)N * C * 2;  // [N][nblk][32][2]
     const long chunks = (long)N * hw * (C / 8);
     if (x_is_bf16)
         hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)x, (long)hw, C,
@@ -307,15 +312,14 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
     else
         hipLaunchKernelGGL(groupnorm_stats_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (long)hw, C,
                            pix_per_block, partial);
-    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv((long)N * 64, 256)), dim3(256), 0, s, partial, nblk, N * 64,
-                       stats_scratch);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, s, partial, nblk, N, C,
+                       (float)hw * (float)(C / 32), eps, w, b, ab);
     if (x_is_bf16)
         hipLaunchKernelGGL(groupnorm_apply_kernel<bf16_t>, dim3(cdiv(chunks, 256)), dim3(256), 0, s,
-                           (const bf16_t*)x, (long)hw, C, stats_scratch, w, b, eps, swish, (bf16_t*)y_bf16, y_f32,
-                           chunks);
+                           (const bf16_t*)x, (long)hw, C, ab, swish, (bf16_t*)y_bf16, y_f32, chunks);
     else
         hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3(cdiv(chunks, 256)), dim3(256), 0, s, (const float*)x,
-                           (long)hw, C, stats_scratch, w, b, eps, swish, (bf16_t*)y_bf16, y_f32, chunks);
+                           (long)hw, C, ab, swish, (bf16_t*)y_bf16, y_f32, chunks);
     MMVID_LAUNCH_CHECK("groupnorm");
     return MMVID_OK;
 }

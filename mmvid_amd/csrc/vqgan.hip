@@ -1,0 +1,61 @@
+// Native executor for the VQGAN encoder / decoder op sequence (taming Encoder/Decoder.forward,
+// model.py:439-466, 551-582; vae.py:38-56).  The host builds the op list once per input shape
+// (mmvid_amd/vae.py) -- convs, GroupNorm+swish, casts, spatial attention, VQ lookup, codebook gather, layout
+// kernels, all on offsets into one arena -- and each call is then a single host->native transition that
+// enqueues ~190 kernels back to back (the Python-per-op version was host-bound: 12 ms of launch overhead for
+// 8.5 ms of GPU work per 48-frame encode).  No allocation, no sync: graph-capturable.
+#include "../../include/mmvid_hip.h"
+#include "common.h"
+
+namespace {
+inline char* at(void* arena, int64_t off) { return off < 0 ? nullptr : (char*)arena + off; }
+}  // namespace
+
+extern "C" int mmvid_vqgan_run(const mmvid_vqgan_op_t* ops, int nops, void* arena, void* stream) {
+    MMVID_REQUIRE(ops && arena && nops >= 0, "vqgan_run: bad arguments");
+    for (int i = 0; i < nops; ++i) {
+        const mmvid_vqgan_op_t& o = ops[i];
+        int rc = 0;
+        switch (o.op) {
+            case MMVID_VQOP_IMG2NHWC8:
+                rc = mmvid_image_to_nhwc8((const float*)o.ext_in, o.N, o.H, o.W, at(arena, o.out_bf16), stream);
+                break;
+            case MMVID_VQOP_CONV:
+                rc = mmvid_conv2d_nhwc(o.mode, at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
+                                       (o.flags & 1) ? nullptr : at(arena, o.in1),
+                                       (o.flags & 1) ? (const float*)at(arena, o.in1) : nullptr, (o.flags >> 1) & 1,
+                                       at(arena, o.out_bf16), (float*)at(arena, o.out_f32), stream);
+                break;
+            case MMVID_VQOP_GROUPNORM:
+                rc = mmvid_groupnorm_swish_nhwc(at(arena, o.in0), (o.flags & 1) ? 0 : 1, o.N, (int64_t)o.H * o.W, o.C,
+                                                (const float*)o.w, o.b, o.eps, o.mode, (float*)at(arena, o.scratch),
+                                                at(arena, o.out_bf16), (float*)at(arena, o.out_f32), stream);
+                break;
+            case MMVID_VQOP_CAST:
+                rc = mmvid_cast_f32_to_bf16((const float*)at(arena, o.in0), at(arena, o.out_bf16),
+                                            (int64_t)o.N * o.H * o.W * o.C, stream);
+                break;
+            case MMVID_VQOP_SPATIAL_ATTN:
+                rc = mmvid_spatial_attention(at(arena, o.in0), at(arena, o.in1), at(arena, o.in2), o.N, o.H * o.W, o.C,
+                                             o.eps, (float*)at(arena, o.scratch), at(arena, o.out_bf16), stream);
+                break;
+            case MMVID_VQOP_VQ_ARGMIN:
+                rc = mmvid_vq_argmin_l2((const float*)at(arena, o.in0), (const float*)o.w, o.b, (int64_t)o.N * o.H * o.W,
+                                        o.Cout, o.C, (int64_t*)o.ext_out, nullptr, stream);
+                break;
+            case MMVID_VQOP_GATHER:
+                rc = mmvid_gather_rows((const float*)o.w, o.Cout, (const int64_t*)o.ext_in, (int64_t)o.N * o.H * o.W, o.C,
+                                       nullptr, at(arena, o.out_bf16), stream);
+                break;
+            case MMVID_VQOP_NHWC2NCHW:
+                rc = mmvid_nhwc_to_nchw_f32((const float*)at(arena, o.in0), o.N, o.H, o.W, o.C, o.Cout, (float*)o.ext_out,
+                                            stream);
+                break;
+            default:
+                mmvid_set_error("vqgan_run: unknown op %d at %d", o.op, i);
+                return MMVID_ERR_ARG;
+        }
+        if (rc) return rc;
+    }
+    return MMVID_OK;
+}

@@ -136,7 +136,7 @@ def groupnorm_swish(x, w, b, eps=1e-6, swish=True, out_dtype=bf16):
     """x NHWC [N,H,W,C] bf16 or f32 -> same shape."""
     N, H, W, C = x.shape
     assert x.is_contiguous() and x.dtype in (bf16, f32)
-    stats = torch.empty(N * 64 * (1 + (H * W + 255) // 256), device=x.device, dtype=f32)
+    stats = torch.empty(N * (2 * C + 64 * ((H * W + 255) // 256)), device=x.device, dtype=f32)
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     call('mmvid_groupnorm_swish_nhwc', _p(x), int(x.dtype == bf16), N, H * W, C, _p(w), _p(b), float(eps), int(swish),
          _p(stats), _p(y) if out_dtype == bf16 else None, _p(y) if out_dtype == f32 else None, _stream())
