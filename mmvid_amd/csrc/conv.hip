@@ -83,7 +83,7 @@ struct ConvAStage {
     }
 };
 
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -112,41 +112,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         }
         mma_tile<false, false>(cur, cur + TILE_BYTES, acc, wm, wn, lane);
     }
-    const int frow = lane & 31, fh = lane >> 5;
+    // epilogue through LDS (row-contiguous global traffic; see gemm.hip)
+    float* slab = reinterpret_cast<float*>(smem);
+    const int n = bn0 + 4 * (tid & 31);
+    const bool n_ok = n < p.Cout;
+    const float4 bias4 = (p.bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const long m = bm0 + wm * 64 + i * 32 + frow;
-        if (m >= p.M) continue;
+        __syncthreads();
+        slab_write(acc, i, slab, wm, wn, lane);
+        __syncthreads();
+        float4 v4[8], rf[8];
+        uint2 rb[8];
+        long mrow[8];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 8; ++k) {
+            int r, ml, c;
+            slab_piece(tid, k, i, r, ml, c);
+            mrow[k] = bm0 + ml;
+            const bool ok = n_ok && mrow[k] < p.M;
+            const long o = mrow[k] * p.Cout + n;
+            v4[k] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + c);
+            rf[k] = (p.res_f32 && ok) ? *reinterpret_cast<const float4*>(p.res_f32 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[k] = (p.res_bf16 && ok) ? *reinterpret_cast<const uint2*>(p.res_bf16 + o) : make_uint2(0u, 0u);
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = bn0 + wn * 64 + j * 32 + 8 * q + 4 * fh;
-                if (n >= p.Cout) continue;
-                float v[4];
+        for (int k = 0; k < 8; ++k) {
+            if (!n_ok || mrow[k] >= p.M) continue;
+            float v[4] = {v4[k].x + bias4.x + rf[k].x + bf_lo(rb[k].x), v4[k].y + bias4.y + rf[k].y + bf_hi(rb[k].x),
+                          v4[k].z + bias4.z + rf[k].z + bf_lo(rb[k].y), v4[k].w + bias4.w + rf[k].w + bf_hi(rb[k].y)};
+            if (p.clamp01) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                if (p.bias) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += b4.x, v[1] += b4.y, v[2] += b4.z, v[3] += b4.w;
-                }
-                const long o = m * p.Cout + n;
-                if (p.res_bf16) {
-                    const uint2 r = *reinterpret_cast<const uint2*>(p.res_bf16 + o);
-                    v[0] += bf_lo(r.x), v[1] += bf_hi(r.x), v[2] += bf_lo(r.y), v[3] += bf_hi(r.y);
-                }
-                if (p.res_f32) {
-                    const float4 r = *reinterpret_cast<const float4*>(p.res_f32 + o);
-                    v[0] += r.x, v[1] += r.y, v[2] += r.z, v[3] += r.w;
-                }
-                if (p.clamp01) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (fminf(fmaxf(v[e], -1.f), 1.f) + 1.f) * 0.5f;
-                }
-                if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
-                if (p.out_bf16)
-                    *reinterpret_cast<uint2*>(p.out_bf16 + o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                for (int e = 0; e < 4; ++e) v[e] = (fminf(fmaxf(v[e], -1.f), 1.f) + 1.f) * 0.5f;
             }
+            const long o = mrow[k] * p.Cout + n;
+            if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.out_bf16) *reinterpret_cast<uint2*>(p.out_bf16 + o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
     }
 }
 

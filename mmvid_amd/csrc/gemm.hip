@@ -56,7 +56,7 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 }
 
 template <bool AKM, bool BKM>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A tile | B tile]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -99,72 +99,70 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         mma_tile<AKM, BKM>(cur, cur + TILE_BYTES, acc, wm, wn, lane);
     }
 
-    const int frow = lane & 31, fh = lane >> 5;
-    // ---- epilogue: lane holds, for m = l&31, n = 8q + 4*(l>>5) + (0..3), q = 0..3 ----
+    // ---- epilogue through LDS: every global read/write below is row-contiguous (16 B per lane, 512 B per row).
+    // Thread t owns column n = bn0 + 4*(t&31) of rows (t>>5)+8k of each 64-row slab; all its reads are issued
+    // before any is consumed.
+    float* slab = reinterpret_cast<float*>(smem);
     const long cb = (long)batch * p.strideC;
+    const int n = bn0 + 4 * (tid & 31);
+    const bool n_ok = n < p.N;
+    const bool use_bias = p.bias && (p.splitk == 1 || ks == 0);
+    const float4 bias4 = (use_bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* addbase = p.residual ? p.residual + cb
+                                      : ((p.accumulate && !p.partial && p.splitk == 1) ? p.out_f32 + cb : nullptr);
+    const long ldadd = p.residual ? p.ldr : p.ldc;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int m = bm0 + wm * 64 + i * 32 + frow;
-        if (m >= p.M) continue;
+        __syncthreads();
+        slab_write(acc, i, slab, wm, wn, lane);
+        __syncthreads();
+        float4 v4[8], add4[8];
+        uint2 pre2[8];
+        int mrow[8];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int k = 0; k < 8; ++k) {
+            int r, ml, c;
+            slab_piece(tid, k, i, r, ml, c);
+            mrow[k] = bm0 + ml;
+            const bool ok = n_ok && mrow[k] < p.M;
+            v4[k] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + c);
+            add4[k] = (addbase && ok) ? *reinterpret_cast<const float4*>(addbase + (long)mrow[k] * ldadd + n)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre2[k] = (p.dact_pre && ok) ? *reinterpret_cast<const uint2*>(p.dact_pre + cb + (long)mrow[k] * p.ldp + n)
+                                         : make_uint2(0u, 0u);
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = bn0 + wn * 64 + j * 32 + 8 * q + 4 * fh;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
-                if (p.partial) {
-                    *reinterpret_cast<float4*>(p.partial + ((long)ks * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-                    continue;
-                }
-                if (p.splitk > 1) {
-                    float* o = p.out_f32 + cb + (long)m * p.ldc + n;
-                    if (p.bias && ks == 0) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-                        v[0] += b4.x, v[1] += b4.y, v[2] += b4.z, v[3] += b4.w;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, v[e]);
-                    continue;
-                }
-                if (p.bias) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += b4.x, v[1] += b4.y, v[2] += b4.z, v[3] += b4.w;
-                }
-                if (p.save_pre) {
-                    *reinterpret_cast<uint2*>(p.save_pre + cb + (long)m * p.ldp + n) =
-                        make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                }
-                if (p.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-                }
-                if (p.dact_pre) {
-                    const uint2 pr = *reinterpret_cast<const uint2*>(p.dact_pre + cb + (long)m * p.ldp + n);
-                    v[0] *= quick_gelu_grad(bf_lo(pr.x));
-                    v[1] *= quick_gelu_grad(bf_hi(pr.x));
-                    v[2] *= quick_gelu_grad(bf_lo(pr.y));
-                    v[3] *= quick_gelu_grad(bf_hi(pr.y));
-                }
-                if (p.residual) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(p.residual + cb + (long)m * p.ldr + n);
-                    v[0] += r4.x, v[1] += r4.y, v[2] += r4.z, v[3] += r4.w;
-                }
-                if (p.out_f32) {
-                    float4* o = reinterpret_cast<float4*>(p.out_f32 + cb + (long)m * p.ldc + n);
-                    if (p.accumulate) {
-                        const float4 o4 = *o;
-                        v[0] += o4.x, v[1] += o4.y, v[2] += o4.z, v[3] += o4.w;
-                    }
-                    *o = make_float4(v[0], v[1], v[2], v[3]);
-                }
-                if (p.out_bf16) {
-                    *reinterpret_cast<uint2*>(p.out_bf16 + cb + (long)m * p.ldc + n) =
-                        make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                }
+        for (int k = 0; k < 8; ++k) {
+            const int m = mrow[k];
+            if (!n_ok || m >= p.M) continue;
+            float v[4] = {v4[k].x * p.alpha + bias4.x, v4[k].y * p.alpha + bias4.y, v4[k].z * p.alpha + bias4.z,
+                          v4[k].w * p.alpha + bias4.w};
+            if (p.partial) {
+                *reinterpret_cast<float4*>(p.partial + ((long)ks * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                continue;
             }
+            if (p.splitk > 1) {
+                float* o = p.out_f32 + cb + (long)m * p.ldc + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, v[e]);
+                continue;
+            }
+            if (p.save_pre)
+                *reinterpret_cast<uint2*>(p.save_pre + cb + (long)m * p.ldp + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            }
+            if (p.dact_pre) {
+                v[0] *= quick_gelu_grad(bf_lo(pre2[k].x));
+                v[1] *= quick_gelu_grad(bf_hi(pre2[k].x));
+                v[2] *= quick_gelu_grad(bf_lo(pre2[k].y));
+                v[3] *= quick_gelu_grad(bf_hi(pre2[k].y));
+            }
+            v[0] += add4[k].x, v[1] += add4[k].y, v[2] += add4[k].z, v[3] += add4[k].w;
+            if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + cb + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.out_bf16)
+                *reinterpret_cast<uint2*>(p.out_bf16 + cb + (long)m * p.ldc + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
         }
     }
 }
@@ -217,7 +215,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
         MMVID_REQUIRE(out_f32 && !out_bf16 && !act && !dact_pre && !save_pre && !residual,
                       "gemm_bf16: split-K supports only fp32 atomic accumulation (+bias)");
     if (dact_pre || save_pre) MMVID_REQUIRE(ldp % 4 == 0, "gemm_bf16: ldp must be a multiple of 4");
-    if (residual) MMVID_REQUIRE(ldr % 4 == 0, "gemm_bf16: ldr must be a multiple of 4");
+    if (residual) MMVID_REQUIRE(ldr % 4 == 0 && !accumulate, "gemm_bf16: ldr must be a multiple of 4; residual and accumulate are exclusive");
     GemmParams p;
     p.A = (const bf16_t*)A, p.B = (const bf16_t*)B;
     p.M = M, p.N = N, p.K = K, p.lda = lda, p.ldb = ldb;

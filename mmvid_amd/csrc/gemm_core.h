@@ -115,4 +115,24 @@ __device__ __forceinline__ void mma_tile(const char* At, const char* Bt, f32x16 
     }
 }
 
+// ---- epilogue staging: one 32-row slab of every wave's accumulators -> LDS [64][SLAB_PITCH] fp32, so that the
+// global reads/writes of the epilogue are row-contiguous (512 B per row) instead of 16-B pieces at a row stride.
+constexpr int SLAB_PITCH = 132;  // floats; +4 keeps the 8-lane ds_write_b128 groups on distinct banks
+__device__ __forceinline__ void slab_write(const f32x16 (&acc)[2][2], int i, float* slab, int wm, int wn, int lane) {
+    const int frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(slab + (wm * 32 + frow) * SLAB_PITCH + wn * 64 + j * 32 + 8 * q + 4 * fh) =
+                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+}
+// piece k (0..7) of thread tid: slab row r, tile-local row m_local (for slab i), tile-local column c
+__device__ __forceinline__ void slab_piece(int tid, int k, int i, int& r, int& m_local, int& c) {
+    const int idx = tid + 256 * k;
+    r = idx >> 5;
+    c = (idx & 31) * 4;
+    m_local = (r >> 5) * 64 + i * 32 + (r & 31);
+}
+
 }  // namespace mmvid_core

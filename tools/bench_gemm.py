@@ -25,26 +25,31 @@ def timeit(fn, iters=20):
     return a.elapsed_time(b) / iters
 
 
-M = 10422
-for name, N, K in (('qkv', 2304, 768), ('out', 768, 768), ('fc', 3072, 768), ('proj', 768, 3072)):
-    X = torch.randn(M, K, device=dev).to(bf)
-    W = (torch.randn(N, K, device=dev) * 0.03).to(bf)
-    dY = torch.randn(M, N, device=dev).to(bf)
-    dW = torch.zeros(N, K, device=dev)
-    fl = 2.0 * M * N * K
-    t = timeit(lambda: ops.gemm(X, W))
-    print(f'{name:5s} fwd  NT {M}x{N}x{K}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
-    t = timeit(lambda: ops.gemm(dY, W, b_kmajor=True))
-    print(f'{name:5s} dX   NN {M}x{K}x{N}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
-    for sk in (1, 2, 4, 8):
-        t = timeit(lambda: ops.gemm_dw(dY, X, dW, splitk=sk))
-        print(f'{name:5s} dW   TN sk={sk} {N}x{K}x{M}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
-for name, N, H, Cin, Cout, mode in (('c128@128', 96, 128, 128, 128, 0), ('c256@32', 96, 32, 256, 256, 0), ('c512@8', 96, 8, 512, 512, 0),
-                                    ('down128', 96, 128, 128, 128, 1), ('conv_in', 96, 128, 8, 128, 0)):
-    x = torch.randn(N, H, H, Cin, device=dev).to(bf)
-    w = (torch.randn(Cout, 9, Cin, device=dev) * 0.03).to(bf)
-    b = torch.zeros(Cout, device=dev)
-    Ho = H // 2 if mode == 1 else H
-    fl = 2.0 * N * Ho * Ho * Cout * 9 * Cin
-    t = timeit(lambda: ops.conv2d_nhwc(x, w, b, mode), 5)
-    print(f'{name:9s} conv N={N} {H}x{H} {Cin}->{Cout}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
+def main():
+    M = 10422
+    for name, N, K in (('qkv', 2304, 768), ('out', 768, 768), ('fc', 3072, 768), ('proj', 768, 3072)):
+        X = torch.randn(M, K, device=dev).to(bf)
+        W = (torch.randn(N, K, device=dev) * 0.03).to(bf)
+        dY = torch.randn(M, N, device=dev).to(bf)
+        dW = torch.zeros(N, K, device=dev)
+        fl = 2.0 * M * N * K
+        t = timeit(lambda: ops.gemm(X, W))
+        print(f'{name:5s} fwd  NT {M}x{N}x{K}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
+        t = timeit(lambda: ops.gemm(dY, W, b_kmajor=True))
+        print(f'{name:5s} dX   NN {M}x{K}x{N}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
+        for sk in (1, 2, 4, 8):
+            t = timeit(lambda: ops.gemm_dw(dY, X, dW, splitk=sk))
+            print(f'{name:5s} dW   TN sk={sk} {N}x{K}x{M}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
+    for name, N, H, Cin, Cout, mode in (('c128@128', 96, 128, 128, 128, 0), ('c256@32', 96, 32, 256, 256, 0), ('c512@8', 96, 8, 512, 512, 0),
+                                        ('down128', 96, 128, 128, 128, 1), ('conv_in', 96, 128, 8, 128, 0)):
+        x = torch.randn(N, H, H, Cin, device=dev).to(bf)
+        w = (torch.randn(Cout, 9, Cin, device=dev) * 0.03).to(bf)
+        b = torch.zeros(Cout, device=dev)
+        Ho = H // 2 if mode == 1 else H
+        fl = 2.0 * N * Ho * Ho * Cout * 9 * Cin
+        t = timeit(lambda: ops.conv2d_nhwc(x, w, b, mode), 5)
+        print(f'{name:9s} conv N={N} {H}x{H} {Cin}->{Cout}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
+
+
+if __name__ == '__main__':
+    main()
