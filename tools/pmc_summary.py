@@ -18,6 +18,7 @@ def main(src, out):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 k = row.get('Kernel_Name', '?')
+                k = k.replace('(anonymous namespace)::', '').replace('void ', '')
                 k = k.split('(')[0][:120]
                 c = row.get('Counter_Name')
                 v = float(row.get('Counter_Value', 0) or 0)
