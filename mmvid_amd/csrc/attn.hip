@@ -1,18 +1,20 @@
-// Multi-head attention core of the CLIP tower, forward and backward, head_dim 64.
+// Multi-head attention core of the CLIP tower, forward and backward, head_dim 64, for gfx950.
 // Replaces nn.MultiheadAttention's softmax(QK^T/8 + mask)V at clip_model.py:217-222 for the three mask
 // shapes the reference builds (clip_model.py:561-578): none, causal (ART-V), and "mask_prev" = up to two
 // query rows that may not look at earlier columns (BERT).  The mask is a predicate, never an L x L tensor.
 //
-// Flash-style, wave64 / MFMA 16x16x32 bf16, everything lane-local in the query (or key) index:
-//   forward : S^T = K Q^T  -> lane holds S[key=4g+r][q=l&15]; online softmax per lane; O^T = V^T P^T.
-//   dQ      : S^T, dP^T = V dO^T, dS^T = P(dP - delta), dQ^T = K^T dS^T        (loop over key tiles)
-//   dK,dV   : S = Q K^T -> lane holds [q=4g+r][key=l&15]; dV^T = dO^T P, dK^T = Q^T dS (loop over q tiles)
+// Flash-style on v_mfma_f32_32x32x16_bf16; a wave owns 32 queries (or 32 keys) and keeps them LANE-LOCAL:
+//   forward : S^T = K Q^T -> lane holds 16 keys x its query (col = lane&31); row max/sum need one shfl_xor(32);
+//             O^T = V^T P^T with P taken straight from the S registers (a fixed key permutation shared with the
+//             V^T fragment), so the online-softmax rescale is lane-local too.
+//   dQ      : S^T, dP^T = V dO^T, dS^T = P (dP - delta), dQ^T = K^T dS^T              (loop over key tiles)
+//   dK, dV  : S = Q K^T -> lane holds 16 queries x its key; dV^T = dO^T P, dK^T = Q^T dS (loop over query tiles)
 // Operands whose reduction index is the sequence position come from [B,H,64,Lp] transposed copies
-// (head_transpose kernel) so every fragment load is an 8/16-byte contiguous read.
-// K/V (or Q/dO) tiles of 64 positions are staged through LDS once per block (4 waves x 16 rows share
-// them), double-buffered with register prefetch; row tiles use the GEMM's XOR swizzle, transposed tiles
-// use 136-byte rows.  Probabilities are exp2 with the 1/sqrt(d)*log2(e) scale folded in; the row
-// statistic saved for backward is lse2 = m + log2(sum).
+// (head_transpose) so every fragment is an 8/16-byte contiguous LDS read.  64-position tiles of K/V (or Q/dO)
+// are staged once per block (4 waves x 32 rows share them), double-buffered with register prefetch; row tiles
+// use the GEMM's XOR swizzle (conflict-free ds_read_b128), transposed tiles 136-byte rows (17*d mod 32:
+// conflict-free ds_read_b64).  exp2 with the 1/sqrt(d)*log2(e) scale folded in; lse2 = m + log2(sum) is kept
+// for the backward.  No atomics: bit-reproducible.
 #include "common.h"
 #include "prof.h"
 
@@ -24,15 +26,17 @@ struct MaskSpec {
 };
 
 __device__ __forceinline__ bool is_masked(const MaskSpec& m, int q, int key, int L) {
-    if (key >= L) return true;
-    if (m.mode == 1) return key > q;
-    if (m.mode == 2) return (q == m.r0 && key < m.c0) || (q == m.r1 && key < m.c1);
-    return false;
+    // branch-free on purpose (bitwise ops, no short circuit): it is evaluated per accumulator element
+    const bool pad = key >= L;
+    const bool causal = (m.mode == 1) & (key > q);
+    const bool rows = (m.mode == 2) & (((q == m.r0) & (key < m.c0)) | ((q == m.r1) & (key < m.c1)));
+    return pad | causal | rows;
 }
 
 constexpr int ROW_TILE_BYTES = 64 * 128;  // [64 pos][64 d] bf16, swizzled 16-B chunks
 constexpr int T_ROW = 136;                // bytes per row of a transposed tile ([64 d][64 pos] + 8 pad)
 constexpr int T_TILE_BYTES = 64 * T_ROW;
+constexpr int ROWS_PER_BLOCK = 128;       // 4 waves x 32
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -68,23 +72,46 @@ __device__ __forceinline__ void t_tile_store(const uint4 (&v)[2], char* tile, in
         *reinterpret_cast<uint2*>(p + 8) = make_uint2(v[i].z, v[i].w);
     }
 }
-// A fragment from a transposed tile: row d, 4 positions at ss*32+4g and 4 at ss*32+16+4g
-__device__ __forceinline__ bf16x8_t t_frag(const char* tile, int d, int ss, int g) {
-    const char* p = tile + d * T_ROW + (ss * 32 + 4 * g) * 2;
+
+// MFMA 32x32x16 operand from a row tile: row `row` (= lane&31 + base), k-step s (16 d), half h
+__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int s, int h) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + lds_off(row, 2 * s + h));
+}
+// MFMA operand from a transposed tile for reduction step m (16 positions) of sub-step ss (32 positions):
+// row d, positions pos(m,h,e) = 32 ss + 16 m + 4 h + (e&3) + 8 (e>>2): two 8-byte reads 16 bytes apart.
+__device__ __forceinline__ bf16x8_t t_frag(const char* tile, int d, int ss, int m, int h) {
+    const char* p = tile + d * T_ROW + (32 * ss + 16 * m + 4 * h) * 2;
     const uint2 lo = *reinterpret_cast<const uint2*>(p);
-    const uint2 hi = *reinterpret_cast<const uint2*>(p + 32);
+    const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
     const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
     return __builtin_bit_cast(bf16x8_t, u);
 }
-__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int ks, int g) {
-    return *reinterpret_cast<const bf16x8_t*>(tile + lds_off(row, 4 * ks + g));
-}
-__device__ __forceinline__ bf16x8_t pack8(const f32x4& a, const f32x4& b) {
-    const uint4 u = make_uint4(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3]));
+// The matching B operand: accumulator registers 8m..8m+7 of a 32x32 tile whose ROW index is the reduction
+// position: row(r, h) = (r&3) + 8 (r>>2) + 4 h  ==  pos(m, h, e) - 32 ss with r = 8 m + e.
+__device__ __forceinline__ bf16x8_t pack_half(const f32x16& a, int m) {
+    const int o = 8 * m;
+    const uint4 u = make_uint4(pack_bf2(a[o], a[o + 1]), pack_bf2(a[o + 2], a[o + 3]), pack_bf2(a[o + 4], a[o + 5]),
+                               pack_bf2(a[o + 6], a[o + 7]));
     return __builtin_bit_cast(bf16x8_t, u);
 }
-__device__ __forceinline__ f32x4 mfma16(bf16x8_t a, bf16x8_t b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma32(bf16x8_t a, bf16x8_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Does any (q, key) pair of a 32x32 sub-tile need the mask predicate?  Wave-uniform.
+__device__ __forceinline__ bool tile_needs_mask(const MaskSpec& m, int q_lane, int key0, int L) {
+    bool need = key0 + 32 > L;
+    if (m.mode == 1) need = need || (key0 + 31 > q_lane);
+    if (m.mode == 2) need = need || q_lane == m.r0 || q_lane == m.r1;
+    return __any(need);
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -93,18 +120,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                                                        float scale_log2, MaskSpec mask, bf16_t* __restrict__ out,
                                                        long ldo, float* __restrict__ lse2) {
     __shared__ __attribute__((aligned(16))) char smem[2][ROW_TILE_BYTES + T_TILE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int q = qt * 64 + wave * 16 + i16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int qt = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    const int q = qt * ROWS_PER_BLOCK + wave * 32 + l32;
     const int qc = q < L ? q : L - 1;
-    const bf16_t* Qp = qkv + ((long)b * L + qc) * ld + h * 64;
-    bf16x8_t qf[2];
+    const bf16_t* Qp = qkv + ((long)b * L + qc) * ld + hd * 64;
+    bf16x8_t qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qp + 32 * ks + 8 * g);
-    const bf16_t* Kbase = qkv + (long)b * L * ld + E + h * 64;
-    const bf16_t* VTb = VT + ((long)(b * H + h) * 64) * Lp;
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(Qp + 16 * s + 8 * h);
+    const bf16_t* Kbase = qkv + (long)b * L * ld + E + hd * 64;
+    const bf16_t* VTb = VT + ((long)(b * H + hd) * 64) * Lp;
     int kv_end = L;
-    if (mask.mode == 1 && qt * 64 + 64 < L) kv_end = qt * 64 + 64;
+    if (mask.mode == 1 && (qt + 1) * ROWS_PER_BLOCK < L) kv_end = (qt + 1) * ROWS_PER_BLOCK;
     const int ntiles = (kv_end + 63) >> 6;
 
     uint4 kr[2], vr[2];
@@ -115,9 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     __syncthreads();
 
     float m = -INFINITY, lsum = 0.f;
-    f32x4 oacc[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) oacc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x16 oacc[2] = {zero16(), zero16()};
 
     for (int t = 0; t < ntiles; ++t) {
         const char* Kt = smem[t & 1];
@@ -129,46 +154,49 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         }
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            f32x4 s[2];
+            const int key0 = t * 64 + 32 * ss;
+            f32x16 s = zero16();
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                s[st] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) s[st] = mfma16(row_frag(Kt, 32 * ss + 16 * st + i16, ks, g), qf[ks], s[st]);
-            }
+            for (int ks = 0; ks < 4; ++ks) s = mfma32(row_frag(Kt, 32 * ss + l32, ks, h), qf[ks], s);
+            mfma_settle(s);
             float mx = -INFINITY;
+            if (tile_needs_mask(mask, q, key0, L)) {
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = t * 64 + 32 * ss + 16 * st + 4 * g + r;
-                    const float v = is_masked(mask, q, key, L) ? -INFINITY : s[st][r] * scale_log2;
-                    s[st][r] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const float v = is_masked(mask, q, key0 + acc_row(r, h), L) ? -INFINITY : s[r] * scale_log2;
+                    s[r] = v;
                     mx = fmaxf(mx, v);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] *= scale_log2;
+                    mx = fmaxf(mx, s[r]);
+                }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = exp2f(m - m_use);
+            const float alpha = fast_exp2(m - m_use);
             float psum = 0.f;
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(s[st][r] - m_use);
-                    s[st][r] = p;
-                    psum += p;
-                }
+            for (int r = 0; r < 16; ++r) {
+                s[r] = fast_exp2(s[r] - m_use);
+                psum += s[r];
+            }
             lsum = lsum * alpha + psum;
             m = m_new;
-            const bf16x8_t pf = pack8(s[0], s[1]);
+            if (!__all(alpha == 1.0f)) {
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) oacc[db][r] *= alpha;
-                oacc[db] = mfma16(t_frag(Vt, 16 * db + i16, ss, g), pf, oacc[db]);
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
             }
+            const bf16x8_t pf[2] = {pack_half(s, 0), pack_half(s, 1)};
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) oacc[dt] = mfma32(t_frag(Vt, 32 * dt + l32, ss, mm, h), pf[mm], oacc[dt]);
         }
         if (more) {
             row_tile_store(kr, smem[(t + 1) & 1], tid);
@@ -176,16 +204,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         }
         __syncthreads();
     }
-    lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
+    mfma_settle(oacc[0]), mfma_settle(oacc[1]);
     if (q < L) {
         const float inv = 1.0f / lsum;
-        bf16_t* op = out + ((long)b * L + q) * ldo + h * 64 + 4 * g;
+        bf16_t* op = out + ((long)b * L + q) * ldo + hd * 64 + 4 * h;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
-            *reinterpret_cast<uint2*>(op + 16 * db) =
-                make_uint2(pack_bf2(oacc[db][0] * inv, oacc[db][1] * inv), pack_bf2(oacc[db][2] * inv, oacc[db][3] * inv));
-        if (g == 0) lse2[((long)b * H + h) * L + q] = m + log2f(lsum);
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4) =
+                    make_uint2(pack_bf2(oacc[dt][4 * g4] * inv, oacc[dt][4 * g4 + 1] * inv),
+                               pack_bf2(oacc[dt][4 * g4 + 2] * inv, oacc[dt][4 * g4 + 3] * inv));
+        if (h == 0) lse2[((long)b * H + hd) * L + q] = m + log2f(lsum);
     }
 }
 
@@ -198,25 +229,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           int E, float scale, float scale_log2, MaskSpec mask,
                                                           bf16_t* __restrict__ dqkv, long ldg) {
     __shared__ __attribute__((aligned(16))) char smem[2][2 * ROW_TILE_BYTES + T_TILE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int q = qt * 64 + wave * 16 + i16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int qt = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    const int q = qt * ROWS_PER_BLOCK + wave * 32 + l32;
     const int qc = q < L ? q : L - 1;
-    const bf16_t* Qp = qkv + ((long)b * L + qc) * ld + h * 64;
-    const bf16_t* dOp = dO + ((long)b * L + qc) * lddo + h * 64;
-    bf16x8_t qf[2], dof[2];
+    const bf16_t* Qp = qkv + ((long)b * L + qc) * ld + hd * 64;
+    const bf16_t* dOp = dO + ((long)b * L + qc) * lddo + hd * 64;
+    bf16x8_t qf[4], dof[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qp + 32 * ks + 8 * g);
-        dof[ks] = *reinterpret_cast<const bf16x8_t*>(dOp + 32 * ks + 8 * g);
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *reinterpret_cast<const bf16x8_t*>(Qp + 16 * s + 8 * h);
+        dof[s] = *reinterpret_cast<const bf16x8_t*>(dOp + 16 * s + 8 * h);
     }
-    const float my_lse = lse2[((long)b * H + h) * L + qc];
-    const float my_delta = delta[((long)b * H + h) * L + qc];
-    const bf16_t* Kbase = qkv + (long)b * L * ld + E + h * 64;
-    const bf16_t* Vbase = qkv + (long)b * L * ld + 2 * E + h * 64;
-    const bf16_t* KTb = KT + ((long)(b * H + h) * 64) * Lp;
+    const float my_lse = lse2[((long)b * H + hd) * L + qc];
+    const float my_delta = delta[((long)b * H + hd) * L + qc];
+    const bf16_t* Kbase = qkv + (long)b * L * ld + E + hd * 64;
+    const bf16_t* Vbase = qkv + (long)b * L * ld + 2 * E + hd * 64;
+    const bf16_t* KTb = KT + ((long)(b * H + hd) * 64) * Lp;
     int kv_end = L;
-    if (mask.mode == 1 && qt * 64 + 64 < L) kv_end = qt * 64 + 64;
+    if (mask.mode == 1 && (qt + 1) * ROWS_PER_BLOCK < L) kv_end = (qt + 1) * ROWS_PER_BLOCK;
     const int ntiles = (kv_end + 63) >> 6;
 
     uint4 kr[2], vr[2], tr[2];
@@ -228,10 +259,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     t_tile_store(tr, smem[0] + 2 * ROW_TILE_BYTES, tid);
     __syncthreads();
 
-    f32x4 dq[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+    f32x16 dq[2] = {zero16(), zero16()};
     for (int t = 0; t < ntiles; ++t) {
         const char* Kt = smem[t & 1];
         const char* Vt = Kt + ROW_TILE_BYTES;
@@ -244,27 +272,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         }
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            f32x4 s[2], dp[2];
+            const int key0 = t * 64 + 32 * ss;
+            f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                s[st] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                dp[st] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const int row = 32 * ss + 16 * st + i16;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    s[st] = mfma16(row_frag(Kt, row, ks, g), qf[ks], s[st]);
-                    dp[st] = mfma16(row_frag(Vt, row, ks, g), dof[ks], dp[st]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = t * 64 + 32 * ss + 16 * st + 4 * g + r;
-                    const float p = is_masked(mask, q, key, L) ? 0.f : exp2f(s[st][r] * scale_log2 - my_lse);
-                    s[st][r] = p * (dp[st][r] - my_delta);  // dS
-                }
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(row_frag(Kt, 32 * ss + l32, ks, h), qf[ks], s);
+                dp = mfma32(row_frag(Vt, 32 * ss + l32, ks, h), dof[ks], dp);
             }
-            const bf16x8_t dsf = pack8(s[0], s[1]);
+            mfma_settle(s), mfma_settle(dp);
+            const bool nm = tile_needs_mask(mask, q, key0, L);
 #pragma unroll
-            for (int db = 0; db < 4; ++db) dq[db] = mfma16(t_frag(KTt, 16 * db + i16, ss, g), dsf, dq[db]);
+            for (int r = 0; r < 16; ++r) {
+                float p = fast_exp2(s[r] * scale_log2 - my_lse);
+                if (nm && is_masked(mask, q, key0 + acc_row(r, h), L)) p = 0.f;
+                s[r] = p * (dp[r] - my_delta);  // dS
+            }
+            const bf16x8_t dsf[2] = {pack_half(s, 0), pack_half(s, 1)};
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) dq[dt] = mfma32(t_frag(KTt, 32 * dt + l32, ss, mm, h), dsf[mm], dq[dt]);
         }
         if (more) {
             char* nx = smem[(t + 1) & 1];
@@ -274,12 +301,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         }
         __syncthreads();
     }
+    mfma_settle(dq[0]), mfma_settle(dq[1]);
     if (q < L) {
-        bf16_t* op = dqkv + ((long)b * L + q) * ldg + h * 64 + 4 * g;
+        bf16_t* op = dqkv + ((long)b * L + q) * ldg + hd * 64 + 4 * h;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
-            *reinterpret_cast<uint2*>(op + 16 * db) =
-                make_uint2(pack_bf2(dq[db][0] * scale, dq[db][1] * scale), pack_bf2(dq[db][2] * scale, dq[db][3] * scale));
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4) =
+                    make_uint2(pack_bf2(dq[dt][4 * g4] * scale, dq[dt][4 * g4 + 1] * scale),
+                               pack_bf2(dq[dt][4 * g4 + 2] * scale, dq[dt][4 * g4 + 3] * scale));
     }
 }
 
@@ -295,26 +326,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            int E, float scale, float scale_log2, MaskSpec mask,
                                                            bf16_t* __restrict__ dqkv, long ldg) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];  // [2][DKV_BUF]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int key = kt * 64 + wave * 16 + i16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int kt = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+    const int key = kt * ROWS_PER_BLOCK + wave * 32 + l32;
     const int keyc = key < L ? key : L - 1;
-    const bf16_t* Kp = qkv + ((long)b * L + keyc) * ld + E + h * 64;
-    const bf16_t* Vp = qkv + ((long)b * L + keyc) * ld + 2 * E + h * 64;
-    bf16x8_t kf[2], vf[2];
+    const bf16_t* Kp = qkv + ((long)b * L + keyc) * ld + E + hd * 64;
+    const bf16_t* Vp = qkv + ((long)b * L + keyc) * ld + 2 * E + hd * 64;
+    bf16x8_t kf[4], vf[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8_t*>(Kp + 32 * ks + 8 * g);
-        vf[ks] = *reinterpret_cast<const bf16x8_t*>(Vp + 32 * ks + 8 * g);
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = *reinterpret_cast<const bf16x8_t*>(Kp + 16 * s + 8 * h);
+        vf[s] = *reinterpret_cast<const bf16x8_t*>(Vp + 16 * s + 8 * h);
     }
-    const bf16_t* Qbase = qkv + (long)b * L * ld + h * 64;
-    const bf16_t* dObase = dO + (long)b * L * lddo + h * 64;
-    const bf16_t* QTb = QT + ((long)(b * H + h) * 64) * Lp;
-    const bf16_t* dOTb = dOT + ((long)(b * H + h) * 64) * Lp;
-    const float* lse_b = lse2 + ((long)b * H + h) * L;
-    const float* del_b = delta + ((long)b * H + h) * L;
+    const bf16_t* Qbase = qkv + (long)b * L * ld + hd * 64;
+    const bf16_t* dObase = dO + (long)b * L * lddo + hd * 64;
+    const bf16_t* QTb = QT + ((long)(b * H + hd) * 64) * Lp;
+    const bf16_t* dOTb = dOT + ((long)(b * H + hd) * 64) * Lp;
+    const float* lse_b = lse2 + ((long)b * H + hd) * L;
+    const float* del_b = delta + ((long)b * H + hd) * L;
     const int nq_tiles = (L + 63) >> 6;
-    const int t0 = (mask.mode == 1) ? kt : 0;  // causal: only queries >= keys contribute
+    const int t0 = (mask.mode == 1) ? (kt * ROWS_PER_BLOCK) >> 6 : 0;  // causal: only queries >= keys contribute
 
     uint4 qr[2], dor[2], qtr[2], dotr[2];
     float stat = 0.f;
@@ -326,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         if (tid < 128) {
             const int qq = t * 64 + (tid & 63);
             if (tid < 64)
-                stat = qq < L ? lse_b[qq] : INFINITY;
+                stat = qq < L ? lse_b[qq] : INFINITY;  // exp2(-inf) = 0 for padded queries
             else
                 stat = qq < L ? del_b[qq] : 0.f;
         }
@@ -342,12 +373,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     lstore(dsm);
     __syncthreads();
 
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
     for (int t = t0; t < nq_tiles; ++t) {
         const int bi = (t - t0) & 1;
         const char* Qt = dsm + bi * DKV_BUF;
@@ -360,47 +386,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         if (more) gload(t + 1);
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            f32x4 s[2], dp[2];
+            const int q0 = t * 64 + 32 * ss;
+            f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                s[st] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                dp[st] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const int row = 32 * ss + 16 * st + i16;
+            for (int ks = 0; ks < 4; ++ks) {
+                s = mfma32(row_frag(Qt, 32 * ss + l32, ks, h), kf[ks], s);
+                dp = mfma32(row_frag(dOt, 32 * ss + l32, ks, h), vf[ks], dp);
+            }
+            mfma_settle(s), mfma_settle(dp);
+            // mask needed?  (wave-uniform) key padding, causal diagonal region, or a restricted query row in range
+            bool nm = key >= L;
+            if (mask.mode == 1) nm = nm || (key > q0);
+            if (mask.mode == 2) nm = nm || (mask.r0 >= q0 && mask.r0 < q0 + 32) || (mask.r1 >= q0 && mask.r1 < q0 + 32);
+            nm = __any(nm);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    s[st] = mfma16(row_frag(Qt, row, ks, g), kf[ks], s[st]);
-                    dp[st] = mfma16(row_frag(dOt, row, ks, g), vf[ks], dp[st]);
-                }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int ql = 32 * ss + 8 * g4 + 4 * h;  // 4 consecutive query rows: registers 4 g4 .. 4 g4 + 3
+                const float4 l4 = *reinterpret_cast<const float4*>(st_lse + ql);
+                const float4 d4 = *reinterpret_cast<const float4*>(st_del + ql);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ql = 32 * ss + 16 * st + 4 * g + r;
-                    const int qg = t * 64 + ql;
-                    const float p = is_masked(mask, qg, key, L) ? 0.f : exp2f(s[st][r] * scale_log2 - st_lse[ql]);
-                    s[st][r] = p;
-                    dp[st][r] = p * (dp[st][r] - st_del[ql]);
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    float p = fast_exp2(s[r] * scale_log2 - lv[e]);
+                    if (nm && is_masked(mask, t * 64 + ql + e, key, L)) p = 0.f;
+                    s[r] = p;
+                    dp[r] = p * (dp[r] - dl[e]);
                 }
             }
-            const bf16x8_t pf = pack8(s[0], s[1]);
-            const bf16x8_t dsf = pack8(dp[0], dp[1]);
+            const bf16x8_t pf[2] = {pack_half(s, 0), pack_half(s, 1)};
+            const bf16x8_t dsf[2] = {pack_half(dp, 0), pack_half(dp, 1)};
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                dv[db] = mfma16(t_frag(dOTt, 16 * db + i16, ss, g), pf, dv[db]);
-                dk[db] = mfma16(t_frag(QTt, 16 * db + i16, ss, g), dsf, dk[db]);
-            }
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    dv[dt] = mfma32(t_frag(dOTt, 32 * dt + l32, ss, mm, h), pf[mm], dv[dt]);
+                    dk[dt] = mfma32(t_frag(QTt, 32 * dt + l32, ss, mm, h), dsf[mm], dk[dt]);
+                }
         }
         if (more) lstore(dsm + (bi ^ 1) * DKV_BUF);
         __syncthreads();
     }
+    mfma_settle(dk[0]), mfma_settle(dk[1]), mfma_settle(dv[0]), mfma_settle(dv[1]);
     if (key < L) {
-        bf16_t* kp = dqkv + ((long)b * L + key) * ldg + E + h * 64 + 4 * g;
-        bf16_t* vp = dqkv + ((long)b * L + key) * ldg + 2 * E + h * 64 + 4 * g;
+        bf16_t* kp = dqkv + ((long)b * L + key) * ldg + E + hd * 64 + 4 * h;
+        bf16_t* vp = dqkv + ((long)b * L + key) * ldg + 2 * E + hd * 64 + 4 * h;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            *reinterpret_cast<uint2*>(kp + 16 * db) =
-                make_uint2(pack_bf2(dk[db][0] * scale, dk[db][1] * scale), pack_bf2(dk[db][2] * scale, dk[db][3] * scale));
-            *reinterpret_cast<uint2*>(vp + 16 * db) =
-                make_uint2(pack_bf2(dv[db][0], dv[db][1]), pack_bf2(dv[db][2], dv[db][3]));
-        }
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                *reinterpret_cast<uint2*>(kp + 32 * dt + 8 * g4) =
+                    make_uint2(pack_bf2(dk[dt][4 * g4] * scale, dk[dt][4 * g4 + 1] * scale),
+                               pack_bf2(dk[dt][4 * g4 + 2] * scale, dk[dt][4 * g4 + 3] * scale));
+                *reinterpret_cast<uint2*>(vp + 32 * dt + 8 * g4) =
+                    make_uint2(pack_bf2(dv[dt][4 * g4], dv[dt][4 * g4 + 1]), pack_bf2(dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]));
+            }
     }
 }
 
@@ -489,7 +529,7 @@ extern "C" int mmvid_attention_fwd(const void* qkv, int64_t ld, const void* VT, 
     ATTN_COMMON_CHECKS("attention_fwd");
     MMVID_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, "attention_fwd: bad leading dims");
     MmvidProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * 64, (hipStream_t)stream);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((L + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(L, ROWS_PER_BLOCK), H, B), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)qkv, (long)ld, (const bf16_t*)VT, L, Lp, H, E, scale * 1.4426950408889634f,
                        make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out, (long)ldo, lse2);
     MMVID_LAUNCH_CHECK("attention_fwd");
@@ -510,17 +550,17 @@ extern "C" int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* QT, 
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(items, 256)), dim3(256), 0, s, (const bf16_t*)O, (long)ldo,
                        (const bf16_t*)dO, (long)lddo, B, L, H, delta);
     MmvidProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)L * L * 64, s);  // 5 GEMM-equivalents (recompute counted once)
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((L + 63) / 64, H, B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)KT, (const bf16_t*)dO, (long)lddo, lse2, delta, L, Lp, H, E, scale, sl2, m,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(L, ROWS_PER_BLOCK), H, B), dim3(256), 0, s, (const bf16_t*)qkv,
+                       (long)ld, (const bf16_t*)KT, (const bf16_t*)dO, (long)lddo, lse2, delta, L, Lp, H, E, scale, sl2, m,
                        (bf16_t*)dqkv, (long)ldg);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DKV_BUF);
         attr = true;
     }
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((L + 63) / 64, H, B), dim3(256), 2 * DKV_BUF, s, (const bf16_t*)qkv,
-                       (long)ld, (const bf16_t*)QT, (const bf16_t*)dO, (long)lddo, (const bf16_t*)dOT, lse2, delta, L,
-                       Lp, H, E, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(L, ROWS_PER_BLOCK), H, B), dim3(256), 2 * DKV_BUF, s,
+                       (const bf16_t*)qkv, (long)ld, (const bf16_t*)QT, (const bf16_t*)dO, (long)lddo, (const bf16_t*)dOT,
+                       lse2, delta, L, Lp, H, E, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
     MMVID_LAUNCH_CHECK("attention_bwd");
     return MMVID_OK;
 }

@@ -63,4 +63,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Guard against reading MFMA results too early.  v_mfma_f32_32x32x16_bf16 needs 12 wait states before a VALU may
+// read its destination; hipcc (ROCm 7.2) counts them along the fall-through path only, so a conditional branch
+// right after an MFMA chain can reach the first reader after ~7 (observed: intermittent stale accumulators in the
+// attention kernels under load).  Tying 16 nops to the accumulator makes every path safe.
+__device__ __forceinline__ void mfma_settle(f32x16& acc) { asm volatile("s_nop 15" : "+v"(acc)); }
+__device__ __forceinline__ void mfma_settle(f32x4& acc) { asm volatile("s_nop 15" : "+v"(acc)); }
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         mma_tile<false, false>(cur, cur + TILE_BYTES, acc, wm, wn, lane);
     }
     // epilogue through LDS (row-contiguous global traffic; see gemm.hip)
+    mfma_settle(acc[0][0]), mfma_settle(acc[0][1]), mfma_settle(acc[1][0]), mfma_settle(acc[1][1]);
     float* slab = reinterpret_cast<float*>(smem);
     const int n = bn0 + 4 * (tid & 31);
     const bool n_ok = n < p.Cout;

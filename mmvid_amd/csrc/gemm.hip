@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     // ---- epilogue through LDS: every global read/write below is row-contiguous (16 B per lane, 512 B per row).
     // Thread t owns column n = bn0 + 4*(t&31) of rows (t>>5)+8k of each 64-row slab; all its reads are issued
     // before any is consumed.
+    mfma_settle(acc[0][0]), mfma_settle(acc[0][1]), mfma_settle(acc[1][0]), mfma_settle(acc[1][1]);
     float* slab = reinterpret_cast<float*>(smem);
     const long cb = (long)batch * p.strideC;
     const int n = bn0 + 4 * (tid & 31);
