@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bn0 = blockIdx.x * BN;
-    const long bm0 = (long)blockIdx.y * BM;
+    const int wg = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int bn0 = (wg % gridDim.x) * BN;
+    const long bm0 = (long)(wg / gridDim.x) * BM;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -35,6 +35,16 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_dst_wave_unifo
     __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)lds_dst_wave_uniform, 16, 0, 0);
 }
 
+// ---- XCD-aware tile order ----------------------------------------------------------------------------------
+// MI355X dispatches workgroup i to XCD i % 8, each XCD with its own L2.  Give every XCD a CONTIGUOUS chunk of
+// the (n fastest, then m) tile order, so that tiles sharing an A row-block (and conv tiles sharing halo rows)
+// hit the same L2 instead of pulling the operand through all eight.  Bijective for any grid size (guide T1).
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+    const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (id >> 3);
+}
+
 // ---- row-major operand -------------------------------------------------------------------------------------
 __device__ __forceinline__ int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -113,6 +123,74 @@ __device__ __forceinline__ void mma_tile(const char* At, const char* Bt, f32x16 
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
+}
+
+// =====================================================================================================
+// 4-stage variant with a 32-deep K tile ("P4"): 4 x (8 KiB A + 8 KiB B) = 64 KiB, three tiles of LDS-DMA in flight
+// across the per-tile barrier (raw s_barrier + COUNTED s_waitcnt vmcnt, guide T3/T4) instead of one tile and a
+// vmcnt(0) drain.  Row-major tile: [128 rows][32 k] (64-B rows), chunk ^= (row>>2)&3; k-major tile: [32 k][128 rows].
+constexpr int BK4 = 32;
+constexpr int TILE4_BYTES = BM * BK4 * 2;  // 8 KiB
+constexpr int STAGE4_BYTES = 2 * TILE4_BYTES;
+
+__device__ __forceinline__ int rm4_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <bool KM>
+__device__ __forceinline__ void stage4(const bf16_t* base, long ld, int rows, int K, int r0, int k0, char* tile, int wave,
+                                       int lane) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = wave * 2 + jj;  // 8 DMA pieces of 1 KiB per tile, 2 per wave
+        const void* src;
+        if constexpr (KM) {
+            const int kr = j * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ ((kr & 3) << 2);
+            const int k = k0 + kr, r = r0 + c * 8;
+            src = (k < K && r < rows) ? (const void*)(base + (long)k * ld + r) : (const void*)g_zero16;
+        } else {
+            const int row = j * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int gr = r0 + row, k = k0 + c * 8;
+            src = (gr < rows && k < K) ? (const void*)(base + (long)gr * ld + k) : (const void*)g_zero16;
+        }
+        glds16(src, tile + j * 1024);
+    }
+}
+template <bool KM>
+__device__ __forceinline__ bf16x8_t frag4(const char* tile, int rowbase, int s, int lane) {
+    if constexpr (KM) {
+        return frag_kmajor(tile, rowbase, s, lane);  // same [k][128 rows] image, s in {0,1}
+    } else {
+        const int row = rowbase + (lane & 31);
+        return *reinterpret_cast<const bf16x8_t*>(tile + rm4_off(row, 2 * s + (lane >> 5)));
+    }
+}
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void mma_tile4(const char* At, const char* Bt, f32x16 (&acc)[2][2], int wm, int wn, int lane) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bf16x8_t af[2], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i] = frag4<AKM>(At, wm * 64 + i * 32, s, lane);
+            bfr[i] = frag4<BKM>(Bt, wn * 64 + i * 32, s, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+}
+// wait until at most `tiles_in_flight` later tiles (4 DMA pieces each per wave) are outstanding, then barrier
+__device__ __forceinline__ void wait_tiles_and_barrier(int tiles_in_flight) {
+    if (tiles_in_flight >= 2)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (tiles_in_flight == 1)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 }
 
 // ---- epilogue staging: one 32-row slab of every wave's accumulators -> LDS [64][SLAB_PITCH] fp32, so that the
