@@ -52,10 +52,11 @@ int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64_t ldy, con
 /* ---- LayerNorm: clip_model.py:188-193 (fp32 statistics, eps 1e-5) and the nn.LayerNorm of the heads. */
 int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const float* w, const float* b, float eps,
                         void* y_bf16, float* y_f32, int64_t ldy, float* mean, float* rstd, void* stream);
-/* dx (+)= LN backward of dy; dw/db accumulated with atomics (may be NULL). */
+/* dx (+)= LN backward of dy; optional bf16 copy of the resulting dx (same lddx); dw/db accumulated with atomics
+ * (may be NULL). */
 int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                         const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
-                        int add_into_dx, float* dw, float* db, void* stream);
+                        int add_into_dx, void* dx_bf16, float* dw, float* db, void* stream);
 /* GroupNorm(32, eps) [+ swish] on NHWC: taming/modules/diffusionmodules/model.py:38-42, 33-35.
  * stats_scratch: fp32 [N * (2*C + 64 * ceil(hw / 256))]; deterministic (fixed-order reductions, no atomics). */
 int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, int C, const float* w,

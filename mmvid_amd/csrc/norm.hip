@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ w, long rows, int E,
                                                             float* __restrict__ dx, long lddx, int add,
+                                                            bf16_t* __restrict__ dx_bf16,
                                                             float* __restrict__ dw, float* __restrict__ db) {
     __shared__ float red[2][4][LN_MAXV * 64 * 4];  // [dw|db][wave][E]  = 32 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -118,6 +119,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     o.x += p.x, o.y += p.y, o.z += p.z, o.w += p.w;
                 }
                 *d = o;
+                if (dx_bf16)  // bf16 copy of the updated residual gradient: the next backward GEMMs' operand
+                    reinterpret_cast<uint2*>(dx_bf16 + r * lddx)[c] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
             }
         }
     }
@@ -278,7 +281,7 @@ extern "C" int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, in
 
 extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                                    const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
-                                   int add_into_dx, float* dw, float* db, void* stream) {
+                                   int add_into_dx, void* dx_bf16, float* dw, float* db, void* stream) {
     MMVID_REQUIRE(dy && x && mean && rstd && w && dx, "layernorm_bwd: null pointer");
     MMVID_REQUIRE(E % 4 == 0 && E <= 64 * 4 * LN_MAXV && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0,
                   "layernorm_bwd: bad E/strides");
@@ -286,7 +289,7 @@ extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x
     int blocks = cdiv(rows, 4);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x,
-                       (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, dw, db);
+                       (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16, dw, db);
     MMVID_LAUNCH_CHECK("layernorm_bwd");
     return MMVID_OK;
 }

@@ -193,16 +193,16 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
         const mmvid_tower_layer_t& ly = layers[i];
         const char* sv = (const char*)saved + (int64_t)i * sl.total;
         // ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(LN2 x_mid)))
-        TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
+        // gb = bf16(g): cast once for the top layer, afterwards written by the LayerNorm backward that updates g
+        if (i == d.layers - 1) TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
         TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, ly.g_pj_b, ws, stream));
         TRY(linear_dx(d.M, d.E, d.F, gb, ly.pj_w, sv + sl.pre, nullptr, scr + sc.d_pre, stream));
         TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, ly.g_fc_b, ws, stream));
         TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, d_h, nullptr, stream));
         TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
-                                (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, ly.g_ln2_w, ly.g_ln2_b,
+                                (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, gb, ly.g_ln2_w, ly.g_ln2_b,
                                 stream));
         // ---- attention branch: x_mid = x_in + out_proj(MHA(LN1 x_in))
-        TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
         TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, ly.g_out_b, ws, stream));
         TRY(linear_dx(d.M, d.E, d.E, gb, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
         TRY(mmvid_head_transpose(sv + sl.qkv, 3 * d.E, 0, d.B, d.L, d.Lp, d.H, scr + sc.xt0, stream));        // Q^T
@@ -215,8 +215,8 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
         TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, ly.g_in_b, ws, stream));
         TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, d_h, nullptr, stream));
         TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
-                                (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, ly.g_ln1_w, ly.g_ln1_b,
-                                stream));
+                                (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, i > 0 ? gb : nullptr, ly.g_ln1_w,
+                                ly.g_ln1_b, stream));
     }
     return MMVID_OK;
 }

@@ -426,13 +426,24 @@ class BERT(nn.Module):
         if not return_loss:
             return self._assemble(ctrl_ids, csl)
 
-        target_orig = target.detach().clone() if (exists(target) and len(target)) else None
-        target = self.get_image_tokens(target)
+        # Host-side stochastic choices first, in the reference's RNG order (mask strategies 992-1029, then warp 1094);
+        # neither depends on device results, so both VQGAN encodes of the step can run as ONE batch of 2*B*T frames.
         if _mask1 is None:
             mask1, not_fully_masked = self._msm_mask(B, device, msm_strategy_prob, msm_bernoulli_prob, pc_prob)
         else:
             mask1 = _mask1.to(device)
             not_fully_masked = kwargs.get('_not_fully_masked', torch.ones(B, device=device))
+        do_vid = vid and self.num_targets > 1
+        target_warp = None
+        if do_vid:
+            target_warp = (_target_warp if _target_warp is not None else warp(target.detach(), vid_strategy_prob)).to(device)
+        if do_vid and torch.is_tensor(target) and target.dim() == 5 and target_warp.shape == target.shape:
+            toks = self.get_image_tokens(torch.cat((target, target_warp), 0))
+            target, target_warp = toks[:B], toks[B:]
+        else:
+            target = self.get_image_tokens(target)
+            if do_vid:
+                target_warp = self.get_image_tokens(target_warp)
         MASK = self.image_token_lut['[MASK]']
         target_masked = torch.where(mask1, target, torch.full_like(target, MASK))
 
@@ -448,10 +459,7 @@ class BERT(nn.Module):
             else:
                 neg_ids = swap(ctrl_ids, 0)
             seqs.append(torch.cat((neg_ids, target_masked), 1))
-        do_vid = vid and self.num_targets > 1
         if do_vid:
-            target_warp = _target_warp if _target_warp is not None else warp(target_orig, vid_strategy_prob)
-            target_warp = self.get_image_tokens(target_warp.to(device))
             warp_masked = torch.where(mask1, target_warp, torch.full_like(target_warp, MASK))
             seqs.append(torch.cat((ctrl_ids, warp_masked), 1))
         ids = torch.cat(seqs, 0)

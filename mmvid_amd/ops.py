@@ -127,8 +127,8 @@ def layernorm_bwd(dy, x, mean, rstd, w, dx=None, add=False, dw=None, db=None):
     if dx is None:
         dx = torch.empty_like(x)
         add = False
-    call('mmvid_layernorm_bwd', _p(dy), E, _p(x), E, _p(mean), _p(rstd), _p(w), rows, E, _p(dx), E, int(add), _p(dw),
-         _p(db), _stream())
+    call('mmvid_layernorm_bwd', _p(dy), E, _p(x), E, _p(mean), _p(rstd), _p(w), rows, E, _p(dx), E, int(add), None,
+         _p(dw), _p(db), _stream())
     return dx
 
 

@@ -172,11 +172,19 @@ def _with_tokens(m, g, fn):
         originals[vae] = orig
 
         def fake(img):
-            for fr, tok in table:
-                fl = fr.reshape(-1, *fr.shape[2:])
-                if fl.shape == img.shape and torch.equal(fl.to(img.device), img):
-                    return tok.reshape(fl.shape[0], -1).to(img.device)
-            return orig(img)
+            # cover `img` by a concatenation of known frame sets (forward batches target + warped frames)
+            out, pos = [], 0
+            while pos < img.shape[0]:
+                for fr, tok in table:
+                    fl = fr.reshape(-1, *fr.shape[2:])
+                    n = fl.shape[0]
+                    if pos + n <= img.shape[0] and torch.equal(fl.to(img.device), img[pos:pos + n]):
+                        out.append(tok.reshape(n, -1).to(img.device))
+                        pos += n
+                        break
+                else:
+                    return orig(img)
+            return torch.cat(out, 0)
 
         vae.get_codebook_indices = fake
 
