@@ -140,21 +140,37 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
-// db[n] += sum_m dY[m][n] (bf16 in, fp32 atomic out); block = 64 rows x 256 columns (2 per thread)
+// db[n] += sum_m dY[m][n] (bf16 in, fp32 atomic out).  Thread = 8 columns (one 16-B load per row), block = 256
+// rows as 8 row-groups x 32 column-chunks reduced through LDS: one atomic per column per 256 rows.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ dy, long ld, long M, int N,
                                                           float* __restrict__ db) {
-    const int n = (blockIdx.x * 256 + threadIdx.x) * 2;
-    if (n >= N) return;
-    const long m0 = (long)blockIdx.y * 64;
-    long m1 = m0 + 64;
-    if (m1 > M) m1 = M;
-    float a = 0.f, b = 0.f;
-    for (long m = m0; m < m1; ++m) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(dy + m * ld + n);
-        a += bf_lo(w), b += bf_hi(w);
+    __shared__ float red[8][256];
+    const int cc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int n = (blockIdx.x * 32 + cc) * 8;
+    const long m0 = (long)blockIdx.y * 256;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    if (n < N) {
+        long m1 = m0 + 256;
+        if (m1 > M) m1 = M;
+        for (long m = m0 + rg; m < m1; m += 8) {
+            const uint4 w = *reinterpret_cast<const uint4*>(dy + m * ld + n);
+            a[0] += bf_lo(w.x), a[1] += bf_hi(w.x), a[2] += bf_lo(w.y), a[3] += bf_hi(w.y);
+            a[4] += bf_lo(w.z), a[5] += bf_hi(w.z), a[6] += bf_lo(w.w), a[7] += bf_hi(w.w);
+        }
     }
-    unsafeAtomicAdd(db + n, a);
-    unsafeAtomicAdd(db + n + 1, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rg][cc * 8 + e] = a[e];
+    __syncthreads();
+    const int col = threadIdx.x;  // 256 columns of this block
+    const int gn = blockIdx.x * 256 + col;
+    if (gn < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][col];
+        unsafeAtomicAdd(db + gn, s);
+    }
 }
 
 }  // namespace
@@ -227,9 +243,9 @@ extern "C" int mmvid_cross_entropy_bwd(const float* logits, int64_t ldl, const i
 
 extern "C" int mmvid_colsum_bf16(const void* dy, int64_t ld, int64_t M, int N, float* db, void* stream) {
     MMVID_REQUIRE(dy && db, "colsum_bf16: null pointer");
-    MMVID_REQUIRE(N % 2 == 0 && ld % 2 == 0, "colsum_bf16: N and ld must be even");
+    MMVID_REQUIRE(N % 8 == 0 && ld % 8 == 0, "colsum_bf16: N and ld must be multiples of 8");
     if (M == 0) return MMVID_OK;
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N / 2, 256), cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N, 256), cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dy, (long)ld, (long)M, N, db);
     MMVID_LAUNCH_CHECK("colsum_bf16");
     return MMVID_OK;

@@ -332,3 +332,26 @@ def test_spatial_attention(ops, N, HW, C):
     q, k, v = (rnd(N, HW, C, seed=s, dtype=torch.bfloat16) for s in (1, 2, 3))
     p = torch.softmax(q.float() @ k.float().transpose(1, 2) * C**-0.5, -1)
     close(ops.spatial_attention(q, k, v), p @ v.float(), 1.5e-2, 'spatial attn')
+
+
+def test_colsum_and_dw_workspace(ops):
+    for M, N in ((10422, 768), (300, 3072), (1, 8), (257, 264)):
+        dy = rnd(M, N, seed=M, dtype=torch.bfloat16)
+        db = rnd(N, seed=1)
+        ref = db + dy.float().sum(0)
+        ops.colsum_bf16(dy, db)
+        close(db, ref, 2e-5, f'colsum {M}x{N}')
+    # deterministic split-K dW: bit-identical across runs and across split factors' own repetitions
+    dY, X = rnd(3000, 768, seed=3, dtype=torch.bfloat16), rnd(3000, 256, seed=4, dtype=torch.bfloat16)
+    ref = dY.float().t() @ X.float()
+    outs = []
+    for _ in range(3):
+        dW = torch.zeros(768, 256, device=DEV)
+        ops.gemm_dw(dY, X, dW, accumulate=True, splitk=5)
+        outs.append(dW)
+    close(outs[0], ref, 2e-4, 'dW splitk=5')
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    base = rnd(768, 256, seed=5)
+    dW = base.clone()
+    ops.gemm_dw(dY, X, dW, accumulate=True)
+    close(dW, base + ref, 2e-4, 'dW accumulate auto-split')
