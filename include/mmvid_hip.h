@@ -65,17 +65,14 @@ int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, 
 
 /* ---- attention core, head_dim 64: clip_model.py:217-222 with the masks of clip_model.py:561-578.
  * qkv: token-major [B*L, ld] bf16 with Q at column 0, K at E, V at 2E (nn.MultiheadAttention packing).
- * XT buffers: [B, H, 64, Lp] bf16 transposed copies made by mmvid_head_transpose (Lp % 64 == 0, zero padded).
+ * K/V (and Q/dO in the backward) tiles are read from this layout directly; no transposed copies are needed.
  * mask_mode 0 none | 1 causal | 2 rows (r0: columns < c0 masked, r1: columns < c1 masked; use -1 for unused).
- * lse2[b][h][q] = log2-domain log-sum-exp, consumed by the backward. */
-int mmvid_head_transpose(const void* src, int64_t ld, int col0, int B, int L, int Lp, int H, void* dst, void* stream);
-int mmvid_attention_fwd(const void* qkv, int64_t ld, const void* VT, int B, int L, int Lp, int H, int E, float scale,
-                        int mask_mode, int r0, int c0, int r1, int c1, void* out, int64_t ldo, float* lse2,
-                        void* stream);
-int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* QT, const void* KT, const void* O, int64_t ldo,
-                        const void* dO, int64_t lddo, const void* dOT, const float* lse2, float* delta, int B, int L,
-                        int Lp, int H, int E, float scale, int mask_mode, int r0, int c0, int r1, int c1, void* dqkv,
-                        int64_t ldg, void* stream);
+ * lse2[b][h][q] = log2-domain log-sum-exp, consumed by the backward.  delta: fp32 [B,H,L] scratch. */
+int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, int H, int E, float scale, int mask_mode, int r0,
+                        int c0, int r1, int c1, void* out, int64_t ldo, float* lse2, void* stream);
+int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
+                        const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode,
+                        int r0, int c0, int r1, int c1, void* dqkv, int64_t ldg, void* stream);
 
 /* ---- sequence assembly + losses: dalle_bert.py:899-973,1030-1040; dalle_artv.py:441-491,526-539. */
 int mmvid_assemble_sequence(const float* const* tables, const int64_t* table_rows, int ntables, const int64_t* ids,

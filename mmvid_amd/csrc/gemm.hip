@@ -19,8 +19,6 @@
 // (global_load_lds_dwordx4), double buffered: one barrier per K tile.  MFMA operands are swapped (a=B-frag, b=A-frag) so that
 // each lane ends up with 4 consecutive n for one m: 16-B epilogue loads/stores.
 // Roofline: bf16 MFMA (2.5 PFLOP/s dense); algorithmic FLOPs = 2*M*N*K.
-#include <stdlib.h>
-
 #include "gemm_core.h"
 #include "prof.h"
 
@@ -57,7 +55,7 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
-template <bool AKM, bool BKM, bool P4>
+template <bool AKM, bool BKM>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A tile | B tile]
     const int tid = threadIdx.x;
@@ -85,29 +83,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    if constexpr (P4) {
-        // 4 stages x 32-deep tiles, three tiles of DMA in flight across the barrier (counted vmcnt)
-        const int kbeg = kt0 * BK;
-        const int nt4 = 2 * nt;
-#pragma unroll
-        for (int st = 0; st < 3; ++st) {
-            if (st < nt4) {
-                stage4<AKM>(A, p.lda, p.M, p.K, bm0, kbeg + st * BK4, smem + st * STAGE4_BYTES, wave, lane);
-                stage4<BKM>(B, p.ldb, p.N, p.K, bn0, kbeg + st * BK4, smem + st * STAGE4_BYTES + TILE4_BYTES, wave, lane);
-            }
-        }
-        for (int t = 0; t < nt4; ++t) {
-            const int later = nt4 - 1 - t;
-            wait_tiles_and_barrier(later < 2 ? later : 2);
-            if (t + 3 < nt4) {
-                char* dst = smem + ((t + 3) & 3) * STAGE4_BYTES;
-                stage4<AKM>(A, p.lda, p.M, p.K, bm0, kbeg + (t + 3) * BK4, dst, wave, lane);
-                stage4<BKM>(B, p.ldb, p.N, p.K, bn0, kbeg + (t + 3) * BK4, dst + TILE4_BYTES, wave, lane);
-            }
-            const char* cur = smem + (t & 3) * STAGE4_BYTES;
-            mma_tile4<AKM, BKM>(cur, cur + TILE4_BYTES, acc, wm, wn, lane);
-        }
-    } else {
+    {
         // 2 stages x 64-deep tiles, one barrier per K tile: the barrier (with the compiler's vmcnt(0) in front of it)
         // makes tile t visible to every wave and proves everyone is done reading the buffer tile t+1 overwrites.
         if (nt > 0) {
@@ -208,30 +184,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(out + i) = a;
 }
 
-int gemm_pipeline() {  // MMVID_GEMM_PIPE=4 selects the 4-stage counted-vmcnt pipeline (A/B testing); default 2-stage
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MMVID_GEMM_PIPE");
-        v = (e && e[0] == '4') ? 4 : 2;  // measured: the 4-stage/32-deep variant is ~11 % slower
-    }
-    return v;
-}
-
 template <bool AKM, bool BKM>
 int launch(const GemmParams& p, int batch, hipStream_t stream) {
     static bool attr = false;
     const int lds = 4 * TILE_BYTES;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), batch * p.splitk);
     MmvidProfScope prof(AKM ? PROF_GEMM_TN : (BKM ? PROF_GEMM_NN : PROF_GEMM_NT), 2.0 * p.M * p.N * (double)p.K * batch, stream);
-    if (gemm_pipeline() == 4)
-        hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, true>), grid, dim3(256), lds, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, false>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM>), grid, dim3(256), lds, stream, p);
     return 0;
 }
 

@@ -79,14 +79,46 @@ __device__ __forceinline__ void stage_kmajor(const bf16_t* base, long ld, int ro
         glds16(src, tile + j * 1024);
     }
 }
-// 8 consecutive k (k-step s of 16, half fh) for row `rowbase + (lane&31)`: two transpose reads 4 k-rows apart.
-__device__ __forceinline__ bf16x8_t frag_kmajor(const char* tile, int rowbase, int s, int lane) {
+// The transpose read is issued as inline asm: hipcc (ROCm 7.2) treats the ds_read_tr16 builtin as a possible LDS
+// STORE and puts an s_waitcnt vmcnt(0) in front of it whenever LDS-DMA is in flight -- i.e. it would drain the
+// prefetch of tile t+1 before the first fragment of tile t is read.  In asm form the compiler does not track the
+// read either, so its completion is awaited by hand: lgkm_wait_tied<N>() = s_waitcnt lgkmcnt(N) with the fragment
+// registers tied to it (a register-only MFMA cannot be hoisted above it).  LDS returns in order and the counter
+// also counts the compiler's own reads, so waiting for "<= N younger asm reads" can only over-wait.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(size_t)(lds_void_t*)p; }
+template <int OFF>
+__device__ __forceinline__ bf16x4_t ds_read_tr16(uint32_t addr) {
+    bf16x4_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_tied(bf16x8_t& a, bf16x8_t& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_tied(bf16x8_t& a, bf16x8_t& b, bf16x8_t& c, bf16x8_t& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+// 4 fragments + the two B operands they will be multiplied with: places the wait AFTER the arithmetic that produced x, y
+template <int N>
+__device__ __forceinline__ void lgkm_wait_tied(bf16x8_t& a, bf16x8_t& b, bf16x8_t& c, bf16x8_t& d, bf16x8_t& x,
+                                               bf16x8_t& y) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(x), "+v"(y) : "n"(N) : "memory");
+}
+// per-lane byte offset into a k-major tile for the 32 operand rows [rowbase, rowbase+32): k row 8 (G>>1) + (si>>2),
+// 4 rows starting at rowbase + 16 (G&1) + 4 (si&3)
+__device__ __forceinline__ int km_lane_off(int rowbase, int lane) {
     const int G = lane >> 4, si = lane & 15;
-    const int kk = 16 * s + 8 * (G >> 1) + (si >> 2);
+    const int kk = 8 * (G >> 1) + (si >> 2);
     const int mbyte = (rowbase + 16 * (G & 1) + 4 * (si & 3)) * 2;
-    const char* p = tile + kk * 256 + (mbyte ^ ((kk & 3) << 6));
-    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)p);
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(p + 1024));
+    return kk * 256 + (mbyte ^ ((kk & 3) << 6));
+}
+// 8 consecutive k (k-step S of 16) for row `rowbase + (lane&31)`: two transpose reads 4 k-rows apart.
+template <int S>
+__device__ __forceinline__ bf16x8_t frag_kmajor(uint32_t lane_addr) {
+    const bf16x4_t lo = ds_read_tr16<S * 4096>(lane_addr);
+    const bf16x4_t hi = ds_read_tr16<S * 4096 + 1024>(lane_addr);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -98,99 +130,60 @@ __device__ __forceinline__ void stage(const bf16_t* base, long ld, int rows, int
     else
         stage_rowmajor(base, ld, rows, K, r0, k0, tile, wave, lane);
 }
-template <bool KM>
-__device__ __forceinline__ bf16x8_t frag(const char* tile, int rowbase, int s, int lane) {
-    if constexpr (KM)
-        return frag_kmajor(tile, rowbase, s, lane);
-    else
-        return frag_rowmajor(tile, rowbase + (lane & 31), s, lane >> 5);
+
+// the two 32-row fragments (i = 0, 1) of a wave's 64 operand rows for k-step S
+template <bool KM, int S>
+__device__ __forceinline__ void load_frags(const char* tile, const uint32_t (&km_addr)[2], int rowbase, int lane,
+                                           bf16x8_t (&f)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if constexpr (KM)
+            f[i] = frag_kmajor<S>(km_addr[i]);
+        else
+            f[i] = frag_rowmajor(tile, rowbase + i * 32 + (lane & 31), S, lane >> 5);
+    }
+}
+__device__ __forceinline__ void mma_step(const bf16x8_t (&af)[2], const bf16x8_t (&bfr)[2], f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+}
+template <bool AKM, bool BKM, int N>
+__device__ __forceinline__ void frags_ready(bf16x8_t (&af)[2], bf16x8_t (&bfr)[2]) {
+    if constexpr (AKM && BKM)
+        lgkm_wait_tied<N>(af[0], af[1], bfr[0], bfr[1]);
+    else if constexpr (AKM)
+        lgkm_wait_tied<N>(af[0], af[1]);
+    else if constexpr (BKM)
+        lgkm_wait_tied<N>(bfr[0], bfr[1]);
 }
 
 // One 64-deep K tile: acc[i][j] (+)= B-frag(j) x A-frag(i)  (operands swapped: a lane gets 4 consecutive n).
+// Fragments of k-step s+1 are requested before the MFMAs of step s.
 template <bool AKM, bool BKM>
 __device__ __forceinline__ void mma_tile(const char* At, const char* Bt, f32x16 (&acc)[2][2], int wm, int wn, int lane) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        bf16x8_t af[2], bfr[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            af[i] = frag<AKM>(At, wm * 64 + i * 32, s, lane);
-            bfr[i] = frag<BKM>(Bt, wn * 64 + i * 32, s, lane);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    constexpr int NASM = (AKM ? 4 : 0) + (BKM ? 4 : 0);  // asm reads per k-step
+    uint32_t ka[2] = {0, 0}, kb[2] = {0, 0};
+    if constexpr (AKM) {
+        ka[0] = lds_addr(At) + km_lane_off(wm * 64, lane), ka[1] = lds_addr(At) + km_lane_off(wm * 64 + 32, lane);
     }
-}
-
-// =====================================================================================================
-// 4-stage variant with a 32-deep K tile ("P4"): 4 x (8 KiB A + 8 KiB B) = 64 KiB, three tiles of LDS-DMA in flight
-// across the per-tile barrier (raw s_barrier + COUNTED s_waitcnt vmcnt, guide T3/T4) instead of one tile and a
-// vmcnt(0) drain.  Row-major tile: [128 rows][32 k] (64-B rows), chunk ^= (row>>2)&3; k-major tile: [32 k][128 rows].
-constexpr int BK4 = 32;
-constexpr int TILE4_BYTES = BM * BK4 * 2;  // 8 KiB
-constexpr int STAGE4_BYTES = 2 * TILE4_BYTES;
-
-__device__ __forceinline__ int rm4_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-template <bool KM>
-__device__ __forceinline__ void stage4(const bf16_t* base, long ld, int rows, int K, int r0, int k0, char* tile, int wave,
-                                       int lane) {
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int j = wave * 2 + jj;  // 8 DMA pieces of 1 KiB per tile, 2 per wave
-        const void* src;
-        if constexpr (KM) {
-            const int kr = j * 4 + (lane >> 4);
-            const int c = (lane & 15) ^ ((kr & 3) << 2);
-            const int k = k0 + kr, r = r0 + c * 8;
-            src = (k < K && r < rows) ? (const void*)(base + (long)k * ld + r) : (const void*)g_zero16;
-        } else {
-            const int row = j * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
-            const int gr = r0 + row, k = k0 + c * 8;
-            src = (gr < rows && k < K) ? (const void*)(base + (long)gr * ld + k) : (const void*)g_zero16;
-        }
-        glds16(src, tile + j * 1024);
+    if constexpr (BKM) {
+        kb[0] = lds_addr(Bt) + km_lane_off(wn * 64, lane), kb[1] = lds_addr(Bt) + km_lane_off(wn * 64 + 32, lane);
     }
-}
-template <bool KM>
-__device__ __forceinline__ bf16x8_t frag4(const char* tile, int rowbase, int s, int lane) {
-    if constexpr (KM) {
-        return frag_kmajor(tile, rowbase, s, lane);  // same [k][128 rows] image, s in {0,1}
-    } else {
-        const int row = rowbase + (lane & 31);
-        return *reinterpret_cast<const bf16x8_t*>(tile + rm4_off(row, 2 * s + (lane >> 5)));
-    }
-}
-template <bool AKM, bool BKM>
-__device__ __forceinline__ void mma_tile4(const char* At, const char* Bt, f32x16 (&acc)[2][2], int wm, int wn, int lane) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        bf16x8_t af[2], bfr[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            af[i] = frag4<AKM>(At, wm * 64 + i * 32, s, lane);
-            bfr[i] = frag4<BKM>(Bt, wn * 64 + i * 32, s, lane);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
-}
-// wait until at most `tiles_in_flight` later tiles (4 DMA pieces each per wave) are outstanding, then barrier
-__device__ __forceinline__ void wait_tiles_and_barrier(int tiles_in_flight) {
-    if (tiles_in_flight >= 2)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (tiles_in_flight == 1)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    bf16x8_t a0[2], b0[2], a1[2], b1[2];
+    load_frags<AKM, 0>(At, ka, wm * 64, lane, a0), load_frags<BKM, 0>(Bt, kb, wn * 64, lane, b0);
+    load_frags<AKM, 1>(At, ka, wm * 64, lane, a1), load_frags<BKM, 1>(Bt, kb, wn * 64, lane, b1);
+    frags_ready<AKM, BKM, NASM>(a0, b0);
+    mma_step(a0, b0, acc);
+    load_frags<AKM, 2>(At, ka, wm * 64, lane, a0), load_frags<BKM, 2>(Bt, kb, wn * 64, lane, b0);
+    frags_ready<AKM, BKM, NASM>(a1, b1);
+    mma_step(a1, b1, acc);
+    load_frags<AKM, 3>(At, ka, wm * 64, lane, a1), load_frags<BKM, 3>(Bt, kb, wn * 64, lane, b1);
+    frags_ready<AKM, BKM, NASM>(a0, b0);
+    mma_step(a0, b0, acc);
+    frags_ready<AKM, BKM, 0>(a1, b1);
+    mma_step(a1, b1, acc);
 }
 
 // ---- epilogue staging: one 32-row slab of every wave's accumulators -> LDS [64][SLAB_PITCH] fp32, so that the

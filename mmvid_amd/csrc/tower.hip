@@ -13,13 +13,12 @@ inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 constexpr int kMaxSplitK = 8;
 
 struct Dims {
-    int B, L, Lp, E, H, F, layers;
+    int B, L, E, H, F, layers;
     int64_t M;
 };
 Dims dims_of(const mmvid_tower_cfg_t& c) {
     Dims d;
     d.B = c.B, d.L = c.L, d.E = c.E, d.H = c.H, d.F = c.F, d.layers = c.layers;
-    d.Lp = (c.L + 63) / 64 * 64;
     d.M = (int64_t)c.B * c.L;
     return d;
 }
@@ -50,7 +49,7 @@ SavedLayer saved_layout(const Dims& d) {
 }
 
 struct Scratch {  // byte offsets inside the scratch arena
-    int64_t xt0, xt1, xt2, delta, dqkv, d_h, d_o, d_pre, g_bf16, splitk_ws, infer, total;
+    int64_t delta, dqkv, d_h, d_o, d_pre, g_bf16, splitk_ws, infer, total;
 };
 Scratch scratch_layout(const Dims& d) {
     Scratch s;
@@ -60,8 +59,6 @@ Scratch scratch_layout(const Dims& d) {
         off += align256(bytes);
         return o;
     };
-    const int64_t xt = (int64_t)d.B * d.H * 64 * d.Lp * 2;
-    s.xt0 = take(xt), s.xt1 = take(xt), s.xt2 = take(xt);
     s.delta = take((int64_t)d.B * d.H * d.L * 4);
     s.dqkv = take(d.M * 3 * d.E * 2);
     s.d_h = take(d.M * d.E * 4);
@@ -163,9 +160,8 @@ extern "C" int mmvid_tower_forward(const mmvid_tower_cfg_t* cfg, const mmvid_tow
         TRY(mmvid_layernorm_fwd(x, d.E, d.M, d.E, ly.ln1_w, ly.ln1_b, cfg->ln_eps, sv + sl.h1, nullptr, d.E,
                                 (float*)(sv + sl.mean1), (float*)(sv + sl.rstd1), stream));
         TRY(linear_fwd(d.M, 3 * d.E, d.E, sv + sl.h1, ly.in_w, ly.in_b, nullptr, nullptr, 0, nullptr, sv + sl.qkv, stream));
-        TRY(mmvid_head_transpose(sv + sl.qkv, 3 * d.E, 2 * d.E, d.B, d.L, d.Lp, d.H, scr + sc.xt0, stream));
-        TRY(mmvid_attention_fwd(sv + sl.qkv, 3 * d.E, scr + sc.xt0, d.B, d.L, d.Lp, d.H, d.E, scale, cfg->mask_mode,
-                                cfg->r0, cfg->c0, cfg->r1, cfg->c1, sv + sl.o, d.E, (float*)(sv + sl.lse2), stream));
+        TRY(mmvid_attention_fwd(sv + sl.qkv, 3 * d.E, d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0, cfg->r1,
+                                cfg->c1, sv + sl.o, d.E, (float*)(sv + sl.lse2), stream));
         TRY(linear_fwd(d.M, d.E, d.E, sv + sl.o, ly.out_w, ly.out_b, x, nullptr, 0, xmid, nullptr, stream));
         TRY(mmvid_layernorm_fwd(xmid, d.E, d.M, d.E, ly.ln2_w, ly.ln2_b, cfg->ln_eps, sv + sl.h2, nullptr, d.E,
                                 (float*)(sv + sl.mean2), (float*)(sv + sl.rstd2), stream));
@@ -205,13 +201,9 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
         // ---- attention branch: x_mid = x_in + out_proj(MHA(LN1 x_in))
         TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, ly.g_out_b, ws, stream));
         TRY(linear_dx(d.M, d.E, d.E, gb, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
-        TRY(mmvid_head_transpose(sv + sl.qkv, 3 * d.E, 0, d.B, d.L, d.Lp, d.H, scr + sc.xt0, stream));        // Q^T
-        TRY(mmvid_head_transpose(sv + sl.qkv, 3 * d.E, d.E, d.B, d.L, d.Lp, d.H, scr + sc.xt1, stream));      // K^T
-        TRY(mmvid_head_transpose(scr + sc.d_o, d.E, 0, d.B, d.L, d.Lp, d.H, scr + sc.xt2, stream));           // dO^T
-        TRY(mmvid_attention_bwd(sv + sl.qkv, 3 * d.E, scr + sc.xt0, scr + sc.xt1, sv + sl.o, d.E, scr + sc.d_o, d.E,
-                                scr + sc.xt2, (const float*)(sv + sl.lse2), (float*)(scr + sc.delta), d.B, d.L, d.Lp,
-                                d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0, cfg->r1, cfg->c1, scr + sc.dqkv,
-                                3 * d.E, stream));
+        TRY(mmvid_attention_bwd(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
+                                (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
+                                cfg->r1, cfg->c1, scr + sc.dqkv, 3 * d.E, stream));
         TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, ly.g_in_b, ws, stream));
         TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, d_h, nullptr, stream));
         TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),

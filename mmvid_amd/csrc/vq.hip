@@ -211,7 +211,7 @@ extern "C" int mmvid_vq_argmin_l2(const float* z, const float* codebook, const f
     size_t lds = (size_t)(2 * kTileCodes * (DIM + 2) + kWaves * kRowsPerWave) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)vq_argmin_kernel<DIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)vq_argmin_kernel<DIM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     int blocks = cdiv(rows, kWaves * kRowsPerWave);

@@ -144,19 +144,6 @@ def groupnorm_swish(x, w, b, eps=1e-6, swish=True, out_dtype=bf16):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def round_up(x, m):
-    return (x + m - 1) // m * m
-
-
-def head_transpose(src, col0, B, L, H):
-    """src token-major [B*L, ld] bf16 -> [B, H, 64, Lp] bf16 (zero padded)."""
-    _chk(src, bf16, 'src')
-    Lp = round_up(L, 64)
-    dst = torch.empty(B, H, 64, Lp, device=src.device, dtype=bf16)
-    call('mmvid_head_transpose', _p(src), src.shape[-1], col0, B, L, Lp, H, _p(dst), _stream())
-    return dst
-
-
 def _mask_args(mask):
     """mask: None | 'causal' | ('rows', [(row, first_allowed_col), ...])."""
     if mask is None:
@@ -173,24 +160,20 @@ def attention_fwd(qkv, B, L, H, mask=None, scale=0.125):
     """qkv [B*L, 3E] bf16 -> (out [B*L, E] bf16, lse2 [B,H,L] f32)."""
     _chk(qkv, bf16, 'qkv')
     E = H * 64
-    VT = head_transpose(qkv, 2 * E, B, L, H)
     out = torch.empty(B * L, E, device=qkv.device, dtype=bf16)
     lse2 = torch.empty(B, H, L, device=qkv.device, dtype=f32)
-    call('mmvid_attention_fwd', _p(qkv), 3 * E, _p(VT), B, L, VT.shape[-1], H, E, float(scale), *_mask_args(mask),
-         _p(out), E, _p(lse2), _stream())
+    call('mmvid_attention_fwd', _p(qkv), 3 * E, B, L, H, E, float(scale), *_mask_args(mask), _p(out), E, _p(lse2),
+         _stream())
     return out, lse2
 
 
 def attention_bwd(qkv, out, dout, lse2, B, L, H, mask=None, scale=0.125):
     """-> dqkv [B*L, 3E] bf16."""
     E = H * 64
-    QT = head_transpose(qkv, 0, B, L, H)
-    KT = head_transpose(qkv, E, B, L, H)
-    dOT = head_transpose(dout, 0, B, L, H)
     delta = torch.empty(B, H, L, device=qkv.device, dtype=f32)
     dqkv = torch.empty_like(qkv)
-    call('mmvid_attention_bwd', _p(qkv), 3 * E, _p(QT), _p(KT), _p(out), E, _p(dout), E, _p(dOT), _p(lse2), _p(delta),
-         B, L, QT.shape[-1], H, E, float(scale), *_mask_args(mask), _p(dqkv), 3 * E, _stream())
+    call('mmvid_attention_bwd', _p(qkv), 3 * E, _p(out), E, _p(dout), E, _p(lse2), _p(delta), B, L, H, E, float(scale),
+         *_mask_args(mask), _p(dqkv), 3 * E, _stream())
     return dqkv
 
 

@@ -220,15 +220,39 @@ def test_attention_fwd_bwd(ops, B, L, H, spec):
     close(dqkv[:, 2 * E:], g[:, 2 * E:], 2e-2, 'dV')
 
 
-def test_attention_softmax_spike(ops):
-    # one key dominates late in the sequence: exercises the online-softmax rescale path
+@pytest.mark.parametrize('spike_at', [40, 150, 190])
+def test_attention_softmax_spike(ops, spike_at):
+    # one key dominates late in the sequence: forces the (lazy, thresholded) online-softmax rescale branch to be
+    # taken at a chosen tile, with a jump far beyond the 2^8 threshold for some rows and below it for others
     B, L, H = 1, 200, 1
     qkv = rnd(B * L, 192, seed=9, dtype=torch.bfloat16)
     q = qkv[:, :64].float()
-    qkv[150, 64:128] = (q[3] * 6).bfloat16()
-    ref, _ = _attn_ref(qkv.float(), B, L, H, None)
-    out, _ = ops.attention_fwd(qkv, B, L, H, None)
-    close(out, ref, 1e-2, 'spike')
+    qkv[spike_at, 64:128] = (q[3] * 6).bfloat16()
+    qkv[spike_at - 7, 64:128] = (q[100] * 0.8).bfloat16()  # a mild bump: stays under the threshold
+    qkv_r = qkv.float().requires_grad_(True)
+    ref, _ = _attn_ref(qkv_r, B, L, H, None)
+    out, lse2 = ops.attention_fwd(qkv, B, L, H, None)
+    close(out, ref, 1e-2, 'spike fwd')
+    # lse2 is the log2-domain logsumexp whatever reference maximum the kernel kept
+    s = (qkv[:, :64].float() @ qkv[:, 64:128].float().t()) * 0.125
+    close(lse2.view(-1), torch.logsumexp(s, -1) * 1.4426950408889634, 1e-4, 'spike lse2')
+    dout = rnd(B * L, 64, seed=10, dtype=torch.bfloat16)
+    ref.backward(dout.float())
+    dqkv = ops.attention_bwd(qkv, out, dout, lse2, B, L, H, None)
+    close(dqkv, qkv_r.grad, 2e-2, 'spike bwd')
+
+
+def test_attention_deterministic(ops):
+    B, L, H = 3, 579, 12
+    qkv = rnd(B * L, 3 * H * 64, seed=77, dtype=torch.bfloat16)
+    dout = rnd(B * L, H * 64, seed=78, dtype=torch.bfloat16)
+    spec = ('rows', [(65, 65), (66, 66)])
+    outs = []
+    for _ in range(4):
+        out, lse2 = ops.attention_fwd(qkv, B, L, H, spec)
+        outs.append((out, lse2, ops.attention_bwd(qkv, out, dout, lse2, B, L, H, spec)))
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
 
 
 # ------------------------------------------------------------------------------------- embed / losses
