@@ -48,6 +48,8 @@ int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void*
  * ([splitk][N][K] fp32) with a fixed-order reduction: deterministic. */
 int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64_t ldy, const void* X, int64_t ldx, int splitk,
                        float* workspace, float* dW, int accumulate, void* stream);
+/* The split factor this library would choose for that GEMM on MI355X (1..16): size `workspace` with it. */
+int mmvid_gemm_dw_pick_splitk(int64_t M, int N, int K);
 
 /* ---- LayerNorm: clip_model.py:188-193 (fp32 statistics, eps 1e-5) and the nn.LayerNorm of the heads. */
 int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const float* w, const float* b, float eps,

@@ -21,8 +21,9 @@
 #include "prof.h"
 
 namespace {
-using mmvid_core::g_zero16;
-using mmvid_core::glds16;
+using mmvid_core::blds16;
+using mmvid_core::make_rsrc;
+using mmvid_core::rsrc_t;
 using mmvid_core::bf16x4_t;
 using mmvid_core::ds_read_tr16;
 using mmvid_core::lds_addr;
@@ -48,18 +49,27 @@ constexpr float RESCALE_THR = 8.0f;  // log2 domain
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// LDS-DMA of positions [p0, p0+64) x 64 d of a token-major matrix (zero block beyond L): 8 pieces of 1 KiB, 2 per wave
-__device__ __forceinline__ void stage_tile(const bf16_t* base, long ld, int p0, int L, char* tile, int wave, int lane) {
+// LDS-DMA of positions [p0, p0+64) x 64 d of one (batch, head) slice of a token-major matrix: 8 pieces of 1 KiB, 2 per
+// wave, through a buffer descriptor that ends at row L-1 -- positions >= L are zero-filled by the range check.
+// Per-lane offsets are computed once; a tile costs its two buffer_load ... lds and a scalar offset.
+struct TileStage {
+    rsrc_t rsrc;
+    uint32_t voff[2], rowbytes;
+    __device__ __forceinline__ void init(const bf16_t* slice, long ld, int L, int wave, int lane) {
+        rsrc = make_rsrc(slice, (uint32_t)(((long)(L - 1) * ld + 64) * 2));
+        rowbytes = (uint32_t)(ld * 2);
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int j = wave * 2 + jj;
-        const int row = j * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int pos = p0 + row;
-        const void* src = pos < L ? (const void*)(base + (long)pos * ld + chunk * 8) : (const void*)g_zero16;
-        glds16(src, tile + j * 1024);
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = (wave * 2 + jj) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            voff[jj] = (uint32_t)(((long)row * ld + chunk * 8) * 2);
+        }
     }
-}
+    __device__ __forceinline__ void issue(int p0, char* tile, int wave) const {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) blds16(rsrc, voff[jj], (uint32_t)p0 * rowbytes, tile + (wave * 2 + jj) * 1024);
+    }
+};
 
 // MFMA 32x32x16 operand whose rows are positions: row `row`, 8 consecutive d = 16 s + 8 h ..
 __device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int s, int h) {
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                                                           int nrt, float scale_log2, MaskSpec mask,
                                                           bf16_t* __restrict__ out, long ldo, float* __restrict__ lse2) {
     __shared__ __attribute__((aligned(16))) char smem[2][2 * TILE];  // K tile, V tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
     int qt, hd, b;
     block_coords(nrt, H, qt, hd, b);
     const int q = qt * ROWS_PER_BLOCK + wave * 32 + l32;
@@ -180,8 +190,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int ntiles = (kv_end + 63) >> 6;
     const int trl = tr_lane_off(lane);
 
-    stage_tile(Kbase, ld, 0, L, smem[0], wave, lane);
-    stage_tile(Vbase, ld, 0, L, smem[0] + TILE, wave, lane);
+    TileStage sk, sv;
+    sk.init(Kbase, ld, L, wave, lane), sv.init(Vbase, ld, L, wave, lane);
+    sk.issue(0, smem[0], wave), sv.issue(0, smem[0] + TILE, wave);
 
     float m_run = -INFINITY, lsum = 0.f;
     f32x16 oacc[2] = {zero16(), zero16()};
@@ -191,8 +202,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         const char* Vt = Kt + TILE;
         __syncthreads();  // tile t has landed (the barrier's release drains vmcnt); everyone is done with tile t-1
         if (t + 1 < ntiles) {
-            stage_tile(Kbase, ld, (t + 1) * 64, L, smem[(t + 1) & 1], wave, lane);
-            stage_tile(Vbase, ld, (t + 1) * 64, L, smem[(t + 1) & 1] + TILE, wave, lane);
+            sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
         }
         if (!wave_active) continue;
 #pragma unroll
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                                                              int nrt, float scale, float scale_log2, MaskSpec mask,
                                                              bf16_t* __restrict__ dqkv, long ldg) {
     __shared__ __attribute__((aligned(16))) char smem[2][2 * TILE];  // K tile, V tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
     int qt, hd, b;
     block_coords(nrt, H, qt, hd, b);
     const int q = qt * ROWS_PER_BLOCK + wave * 32 + l32;
@@ -280,8 +290,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const int ntiles = (kv_end + 63) >> 6;
     const int trl = tr_lane_off(lane);
 
-    stage_tile(Kbase, ld, 0, L, smem[0], wave, lane);
-    stage_tile(Vbase, ld, 0, L, smem[0] + TILE, wave, lane);
+    TileStage sk, sv;
+    sk.init(Kbase, ld, L, wave, lane), sv.init(Vbase, ld, L, wave, lane);
+    sk.issue(0, smem[0], wave), sv.issue(0, smem[0] + TILE, wave);
 
     f32x16 dq[2] = {zero16(), zero16()};
     for (int t = 0; t < ntiles; ++t) {
@@ -289,8 +300,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         const char* Vt = Kt + TILE;
         __syncthreads();
         if (t + 1 < ntiles) {
-            stage_tile(Kbase, ld, (t + 1) * 64, L, smem[(t + 1) & 1], wave, lane);
-            stage_tile(Vbase, ld, (t + 1) * 64, L, smem[(t + 1) & 1] + TILE, wave, lane);
+            sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
         }
         if (!wave_active) continue;
 #pragma unroll
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                                                               int nrt, float scale, float scale_log2, MaskSpec mask,
                                                               bf16_t* __restrict__ dqkv, long ldg) {
     __shared__ __attribute__((aligned(16))) char dsm[2 * DKV_BUF];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
     int kt, hd, b;
     block_coords(nrt, H, kt, hd, b);
     const int key = kt * ROWS_PER_BLOCK + wave * 32 + l32;
@@ -374,8 +384,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         if (tid < 64) return qq < L ? -lse_b[qq] : -INFINITY;
         return qq < L ? del_b[qq] : 0.f;
     };
-    stage_tile(Qbase, ld, t0 * 64, L, dsm, wave, lane);
-    stage_tile(dObase, lddo, t0 * 64, L, dsm + TILE, wave, lane);
+    TileStage sq, sdo;
+    sq.init(Qbase, ld, L, wave, lane), sdo.init(dObase, lddo, L, wave, lane);
+    sq.issue(t0 * 64, dsm, wave), sdo.issue(t0 * 64, dsm + TILE, wave);
     float stat = load_stat(t0);
     if (tid < 128) reinterpret_cast<float*>(dsm + 2 * TILE)[tid] = stat;
 
@@ -390,8 +401,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         const bool more = t + 1 < nq_tiles;
         __syncthreads();
         if (more) {
-            stage_tile(Qbase, ld, (t + 1) * 64, L, nx, wave, lane);
-            stage_tile(dObase, lddo, (t + 1) * 64, L, nx + TILE, wave, lane);
+            sq.issue((t + 1) * 64, nx, wave), sdo.issue((t + 1) * 64, nx + TILE, wave);
             stat = load_stat(t + 1);
         }
         if (wave_active) {
@@ -511,6 +521,7 @@ extern "C" int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, in
     MMVID_REQUIRE(qkv && out && lse2, "attention_fwd: null pointer");
     ATTN_COMMON_CHECKS("attention_fwd");
     MMVID_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, "attention_fwd: bad leading dims");
+    MMVID_REQUIRE((int64_t)L * ld * 2 < (1ll << 31), "attention_fwd: one batch entry of qkv must be smaller than 2 GiB");
     MmvidProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * 64, (hipStream_t)stream);
     const int nrt = cdiv(L, ROWS_PER_BLOCK);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
@@ -527,6 +538,8 @@ extern "C" int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, i
     MMVID_REQUIRE(qkv && O && dO && lse2 && delta && dqkv, "attention_bwd: null pointer");
     ATTN_COMMON_CHECKS("attention_bwd");
     MMVID_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldg % 4 == 0, "attention_bwd: bad leading dims");
+    MMVID_REQUIRE((int64_t)L * ld * 2 < (1ll << 31) && (int64_t)L * lddo * 2 < (1ll << 31),
+                  "attention_bwd: one batch entry of qkv / dO must be smaller than 2 GiB");
     hipStream_t s = (hipStream_t)stream;
     const MaskSpec m = make_mask(mask_mode, r0, c0, r1, c1);
     const float sl2 = scale * 1.4426950408889634f;

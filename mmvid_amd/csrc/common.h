@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
@@ -69,3 +70,12 @@ __device__ __forceinline__ void mfma_settle(f32x16& acc) { asm volatile("s_nop 1
 __device__ __forceinline__ void mfma_settle(f32x4& acc) { asm volatile("s_nop 15" : "+v"(acc)); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// MMVID_GEMM_TILE=128|256 forces the block shape of the MFMA GEMM / conv kernels (A/B testing); 0 = by grid fill
+static inline int mmvid_tile_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MMVID_GEMM_TILE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}

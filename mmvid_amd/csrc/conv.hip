@@ -2,7 +2,8 @@
 //   M = N*Hout*Wout output pixels, N_gemm = Cout, K = taps*Cin with k = (ky*3+kx)*Cin + ci.
 // The A tile is gathered straight from the NHWC activation by LDS-DMA (each 16-B chunk = 8 input channels of
 // one tap of one pixel: contiguous; padding taps read a zero block); the weight [Cout][taps][Cin] is the
-// row-major B operand.  Same 128x128x64 tile / swizzled LDS / 32x32x16 MFMA core as gemm.hip.
+// row-major B operand.  Same block shapes (128x128 2-stage / 256x128 3-stage ring), swizzled LDS and 32x32x16 MFMA
+// core as gemm.hip.
 //   mode 0: 3x3 s1 p1                     (model.py:102-115 ResnetBlock convs, conv_in/out)
 //   mode 1: 3x3 s2, zero pad right/bottom (model.py:77-81 Downsample)
 //   mode 2: nearest x2 upsample + 3x3 p1  (model.py:56-62 Upsample; the upsampled image is never materialised)
@@ -32,7 +33,61 @@ struct ConvParams {
 
 // A-operand gather by LDS-DMA: this lane owns, in each of its wave's 4 DMA pieces, LDS slot (lane&7) of tile row
 // (wave*4+jj)*8 + (lane>>3); the logical k chunk that belongs in that slot follows the row swizzle of gemm_core.h.
-struct ConvAStage {
+//
+// FAST form (Cin % 64 == 0, modes 0/1/3 -- every encoder layer but conv_in): a 64-deep K tile lies inside ONE tap,
+// so the tap is wave-uniform.  Per piece the lane keeps the byte offset of its centre pixel (+ channel chunk) and a
+// 9-bit mask of the taps that fall inside the image; a tile is then: move the buffer descriptor's base by the tap
+// displacement (SALU), and per piece one mask test -> offset or the out-of-range marker (zero fill by the range
+// check) -> buffer_load ... lds.  No per-tile address arithmetic in VGPRs.
+template <bool FAST>
+struct ConvAStage;
+
+template <>
+struct ConvAStage<true> {
+    uint32_t voff[4], mask[4];
+    __device__ __forceinline__ void init(const ConvParams& p, long m0, int wave, int lane) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int row = (wave * 4 + jj) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const long m = m0 + row;
+            voff[jj] = 0, mask[jj] = 0;
+            if (m < p.M) {
+                const long hw = (long)p.Hout * p.Wout;
+                const long n = m / hw;
+                const int rem = (int)(m - n * hw);
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                const int cy = p.mode == 1 ? 2 * oy : oy, cx = p.mode == 1 ? 2 * ox : ox;
+                voff[jj] = (uint32_t)(((((n * p.Hin + cy) * p.Win + cx) << p.cin_log2) + chunk * 8) * 2);
+                uint32_t rb, cb;  // valid ky / kx bits
+                if (p.mode == 0) {
+                    rb = (oy >= 1 ? 1u : 0u) | 2u | (oy + 1 < p.Hin ? 4u : 0u);
+                    cb = (ox >= 1 ? 1u : 0u) | 2u | (ox + 1 < p.Win ? 4u : 0u);
+                } else if (p.mode == 1) {
+                    rb = 3u | (2 * oy + 2 < p.Hin ? 4u : 0u);
+                    cb = 3u | (2 * ox + 2 < p.Win ? 4u : 0u);
+                } else {
+                    rb = 1u, cb = 1u;
+                }
+                mask[jj] = ((rb & 1u) ? cb : 0u) | ((rb & 2u) ? cb << 3 : 0u) | ((rb & 4u) ? cb << 6 : 0u);
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(const ConvParams& p, int k0, char* tile, int wave) const {
+        const int tap = k0 >> p.cin_log2, ci0 = k0 & (p.Cin - 1);  // wave-uniform
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int disp = p.mode == 0 ? (ky - 1) * p.Win + (kx - 1) : (p.mode == 1 ? ky * p.Win + kx : 0);
+        const long byte_disp = (((long)disp << p.cin_log2) + ci0) * 2;
+        const rsrc_t rsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + byte_disp, 0x7fffffffu);
+        const uint32_t bit = 1u << tap;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            blds16(rsrc, (mask[jj] & bit) ? voff[jj] : OOB, 0, tile + (wave * 4 + jj) * 1024);
+    }
+};
+
+template <>
+struct ConvAStage<false> {
     int oy[4], ox[4], chunk[4];
     long nbase[4];  // n*Hin*Win, or -1 when the output pixel is out of range
     __device__ __forceinline__ void init(const ConvParams& p, long m0, int wave, int lane) {
@@ -83,13 +138,15 @@ struct ConvAStage {
     }
 };
 
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
+template <int WM, bool FAST>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(ConvParams p) {
+    using S = BlockShape<WM>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int wg = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
     const int bn0 = (wg % gridDim.x) * BN;
-    const long bm0 = (long)(wg / gridDim.x) * BM;
+    const long bm0 = (long)(wg / gridDim.x) * S::ROWS;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -98,20 +155,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    ConvAStage sa;
+    ConvAStage<FAST> sa;  // 4 pieces (32 output pixels) per wave: 4 waves cover 128 rows, 8 waves 256
     sa.init(p, bm0, wave, lane);
+    OperandStage<false, 1, S::PPW> sb;  // weights [Cout][K] row-major
+    sb.init(p.w, p.K, p.Cout, p.K, bn0, wave, lane);
     const int nt = (p.K + BK - 1) / BK;
-    sa.issue(p, 0, smem, wave);
-    stage<false>(p.w, p.K, p.Cout, p.K, bn0, 0, smem + TILE_BYTES, wave, lane);
-    for (int t = 0; t < nt; ++t) {
-        char* cur = smem + (t & 1) * (2 * TILE_BYTES);
-        char* nxt = smem + ((t + 1) & 1) * (2 * TILE_BYTES);
-        __syncthreads();
-        if (t + 1 < nt) {
-            sa.issue(p, (t + 1) * BK, nxt, wave);
-            stage<false>(p.w, p.K, p.Cout, p.K, bn0, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+    auto stage_tile = [&](int t, char* buf) {
+        sa.issue(p, t * BK, buf, wave);
+        sb.issue(t * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane);
+    };
+    auto compute_tile = [&](const char* buf) {
+        mma_tile<false, false>(buf + (wm >> 1) * TILE_BYTES, buf + S::NSUB * TILE_BYTES, acc, wm & 1, wn, lane);
+    };
+    if constexpr (S::NSTAGE == 2) {
+        stage_tile(0, smem);
+        for (int t = 0; t < nt; ++t) {
+            char* cur = smem + (t & 1) * S::STAGE_BYTES;
+            char* nxt = smem + ((t + 1) & 1) * S::STAGE_BYTES;
+            __syncthreads();
+            if (t + 1 < nt) stage_tile(t + 1, nxt);
+            compute_tile(cur);
         }
-        mma_tile<false, false>(cur, cur + TILE_BYTES, acc, wm, wn, lane);
+    } else {  // 3-stage ring with counted vmcnt (see gemm.hip)
+        char* b0 = smem;
+        char* b1 = smem + S::STAGE_BYTES;
+        char* b2 = smem + 2 * S::STAGE_BYTES;
+        stage_tile(0, b0);
+        if (nt > 1) stage_tile(1, b1);
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt)
+                wait_dma_and_barrier<S::DMA_PER_TILE>();
+            else
+                wait_dma_and_barrier<0>();
+            if (t + 2 < nt) stage_tile(t + 2, b2);
+            compute_tile(b0);
+            char* tmp = b0;
+            b0 = b1, b1 = b2, b2 = tmp;
+        }
     }
     // epilogue through LDS (row-contiguous global traffic; see gemm.hip)
     mfma_settle(acc[0][0]), mfma_settle(acc[0][1]), mfma_settle(acc[1][0]), mfma_settle(acc[1][1]);
@@ -130,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int r, ml, c;
-            slab_piece(tid, k, i, r, ml, c);
+            slab_piece<S::THREADS>(tid, k, i, r, ml, c);
             mrow[k] = bm0 + ml;
             const bool ok = n_ok && mrow[k] < p.M;
             const long o = mrow[k] * p.Cout + n;
@@ -204,6 +284,19 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
+template <int WM, bool FAST>
+void launch_conv(const ConvParams& p, hipStream_t stream) {
+    using S = BlockShape<WM>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<WM, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  S::LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, FAST>), dim3(cdiv(p.Cout, BN), cdiv(p.M, S::ROWS)), dim3(S::THREADS), S::LDS_BYTES,
+                       stream, p);
+}
+
 int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -237,14 +330,22 @@ extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Wi
     p.bias = bias, p.res_bf16 = (const bf16_t*)residual_bf16, p.res_f32 = residual_f32, p.clamp01 = clamp01;
     p.out_bf16 = (bf16_t*)out_bf16, p.out_f32 = out_f32;
     if (p.M == 0) return MMVID_OK;
-    static bool attr = false;
-    const int lds = 4 * TILE_BYTES;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
-    }
+    MMVID_REQUIRE((long)N * Hin * Win * Cin * 2 < (1ll << 31) && (long)Cout * p.K * 2 < (1ll << 31),
+                  "conv2d_nhwc: input or weight of 2 GiB or more (32-bit buffer offsets)");
     MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * p.K, (hipStream_t)stream);
-    hipLaunchKernelGGL(conv_igemm_kernel, dim3(cdiv(Cout, BN), cdiv(p.M, BM)), dim3(256), lds, (hipStream_t)stream, p);
+    const int tile = mmvid_tile_override();
+    bool big = false;
+    if (tile == 256 || (tile != 128 && (long)cdiv(p.M, 256) * cdiv(Cout, BN) >= 200))
+        big = true;
+    const bool fast = Cin % 64 == 0 && mode != 2;
+    if (big && fast)
+        launch_conv<4, true>(p, (hipStream_t)stream);
+    else if (big)
+        launch_conv<4, false>(p, (hipStream_t)stream);
+    else if (fast)
+        launch_conv<2, true>(p, (hipStream_t)stream);
+    else
+        launch_conv<2, false>(p, (hipStream_t)stream);
     MMVID_LAUNCH_CHECK("conv2d_nhwc");
     return MMVID_OK;
 }

@@ -55,14 +55,15 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
-template <bool AKM, bool BKM>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A tile | B tile]
+template <bool AKM, bool BKM, int WM>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(GemmParams p) {
+    using S = BlockShape<WM>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSTAGE][A sub-tiles | B tile]
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS bases stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int wg = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-    const int bn0 = (wg % gridDim.x) * BN, bm0 = (wg / gridDim.x) * BM;
+    const int bn0 = (wg % gridDim.x) * BN, bm0 = (wg / gridDim.x) * S::ROWS;
     const int batch = blockIdx.z / p.splitk, ks = blockIdx.z % p.splitk;
     const bf16_t* A = p.A + (long)batch * p.strideA;
     const bf16_t* B = p.B + (long)batch * p.strideB;
@@ -83,22 +84,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    {
-        // 2 stages x 64-deep tiles, one barrier per K tile: the barrier (with the compiler's vmcnt(0) in front of it)
-        // makes tile t visible to every wave and proves everyone is done reading the buffer tile t+1 overwrites.
-        if (nt > 0) {
-            stage<AKM>(A, p.lda, p.M, p.K, bm0, kt0 * BK, smem, wave, lane);
-            stage<BKM>(B, p.ldb, p.N, p.K, bn0, kt0 * BK, smem + TILE_BYTES, wave, lane);
-        }
+    OperandStage<AKM, S::NSUB, S::PPW> sa;
+    OperandStage<BKM, 1, S::PPW> sb;
+    sa.init(A, p.lda, p.M, p.K, bm0, wave, lane);
+    sb.init(B, p.ldb, p.N, p.K, bn0, wave, lane);
+    auto stage_tile = [&](int t, char* buf) {
+        const int k0 = (kt0 + t) * BK;
+        sa.issue(k0, p.K, buf, wave, lane);
+        sb.issue(k0, p.K, buf + S::NSUB * TILE_BYTES, wave, lane);
+    };
+    auto compute_tile = [&](const char* buf) {
+        mma_tile<AKM, BKM>(buf + (wm >> 1) * TILE_BYTES, buf + S::NSUB * TILE_BYTES, acc, wm & 1, wn, lane);
+    };
+    if constexpr (S::NSTAGE == 2) {
+        // 2 stages, one barrier per K tile: the barrier (with the compiler's vmcnt(0) in front of it) makes tile t
+        // visible to every wave and proves everyone is done reading the buffer tile t+1 overwrites.
+        if (nt > 0) stage_tile(0, smem);
         for (int t = 0; t < nt; ++t) {
-            char* cur = smem + (t & 1) * (2 * TILE_BYTES);
-            char* nxt = smem + ((t + 1) & 1) * (2 * TILE_BYTES);
+            char* cur = smem + (t & 1) * S::STAGE_BYTES;
+            char* nxt = smem + ((t + 1) & 1) * S::STAGE_BYTES;
             __syncthreads();
-            if (t + 1 < nt) {
-                stage<AKM>(A, p.lda, p.M, p.K, bm0, (kt0 + t + 1) * BK, nxt, wave, lane);
-                stage<BKM>(B, p.ldb, p.N, p.K, bn0, (kt0 + t + 1) * BK, nxt + TILE_BYTES, wave, lane);
-            }
-            mma_tile<AKM, BKM>(cur, cur + TILE_BYTES, acc, wm, wn, lane);
+            if (t + 1 < nt) stage_tile(t + 1, nxt);
+            compute_tile(cur);
+        }
+    } else {
+        // 3-stage ring: tile t+2 is requested right after the barrier that ends tile t-1 (its buffer is free then);
+        // each wave only waits for ITS OWN pieces of tile t (counted vmcnt: tile t+1's stay in flight).
+        char* b0 = smem;
+        char* b1 = smem + S::STAGE_BYTES;
+        char* b2 = smem + 2 * S::STAGE_BYTES;
+        if (nt > 0) stage_tile(0, b0);
+        if (nt > 1) stage_tile(1, b1);
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt)
+                wait_dma_and_barrier<S::DMA_PER_TILE>();
+            else
+                wait_dma_and_barrier<0>();
+            if (t + 2 < nt) stage_tile(t + 2, b2);
+            compute_tile(b0);
+            char* tmp = b0;
+            b0 = b1, b1 = b2, b2 = tmp;
         }
     }
 
@@ -126,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int r, ml, c;
-            slab_piece(tid, k, i, r, ml, c);
+            slab_piece<S::THREADS>(tid, k, i, r, ml, c);
             mrow[k] = bm0 + ml;
             const bool ok = n_ok && mrow[k] < p.M;
             v4[k] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + c);
@@ -184,17 +209,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<float4*>(out + i) = a;
 }
 
-template <bool AKM, bool BKM>
-int launch(const GemmParams& p, int batch, hipStream_t stream) {
+// Block shape by grid fill: the 256x128 / 3-stage kernel runs one block per CU, so it needs ~a full wave of blocks.
+bool use_big_tile(long M, long N, long zdim) {
+    const int o = mmvid_tile_override();
+    if (o == 128) return false;
+    if (o == 256) return true;
+    const long blocks = (long)cdiv(M, 256) * cdiv(N, BN) * zdim;
+    return M >= 256 && blocks >= 200;
+}
+
+template <bool AKM, bool BKM, int WM>
+void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
+    using S = BlockShape<WM>;
     static bool attr = false;
-    const int lds = 4 * TILE_BYTES;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  S::LDS_BYTES);
         attr = true;
     }
-    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), batch * p.splitk);
+    dim3 grid(cdiv(p.N, BN), cdiv(p.M, S::ROWS), batch * p.splitk);
+    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM>), grid, dim3(S::THREADS), S::LDS_BYTES, stream, p);
+}
+
+template <bool AKM, bool BKM>
+int launch(const GemmParams& p, int batch, hipStream_t stream) {
     MmvidProfScope prof(AKM ? PROF_GEMM_TN : (BKM ? PROF_GEMM_NN : PROF_GEMM_NT), 2.0 * p.M * p.N * (double)p.K * batch, stream);
-    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM>), grid, dim3(256), lds, stream, p);
+    if (use_big_tile(p.M, p.N, (long)batch * p.splitk))
+        launch_shape<AKM, BKM, 4>(p, batch, stream);
+    else
+        launch_shape<AKM, BKM, 2>(p, batch, stream);
     return 0;
 }
 
@@ -215,6 +258,10 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     if (a_kmajor) MMVID_REQUIRE(M % 8 == 0, "gemm_bf16: M (%d) must be a multiple of 8 for a k-major A", M);
     MMVID_REQUIRE(!(a_kmajor && !b_kmajor), "gemm_bf16: layout (A k-major, B row-major) is not used on this path");
     MMVID_REQUIRE(splitk >= 1, "gemm_bf16: splitk must be >= 1");
+    {  // operands are addressed with 32-bit byte offsets through buffer descriptors
+        const int64_t ea = a_kmajor ? (int64_t)K * lda : (int64_t)M * lda, eb = b_kmajor ? (int64_t)K * ldb : (int64_t)N * ldb;
+        MMVID_REQUIRE(ea * 2 < (1ll << 31) && eb * 2 < (1ll << 31), "gemm_bf16: an operand of 2 GiB or more per batch entry");
+    }
     if (splitk > 1)
         MMVID_REQUIRE(out_f32 && !out_bf16 && !act && !dact_pre && !save_pre && !residual,
                       "gemm_bf16: split-K supports only fp32 atomic accumulation (+bias)");
@@ -240,6 +287,18 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     return MMVID_OK;
 }
 
+// Split factor for the dW GEMM: its output [N][K] has few tiles and the reduction (tokens) is long.  One wave of
+// 256x128 blocks (one per CU); at least 6 K tiles per split; the workspace holds up to 16 partial copies.
+extern "C" int mmvid_gemm_dw_pick_splitk(int64_t M, int N, int K) {
+    const long tiles = (long)cdiv(N, 256) * cdiv(K, BN);
+    const long ktiles = cdiv(M, BK);
+    long sk = tiles > 0 ? 256 / tiles : 1;
+    if (sk > ktiles / 6) sk = ktiles / 6;
+    if (sk > 16) sk = 16;
+    if (sk < 1) sk = 1;
+    return (int)sk;
+}
+
 // dW[N][K] (+)= dY^T X reduced over M tokens: both operands k-major.  Split-K goes through `workspace`
 // ([splitk][N][K] fp32) and a fixed-order reduction: deterministic, no atomics.  dY [M][ldy>=N], X [M][ldx>=K].
 extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64_t ldy, const void* X, int64_t ldx,
@@ -247,6 +306,7 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     MMVID_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "gemm_bf16_dw: bad arguments");
     MMVID_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "gemm_bf16_dw: N, K, ldy, ldx must be multiples of 8");
     MMVID_REQUIRE(splitk >= 1 && (splitk == 1 || workspace), "gemm_bf16_dw: split-K needs a workspace");
+    MMVID_REQUIRE(M * ldy * 2 < (1ll << 31) && M * ldx * 2 < (1ll << 31), "gemm_bf16_dw: an operand of 2 GiB or more");
     GemmParams p;
     p.A = (const bf16_t*)dY, p.B = (const bf16_t*)X;
     p.M = N, p.N = K, p.K = (int)M, p.lda = ldy, p.ldb = ldx;

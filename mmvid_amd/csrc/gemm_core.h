@@ -14,8 +14,7 @@
 //                                    j=0..3 -- verified on hardware by tools/gpu_probe.py), so dX / dW GEMMs need
 //                                    neither transposed copies in HBM nor register transposes.
 //
-// Out-of-range chunks (row >= rows, k >= K) read a 16-byte zero block instead: the DMA cannot be predicated per
-// lane without leaving stale LDS bytes.
+// Out-of-range chunks (row >= rows, k >= K) are zero-filled by the buffer range check (OperandStage below).
 #pragma once
 #include "common.h"
 
@@ -45,40 +44,89 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     return base + (id >> 3);
 }
 
-// ---- row-major operand -------------------------------------------------------------------------------------
-__device__ __forceinline__ int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-// Issue the 4 DMA pieces this wave owns of a row-major tile: rows [r0, r0+128) x k [k0, k0+64) of base[rows][ld].
-__device__ __forceinline__ void stage_rowmajor(const bf16_t* base, long ld, int rows, int K, int r0, int k0, char* tile,
-                                               int wave, int lane) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = wave * 4 + jj;
-        const int row = j * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const int gr = r0 + row, k = k0 + c * 8;
-        const void* src = (gr < rows && k < K) ? (const void*)(base + (long)gr * ld + k) : (const void*)g_zero16;
-        glds16(src, tile + j * 1024);
-    }
+// ---- operand staging by LDS-DMA through a buffer descriptor ---------------------------------------------------
+// buffer_load_dwordx4 ... lds: per-lane 32-bit byte offset (VGPR, computed ONCE per block) + uniform per-tile advance
+// (SGPR soffset) against a bounds-checked descriptor.  Measured with the plain global_load_lds form: ~20 VALU/SALU
+// instructions of 64-bit address arithmetic per 1-KiB piece made the K loop ISSUE-bound (PMC: 170 non-MFMA
+// instructions per 16 MFMAs); here a piece costs its s_mov m0 and the load.  Out-of-range lanes (offset + soffset
+// beyond num_records, or the explicit OOB marker) write ZEROS to LDS -- verified on hardware by
+// tools/gpu_probe_buffer.py -- which pads ragged M / N / K edges without a zero page or per-lane pointer selects.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t OOB = 0x80000000u;  // with num_records <= 0x7fffffff: always out of range
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);  // raw, stride 0
 }
+__device__ __forceinline__ void blds16(rsrc_t r, uint32_t voff, uint32_t soff, char* lds_dst_wave_uniform) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)lds_dst_wave_uniform, 16, voff, soff, 0, 0);
+}
+
+__device__ __forceinline__ int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ bf16x8_t frag_rowmajor(const char* tile, int row, int s, int fh) {
     return *reinterpret_cast<const bf16x8_t*>(tile + rm_off(row, 2 * s + fh));
 }
 
-// ---- k-major operand ---------------------------------------------------------------------------------------
-// tile k [k0, k0+64) x rows [r0, r0+128) of base[K][ld]
-__device__ __forceinline__ void stage_kmajor(const bf16_t* base, long ld, int rows, int K, int r0, int k0, char* tile,
-                                             int wave, int lane) {
+// One GEMM operand = NSUB 128-row sub-tiles per K tile; this wave owns PPW of the 16 DMA pieces of each.
+//   row-major [rows][ld] : LDS [128 rows][64 k], piece j = rows 8j..8j+7, slot lane&7 holds chunk (lane&7)^swz(row)
+//   k-major   [K][ld]    : LDS [64 k][128 rows], piece j = k rows 4j..4j+3, slot lane&15 holds chunk (lane&15)^swz(k)
+// The descriptor covers exactly the operand, so rows >= `rows` (row-major) and k >= K (k-major) read as zeros by the
+// range check; the K tail of a row-major operand and the column tail of a k-major one use the OOB marker.
+template <bool KM, int NSUB, int PPW>
+struct OperandStage {
+    rsrc_t rsrc;
+    uint32_t voff[NSUB * PPW];
+    uint32_t kstep;  // bytes per unit of k
+    __device__ __forceinline__ void init(const bf16_t* base, long ld, int rows, int K, int r0, int wave, int lane) {
+        if constexpr (KM) {
+            rsrc = make_rsrc(base, (uint32_t)(((long)(K - 1) * ld + rows) * 2));
+            kstep = (uint32_t)(ld * 2);
+        } else {
+            rsrc = make_rsrc(base, (uint32_t)(((long)(rows - 1) * ld + K) * 2));
+            kstep = 2;
+        }
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = wave * 4 + jj;
-        const int kr = j * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ ((kr & 3) << 2);  // logical 16-B chunk (8 rows) that lands in slot lane&15
-        const int k = k0 + kr, r = r0 + c * 8;
-        const void* src = (k < K && r < rows) ? (const void*)(base + (long)k * ld + r) : (const void*)g_zero16;
-        glds16(src, tile + j * 1024);
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int jj = 0; jj < PPW; ++jj) {
+                const int j = wave * PPW + jj;
+                uint32_t v;
+                if constexpr (KM) {
+                    const int kr = j * 4 + (lane >> 4);
+                    const int c = (lane & 15) ^ ((kr & 3) << 2);
+                    const int r = r0 + sub * 128 + c * 8;
+                    v = r < rows ? (uint32_t)(((long)kr * ld + r) * 2) : OOB;
+                } else {
+                    const int row = j * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ ((row >> 1) & 7);
+                    const int gr = r0 + sub * 128 + row;
+                    v = gr < rows ? (uint32_t)(((long)gr * ld + c * 8) * 2) : OOB;
+                }
+                voff[sub * PPW + jj] = v;
+            }
     }
-}
+    // request tile k [k0, k0+64) into `stage` (this operand's first sub-tile); `wave` must be wave-uniform (SGPR)
+    __device__ __forceinline__ void issue(int k0, int K, char* stage, int wave, int lane) const {
+        const uint32_t soff = (uint32_t)k0 * kstep;
+        if (!KM && k0 + BK > K) {  // K tail of a row-major operand (k-major tails fall to the range check)
+            asm volatile("; K-tail tile" ::: "memory");  // keeps this a branch: the hot path must not pay for the selects
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+                for (int jj = 0; jj < PPW; ++jj) {
+                    const int j = wave * PPW + jj;
+                    const int row = j * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ ((row >> 1) & 7);
+                    blds16(rsrc, k0 + c * 8 < K ? voff[sub * PPW + jj] : OOB, soff, stage + sub * TILE_BYTES + j * 1024);
+                }
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+                for (int jj = 0; jj < PPW; ++jj)
+                    blds16(rsrc, voff[sub * PPW + jj], soff, stage + sub * TILE_BYTES + (wave * PPW + jj) * 1024);
+        }
+    }
+};
+
 // The transpose read is issued as inline asm: hipcc (ROCm 7.2) treats the ds_read_tr16 builtin as a possible LDS
 // STORE and puts an s_waitcnt vmcnt(0) in front of it whenever LDS-DMA is in flight -- i.e. it would drain the
 // prefetch of tile t+1 before the first fragment of tile t is read.  In asm form the compiler does not track the
@@ -122,13 +170,28 @@ __device__ __forceinline__ bf16x8_t frag_kmajor(uint32_t lane_addr) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool KM>
-__device__ __forceinline__ void stage(const bf16_t* base, long ld, int rows, int K, int r0, int k0, char* tile, int wave,
-                                      int lane) {
-    if constexpr (KM)
-        stage_kmajor(base, ld, rows, K, r0, k0, tile, wave, lane);
-    else
-        stage_rowmajor(base, ld, rows, K, r0, k0, tile, wave, lane);
+// ---- block shapes --------------------------------------------------------------------------------------------
+// WM = wave rows of the block (each wave 64x64, two wave columns):
+//   WM = 2: 128x128 tile, 256 threads, 2 LDS stages of 32 KiB, two blocks per CU.
+//   WM = 4: 256x128 tile, 512 threads, THREE stages of 48 KiB (A = two 128-row sub-tiles, then B), one block per CU:
+//           the LDS-DMA of tile t+2 is in flight while tile t is multiplied (counted s_waitcnt vmcnt, raw s_barrier),
+//           so the ~2 us load latency is covered by two tiles of MFMA work instead of one.
+template <int WM>
+struct BlockShape {
+    static constexpr int THREADS = WM * 128;
+    static constexpr int ROWS = WM * 64;
+    static constexpr int NSUB = WM / 2;                        // 128-row A sub-tiles
+    static constexpr int PPW = 8 / WM;                         // DMA pieces per wave per 16-KiB tile
+    static constexpr int STAGE_BYTES = (NSUB + 1) * TILE_BYTES;
+    static constexpr int NSTAGE = WM == 2 ? 2 : 3;
+    static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
+    static constexpr int DMA_PER_TILE = (NSUB + 1) * PPW;      // per wave
+};
+// wait until this wave's DMA of the current tile has landed (the next tile's may stay in flight), then barrier
+template <int KEEP>
+__device__ __forceinline__ void wait_dma_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+    __builtin_amdgcn_s_barrier();
 }
 
 // the two 32-row fragments (i = 0, 1) of a wave's 64 operand rows for k-step S
@@ -198,9 +261,10 @@ __device__ __forceinline__ void slab_write(const f32x16 (&acc)[2][2], int i, flo
             *reinterpret_cast<float4*>(slab + (wm * 32 + frow) * SLAB_PITCH + wn * 64 + j * 32 + 8 * q + 4 * fh) =
                 make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
 }
-// piece k (0..7) of thread tid: slab row r, tile-local row m_local (for slab i), tile-local column c
+// piece k (0..7) of thread tid (of NT): slab row r, tile-local row m_local (for slab i), tile-local column c
+template <int NT = 256>
 __device__ __forceinline__ void slab_piece(int tid, int k, int i, int& r, int& m_local, int& c) {
-    const int idx = tid + 256 * k;
+    const int idx = tid + NT * k;
     r = idx >> 5;
     c = (idx & 31) * 4;
     m_local = (r >> 5) * 64 + i * 32 + (r & 31);

@@ -10,7 +10,7 @@
 namespace {
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
-constexpr int kMaxSplitK = 8;
+constexpr int kMaxSplitK = 16;  // == the cap of mmvid_gemm_dw_pick_splitk
 
 struct Dims {
     int B, L, E, H, F, layers;
@@ -85,17 +85,6 @@ int check_cfg(const mmvid_tower_cfg_t* c) {
     return 0;
 }
 
-// dW GEMMs have few output tiles (<= 144) and a long reduction (tokens): split K so that ~2 blocks per CU exist.
-int pick_splitk(int Mout, int Nout, int64_t K) {
-    const int tiles = cdiv(Mout, 128) * cdiv(Nout, 128);
-    int sk = (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
-    const int ktiles = cdiv(K, 64);
-    if (sk > ktiles / 4) sk = ktiles / 4;
-    if (sk > kMaxSplitK) sk = kMaxSplitK;
-    if (sk < 1) sk = 1;
-    return sk;
-}
-
 // Y = X W^T + b with epilogue options (A row-major [M,K], B row-major [N,K])
 int linear_fwd(int64_t M, int N, int K, const void* X, const void* W, const float* bias, const float* residual,
                void* save_pre, int act, float* out_f32, void* out_bf16, void* st) {
@@ -110,7 +99,7 @@ int linear_dx(int64_t M, int N, int K, const void* dY, const void* W, const void
 }
 // dW[N,K] += dY^T X (both k-major over the token dimension), db[N] += colsum(dY)
 int linear_dw(int64_t M, int N, int K, const void* dY, const void* X, float* dW, float* db, float* ws, void* st) {
-    const int sk = pick_splitk(N, K, M);
+    const int sk = mmvid_gemm_dw_pick_splitk(M, N, K);
     TRY(mmvid_gemm_bf16_dw(M, N, K, dY, N, X, K, sk, ws, dW, /*accumulate=*/1, st));
     if (db) TRY(mmvid_colsum_bf16(dY, N, M, N, db, st));
     return 0;

@@ -102,8 +102,7 @@ def gemm_dw(dY, X, dW, accumulate=True, splitk=None):
     M, N = dY.shape
     K = X.shape[1]
     if splitk is None:
-        tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        splitk = max(1, min(8, (512 + tiles - 1) // tiles, ((M + 63) // 64) // 4))
+        splitk = _lib.load().mmvid_gemm_dw_pick_splitk(M, N, K)
     ws = torch.empty(splitk * N * K, device=dY.device, dtype=f32) if splitk > 1 else None
     call('mmvid_gemm_bf16_dw', M, N, K, _p(dY), N, _p(X), K, splitk, _p(ws), _p(dW), int(accumulate), _stream())
     return dW

@@ -37,7 +37,7 @@ def main():
         print(f'{name:5s} fwd  NT {M}x{N}x{K}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
         t = timeit(lambda: ops.gemm(dY, W, b_kmajor=True))
         print(f'{name:5s} dX   NN {M}x{K}x{N}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
-        for sk in (1, 2, 4, 8):
+        for sk in (None, 3, 4, 8, 14):
             t = timeit(lambda: ops.gemm_dw(dY, X, dW, splitk=sk))
             print(f'{name:5s} dW   TN sk={sk} {N}x{K}x{M}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
     for name, N, H, Cin, Cout, mode in (('c128@128', 96, 128, 128, 128, 0), ('c256@32', 96, 32, 256, 256, 0), ('c512@8', 96, 8, 512, 512, 0),
