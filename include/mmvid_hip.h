@@ -60,10 +60,12 @@ int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t l
                         const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
                         int add_into_dx, void* dx_bf16, float* dw, float* db, void* stream);
 /* GroupNorm(32, eps) [+ swish] on NHWC: taming/modules/diffusionmodules/model.py:38-42, 33-35.
- * stats_scratch: fp32 [N * (2*C + 64 * ceil(hw / 256))]; deterministic (fixed-order reductions, no atomics). */
+ * stats_scratch: fp32 [N * (2*C + 64 * ceil(hw / 128))] = the per-channel affine [N][C][2], then partial sums
+ * [N][blocks][32][2].  partial_blocks = 0: the statistics pass runs here; = hw/128: the producing convolution
+ * already wrote the partial sums (mmvid_conv2d_nhwc gn_partial).  Deterministic: fixed-order reductions, no atomics. */
 int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, int C, const float* w,
-                               const float* b, float eps, int swish, float* stats_scratch, void* y_bf16,
-                               float* y_f32, void* stream);
+                               const float* b, float eps, int swish, float* stats_scratch, int partial_blocks,
+                               void* y_bf16, float* y_f32, void* stream);
 
 /* ---- attention core, head_dim 64: clip_model.py:217-222 with the masks of clip_model.py:561-578.
  * qkv: token-major [B*L, ld] bf16 with Q at column 0, K at E, V at 2E (nn.MultiheadAttention packing).
@@ -133,10 +135,12 @@ int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t
  * | 2: nearest x2 upsample fused with 3x3 pad 1 (Upsample) | 3: 1x1.
  * x [N, Hin, Win, Cin] bf16 (Cin % 8 == 0), w [Cout][kh][kw][Cin] bf16, bias fp32 [Cout];
  * out = conv + bias (+ residual bf16/f32 NHWC) [-> (clamp(.,-1,1)+1)/2 when clamp01, vae.py:55]
- *     -> bf16 and/or fp32 NHWC [N, Hout, Wout, Cout]. */
+ *     -> bf16 and/or fp32 NHWC [N, Hout, Wout, Cout].
+ * gn_partial (optional; needs Hout*Wout % 128 == 0 and Cout % 128 == 0): GroupNorm(32) partial sums of the output,
+ * [N][Hout*Wout/128][32][sum, sumsq] -- the partial-sum area of mmvid_groupnorm_swish_nhwc's stats_scratch. */
 int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w, const float* bias,
                       int Cout, const void* residual_bf16, const float* residual_f32, int clamp01, void* out_bf16,
-                      float* out_f32, void* stream);
+                      float* out_f32, float* gn_partial, void* stream);
 /* img NCHW fp32 [N,3,H,W] in [0,1] -> NHWC bf16 [N,H,W,8] of 2x-1 (vae.py:41), channels 3..7 zero. */
 int mmvid_image_to_nhwc8(const float* img, int N, int H, int W, void* out_bf16, void* stream);
 /* NHWC fp32 [N,H,W,C] -> NCHW fp32 (first Cuse channels). */
@@ -150,8 +154,10 @@ int mmvid_spatial_attention(const void* q, const void* k, const void* v, int N, 
  * into `arena` (-1 = unused); w/b/ext_* are device pointers. */
 enum {
     MMVID_VQOP_IMG2NHWC8 = 0, /* ext_in img [N,3,H,W] f32 -> out_bf16 [N,H,W,8]                                  */
-    MMVID_VQOP_CONV = 1,      /* in0 x [N,H,W,C] bf16, w, b, Cout, mode; in1 residual (flags&1: f32); flags&2 clamp01 */
-    MMVID_VQOP_GROUPNORM = 2, /* in0 [N,H,W,C] (flags&1: f32), w, b, eps, mode = swish, scratch = stats           */
+    MMVID_VQOP_CONV = 1,      /* in0 x [N,H,W,C] bf16, w, b, Cout, mode; in1 residual (flags&1: f32); flags&2 clamp01;
+                                 flags&4: write GroupNorm partial sums of the output into `scratch` (a GN stats area) */
+    MMVID_VQOP_GROUPNORM = 2, /* in0 [N,H,W,C] (flags&1: f32), w, b, eps, mode = swish, scratch = stats;
+                                 flags&2: the partial sums in `scratch` were written by the producing CONV          */
     MMVID_VQOP_CAST = 3,      /* in0 f32 -> out_bf16, N*H*W*C elements                                           */
     MMVID_VQOP_SPATIAL_ATTN = 4, /* in0,in1,in2 = q,k,v [N,H*W,C] bf16, eps = scale, scratch                        */
     MMVID_VQOP_VQ_ARGMIN = 5, /* in0 z [N*H*W, C] f32, w = codebook [Cout, C], b = ee -> ext_out int64            */

@@ -43,7 +43,7 @@ SIGNATURES = {
     'mmvid_gemm_dw_pick_splitk': [I64, I, I],
     'mmvid_layernorm_fwd': [P, I64, I64, I, P, P, F, P, P, I64, P, P, P],
     'mmvid_layernorm_bwd': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P],
-    'mmvid_groupnorm_swish_nhwc': [P, I, I, I64, I, P, P, F, I, P, P, P, P],
+    'mmvid_groupnorm_swish_nhwc': [P, I, I, I64, I, P, P, F, I, P, I, P, P, P],
     'mmvid_attention_fwd': [P, I64, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
     'mmvid_attention_bwd': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P],
     'mmvid_assemble_sequence': [POINTER(P), POINTER(I64), I, P, P, P, I64, I, I, P, P],
@@ -57,7 +57,7 @@ SIGNATURES = {
     'mmvid_tower_workspace': [POINTER(TowerCfg), POINTER(I64), POINTER(I64)],
     'mmvid_tower_forward': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, P, P],
     'mmvid_tower_backward': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, P],
-    'mmvid_conv2d_nhwc': [I, P, I, I, I, I, P, P, I, P, P, I, P, P, P],
+    'mmvid_conv2d_nhwc': [I, P, I, I, I, I, P, P, I, P, P, I, P, P, P, P],
     'mmvid_image_to_nhwc8': [P, I, I, I, P, P],
     'mmvid_nhwc_to_nchw_f32': [P, I, I, I, I, I, P, P],
     'mmvid_spatial_attention': [P, P, P, I, I, I, F, P, P, P],

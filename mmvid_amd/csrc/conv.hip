@@ -29,6 +29,7 @@ struct ConvParams {
     int clamp01;
     bf16_t* out_bf16;
     float* out_f32;
+    float* gn_partial;  // GroupNorm partial sums of the OUTPUT: [N][Hout*Wout/128][32 groups][sum, sumsq], or null
 };
 
 // A-operand gather by LDS-DMA: this lane owns, in each of its wave's 4 DMA pieces, LDS slot (lane&7) of tile row
@@ -199,6 +200,12 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
     const int n = bn0 + 4 * (tid & 31);
     const bool n_ok = n < p.Cout;
     const float4 bias4 = (p.bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int HALVES = WM / 2;  // 128-row blocks of the tile = GroupNorm partial blocks
+    float gs[HALVES][4], gq[HALVES][4];
+#pragma unroll
+    for (int hf = 0; hf < HALVES; ++hf)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gs[hf][e] = gq[hf][e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         __syncthreads();
@@ -229,7 +236,52 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
             }
             const long o = mrow[k] * p.Cout + n;
             if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.out_bf16) *reinterpret_cast<uint2*>(p.out_bf16 + o) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            const uint2 packed = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (p.out_bf16) *reinterpret_cast<uint2*>(p.out_bf16 + o) = packed;
+            if (p.gn_partial) {  // statistics of the values the GroupNorm will read (bf16-rounded unless fp32 is stored)
+                const int hf = (WM == 4) ? (k >> 2) : 0;  // pieces 0..3 -> rows 0..127, 4..7 -> 128..255 (slab_piece)
+                const float u[4] = {p.out_f32 ? v[0] : bf_lo(packed.x), p.out_f32 ? v[1] : bf_hi(packed.x),
+                                    p.out_f32 ? v[2] : bf_lo(packed.y), p.out_f32 ? v[3] : bf_hi(packed.y)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gs[hf][e] += u[e], gq[hf][e] += u[e] * u[e];
+            }
+        }
+    }
+    // ---- fused GroupNorm statistics (model.py:38-42 reads this tensor next): fixed-order reductions, no atomics.
+    // thread -> LDS [half][row group][channel][2] -> per channel over row groups -> per group over its channels ->
+    // partial[n][128-row block][group][2]; groupnorm finalisation adds the blocks in order.
+    if (p.gn_partial) {
+        constexpr int RG = S::THREADS / 32;
+        float* red = reinterpret_cast<float*>(smem);             // [HALVES][RG][128][2]
+        float* chs = red + HALVES * RG * 256;                     // [HALVES][128][2]
+        __syncthreads();
+        const int rg = tid >> 5, c4 = (tid & 31) * 4;
+#pragma unroll
+        for (int hf = 0; hf < HALVES; ++hf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<float2*>(red + ((hf * RG + rg) * 128 + c4 + e) * 2) = make_float2(gs[hf][e], gq[hf][e]);
+        __syncthreads();
+        for (int idx = tid; idx < HALVES * 256; idx += S::THREADS) {
+            const int hf = idx >> 8, cw = idx & 255;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) a += red[(hf * RG + r) * 256 + cw];
+            chs[idx] = a;
+        }
+        __syncthreads();
+        const int cpg = p.Cout >> 5, gpt = 128 / cpg;  // channels per group, groups per 128-channel tile
+        const long hw = (long)p.Hout * p.Wout;
+        const int nblk = (int)(hw >> 7);
+        for (int idx = tid; idx < HALVES * gpt * 2; idx += S::THREADS) {
+            const int which = idx & 1, g = (idx >> 1) % gpt, hf = idx / (2 * gpt);
+            const long mh = bm0 + hf * 128;
+            if (mh >= p.M) continue;
+            float a = 0.f;
+            for (int e = 0; e < cpg; ++e) a += chs[hf * 256 + (g * cpg + e) * 2 + which];
+            const long img = mh / hw;
+            const int blk = (int)((mh - img * hw) >> 7);
+            p.gn_partial[((img * nblk + blk) * 32 + bn0 / cpg + g) * 2 + which] = a;
         }
     }
 }
@@ -307,7 +359,7 @@ int ilog2_exact(int v) {
 
 extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w,
                                  const float* bias, int Cout, const void* residual_bf16, const float* residual_f32,
-                                 int clamp01, void* out_bf16, float* out_f32, void* stream) {
+                                 int clamp01, void* out_bf16, float* out_f32, float* gn_partial, void* stream) {
     MMVID_REQUIRE(x && w && (out_bf16 || out_f32), "conv2d_nhwc: null pointer");
     MMVID_REQUIRE(mode >= 0 && mode <= 3, "conv2d_nhwc: mode %d", mode);
     const int l2 = ilog2_exact(Cin);
@@ -328,14 +380,22 @@ extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Wi
     p.M = (long)N * p.Hout * p.Wout;
     p.K = p.taps * Cin;
     p.bias = bias, p.res_bf16 = (const bf16_t*)residual_bf16, p.res_f32 = residual_f32, p.clamp01 = clamp01;
-    p.out_bf16 = (bf16_t*)out_bf16, p.out_f32 = out_f32;
+    p.out_bf16 = (bf16_t*)out_bf16, p.out_f32 = out_f32, p.gn_partial = gn_partial;
+    if (gn_partial)
+        MMVID_REQUIRE(((long)p.Hout * p.Wout) % 128 == 0 && Cout % 128 == 0,
+                      "conv2d_nhwc: fused GroupNorm statistics need Hout*Wout %% 128 == 0 and Cout %% 128 == 0");
     if (p.M == 0) return MMVID_OK;
     MMVID_REQUIRE((long)N * Hin * Win * Cin * 2 < (1ll << 31) && (long)Cout * p.K * 2 < (1ll << 31),
                   "conv2d_nhwc: input or weight of 2 GiB or more (32-bit buffer offsets)");
     MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * p.K, (hipStream_t)stream);
     const int tile = mmvid_tile_override();
     bool big = false;
-    if (tile == 256 || (tile != 128 && (long)cdiv(p.M, 256) * cdiv(Cout, BN) >= 200))
+    // with fused GroupNorm statistics the block shape must not depend on the batch size: the order in which a
+    // 128-pixel block's partial sums are formed differs between the shapes, and a frame's tokens must not depend on
+    // which other frames share its batch (tests/test_models_gpu.py::test_vqgan_roundtrip_full_size)
+    if (gn_partial) {
+        big = false;
+    } else if (tile == 256 || (tile != 128 && (long)cdiv(p.M, 256) * cdiv(Cout, BN) >= 200))
         big = true;
     const bool fast = Cin % 64 == 0 && mode != 2;
     if (big && fast)

@@ -206,26 +206,33 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
     }
 }
 
-// Per (image, channel) affine of the normalisation: y = x*a + b with a = rstd*w, b = bias - mean*a.  Group sums are
-// the fixed-order sums over blocks of partial[n][blk][grp][which].  ab[n][C][2].
-__global__ void groupnorm_finalize_kernel(const float* __restrict__ partial, int nblk, int N, int C, float cnt,
-                                          float eps, const float* __restrict__ w, const float* __restrict__ b,
-                                          float* __restrict__ ab) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N*C
-    if (i >= N * C) return;
-    const int n = i / C, ch = i - n * C;
-    const int grp = ch / (C / 32);
+// Per (image, channel) affine of the normalisation: y = x*a + b with a = rstd*w, b = bias - mean*a.  One wave per
+// (image, group): lanes stride over the partial blocks (partial[n][blk][grp][which]) and are combined by a fixed
+// xor-butterfly, so the result does not depend on scheduling.  ab[n][C][2].
+__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const float* __restrict__ partial, int nblk, int N,
+                                                                 int C, float cnt, float eps,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ b, float* __restrict__ ab) {
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);  // (n, grp)
+    if (item >= N * 32) return;
+    const int lane = threadIdx.x & 63;
+    const int n = item >> 5, grp = item & 31;
     float sm = 0.f, sq = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        const float* p = partial + ((long)n * nblk + k) * 64 + grp * 2;
-        sm += p[0], sq += p[1];
+    for (int k = lane; k < nblk; k += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(partial + (((long)n * nblk + k) * 32 + grp) * 2);
+        sm += v.x, sq += v.y;
     }
+    sm = wave_sum(sm), sq = wave_sum(sq);
     const float mu = sm / cnt;
     float var = sq / cnt - mu * mu;
     var = var < 0.f ? 0.f : var;
-    const float a = rsqrtf(var + eps) * w[ch];
-    ab[2 * (long)i] = a;
-    ab[2 * (long)i + 1] = b[ch] - mu * a;
+    const float rstd = rsqrtf(var + eps);
+    const int cpg = C >> 5;
+    if (lane < cpg) {
+        const int ch = grp * cpg + lane;
+        const float a = rstd * w[ch];
+        *reinterpret_cast<float2*>(ab + ((long)n * C + ch) * 2) = make_float2(a, b[ch] - mu * a);
+    }
 }
 
 // apply: y = swish?(x*a + b) -> bf16 NHWC (and/or f32).  8 channels per thread, 16-B accesses.
@@ -294,28 +301,33 @@ extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x
     return MMVID_OK;
 }
 
-// x NHWC [N, hw, C] (bf16 when x_is_bf16 else f32).  stats_scratch: fp32 [N*(2*C + 64*ceil(hw/256))]
-// (per-channel affine first, then the per-block partial sums).  Deterministic: no atomics anywhere.
+// x NHWC [N, hw, C] (bf16 when x_is_bf16 else f32).  stats_scratch: fp32 [N*(2*C + 64*ceil(hw/128))]
+// (per-channel affine first, then the per-block partial sums).  partial_blocks > 0: the producer (conv epilogue)
+// already wrote that many partial blocks per image; 0: a statistics pass runs here.  Deterministic: no atomics.
 extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, int C, const float* w,
-                                          const float* b, float eps, int swish, float* stats_scratch, void* y_bf16,
-                                          float* y_f32, void* stream) {
+                                          const float* b, float eps, int swish, float* stats_scratch,
+                                          int partial_blocks, void* y_bf16, float* y_f32, void* stream) {
     MMVID_REQUIRE(x && w && b && stats_scratch && (y_bf16 || y_f32), "groupnorm: null pointer");
     MMVID_REQUIRE(C % 32 == 0 && C <= 512 && 256 % (C / 8) == 0, "groupnorm: C=%d unsupported", C);
+    MMVID_REQUIRE(partial_blocks >= 0 && partial_blocks <= cdiv(hw, 128), "groupnorm: partial_blocks %d", partial_blocks);
     if (N == 0 || hw == 0) return MMVID_OK;
     hipStream_t s = (hipStream_t)stream;
     const int pix_per_block = 256;
-    const int nblk = cdiv(hw, pix_per_block);
-    dim3 g1(nblk, N);
-    float* ab = stats_scratch;                       // [N][C][2]
+    int nblk = partial_blocks;
+    float* ab = stats_scratch;                         // [N][C][2]
     float* partial = stats_scratch + (long)N * C * 2;  // [N][nblk][32][2]
     const long chunks = (long)N * hw * (C / 8);
-    if (x_is_bf16)
-        hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)x, (long)hw, C,
-                           pix_per_block, partial);
-    else
-        hipLaunchKernelGGL(groupnorm_stats_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (long)hw, C,
-                           pix_per_block, partial);
-    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, s, partial, nblk, N, C,
+    if (partial_blocks == 0) {
+        nblk = cdiv(hw, pix_per_block);
+        dim3 g1(nblk, N);
+        if (x_is_bf16)
+            hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)x, (long)hw, C,
+                               pix_per_block, partial);
+        else
+            hipLaunchKernelGGL(groupnorm_stats_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (long)hw, C,
+                               pix_per_block, partial);
+    }
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv((long)N * 32, 4)), dim3(256), 0, s, partial, nblk, N, C,
                        (float)hw * (float)(C / 32), eps, w, b, ab);
     if (x_is_bf16)
         hipLaunchKernelGGL(groupnorm_apply_kernel<bf16_t>, dim3(cdiv(chunks, 256)), dim3(256), 0, s,

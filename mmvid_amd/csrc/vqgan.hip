@@ -24,12 +24,15 @@ extern "C" int mmvid_vqgan_run(const mmvid_vqgan_op_t* ops, int nops, void* aren
                 rc = mmvid_conv2d_nhwc(o.mode, at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
                                        (o.flags & 1) ? nullptr : at(arena, o.in1),
                                        (o.flags & 1) ? (const float*)at(arena, o.in1) : nullptr, (o.flags >> 1) & 1,
-                                       at(arena, o.out_bf16), (float*)at(arena, o.out_f32), stream);
+                                       at(arena, o.out_bf16), (float*)at(arena, o.out_f32),
+                                       (o.flags & 4) ? (float*)at(arena, o.scratch) + (int64_t)o.N * o.Cout * 2 : nullptr,
+                                       stream);
                 break;
             case MMVID_VQOP_GROUPNORM:
                 rc = mmvid_groupnorm_swish_nhwc(at(arena, o.in0), (o.flags & 1) ? 0 : 1, o.N, (int64_t)o.H * o.W, o.C,
                                                 (const float*)o.w, o.b, o.eps, o.mode, (float*)at(arena, o.scratch),
-                                                at(arena, o.out_bf16), (float*)at(arena, o.out_f32), stream);
+                                                (o.flags & 2) ? (o.H * o.W) / 128 : 0, at(arena, o.out_bf16),
+                                                (float*)at(arena, o.out_f32), stream);
                 break;
             case MMVID_VQOP_CAST:
                 rc = mmvid_cast_f32_to_bf16((const float*)at(arena, o.in0), at(arena, o.out_bf16),

@@ -131,14 +131,25 @@ def layernorm_bwd(dy, x, mean, rstd, w, dx=None, add=False, dw=None, db=None):
     return dx
 
 
-def groupnorm_swish(x, w, b, eps=1e-6, swish=True, out_dtype=bf16):
-    """x NHWC [N,H,W,C] bf16 or f32 -> same shape."""
+def gn_stats_buffer(N, hw, C, device):
+    """fp32 scratch of mmvid_groupnorm_swish_nhwc: [N][C][2] affine, then [N][ceil(hw/128)][32][2] partial sums."""
+    return torch.empty(N * (2 * C + 64 * ((hw + 127) // 128)), device=device, dtype=f32)
+
+
+def groupnorm_swish(x, w, b, eps=1e-6, swish=True, out_dtype=bf16, stats=None):
+    """x NHWC [N,H,W,C] bf16 or f32 -> same shape.  `stats`: a gn_stats_buffer whose partial sums were already
+    written by the convolution that produced x (conv2d_nhwc(..., gn_stats=...))."""
     N, H, W, C = x.shape
     assert x.is_contiguous() and x.dtype in (bf16, f32)
-    stats = torch.empty(N * (2 * C + 64 * ((H * W + 255) // 256)), device=x.device, dtype=f32)
+    blocks = 0
+    if stats is None:
+        stats = gn_stats_buffer(N, H * W, C, x.device)
+    else:
+        assert (H * W) % 128 == 0
+        blocks = H * W // 128
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     call('mmvid_groupnorm_swish_nhwc', _p(x), int(x.dtype == bf16), N, H * W, C, _p(w), _p(b), float(eps), int(swish),
-         _p(stats), _p(y) if out_dtype == bf16 else None, _p(y) if out_dtype == f32 else None, _stream())
+         _p(stats), blocks, _p(y) if out_dtype == bf16 else None, _p(y) if out_dtype == f32 else None, _stream())
     return y
 
 
@@ -254,8 +265,9 @@ def cast_bf16(x, out=None):
 
 
 # ---------------------------------------------------------------------------------------------- VQGAN
-def conv2d_nhwc(x, w, bias, mode, residual=None, clamp01=False, out_dtype=bf16):
-    """x [N,H,W,Cin] bf16; w [Cout,taps,Cin] bf16 (taps 9 or 1); mode 0 3x3 | 1 down | 2 up | 3 1x1."""
+def conv2d_nhwc(x, w, bias, mode, residual=None, clamp01=False, out_dtype=bf16, gn_stats=None):
+    """x [N,H,W,Cin] bf16; w [Cout,taps,Cin] bf16 (taps 9 or 1); mode 0 3x3 | 1 down | 2 up | 3 1x1.
+    gn_stats: a gn_stats_buffer for the OUTPUT shape; its partial-sum area is filled by the epilogue."""
     _chk(x, bf16, 'x'), _chk(w, bf16, 'w')
     N, H, W, Cin = x.shape
     Cout = w.shape[0]
@@ -263,8 +275,11 @@ def conv2d_nhwc(x, w, bias, mode, residual=None, clamp01=False, out_dtype=bf16):
     out = torch.empty(N, Ho, Wo, Cout, device=x.device, dtype=out_dtype)
     rb = residual if (residual is not None and residual.dtype == bf16) else None
     rf = residual if (residual is not None and residual.dtype == f32) else None
+    gp = None
+    if gn_stats is not None:
+        gp = ctypes.c_void_p(gn_stats.data_ptr() + N * Cout * 2 * 4)
     call('mmvid_conv2d_nhwc', mode, _p(x), N, H, W, Cin, _p(w), _p(bias), Cout, _p(rb), _p(rf), int(clamp01),
-         _p(out) if out_dtype == bf16 else None, _p(out) if out_dtype == f32 else None, _stream())
+         _p(out) if out_dtype == bf16 else None, _p(out) if out_dtype == f32 else None, gp, _stream())
     return out
 
 

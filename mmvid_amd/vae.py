@@ -9,6 +9,8 @@ input is bf16 (MFMA, fp32 accumulate); GroupNorm statistics are fp32.  The froze
 into [Cout][ky][kx][Cin] bf16 (cached, refreshed when a parameter changes)."""
 from math import sqrt
 
+import os
+
 import torch
 from torch import nn
 
@@ -130,6 +132,11 @@ class VQModel(_H):  # vqgan.py:16-53
         self.post_quant_conv = _conv(embed_dim, ddconfig['z_channels'], 1)
 
 
+# A/B switches for the planner's fusions (diagnostics; both on by default)
+_FUSE_GN = os.environ.get('MMVID_FUSE_GN', '1') != '0'
+_DUAL_OUT = os.environ.get('MMVID_DUAL_OUT', '1') != '0'
+
+
 def _pow2_at_least8(c):
     p = 8
     while p < c:
@@ -198,27 +205,50 @@ class _Planner:
         self.patches.append((i, 'ext_in', 'img'))
         return out
 
-    def conv(self, x, holder, mode, residual=None, out32=False, clamp01=False):
+    def conv(self, x, holder, mode, residual=None, out32=False, clamp01=False, feeds_gn=False, also_bf16=False):
+        """feeds_gn: a GroupNorm reads this output next -> the epilogue also emits its partial statistics (when the
+        shape allows), into a stats area that lives as long as the output buffer.
+        also_bf16 (with out32): the epilogue stores a bf16 copy too (`out.bf16`), instead of a later cast pass."""
         w, b, _ = self.vae._cw(holder)
         n, h, wd, cin = x.shape
         assert x.dtype == bf16 and cin == w.shape[2], (x.shape, w.shape)
         ho, wo = (h // 2, wd // 2) if mode == 1 else ((2 * h, 2 * wd) if mode == 2 else (h, wd))
-        out = self.alloc((n, ho, wo, w.shape[0]), f32 if out32 else bf16)
+        cout = w.shape[0]
+        out = self.alloc((n, ho, wo, cout), f32 if out32 else bf16)
         flags = (1 if (residual is not None and residual.dtype == f32) else 0) | (2 if clamp01 else 0)
-        self._op(op=self.OP_CONV, mode=mode, N=n, H=h, W=wd, C=cin, Cout=w.shape[0], flags=flags, in0=x.off,
-                 in1=residual.off if residual is not None else -1, out_bf16=-1 if out32 else out.off,
-                 out_f32=out.off if out32 else -1, w=w.data_ptr(), b=b.data_ptr())
+        scratch = -1
+        if feeds_gn and _FUSE_GN and (ho * wo) % 128 == 0 and cout % 128 == 0:
+            out.gn_stats = self._gn_stats(n, ho * wo, cout)
+            flags |= 4
+            scratch = out.gn_stats.off
+        o16 = out.off if not out32 else -1
+        if out32 and also_bf16 and _DUAL_OUT:
+            out.bf16 = self.alloc((n, ho, wo, cout), bf16)
+            o16 = out.bf16.off
+        self._op(op=self.OP_CONV, mode=mode, N=n, H=h, W=wd, C=cin, Cout=cout, flags=flags, in0=x.off,
+                 in1=residual.off if residual is not None else -1, out_bf16=o16,
+                 out_f32=out.off if out32 else -1, scratch=scratch, w=w.data_ptr(), b=b.data_ptr())
         return out
+
+    def _gn_stats(self, n, hw, c):
+        return self.alloc((n * (2 * c + 64 * ((hw + 127) // 128)), ), f32)
 
     def gn(self, x, holder, swish=True):
         n, h, wd, c = x.shape
         out = self.alloc(x.shape, bf16)
-        st = self.alloc((n * (2 * c + 64 * ((h * wd + 255) // 256)), ), f32)
-        self._op(op=self.OP_GN, mode=int(swish), N=n, H=h, W=wd, C=c, flags=1 if x.dtype == f32 else 0, in0=x.off,
+        st = getattr(x, 'gn_stats', None)
+        flags = (1 if x.dtype == f32 else 0) | (2 if st is not None else 0)
+        if st is None:
+            st = self._gn_stats(n, h * wd, c)
+        self._op(op=self.OP_GN, mode=int(swish), N=n, H=h, W=wd, C=c, flags=flags, in0=x.off,
                  out_bf16=out.off, scratch=st.off, w=holder.weight.data_ptr(), b=holder.bias.data_ptr(), eps=1e-6)
         return out
 
     def cast(self, x):
+        if x.dtype == bf16:
+            return x
+        if getattr(x, 'bf16', None) is not None:  # the producing conv already stored the bf16 copy
+            return x.bf16
         out = self.alloc(x.shape, bf16)
         n, h, wd, c = x.shape
         self._op(op=self.OP_CAST, N=n, H=h, W=wd, C=c, in0=x.off, out_bf16=out.off)
@@ -324,33 +354,48 @@ class VQGanVAE1024(nn.Module):
             prep[key] = pl.finish(next(self.model.parameters()).device)
         return prep[key]
 
-    def _plan_resblock(self, pl, x32, blk):
-        """model.py:130-150 on an fp32 residual stream."""
-        h = pl.conv(pl.gn(x32, blk.norm1), blk.conv1, 0)
+    def _plan_resblock(self, pl, x32, blk, final='f32'):
+        """model.py:130-150 on an fp32 residual stream.  final: 'f32' (residual stream continues), 'both' (a conv reads
+        the result next as well) or 'bf16' (ONLY a conv reads it: no fp32 store at all)."""
+        h = pl.conv(pl.gn(x32, blk.norm1), blk.conv1, 0, feeds_gn=True)
         h = pl.gn(h, blk.norm2)
         skip = x32
         if hasattr(blk, 'nin_shortcut'):
             skip = pl.conv(pl.cast(x32), blk.nin_shortcut, 3, out32=True)
-        return pl.conv(h, blk.conv2, 0, residual=skip, out32=True)
+        return pl.conv(h, blk.conv2, 0, residual=skip, out32=final != 'bf16', feeds_gn=final != 'bf16',
+                       also_bf16=final == 'both')
 
-    def _plan_attn(self, pl, x32, blk):
+    def _plan_attn(self, pl, x32, blk, final='f32'):
         """model.py:180-205."""
         h = pl.gn(x32, blk.norm, swish=False)
         q, k, v = pl.conv(h, blk.q, 3), pl.conv(h, blk.k, 3), pl.conv(h, blk.v, 3)
         o = pl.spatial_attention(q, k, v)
-        return pl.conv(o, blk.proj_out, 3, residual=x32, out32=True)
+        return pl.conv(o, blk.proj_out, 3, residual=x32, out32=final != 'bf16', feeds_gn=final != 'bf16',
+                       also_bf16=final == 'both')
 
     def _plan_encode(self, pl, n, s):
         """Encoder.forward (model.py:439-466) + quant_conv (vqgan.py:67-68) + VQ lookup (quantize.py:302-310)."""
         enc = self.model.encoder
-        h = pl.conv(pl.image(n, s), enc.conv_in, 0, out32=True)
-        for d in enc.down:
+
+        def needs_bf16(blk):  # a resblock whose shortcut is a 1x1 conv reads its input in bf16 too
+            return hasattr(blk, 'nin_shortcut')
+
+        h = pl.conv(pl.image(n, s), enc.conv_in, 0, out32=True, feeds_gn=True, also_bf16=needs_bf16(enc.down[0].block[0]))
+        for li, d in enumerate(enc.down):
+            has_down = hasattr(d, 'downsample')
+            nxt = enc.down[li + 1].block[0] if li + 1 < len(enc.down) else enc.mid.block_1
             for bi, blk in enumerate(d.block):
-                h = self._plan_resblock(pl, h, blk)
-                if len(d.attn) > 0:
-                    h = self._plan_attn(pl, h, d.attn[bi])
-            if hasattr(d, 'downsample'):
-                h = pl.conv(pl.cast(h), d.downsample.conv, 1, out32=True)
+                last = bi == len(d.block) - 1
+                with_attn = len(d.attn) > 0
+                # what the level's last tensor feeds: only the downsample conv (bf16) / the next block's shortcut too
+                end = 'bf16' if has_down else ('both' if needs_bf16(nxt) else 'f32')
+                mid = 'both' if (not last and needs_bf16(d.block[bi + 1])) else 'f32'
+                want = (end if last else mid) if _DUAL_OUT else 'f32'
+                h = self._plan_resblock(pl, h, blk, final='f32' if with_attn else want)
+                if with_attn:
+                    h = self._plan_attn(pl, h, d.attn[bi], final=want)
+            if has_down:
+                h = pl.conv(pl.cast(h), d.downsample.conv, 1, out32=True, feeds_gn=True, also_bf16=needs_bf16(nxt))
         h = self._plan_resblock(pl, h, enc.mid.block_1)
         h = self._plan_attn(pl, h, enc.mid.attn_1)
         h = self._plan_resblock(pl, h, enc.mid.block_2)
@@ -363,7 +408,7 @@ class VQGanVAE1024(nn.Module):
         """codebook gather (vae.py:50) + post_quant_conv + Decoder.forward (model.py:551-582) + vae.py:55."""
         dec = self.model.decoder
         h = pl.conv(pl.gather(n, hw), self.model.post_quant_conv, 3)
-        h = pl.conv(h, dec.conv_in, 0, out32=True)
+        h = pl.conv(h, dec.conv_in, 0, out32=True, feeds_gn=True)
         h = self._plan_resblock(pl, h, dec.mid.block_1)
         h = self._plan_attn(pl, h, dec.mid.attn_1)
         h = self._plan_resblock(pl, h, dec.mid.block_2)
@@ -374,7 +419,7 @@ class VQGanVAE1024(nn.Module):
                 if len(u.attn) > 0:
                     h = self._plan_attn(pl, h, u.attn[bi])
             if hasattr(u, 'upsample'):
-                h = pl.conv(pl.cast(h), u.upsample.conv, 2, out32=True)
+                h = pl.conv(pl.cast(h), u.upsample.conv, 2, out32=True, feeds_gn=True)
         h = pl.gn(h, dec.norm_out)
         img = pl.conv(h, dec.conv_out, 0, out32=True, clamp01=True)  # (clamp(x,-1,1)+1)/2 fused, vae.py:55
         pl.to_nchw(img, 3)

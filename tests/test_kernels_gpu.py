@@ -343,6 +343,35 @@ def test_conv_modes(ops, mode, N, H, Cin, Cout):
     close(out, (ref.clamp(-1, 1) + 1) * 0.5, 2e-4, 'conv clamp01')
 
 
+@pytest.mark.parametrize('mode,N,H,Cin,Cout,out32', [(0, 3, 16, 128, 128, True), (0, 2, 32, 64, 256, False),
+                                                     (1, 5, 32, 128, 128, True), (3, 2, 16, 256, 512, False),
+                                                     (0, 1, 48, 128, 128, False)])
+def test_conv_fused_groupnorm_statistics(ops, mode, N, H, Cin, Cout, out32):
+    """The conv epilogue's GroupNorm partial sums (ragged tiles: 5*256 and 48*48 pixels are not multiples of 256)
+    give the same normalisation as the standalone statistics pass, and both match torch."""
+    taps = 1 if mode == 3 else 9
+    x = rnd(N, H, H, Cin, seed=1, dtype=torch.bfloat16)
+    w = rnd(Cout, taps, Cin, seed=2, scale=1 / math.sqrt(taps * Cin), dtype=torch.bfloat16)
+    b = rnd(Cout, seed=3) * 0.1
+    gw, gb = rnd(Cout, seed=4) * 0.1 + 1, rnd(Cout, seed=5) * 0.1
+    Ho = H // 2 if mode == 1 else H
+    dt = torch.float32 if out32 else torch.bfloat16
+    res = rnd(N, Ho, Ho, Cout, seed=6, dtype=dt)
+    st = ops.gn_stats_buffer(N, Ho * Ho, Cout, x.device)
+    y = ops.conv2d_nhwc(x, w, b, mode, residual=res, out_dtype=dt, gn_stats=st)
+    assert torch.equal(y, ops.conv2d_nhwc(x, w, b, mode, residual=res, out_dtype=dt))  # the output itself is unchanged
+    fused = ops.groupnorm_swish(y, gw, gb, out_dtype=torch.float32, stats=st)
+    plain = ops.groupnorm_swish(y, gw, gb, out_dtype=torch.float32)
+    ref = F.group_norm(y.float().permute(0, 3, 1, 2), 32, gw, gb, 1e-6)
+    ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1)
+    close(fused, ref, 2e-5, 'gn(fused stats) vs torch')
+    close(fused, plain, 1e-5, 'gn(fused stats) vs gn(own stats)')
+    st2 = ops.gn_stats_buffer(N, Ho * Ho, Cout, x.device)
+    ops.conv2d_nhwc(x, w, b, mode, residual=res, out_dtype=dt, gn_stats=st2)
+    off = N * Cout * 2
+    assert torch.equal(st[off:], st2[off:])  # deterministic partial sums
+
+
 def test_image_layout_kernels(ops):
     img = torch.rand(2, 3, 16, 16, device=DEV)
     o = ops.image_to_nhwc8(img)
