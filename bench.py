@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 TEXT_LEN, FRAMES, SIZE, TOK_PER_SAMPLE = 64, 8, 128, 512
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PROF_STRIDE = 7  # every 7th launch of a kernel family is HIP-event timed (coprime with the 4 / 12 / 45-launch shape cycles)
 CLASS_NAMES = ['gemm_bf16_kernel<A.B^T> (forward)', 'gemm_bf16_kernel<dX>', 'gemm_bf16_kernel<dW>',
                'conv_igemm_kernel (VQGAN)', 'attn_fwd_kernel', 'attn_bwd (dq+dkv)']
 
@@ -140,7 +141,10 @@ def main():
     from mmvid_amd import _lib
     from mmvid_amd.build import build
     from mmvid_amd.engine import FlatTrainer, backward_order, broadcast_parameters
-    build()
+    if local == 0:
+        build()  # a no-op when the in-tree library is current (it is built by __graft_entry__.build())
+    if world > 1:
+        dist.barrier()
     # seed_everything(seed + rank) as train.py:87; identical initial weights come from the rank-0 broadcast
     seed = 42 + rank
     random.seed(seed), np.random.seed(seed), torch.manual_seed(seed)
@@ -163,15 +167,15 @@ def main():
 
     lib = _lib.load()
     fence()
-    lib.mmvid_prof_begin()
+    lib.mmvid_prof_begin(PROF_STRIDE)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = train_step(model, trainer, text, frames)
     fence()
     dt = time.perf_counter() - t0
     nc = len(CLASS_NAMES)
-    ms, cnt, fl = (ctypes.c_double * nc)(), (ctypes.c_int64 * nc)(), (ctypes.c_double * nc)()
-    lib.mmvid_prof_end(ms, cnt, fl, nc)
+    ms, cnt, fl, tot = (ctypes.c_double * nc)(), (ctypes.c_int64 * nc)(), (ctypes.c_double * nc)(), (ctypes.c_int64 * nc)()
+    lib.mmvid_prof_end(ms, cnt, fl, tot, nc)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,8 +188,9 @@ def main():
         kernels = []
         for i in range(nc):
             if cnt[i]:
-                kernels.append({'kernel': CLASS_NAMES[i], 'launches': int(cnt[i]), 'avg_ms': ms[i] / cnt[i],
-                                'ms_per_step': ms[i] / args.steps, 'tflops': fl[i] / (ms[i] * 1e-3) / 1e12})
+                kernels.append({'kernel': CLASS_NAMES[i], 'launches': int(tot[i]), 'timed_launches': int(cnt[i]),
+                                'avg_ms': ms[i] / cnt[i], 'ms_per_step': ms[i] / cnt[i] * tot[i] / args.steps,
+                                'tflops': fl[i] / (ms[i] * 1e-3) / 1e12})
         dom = max(kernels, key=lambda k: k['ms_per_step']) if kernels else None
         roofline = None
         if dom:

@@ -55,10 +55,11 @@ int mmvid_gemm_dw_pick_splitk(int64_t M, int N, int K);
 int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const float* w, const float* b, float eps,
                         void* y_bf16, float* y_f32, int64_t ldy, float* mean, float* rstd, void* stream);
 /* dx (+)= LN backward of dy; optional bf16 copy of the resulting dx (same lddx); dw/db accumulated with atomics
- * (may be NULL). */
+ * (may be NULL); dx_colsum (may be NULL) += column sums of the resulting dx = the bias gradient of the Linear that
+ * produced the residual branch this gradient flows into next. */
 int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                         const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
-                        int add_into_dx, void* dx_bf16, float* dw, float* db, void* stream);
+                        int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream);
 /* GroupNorm(32, eps) [+ swish] on NHWC: taming/modules/diffusionmodules/model.py:38-42, 33-35.
  * stats_scratch: fp32 [N * (2*C + 64 * ceil(hw / 128))] = the per-channel affine [N][C][2], then partial sums
  * [N][blocks][32][2].  partial_blocks = 0: the statistics pass runs here; = hw/128: the producing convolution
@@ -182,10 +183,12 @@ int mmvid_vqgan_run(const mmvid_vqgan_op_t* ops, int nops, void* arena, void* st
 /* hardware probe (tools/gpu_probe.py): which = 0 -> ds_read_b64_tr_b16 lane layout. */
 int mmvid_probe(int which, const void* in, void* out, void* stream);
 
-/* ---- optional per-launch HIP-event timing of the MFMA kernel families (bench.py roofline line).
- * classes: 0 gemm A.B^T (forward) | 1 gemm dX | 2 gemm dW | 3 conv implicit GEMM | 4 attention fwd | 5 attention bwd */
-int mmvid_prof_begin(void);
-int mmvid_prof_end(double* ms, int64_t* launches, double* flops, int nclass);
+/* ---- optional HIP-event timing of the MFMA kernel families on their launch stream (bench.py roofline line).
+ * classes: 0 gemm A.B^T (forward) | 1 gemm dX | 2 gemm dW | 3 conv implicit GEMM | 4 attention fwd | 5 attention bwd.
+ * Every `stride`-th launch of a class is timed.  prof_end: ms / flops summed over the sampled launches, their count,
+ * and the total launch count per class. */
+int mmvid_prof_begin(int stride);
+int mmvid_prof_end(double* ms, int64_t* sampled, double* flops, int64_t* launches_total, int nclass);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,7 @@ SIGNATURES = {
     'mmvid_gemm_bf16_dw': [I64, I, I, P, I64, P, I64, I, P, P, I, P],
     'mmvid_gemm_dw_pick_splitk': [I64, I, I],
     'mmvid_layernorm_fwd': [P, I64, I64, I, P, P, F, P, P, I64, P, P, P],
-    'mmvid_layernorm_bwd': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P],
+    'mmvid_layernorm_bwd': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P],
     'mmvid_groupnorm_swish_nhwc': [P, I, I, I64, I, P, P, F, I, P, I, P, P, P],
     'mmvid_attention_fwd': [P, I64, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
     'mmvid_attention_bwd': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P],
@@ -63,8 +63,8 @@ SIGNATURES = {
     'mmvid_spatial_attention': [P, P, P, I, I, I, F, P, P, P],
     'mmvid_vqgan_run': [POINTER(VqganOp), I, P, P],
     'mmvid_probe': [I, P, P, P],
-    'mmvid_prof_begin': [],
-    'mmvid_prof_end': [P, P, P, I],
+    'mmvid_prof_begin': [I],
+    'mmvid_prof_end': [P, P, P, P, I],
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I)}
 

@@ -6,7 +6,7 @@
 // Flash-style on v_mfma_f32_32x32x16_bf16; a wave owns 32 queries (or 32 keys) and keeps them LANE-LOCAL:
 //   forward : S^T = K Q^T -> lane holds 16 keys x its query (col = lane&31); row max/sum need one half-swap;
 //             O^T = V^T P^T with P taken straight from the S registers, so the softmax rescale is lane-local.
-//   dQ      : S^T, dP^T = V dO^T, dS^T = P (dP - delta), dQ^T = K^T dS^T              (loop over key tiles)
+//   dQ      : delta = rowsum(dO * O); S^T, dP^T = V dO^T, dS^T = P (dP - delta), dQ^T = K^T dS^T  (loop over key tiles)
 //   dK, dV  : S = Q K^T -> lane holds 16 queries x its key; dV^T = dO^T P, dK^T = Q^T dS (loop over query tiles)
 // Every operand tile is the plain token-major [64 positions][64 d] slice of qkv / dO, brought into LDS by
 // LDS-DMA (no VGPR staging, no ds_write), double-buffered.  Operands whose MFMA rows are positions are read
@@ -261,9 +261,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
 // ------------------------------------------------------------------------------------------ dQ
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld,
+                                                             const bf16_t* __restrict__ O, long ldo,
                                                              const bf16_t* __restrict__ dO, long lddo,
                                                              const float* __restrict__ lse2,
-                                                             const float* __restrict__ delta, int L, int H, int E,
+                                                             float* __restrict__ delta, int L, int H, int E,
                                                              int nrt, float scale, float scale_log2, MaskSpec mask,
                                                              bf16_t* __restrict__ dqkv, long ldg) {
     __shared__ __attribute__((aligned(16))) char smem[2][2 * TILE];  // K tile, V tile
@@ -282,7 +283,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         dof[s] = *reinterpret_cast<const bf16x8_t*>(dOp + 16 * s + 8 * h);
     }
     const float neg_lse = -lse2[((long)b * H + hd) * L + qc];
-    const float my_delta = delta[((long)b * H + hd) * L + qc];
+    // delta[q] = sum_d dO[q][d] * O[q][d]: each half-lane holds 32 of the row's 64 d; also stored for the dK/dV kernel
+    float my_delta = 0.f;
+    {
+        const bf16_t* Op = O + ((long)b * L + qc) * ldo + hd * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint4 o4 = *reinterpret_cast<const uint4*>(Op + 16 * s + 8 * h);
+            const uint4 d4 = __builtin_bit_cast(uint4, dof[s]);
+            my_delta += (bf_lo(o4.x) * bf_lo(d4.x) + bf_hi(o4.x) * bf_hi(d4.x)) + (bf_lo(o4.y) * bf_lo(d4.y) + bf_hi(o4.y) * bf_hi(d4.y)) +
+                        (bf_lo(o4.z) * bf_lo(d4.z) + bf_hi(o4.z) * bf_hi(d4.z)) + (bf_lo(o4.w) * bf_lo(d4.w) + bf_hi(o4.w) * bf_hi(d4.w));
+        }
+        my_delta = half_sum(my_delta);
+        if (h == 0 && q < L) delta[((long)b * H + hd) * L + q] = my_delta;
+    }
     const bf16_t* Kbase = qkv + (long)b * L * ld + E + hd * 64;
     const bf16_t* Vbase = Kbase + E;
     int kv_end = L;
@@ -476,34 +490,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     }
 }
 
-// delta[b][h][q] = sum_d dO[q][h*64+d] * O[q][h*64+d]   (8 lanes x 8 elements per (token, head))
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, long ldo,
-                                                         const bf16_t* __restrict__ dO, long lddo, int B, int L,
-                                                         int H, float* __restrict__ delta) {
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long item = gid >> 3;  // (token, head)
-    const int sub = gid & 7;
-    const long total = (long)B * L * H;
-    float acc = 0.f;
-    long tok = 0;
-    int h = 0;
-    if (item < total) {
-        tok = item / H;
-        h = (int)(item % H);
-        const uint4 a = *reinterpret_cast<const uint4*>(O + tok * ldo + h * 64 + sub * 8);
-        const uint4 c = *reinterpret_cast<const uint4*>(dO + tok * lddo + h * 64 + sub * 8);
-        acc = bf_lo(a.x) * bf_lo(c.x) + bf_hi(a.x) * bf_hi(c.x) + bf_lo(a.y) * bf_lo(c.y) + bf_hi(a.y) * bf_hi(c.y) +
-              bf_lo(a.z) * bf_lo(c.z) + bf_hi(a.z) * bf_hi(c.z) + bf_lo(a.w) * bf_lo(c.w) + bf_hi(a.w) * bf_hi(c.w);
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (item < total && sub == 0) {
-        const long bb = tok / L, q = tok % L;
-        delta[(bb * H + h) * L + q] = acc;
-    }
-}
-
 static MaskSpec make_mask(int mode, int r0, int c0, int r1, int c1) {
     MaskSpec m;
     m.mode = mode, m.r0 = r0, m.c0 = c0, m.r1 = r1, m.c1 = c1;
@@ -543,13 +529,10 @@ extern "C" int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, i
     hipStream_t s = (hipStream_t)stream;
     const MaskSpec m = make_mask(mask_mode, r0, c0, r1, c1);
     const float sl2 = scale * 1.4426950408889634f;
-    const long items = (long)B * L * H * 8;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(items, 256)), dim3(256), 0, s, (const bf16_t*)O, (long)ldo,
-                       (const bf16_t*)dO, (long)lddo, B, L, H, delta);
     MmvidProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)L * L * 64, s);  // 5 GEMM-equivalents (recompute counted once)
     const int nrt = cdiv(L, ROWS_PER_BLOCK);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
+                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
                        (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
     MMVID_LAUNCH_CHECK("attention_bwd");

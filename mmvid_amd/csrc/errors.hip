@@ -37,6 +37,8 @@ struct Rec {
     double flops;
 };
 bool g_prof_on = false;
+int g_prof_stride = 1;
+int64_t g_prof_seen[PROF_NCLASS];
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
@@ -55,6 +57,7 @@ hipEvent_t pool_get() {
 MmvidProfScope::MmvidProfScope(int cls, double flops, hipStream_t stream) : slot(-1), s(stream) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (cls < 0 || cls >= PROF_NCLASS || (g_prof_seen[cls]++ % g_prof_stride) != 0) return;  // sampled launches only
     Rec r;
     r.a = pool_get(), r.b = pool_get(), r.cls = cls, r.flops = flops;
     (void)hipEventRecord(r.a, s);
@@ -67,20 +70,29 @@ MmvidProfScope::~MmvidProfScope() {
     (void)hipEventRecord(g_recs[slot].b, s);
 }
 
-extern "C" int mmvid_prof_begin() {
+// Every `stride`-th launch of each class is bracketed by a pair of HIP events (stride 1 = all of them; an event
+// pair costs a few microseconds of stream time, so the benchmark samples).
+extern "C" int mmvid_prof_begin(int stride) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_recs.clear();
     g_pool_next = 0;
+    g_prof_stride = stride < 1 ? 1 : stride;
+    for (int c = 0; c < PROF_NCLASS; ++c) g_prof_seen[c] = 0;
     g_prof_on = true;
     return 0;
 }
 
-// Stops recording, waits for the device, and returns per class: total ms, launches, total algorithmic flops.
-extern "C" int mmvid_prof_end(double* ms, int64_t* launches, double* flops, int nclass) {
+// Stops recording, waits for the device, and returns per class: ms and algorithmic flops summed over the SAMPLED
+// launches, how many were sampled, and how many launches the class had in total.
+extern "C" int mmvid_prof_end(double* ms, int64_t* sampled, double* flops, int64_t* launches_total, int nclass) {
     (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = false;
-    for (int c = 0; c < nclass; ++c) ms[c] = 0, launches[c] = 0, flops[c] = 0;
+    int64_t* launches = sampled;
+    for (int c = 0; c < nclass; ++c) {
+        ms[c] = 0, launches[c] = 0, flops[c] = 0;
+        if (launches_total) launches_total[c] = c < PROF_NCLASS ? g_prof_seen[c] : 0;
+    }
     for (const Rec& r : g_recs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;

@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*w ;  dx is ADDED into dx_accum (residual-stream
 // gradient) when add != 0, else stored.  dw += sum dy*xhat, db += sum dy  (fp32 atomics, one per block/column).
+// dx_colsum (optional) += column sums of the UPDATED dx: that is the bias gradient of the Linear whose output
+// gradient this tensor is (out_proj / c_proj of the tower), so no separate column-sum pass over it is needed.
 // Each block walks rows blockIdx.x, +gridDim.x, ... with 4 waves; per-lane partial dw/db stay in registers.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, long lddy,
                                                             const float* __restrict__ x, long ldx,
@@ -74,14 +76,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ w, long rows, int E,
                                                             float* __restrict__ dx, long lddx, int add,
                                                             bf16_t* __restrict__ dx_bf16,
-                                                            float* __restrict__ dw, float* __restrict__ db) {
+                                                            float* __restrict__ dw, float* __restrict__ db,
+                                                            float* __restrict__ dx_colsum) {
     __shared__ float red[2][4][LN_MAXV * 64 * 4];  // [dw|db][wave][E]  = 32 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = E >> 2;
-    float4 pw[LN_MAXV], pb[LN_MAXV], w4[LN_MAXV];
+    float4 pw[LN_MAXV], pb[LN_MAXV], pc[LN_MAXV], w4[LN_MAXV];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
-        pw[i] = pb[i] = make_float4(0, 0, 0, 0);
+        pw[i] = pb[i] = pc[i] = make_float4(0, 0, 0, 0);
         const int c = lane + 64 * i;
         w4[i] = (c < nv) ? reinterpret_cast<const float4*>(w)[c] : make_float4(0, 0, 0, 0);
     }
@@ -119,26 +122,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     o.x += p.x, o.y += p.y, o.z += p.z, o.w += p.w;
                 }
                 *d = o;
+                pc[i].x += o.x, pc[i].y += o.y, pc[i].z += o.z, pc[i].w += o.w;
                 if (dx_bf16)  // bf16 copy of the updated residual gradient: the next backward GEMMs' operand
                     reinterpret_cast<uint2*>(dx_bf16 + r * lddx)[c] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
             }
         }
     }
-    if (!dw && !db) return;
+    if (dw || db) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            reinterpret_cast<float4*>(red[0][wave])[c] = pw[i];
-            reinterpret_cast<float4*>(red[1][wave])[c] = pb[i];
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                reinterpret_cast<float4*>(red[0][wave])[c] = pw[i];
+                reinterpret_cast<float4*>(red[1][wave])[c] = pb[i];
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < E; e += 256) {
+            const float sw = (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]);
+            const float sb = (red[1][0][e] + red[1][1][e]) + (red[1][2][e] + red[1][3][e]);
+            if (dw) unsafeAtomicAdd(dw + e, sw);
+            if (db) unsafeAtomicAdd(db + e, sb);
         }
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < E; e += 256) {
-        const float sw = (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]);
-        const float sb = (red[1][0][e] + red[1][1][e]) + (red[1][2][e] + red[1][3][e]);
-        if (dw) unsafeAtomicAdd(dw + e, sw);
-        if (db) unsafeAtomicAdd(db + e, sb);
+    if (dx_colsum) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) reinterpret_cast<float4*>(red[0][wave])[c] = pc[i];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < E; e += 256)
+            unsafeAtomicAdd(dx_colsum + e, (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]));
     }
 }
 
@@ -288,7 +304,8 @@ extern "C" int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, in
 
 extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                                    const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
-                                   int add_into_dx, void* dx_bf16, float* dw, float* db, void* stream) {
+                                   int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
+                                   void* stream) {
     MMVID_REQUIRE(dy && x && mean && rstd && w && dx, "layernorm_bwd: null pointer");
     MMVID_REQUIRE(E % 4 == 0 && E <= 64 * 4 * LN_MAXV && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0,
                   "layernorm_bwd: bad E/strides");
@@ -296,7 +313,8 @@ extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x
     int blocks = cdiv(rows, 4);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x,
-                       (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16, dw, db);
+                       (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16, dw, db,
+                       dx_colsum);
     MMVID_LAUNCH_CHECK("layernorm_bwd");
     return MMVID_OK;
 }

@@ -180,15 +180,17 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
         // ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(LN2 x_mid)))
         // gb = bf16(g): cast once for the top layer, afterwards written by the LayerNorm backward that updates g
         if (i == d.layers - 1) TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
-        TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, ly.g_pj_b, ws, stream));
+        // bias gradients of c_proj / out_proj = column sums of gb: produced by the LayerNorm backward that wrote gb
+        // (dx_colsum), except for the top layer of this call, whose gb comes from the cast above
+        TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, i == d.layers - 1 ? ly.g_pj_b : nullptr, ws, stream));
         TRY(linear_dx(d.M, d.E, d.F, gb, ly.pj_w, sv + sl.pre, nullptr, scr + sc.d_pre, stream));
         TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, ly.g_fc_b, ws, stream));
         TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, d_h, nullptr, stream));
         TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
                                 (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, gb, ly.g_ln2_w, ly.g_ln2_b,
-                                stream));
+                                ly.g_out_b, stream));
         // ---- attention branch: x_mid = x_in + out_proj(MHA(LN1 x_in))
-        TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, ly.g_out_b, ws, stream));
+        TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, nullptr, ws, stream));
         TRY(linear_dx(d.M, d.E, d.E, gb, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
         TRY(mmvid_attention_bwd(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
                                 (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
@@ -197,7 +199,7 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
         TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, d_h, nullptr, stream));
         TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
                                 (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, i > 0 ? gb : nullptr, ly.g_ln1_w,
-                                ly.g_ln1_b, stream));
+                                ly.g_ln1_b, i > 0 ? layers[i - 1].g_pj_b : nullptr, stream));
     }
     return MMVID_OK;
 }

@@ -120,14 +120,14 @@ def layernorm_fwd(x, w, b, eps=1e-5, out_dtype=bf16, save_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, w, dx=None, add=False, dw=None, db=None):
+def layernorm_bwd(dy, x, mean, rstd, w, dx=None, add=False, dw=None, db=None, dx_colsum=None):
     _chk(dy, f32, 'dy'), _chk(x, f32, 'x')
     rows, E = x.numel() // x.shape[-1], x.shape[-1]
     if dx is None:
         dx = torch.empty_like(x)
         add = False
     call('mmvid_layernorm_bwd', _p(dy), E, _p(x), E, _p(mean), _p(rstd), _p(w), rows, E, _p(dx), E, int(add), None,
-         _p(dw), _p(db), _stream())
+         _p(dw), _p(db), _p(dx_colsum), _stream())
     return dx
 
 

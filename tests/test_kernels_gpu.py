@@ -162,8 +162,11 @@ def test_layernorm_fwd_bwd(ops):
         base = rnd(rows, E, seed=5)
         dx = base.clone()
         dw, db = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
-        ops.layernorm_bwd(dy, x, mean, rstd, w, dx=dx, add=True, dw=dw, db=db)
+        cs = rnd(E, seed=6)
+        cs0 = cs.clone()
+        ops.layernorm_bwd(dy, x, mean, rstd, w, dx=dx, add=True, dw=dw, db=db, dx_colsum=cs)
         close(dx, base + xr.grad, 1e-5, 'ln dx')
+        close(cs, cs0 + dx.sum(0), 1e-5, 'ln colsum(dx)')
         close(dw, wr.grad, 1e-4, 'ln dw')
         close(db, br.grad, 1e-4, 'ln db')
 
