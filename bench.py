@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 TEXT_LEN, FRAMES, SIZE, TOK_PER_SAMPLE = 64, 8, 128, 512
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PROF_STRIDE = 7  # every 7th launch of a kernel family is HIP-event timed (coprime with the 4 / 12 / 45-launch shape cycles)
+PROF_EVERY = 5  # every 5th timed step runs with per-launch HIP events (its long sequences launch directly, not as graph replays)
 CLASS_NAMES = ['gemm_bf16_kernel<A.B^T> (forward)', 'gemm_bf16_kernel<dX>', 'gemm_bf16_kernel<dW>',
                'conv_igemm_kernel (VQGAN)', 'attn_fwd_kernel', 'attn_bwd (dq+dkv)']
 
@@ -56,12 +56,32 @@ def synth_batch(B, device, gen):
 def train_step(model, trainer, text, frames):
     trainer.zero_grad()
     lm, lr, lv = model(text, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
-                       msm_strategy_prob=np.array([0.7, 0.1, 0.1, 0.1]), msm_bernoulli_prob=[0.2, 0.2],
-                       vid_strategy_prob=np.array([0.25, 0.25, 0.25, 0.25]))
+                       msm_strategy_prob=MSM_PROB, msm_bernoulli_prob=MSM_BERN, vid_strategy_prob=VID_PROB)
     loss = 7.0 * lm + 0.5 * lr + 0.5 * lv
     loss.backward()
     trainer.step()
     return loss
+
+
+MSM_PROB, MSM_BERN, VID_PROB = np.array([0.7, 0.1, 0.1, 0.1]), [0.2, 0.2], np.array([0.25, 0.25, 0.25, 0.25])
+
+
+def loss_fn(model):
+    """The device part of the step as a capture-safe function of tensors (engine.GraphedStep): the host-side random
+    choices -- masking strategies and the VID warp (dalle_bert.py:992-1029, 1094) -- arrive as inputs."""
+    def fn(text, frames, mask1, nfm, warped):
+        lm, lr, lv = model(text, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
+                           _mask1=mask1, _not_fully_masked=nfm, _target_warp=warped)
+        return 7.0 * lm + 0.5 * lr + 0.5 * lv
+    return fn
+
+
+def host_random_inputs(model, text, frames):
+    """Same RNG call order as BERT.forward (mask strategies first, then the warp)."""
+    from mmvid_amd.dalle_bert import warp
+    mask1, nfm = model._msm_mask(text.shape[0], text.device, MSM_PROB, MSM_BERN, 0)
+    warped = warp(frames.detach(), VID_PROB).to(text.device)
+    return {'text': text, 'frames': frames, 'mask1': mask1, 'nfm': nfm, 'warped': warped}
 
 
 def host_cores():
@@ -125,6 +145,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=6, help='per-GPU batch (even; the recipe is 48 / 8 GPUs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch every step from Python instead of replaying the captured step graph')
     ap.add_argument('--layers', type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the model
     args = ap.parse_args()
 
@@ -140,7 +161,7 @@ def main():
 
     from mmvid_amd import _lib
     from mmvid_amd.build import build
-    from mmvid_amd.engine import FlatTrainer, backward_order, broadcast_parameters
+    from mmvid_amd.engine import FlatTrainer, GraphedStep, backward_order, broadcast_parameters
     if local == 0:
         build()  # a no-op when the in-tree library is current (it is built by __graft_entry__.build())
     if world > 1:
@@ -156,8 +177,15 @@ def main():
     B = args.batch
     text, frames = synth_batch(B, device, gen)
 
-    for _ in range(args.warmup):
+    # Single process: the step is replayed as ONE hipGraph (the host then only draws the random masks / warp and
+    # copies them in); with torch.distributed the eager step keeps the overlapped bucketed all-reduce.
+    use_graph = world == 1 and not args.eager
+    graph_warm = min(2, args.warmup) if use_graph else 0
+    for _ in range(args.warmup - graph_warm):
         train_step(model, trainer, text, frames)
+    graphed = None
+    if use_graph:
+        graphed = GraphedStep(trainer, loss_fn(model), host_random_inputs(model, text, frames), warmup=graph_warm)
 
     def fence():
         torch.cuda.synchronize()
@@ -167,10 +195,17 @@ def main():
 
     lib = _lib.load()
     fence()
-    lib.mmvid_prof_begin(PROF_STRIDE)
+    lib.mmvid_prof_begin(1)
+    lib.mmvid_prof_enable(0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(model, trainer, text, frames)
+    for i in range(args.steps):
+        timed = i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY and i == args.steps - 1
+        if timed or graphed is None:  # per-launch HIP events need direct launches
+            lib.mmvid_prof_enable(1 if timed else 0)
+            loss = train_step(model, trainer, text, frames)
+            lib.mmvid_prof_enable(0)
+        else:
+            loss = graphed(**host_random_inputs(model, text, frames))
     fence()
     dt = time.perf_counter() - t0
     nc = len(CLASS_NAMES)
@@ -181,22 +216,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    gs = (ctypes.c_int64 * 3)()
+    lib.mmvid_graph_stats(gs)
+    graph_stats = {'direct': int(gs[0]), 'captured': int(gs[1]), 'replayed': int(gs[2])}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * TOK_PER_SAMPLE / (dt / args.steps)
         print(f'[bench] {ms_per_step:.2f} ms/step, {value:.0f} video-tokens/s on {world} GPU(s)', file=sys.stderr, flush=True)
         kernels = []
+        n_timed_steps = max(1, sum(1 for i in range(args.steps) if i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY and i == args.steps - 1))
         for i in range(nc):
             if cnt[i]:
-                kernels.append({'kernel': CLASS_NAMES[i], 'launches': int(tot[i]), 'timed_launches': int(cnt[i]),
-                                'avg_ms': ms[i] / cnt[i], 'ms_per_step': ms[i] / cnt[i] * tot[i] / args.steps,
+                kernels.append({'kernel': CLASS_NAMES[i], 'timed_launches': int(cnt[i]), 'avg_ms': ms[i] / cnt[i],
+                                'ms_per_step': ms[i] / n_timed_steps, 'launches_per_step': cnt[i] / n_timed_steps,
                                 'tflops': fl[i] / (ms[i] * 1e-3) / 1e12})
         dom = max(kernels, key=lambda k: k['ms_per_step']) if kernels else None
         roofline = None
         if dom:
             roofline = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS, 'traffic': None,
-                        'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches'] / args.steps}
+                        'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches_per_step'],
+                        'timed_steps': n_timed_steps}
         out = {
             'metric': 'video-tokens/sec training step, 8-frame 128px text-to-video', 'value': value,
             'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -204,9 +244,9 @@ def main():
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'text_to_video 8-frame 128x128, 64 text tokens (L=579), full dalle_bert (12-layer '
                                    'CLIP ViT-B/32 tower) + VQGAN encode in-step, MSM+REL+VID, backward, clip+Adam',
-                       'per_gpu_batch': B, 'global_batch': world * B, 'seq_len': 579, 'parallelism': f'dp{world}',
+                       'per_gpu_batch': B, 'global_batch': world * B, 'seq_len': 579, 'parallelism': f'dp{world}', 'step_launch': 'hipGraph replay' if graphed is not None else 'eager',
                        'layers': args.layers},
-            'loss': float(loss.detach()), 'roofline': roofline, 'kernels': kernels,
+            'loss': float(loss.detach()), 'roofline': roofline, 'kernels': kernels, 'graphs': graph_stats,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model)

@@ -94,9 +94,11 @@ int mmvid_colsum_bf16(const void* dy, int64_t ld, int64_t M, int N, float* db, v
 
 /* ---- optimiser: train.py:322-325 (clip_grad_norm_ 1.0 + Adam), utils_train.py:167-172. */
 int mmvid_grad_sqnorm(const float* g, int64_t n, float* out_accum, void* stream);
+/* step_dev (optional): device fp32 scalar holding the step count t; when given it replaces `step` in the bias
+ * corrections, so that a captured training step can be replayed with an advancing step count. */
 int mmvid_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
-                    const float* sqnorm, float grad_scale, void* stream);
+                    float beta1, float beta2, float eps, float weight_decay, int step, const float* step_dev,
+                    float max_norm, const float* sqnorm, float grad_scale, void* stream);
 int mmvid_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
 /* ---- whole CLIP tower (12 x ResidualAttentionBlock), layer loop in native code:
@@ -188,7 +190,15 @@ int mmvid_probe(int which, const void* in, void* out, void* stream);
  * Every `stride`-th launch of a class is timed.  prof_end: ms / flops summed over the sampled launches, their count,
  * and the total launch count per class. */
 int mmvid_prof_begin(int stride);
+int mmvid_prof_enable(int on); /* pause / resume recording without resetting */
 int mmvid_prof_end(double* ms, int64_t* sampled, double* flops, int64_t* launches_total, int nclass);
+
+/* ---- hipGraph replay of the long launch sequences (mmvid_vqgan_run, mmvid_tower_forward / _backward): a
+ * sequence seen twice with identical arguments (shapes, device pointers, stream) is captured once and replayed
+ * afterwards.  Opt-in (MMVID_GRAPHS=1 or mmvid_graph_enable(1)); bypassed while the profiler above is recording.
+ * counts[0..2] = sequences run directly / captured / replayed since the library was loaded. */
+int mmvid_graph_enable(int on);
+int mmvid_graph_stats(int64_t* counts);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,7 @@ SIGNATURES = {
     'mmvid_cross_entropy_bwd': [P, I64, P, P, P, P, I64, I, P, I64, P],
     'mmvid_colsum_bf16': [P, I64, I64, I, P, P],
     'mmvid_grad_sqnorm': [P, I64, P, P],
-    'mmvid_adam_step': [P, P, P, P, P, I64, F, F, F, F, F, I, F, P, F, P],
+    'mmvid_adam_step': [P, P, P, P, P, I64, F, F, F, F, F, I, P, F, P, F, P],
     'mmvid_cast_f32_to_bf16': [P, P, I64, P],
     'mmvid_tower_workspace': [POINTER(TowerCfg), POINTER(I64), POINTER(I64)],
     'mmvid_tower_forward': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, P, P],
@@ -64,6 +64,9 @@ SIGNATURES = {
     'mmvid_vqgan_run': [POINTER(VqganOp), I, P, P],
     'mmvid_probe': [I, P, P, P],
     'mmvid_prof_begin': [I],
+    'mmvid_prof_enable': [I],
+    'mmvid_graph_stats': [P],
+    'mmvid_graph_enable': [I],
     'mmvid_prof_end': [P, P, P, P, I],
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I)}

@@ -28,6 +28,7 @@ extern "C" int mmvid_device_count() {
 #include <mutex>
 #include <vector>
 
+#include "graphs.h"
 #include "prof.h"
 
 namespace {
@@ -72,6 +73,8 @@ MmvidProfScope::~MmvidProfScope() {
 
 // Every `stride`-th launch of each class is bracketed by a pair of HIP events (stride 1 = all of them; an event
 // pair costs a few microseconds of stream time, so the benchmark samples).
+bool mmvid_prof_recording() { return g_prof_on; }
+
 extern "C" int mmvid_prof_begin(int stride) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_recs.clear();
@@ -79,6 +82,14 @@ extern "C" int mmvid_prof_begin(int stride) {
     g_prof_stride = stride < 1 ? 1 : stride;
     for (int c = 0; c < PROF_NCLASS; ++c) g_prof_seen[c] = 0;
     g_prof_on = true;
+    return 0;
+}
+
+// Pause / resume recording without resetting what was collected (bench.py times a sample of the steps: while
+// recording is on, the long launch sequences run directly instead of as graph replays).
+extern "C" int mmvid_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
     return 0;
 }
 

@@ -36,7 +36,13 @@ struct AdamArgs {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ shadow, long n, AdamArgs a,
-                                                   const float* __restrict__ sqnorm) {
+                                                   const float* __restrict__ sqnorm,
+                                                   const float* __restrict__ step_dev) {
+    if (step_dev) {  // step count kept on the device (whole-step graph replay): bias corrections computed here
+        const float t = *step_dev;
+        a.bc1 = 1.0f - powf(a.beta1, t);
+        a.bc2_sqrt = sqrtf(1.0f - powf(a.beta2, t));
+    }
     float coef = a.grad_scale;
     if (sqnorm && a.max_norm > 0.f) {
         const float c = a.max_norm / (sqrtf(*sqnorm) * a.grad_scale + 1e-6f);
@@ -106,19 +112,20 @@ extern "C" int mmvid_grad_sqnorm(const float* g, int64_t n, float* out_accum, vo
 }
 
 extern "C" int mmvid_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
-                               float beta1, float beta2, float eps, float weight_decay, int step, float max_norm,
-                               const float* sqnorm, float grad_scale, void* stream) {
-    MMVID_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "adam_step: bad arguments");
+                               float beta1, float beta2, float eps, float weight_decay, int step,
+                               const float* step_dev, float max_norm, const float* sqnorm, float grad_scale,
+                               void* stream) {
+    MMVID_REQUIRE(p && g && m && v && n >= 0 && (step >= 1 || step_dev), "adam_step: bad arguments");
     MMVID_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)shadow_bf16 & 7) == 0,
                   "adam_step: buffers must be 16-byte aligned");
     if (n == 0) return MMVID_OK;
     AdamArgs a;
     a.lr = lr, a.beta1 = beta1, a.beta2 = beta2, a.eps = eps, a.weight_decay = weight_decay;
-    a.bc1 = 1.0f - powf(beta1, (float)step);
-    a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    a.bc1 = 1.0f - powf(beta1, (float)(step >= 1 ? step : 1));
+    a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)(step >= 1 ? step : 1)));
     a.max_norm = max_norm, a.grad_scale = grad_scale;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16,
-                       (long)n, a, sqnorm);
+                       (long)n, a, sqnorm, step_dev);
     MMVID_LAUNCH_CHECK("adam_step");
     return MMVID_OK;
 }

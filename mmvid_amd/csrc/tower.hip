@@ -6,6 +6,7 @@
 // transient buffers live in a "scratch" arena.  No allocation, no host sync: graph-capturable.
 #include "../../include/mmvid_hip.h"
 #include "common.h"
+#include "graphs.h"
 
 namespace {
 
@@ -115,10 +116,30 @@ extern "C" int mmvid_tower_workspace(const mmvid_tower_cfg_t* cfg, int64_t* save
     return MMVID_OK;
 }
 
+static int tower_forward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
+                                 float* x_out, void* saved, void* scratch, void* stream);
+static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
+                                  const void* saved, void* scratch, void* stream);
+
+static uint64_t tower_key(uint64_t seed, const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const void* a,
+                          const void* b, const void* c, const void* d, const void* stream) {
+    uint64_t k = mmvid_hash_bytes(cfg, sizeof(*cfg), 0xcbf29ce484222325ull ^ seed);
+    k = mmvid_hash_bytes(layers, sizeof(mmvid_tower_layer_t) * (size_t)cfg->layers, k);
+    return mmvid_hash_ptr(stream, mmvid_hash_ptr(d, mmvid_hash_ptr(c, mmvid_hash_ptr(b, mmvid_hash_ptr(a, k)))));
+}
+
 extern "C" int mmvid_tower_forward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers,
                                    const float* x_in, float* x_out, void* saved, void* scratch, void* stream) {
     TRY(check_cfg(cfg));
     MMVID_REQUIRE(layers && x_in && x_out && scratch, "tower_forward: null pointer");
+    const uint64_t key = tower_key(2, cfg, layers, x_in, x_out, saved, scratch, stream);
+    return mmvid_run_cached(key, (hipStream_t)stream, [=](hipStream_t s) {
+        return tower_forward_enqueue(cfg, layers, x_in, x_out, saved, scratch, (void*)s);
+    });
+}
+
+static int tower_forward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
+                                 float* x_out, void* saved, void* scratch, void* stream) {
     const Dims d = dims_of(*cfg);
     const SavedLayer sl = saved_layout(d);
     const Scratch sc = scratch_layout(d);
@@ -166,6 +187,14 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
                                     const void* saved, void* scratch, void* stream) {
     TRY(check_cfg(cfg));
     MMVID_REQUIRE(layers && g && saved && scratch, "tower_backward: null pointer");
+    const uint64_t key = tower_key(3, cfg, layers, g, saved, scratch, nullptr, stream);
+    return mmvid_run_cached(key, (hipStream_t)stream, [=](hipStream_t s) {
+        return tower_backward_enqueue(cfg, layers, g, saved, scratch, (void*)s);
+    });
+}
+
+static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
+                                  const void* saved, void* scratch, void* stream) {
     const Dims d = dims_of(*cfg);
     const SavedLayer sl = saved_layout(d);
     const Scratch sc = scratch_layout(d);

@@ -6,13 +6,13 @@
 // 8.5 ms of GPU work per 48-frame encode).  No allocation, no sync: graph-capturable.
 #include "../../include/mmvid_hip.h"
 #include "common.h"
+#include "graphs.h"
 
 namespace {
 inline char* at(void* arena, int64_t off) { return off < 0 ? nullptr : (char*)arena + off; }
 }  // namespace
 
-extern "C" int mmvid_vqgan_run(const mmvid_vqgan_op_t* ops, int nops, void* arena, void* stream) {
-    MMVID_REQUIRE(ops && arena && nops >= 0, "vqgan_run: bad arguments");
+static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, void* stream) {
     for (int i = 0; i < nops; ++i) {
         const mmvid_vqgan_op_t& o = ops[i];
         int rc = 0;
@@ -61,4 +61,11 @@ extern "C" int mmvid_vqgan_run(const mmvid_vqgan_op_t* ops, int nops, void* aren
         if (rc) return rc;
     }
     return MMVID_OK;
+}
+
+extern "C" int mmvid_vqgan_run(const mmvid_vqgan_op_t* ops, int nops, void* arena, void* stream) {
+    MMVID_REQUIRE(ops && arena && nops >= 0, "vqgan_run: bad arguments");
+    uint64_t key = mmvid_hash_bytes(ops, sizeof(mmvid_vqgan_op_t) * (size_t)nops, 0xcbf29ce484222325ull ^ 1);
+    key = mmvid_hash_ptr(arena, mmvid_hash_ptr(stream, key));
+    return mmvid_run_cached(key, (hipStream_t)stream, [=](hipStream_t s) { return vqgan_enqueue(ops, nops, arena, (void*)s); });
 }

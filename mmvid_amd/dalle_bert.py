@@ -224,6 +224,7 @@ class BERT(nn.Module):
         # segment table: which embedding table each position reads (0 special, 1 text, 2 visual, 3 image)
         seg = [0] + [1] * self.text_seq_len + [2] * self.visual_seq_len + [0, 0] + [3] * self.target_seq_len
         self.register_buffer('_seg', torch.tensor(seg, dtype=torch.int32), persistent=False)
+        self.register_buffer('_st_vid', torch.tensor([[1, 2]], dtype=torch.long), persistent=False)  # [ST1] [VID]
 
     # ------------------------------------------------------------------------------------ small helpers
     def _w16(self, lin):
@@ -383,7 +384,7 @@ class BERT(nn.Module):
             else:
                 visual = torch.full((B, self.visual_seq_len), self.image_token_lut['[MASK]'], dtype=torch.long, device=device)
             parts.append(visual)
-        parts.append(torch.tensor([[1, 2]], dtype=torch.long, device=device).expand(B, 2))
+        parts.append(self._st_vid.expand(B, 2))  # a buffer, not an upload: the step can be captured in a graph
         return torch.cat(parts, 1)
 
     def _assemble(self, ids, length):

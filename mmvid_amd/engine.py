@@ -57,6 +57,9 @@ class FlatTrainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.bucket_elems = max(ALIGN, int(bucket_mb * (1 << 20) / 4) // ALIGN * ALIGN)
         self._sq = torch.zeros(1, device=dev, dtype=torch.float32)
+        # the step count also lives on the device, advanced by a device op: a captured step (GraphedStep) replays with
+        # the right Adam bias corrections without the host passing a new scalar
+        self._step_dev = torch.zeros(1, device=dev, dtype=torch.float32) if dev.type == 'cuda' else None
         self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self._works = []
         self._sent_from = tot  # gradients at flat offsets >= this are already on the wire this step
@@ -128,15 +131,60 @@ class FlatTrainer:
         gscale = 1.0 / self.world
         # the update itself is the HIP kernel; on a host tensor ops.adam_step raises (there is no CPU path)
         self._sq.zero_()
+        if self._step_dev is not None:
+            self._step_dev.add_(1.0)
         ops.grad_sqnorm(self.G, self._sq)
         ops.adam_step(self.P, self.G, self.M, self.V, self.S, self.step_count, self.lr, self.betas, self.eps, self.wd,
-                      self.max_norm, self._sq, gscale)
+                      self.max_norm, self._sq, gscale, step_dev=self._step_dev)
         tw = getattr(self.model, 'transformer', None)
         if tw is not None and hasattr(tw, 'mark_shadow_fresh'):
             tw.mark_shadow_fresh()
 
     def grad_norm(self):
         return float(self.G.norm()) / self.world
+
+
+class GraphedStep:
+    """One training step -- zero_grad, forward, backward, clip + Adam -- as ONE hipGraph (torch.cuda.CUDAGraph).
+
+    The step is ~700 kernel launches issued from Python and from the native layer loops; replayed as a graph it costs
+    the host one call, so a slow or contended host can no longer stall the GPU.  `fn(**inputs)` returns the loss and
+    must be capture-safe: device work only (no host reads, no host-to-device uploads), fixed shapes, every random
+    choice made by the caller BEFORE the call and passed in as a tensor.  Single process only: with world_size > 1
+    the eager path keeps the overlapped bucketed all-reduce.
+
+        step = GraphedStep(trainer, fn, example_inputs)      # runs `warmup` real steps, then captures
+        loss = step(text=..., frames=..., ...)               # copies into the static inputs, replays
+    """
+
+    def __init__(self, trainer, fn, example_inputs, warmup=2):
+        assert trainer.world == 1, 'GraphedStep is single-process; use the eager step with torch.distributed'
+        self.trainer, self.fn = trainer, fn
+        self.static = {k: v.clone() for k, v in example_inputs.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires (real training steps)
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._step()
+        trainer.step_count -= 1  # the capture pass enqueued nothing: it was not a step
+
+    def _step(self):
+        self.trainer.zero_grad()
+        loss = self.fn(**self.static)
+        loss.backward()
+        self.trainer.step()
+        return loss.detach()
+
+    def __call__(self, **inputs):
+        for k, v in inputs.items():
+            self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        self.trainer.step_count += 1
+        return self.loss
 
 
 def backward_order(params):

@@ -248,12 +248,12 @@ def grad_sqnorm(g, out):
 
 
 def adam_step(p, g, m, v, shadow, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0,
-              sqnorm=None, grad_scale=1.0):
+              sqnorm=None, grad_scale=1.0, step_dev=None):
     for t, n in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
         _chk(t, f32, n)
     call('mmvid_adam_step', _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(betas[0]),
-         float(betas[1]), float(eps), float(weight_decay), int(step), float(max_norm), _p(sqnorm), float(grad_scale),
-         _stream())
+         float(betas[1]), float(eps), float(weight_decay), int(step), _p(step_dev), float(max_norm), _p(sqnorm),
+         float(grad_scale), _stream())
 
 
 def cast_bf16(x, out=None):
