@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 TEXT_LEN, FRAMES, SIZE, TOK_PER_SAMPLE = 64, 8, 128, 512
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PROF_EVERY = 5  # every 5th timed step runs with per-launch HIP events (its long sequences launch directly, not as graph replays)
+PROF_EVERY = 10  # every 10th timed step (at least the last one) runs eagerly with per-launch HIP events; the others are graph replays
 CLASS_NAMES = ['gemm_bf16_kernel<A.B^T> (forward)', 'gemm_bf16_kernel<dX>', 'gemm_bf16_kernel<dW>',
                'conv_igemm_kernel (VQGAN)', 'attn_fwd_kernel', 'attn_bwd (dq+dkv)']
 
@@ -82,6 +82,27 @@ def host_random_inputs(model, text, frames):
     mask1, nfm = model._msm_mask(text.shape[0], text.device, MSM_PROB, MSM_BERN, 0)
     warped = warp(frames.detach(), VID_PROB).to(text.device)
     return {'text': text, 'frames': frames, 'mask1': mask1, 'nfm': nfm, 'warped': warped}
+
+
+def pmc_traffic(prefix):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_{fetch,write}_size.csv: `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate runs, kernel-trace only).
+    Units are KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads, so it is doubled
+    (MI355X_MICROARCH.md, HBM; cross-checked on adam_kernel: 2 x FETCH = 16.0 B, WRITE = 14.0 B per parameter)."""
+    import csv
+    tot, disp = 0.0, 0
+    try:
+        for name, mult in (('fetch', 2.0), ('write', 1.0)):
+            d = 0
+            with open(os.path.join(ROOT, 'profiles', f'r01_pmc_{name}_size.csv')) as fh:
+                for r in csv.DictReader(fh):
+                    if r['kernel'].startswith(prefix):
+                        tot += mult * float(r['total']) * 1024.0
+                        d += int(r['dispatches'])
+            disp = d
+        return tot / disp if disp else None
+    except OSError:
+        return None
 
 
 def host_cores():
@@ -234,7 +255,9 @@ def main():
         roofline = None
         if dom:
             roofline = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS, 'traffic': None,
+                        'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS,
+                        'traffic': pmc_traffic(dom['kernel'].split('<')[0].split(' ')[0]),
+                        'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes committed under profiles/)',
                         'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches_per_step'],
                         'timed_steps': n_timed_steps}
         out = {
