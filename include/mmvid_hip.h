@@ -133,6 +133,7 @@ int mmvid_tower_forward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t*
 int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
                          const void* saved, void* scratch, void* stream);
 
+
 /* ---- VQGAN convolutions on NHWC bf16: taming/modules/diffusionmodules/model.py:56-62,77-81,102-128,159-205,
  * taming/models/vqgan.py:41-43.  mode 0: 3x3 stride 1 pad 1 | 1: 3x3 stride 2, zero pad right/bottom (Downsample)
  * | 2: nearest x2 upsample fused with 3x3 pad 1 (Upsample) | 3: 1x1.
@@ -195,10 +196,15 @@ int mmvid_prof_end(double* ms, int64_t* sampled, double* flops, int64_t* launche
 
 /* ---- hipGraph replay of the long launch sequences (mmvid_vqgan_run, mmvid_tower_forward / _backward): a
  * sequence seen twice with identical arguments (shapes, device pointers, stream) is captured once and replayed
- * afterwards.  Opt-in (MMVID_GRAPHS=1 or mmvid_graph_enable(1)); bypassed while the profiler above is recording.
+ * afterwards.  Opt-in (option "graphs" = 1); bypassed while the profiler above is recording.
  * counts[0..2] = sequences run directly / captured / replayed since the library was loaded. */
-int mmvid_graph_enable(int on);
 int mmvid_graph_stats(int64_t* counts);
+
+/* ---- tuning knobs for A/B measurements (tools/ab_graph.py); each is also read from an environment variable at first
+ * use.  "gemm_tile" (MMVID_GEMM_TILE): 0 = GEMM / conv block shape by grid fill, 128 | 256 = forced.
+ * "tower_streams" (MMVID_TOWER_STREAMS): 1 = tower backward on the caller's stream (default), 2 = weight-gradient
+ * chains on an internal side stream.  "graphs" (MMVID_GRAPHS): 1 = library-level graph replay (default 0). */
+int mmvid_set_option(const char* name, int value);
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,7 @@ SIGNATURES = {
     'mmvid_prof_begin': [I],
     'mmvid_prof_enable': [I],
     'mmvid_graph_stats': [P],
-    'mmvid_graph_enable': [I],
+    'mmvid_set_option': [c_char_p, I],
     'mmvid_prof_end': [P, P, P, P, I],
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I)}

@@ -70,12 +70,10 @@ __device__ __forceinline__ void mfma_settle(f32x16& acc) { asm volatile("s_nop 1
 __device__ __forceinline__ void mfma_settle(f32x4& acc) { asm volatile("s_nop 15" : "+v"(acc)); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
-// MMVID_GEMM_TILE=128|256 forces the block shape of the MFMA GEMM / conv kernels (A/B testing); 0 = by grid fill
-static inline int mmvid_tile_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MMVID_GEMM_TILE");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+// Tuning knobs (A/B testing): set by environment variable at first use or at run time through mmvid_set_option().
+//   gemm_tile      MMVID_GEMM_TILE      0 = block shape by grid fill (default), 128 / 256 = forced
+//   tower_streams  MMVID_TOWER_STREAMS  1 = tower backward on one stream (default), 2 = weight-gradient side stream
+//   graphs         MMVID_GRAPHS         1 = library-level hipGraph replay of the long launch sequences (default 0)
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_COUNT = 3 };
+int mmvid_option(int which);  // errors.hip
+static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

@@ -24,6 +24,40 @@ extern "C" int mmvid_device_count() {
     return n;
 }
 
+// ---------------------------------------------------------------------------------------------- tuning knobs
+namespace {
+struct Opt {
+    const char* name;
+    const char* env;
+    int dflt, value;
+    bool set;
+};
+Opt g_opts[MMVID_OPT_COUNT] = {{"gemm_tile", "MMVID_GEMM_TILE", 0, 0, false},
+                               {"tower_streams", "MMVID_TOWER_STREAMS", 1, 0, false},
+                               {"graphs", "MMVID_GRAPHS", 0, 0, false}};
+}  // namespace
+
+int mmvid_option(int which) {
+    Opt& o = g_opts[which];
+    if (!o.set) {
+        const char* e = getenv(o.env);
+        o.value = e ? atoi(e) : o.dflt;
+        o.set = true;
+    }
+    return o.value;
+}
+
+extern "C" int mmvid_set_option(const char* name, int value) {
+    MMVID_REQUIRE(name, "set_option: null name");
+    for (int i = 0; i < MMVID_OPT_COUNT; ++i)
+        if (strcmp(name, g_opts[i].name) == 0) {
+            g_opts[i].value = value, g_opts[i].set = true;
+            return MMVID_OK;
+        }
+    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs)", name);
+    return MMVID_ERR_ARG;
+}
+
 // ---------------------------------------------------------------------------------------------- profiler
 #include <mutex>
 #include <vector>

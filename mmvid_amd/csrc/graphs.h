@@ -5,7 +5,7 @@
 // graph is cached.  From then on a call is one hipGraphLaunch, bracketed by events so that it is ordered on the
 // user's stream exactly like the direct launches would be.  For callers of the C-ABI that cannot capture a graph
 // themselves (the Python training loop captures the WHOLE step instead: engine.GraphedStep).  Opt-in:
-// MMVID_GRAPHS=1 or mmvid_graph_enable(1); measured on a healthy host it neither gains nor loses (25.6 vs 24.8
+// option "graphs" = 1 (MMVID_GRAPHS=1, mmvid_set_option); measured on a healthy host it neither gains nor loses (25.6 vs 24.8
 // ms/step), it only takes ~3 ms of launch work per step off the host.  Bypassed while the HIP-event profiler is
 // recording (events cannot be read from replays) and while the calling stream is itself being captured.
 #pragma once

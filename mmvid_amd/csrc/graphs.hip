@@ -15,17 +15,10 @@ std::mutex g_mu;
 std::unordered_map<uint64_t, Entry> g_cache;
 hipStream_t g_stream = nullptr;
 hipEvent_t g_in = nullptr, g_out = nullptr;
-int g_enabled = -1;
 int64_t g_stat[3] = {0, 0, 0};  // direct, captured, replayed
 constexpr size_t kMaxEntries = 64;
 
-bool enabled() {
-    if (g_enabled < 0) {
-        const char* e = getenv("MMVID_GRAPHS");
-        g_enabled = (e && e[0] == '1') ? 1 : 0;  // opt-in: see graphs.h
-    }
-    return g_enabled == 1;
-}
+bool enabled() { return mmvid_option(MMVID_OPT_GRAPHS) == 1; }
 bool ensure_stream() {
     if (g_stream) return true;
     if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return false;
@@ -99,13 +92,6 @@ int mmvid_run_cached(uint64_t key, hipStream_t user, const std::function<int(hip
         mmvid_set_error("graph replay: stream ordering failed");
         return MMVID_ERR_HIP;
     }
-    return MMVID_OK;
-}
-
-extern "C" int mmvid_graph_enable(int on) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_enabled = on ? 1 : 0;
-    if (!on) drop_all();
     return MMVID_OK;
 }
 

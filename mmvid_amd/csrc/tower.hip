@@ -6,6 +6,8 @@
 // transient buffers live in a "scratch" arena.  No allocation, no host sync: graph-capturable.
 #include "../../include/mmvid_hip.h"
 #include "common.h"
+#include <vector>
+
 #include "graphs.h"
 
 namespace {
@@ -193,6 +195,40 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
     });
 }
 
+// Weight-gradient side stream.  In the backward of a Linear, dW (+ its split-K reduction and the bias column sum)
+// and dX both only read dY: the dW chain runs on a second stream while the main stream continues with dX, the
+// attention backward and the LayerNorm backwards.  Every kernel here is a few tens of microseconds with a fixed
+// ramp-up (workgroup dispatch ~22 ns each, first-tile latency) and a drain; two streams fill each other's ramps and
+// tails.  Fork / join are events, so the pattern is capturable (the side stream joins the capture and rejoins the
+// main stream before the call returns).  OFF by default (option tower_streams = 2 enables it): measured with
+// tools/ab_graph.py on the captured step it LOSES 1.8 % (22.68 vs 22.27 ms/step) -- the two chains compete for the
+// same CUs and L2 more than they fill each other's gaps.
+struct SideStream {
+    hipStream_t s = nullptr;
+    std::vector<hipEvent_t> ev;
+    size_t next = 0;
+    bool ok = false, tried = false;
+    hipEvent_t get() {
+        if (next == ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            ev.push_back(e);
+        }
+        return ev[next++];
+    }
+};
+static SideStream& side_stream() {
+    static SideStream ss;
+    const bool want = mmvid_option(MMVID_OPT_TOWER_STREAMS) == 2;
+    if (want && !ss.tried) {
+        ss.tried = true;
+        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.s = nullptr;
+    }
+    ss.ok = want && ss.s != nullptr;
+    ss.next = 0;
+    return ss;
+}
+
 static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
                                   const void* saved, void* scratch, void* stream) {
     const Dims d = dims_of(*cfg);
@@ -203,6 +239,27 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
     void* gb = scr + sc.g_bf16;
     float* d_h = (float*)(scr + sc.d_h);
     float* ws = (float*)(scr + sc.splitk_ws);
+    SideStream& ss = side_stream();
+    hipStream_t s0 = (hipStream_t)stream;
+    void* wst = ss.ok ? (void*)ss.s : stream;  // where the dW chains go
+    bool hip_ok = true;
+    // s1 continues from s0's current point (the tensor a dW reads is ready)
+    auto fork = [&]() {
+        if (!ss.ok) return;
+        hipEvent_t e = ss.get();
+        hip_ok = hip_ok && e && hipEventRecord(e, s0) == hipSuccess && hipStreamWaitEvent(ss.s, e, 0) == hipSuccess;
+    };
+    // marks s1's current point (a dW chain has been queued); s0 waits for it before the buffer that chain reads is reused
+    auto mark = [&]() -> hipEvent_t {
+        if (!ss.ok) return nullptr;
+        hipEvent_t e = ss.get();
+        hip_ok = hip_ok && e && hipEventRecord(e, ss.s) == hipSuccess;
+        return e;
+    };
+    auto wait = [&](hipEvent_t e) {
+        if (e) hip_ok = hip_ok && hipStreamWaitEvent(s0, e, 0) == hipSuccess;
+    };
+    hipEvent_t ev_fc = nullptr, ev_in = nullptr;  // previous layer's dW chains that read d_pre / dqkv
     for (int i = d.layers - 1; i >= 0; --i) {
         const mmvid_tower_layer_t& ly = layers[i];
         const char* sv = (const char*)saved + (int64_t)i * sl.total;
@@ -211,24 +268,41 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         if (i == d.layers - 1) TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
         // bias gradients of c_proj / out_proj = column sums of gb: produced by the LayerNorm backward that wrote gb
         // (dx_colsum), except for the top layer of this call, whose gb comes from the cast above
-        TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, i == d.layers - 1 ? ly.g_pj_b : nullptr, ws, stream));
+        fork();
+        TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, i == d.layers - 1 ? ly.g_pj_b : nullptr, ws, wst));
+        const hipEvent_t ev_pj = mark();
+        wait(ev_fc);  // the previous layer's c_fc dW still reads d_pre
         TRY(linear_dx(d.M, d.E, d.F, gb, ly.pj_w, sv + sl.pre, nullptr, scr + sc.d_pre, stream));
-        TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, ly.g_fc_b, ws, stream));
+        fork();
+        TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, ly.g_fc_b, ws, wst));
+        ev_fc = mark();
         TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, d_h, nullptr, stream));
+        wait(ev_pj);  // the LayerNorm backward overwrites gb
         TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
                                 (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, gb, ly.g_ln2_w, ly.g_ln2_b,
                                 ly.g_out_b, stream));
         // ---- attention branch: x_mid = x_in + out_proj(MHA(LN1 x_in))
-        TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, nullptr, ws, stream));
+        fork();
+        TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, nullptr, ws, wst));
+        const hipEvent_t ev_out = mark();
         TRY(linear_dx(d.M, d.E, d.E, gb, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
+        wait(ev_in);  // the previous layer's in_proj dW still reads dqkv
         TRY(mmvid_attention_bwd(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
                                 (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
                                 cfg->r1, cfg->c1, scr + sc.dqkv, 3 * d.E, stream));
-        TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, ly.g_in_b, ws, stream));
+        fork();
+        TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, ly.g_in_b, ws, wst));
+        ev_in = mark();
         TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, d_h, nullptr, stream));
+        wait(ev_out);  // the LayerNorm backward overwrites gb
         TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
                                 (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, i > 0 ? gb : nullptr, ly.g_ln1_w,
                                 ly.g_ln1_b, i > 0 ? layers[i - 1].g_pj_b : nullptr, stream));
+    }
+    wait(mark());  // join: every weight gradient of this call is complete for whatever follows on the caller's stream
+    if (!hip_ok) {
+        mmvid_set_error("tower_backward: stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
+        return MMVID_ERR_HIP;
     }
     return MMVID_OK;
 }

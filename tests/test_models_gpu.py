@@ -308,7 +308,7 @@ def test_graph_replay_is_bit_identical_to_direct_launches():
         _lib.call('mmvid_graph_stats', c)
         return list(c)
 
-    _lib.call('mmvid_graph_enable', 1)
+    _lib.call('mmvid_set_option', b'graphs', 1)
     torch.manual_seed(0)
     tw = OpenAICLIPTransformer(seq_len=579, which_model='openai_clip_visual', causal=False, layers=2).to(DEV).train()
     x = torch.randn(2, 579, 768, device=DEV, requires_grad=True)
@@ -344,7 +344,7 @@ def test_graph_replay_is_bit_identical_to_direct_launches():
     vae.image_size = 64
     img = torch.rand(4, 3, 64, 64, device=DEV)
     idx = [vae.get_codebook_indices(img).clone() for _ in range(4)]
-    _lib.call('mmvid_graph_enable', 0)
+    _lib.call('mmvid_set_option', b'graphs', 0)
     assert all(torch.equal(i, idx[0]) for i in idx[1:])
 
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""In-process A/B of a library tuning knob on the whole training step.
+
+    python tools/ab_graph.py <option> <value> <value> [...]      e.g.  tower_streams 1 2   |   gemm_tile 0 128 256
+
+The step is captured once per value (engine.GraphedStep; the knob is baked into the capture) and the graphs are
+replayed alternately in groups of 5: GPU-bound timing, stable to ~0.2 %, and box-to-box / run-to-run drift cancels
+(eager steps on this pool fluctuate by tens of percent with the host)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+from mmvid_amd import _lib
+from mmvid_amd.engine import FlatTrainer, GraphedStep, backward_order
+
+
+def main():
+    opt, values = sys.argv[1], [int(v) for v in sys.argv[2:]]
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0), np.random.seed(0)
+    model = bench.build_model(dev).train()
+    tr = FlatTrainer(model, order=backward_order)
+    text, frames = bench.synth_batch(6, dev, torch.Generator().manual_seed(0))
+    for _ in range(2):
+        bench.train_step(model, tr, text, frames)
+    inputs = bench.host_random_inputs(model, text, frames)
+    steps = {}
+    for v in values:
+        _lib.call('mmvid_set_option', opt.encode(), v)
+        steps[v] = GraphedStep(tr, bench.loss_fn(model), inputs, warmup=1)
+    res = {v: [] for v in values}
+    for rep in range(8):
+        for v in values:
+            steps[v](**inputs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                steps[v](**inputs)
+            torch.cuda.synchronize()
+            res[v].append((time.perf_counter() - t0) / 5 * 1e3)
+    for v in values:
+        print(f'{opt}={v}: ms/step per group {[round(x, 2) for x in res[v]]}  median {np.median(res[v]):.2f}')
+
+
+if __name__ == '__main__':
+    main()
