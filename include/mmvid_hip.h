@@ -134,6 +134,22 @@ int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t
                          const void* saved, void* scratch, void* stream);
 
 
+/* ---- incremental (KV-cache) decoding of the causal tower: what dalle_artv.py:236-304 recomputes from scratch for
+ * every sampled token (SURVEY next-row N1).  kv_cache: [layers][B][Lmax][2E] bf16, a row = K then V of one position.
+ * prefill = the causal forward over the prompt (cfg->L positions) that also fills the cache; decode = one new
+ * position per sequence (x_in / x_out [B, E] fp32) at index *pos_dev (device scalar: the call can be captured and
+ * replayed for every position) or `pos` when pos_dev is NULL.  Needs cfg->mask_mode == 1; scratch as for the forward. */
+int mmvid_tower_prefill(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
+                        float* x_out, void* kv_cache, int Lmax, void* scratch, void* stream);
+int mmvid_tower_decode(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in, float* x_out,
+                       void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch, void* stream);
+/* building blocks: append K|V rows of qkv [B*L, ldq] at positions pos..pos+L-1, and one-query attention over the
+ * cached positions 0..pos (head_dim 64, Lmax <= 4096). */
+int mmvid_kv_store(const void* qkv, int64_t ldq, int B, int L, int E, const int32_t* pos_dev, int pos0, int Lmax,
+                   void* cache, void* stream);
+int mmvid_attention_decode(const void* qkv, int64_t ldq, const void* cache, int B, int Lmax, int H, int E,
+                           const int32_t* pos_dev, int pos0, float scale, void* out, int64_t ldo, void* stream);
+
 /* ---- VQGAN convolutions on NHWC bf16: taming/modules/diffusionmodules/model.py:56-62,77-81,102-128,159-205,
  * taming/models/vqgan.py:41-43.  mode 0: 3x3 stride 1 pad 1 | 1: 3x3 stride 2, zero pad right/bottom (Downsample)
  * | 2: nearest x2 upsample fused with 3x3 pad 1 (Upsample) | 3: 1x1.

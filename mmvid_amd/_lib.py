@@ -57,6 +57,10 @@ SIGNATURES = {
     'mmvid_tower_workspace': [POINTER(TowerCfg), POINTER(I64), POINTER(I64)],
     'mmvid_tower_forward': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, P, P],
     'mmvid_tower_backward': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, P],
+    'mmvid_tower_prefill': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, P],
+    'mmvid_tower_decode': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, I, P, P],
+    'mmvid_kv_store': [P, I64, I, I, I, P, I, I, P, P],
+    'mmvid_attention_decode': [P, I64, P, I, I, I, I, P, I, F, P, I64, P],
     'mmvid_conv2d_nhwc': [I, P, I, I, I, I, P, P, I, P, P, I, P, P, P, P],
     'mmvid_image_to_nhwc8': [P, I, I, I, P, P],
     'mmvid_nhwc_to_nchw_f32': [P, I, I, I, I, I, P, P],

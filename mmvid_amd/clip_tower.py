@@ -135,6 +135,38 @@ class OpenAICLIPTransformer(nn.Module):
         keep = torch.is_grad_enabled() and (x.requires_grad or self._any_trainable())
         return _TowerFn.apply(x, self, keep, *self.parameters())
 
+    # ---- incremental decoding (causal towers; SURVEY next-row N1) -----------------------------------------
+    def new_kv_cache(self, B, max_len, device):
+        """[layers, B, max_len, 2*width] bf16: per layer and position the key row followed by the value row."""
+        assert self.mask_spec == 'causal', 'incremental decoding needs the causal mask'
+        return torch.empty(self.layers, B, max_len, 2 * self.width, device=device, dtype=torch.bfloat16)
+
+    @torch.no_grad()
+    def prefill(self, x, kv_cache):
+        """Causal forward over the prompt x [B, L, width] that also stores every layer's keys / values."""
+        x = ops._chk(x.contiguous(), torch.float32, 'tower input')
+        B, L, _ = x.shape
+        cfg = self._cfg(B, L)
+        layers, _keep = self._layer_structs(False)
+        _, scratch = self._workspace(cfg, x.device, False)
+        y = torch.empty_like(x)
+        _lib.call('mmvid_tower_prefill', ctypes.byref(cfg), layers, ops._p(x), ops._p(y), ops._p(kv_cache),
+                  kv_cache.shape[2], ops._p(scratch), ops._stream())
+        return y
+
+    @torch.no_grad()
+    def decode_step(self, x_new, kv_cache, pos, pos_dev=None):
+        """One new position: x_new [B, width] at index `pos` (or the int32 device scalar pos_dev) -> [B, width]."""
+        x_new = ops._chk(x_new.contiguous(), torch.float32, 'tower input')
+        B = x_new.shape[0]
+        cfg = self._cfg(B, kv_cache.shape[2])  # scratch sized like a forward over the whole cache length
+        layers, _keep = self._layer_structs(False)
+        _, scratch = self._workspace(cfg, x_new.device, False)
+        y = torch.empty_like(x_new)
+        _lib.call('mmvid_tower_decode', ctypes.byref(cfg), layers, ops._p(x_new), ops._p(y), ops._p(kv_cache),
+                  kv_cache.shape[2], ops._p(pos_dev), int(pos), ops._p(scratch), ops._stream())
+        return y
+
     # ---- native plumbing ---------------------------------------------------------------------------
     def _any_trainable(self):
         return any(p.requires_grad for p in self.parameters())

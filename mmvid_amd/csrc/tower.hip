@@ -119,7 +119,8 @@ extern "C" int mmvid_tower_workspace(const mmvid_tower_cfg_t* cfg, int64_t* save
 }
 
 static int tower_forward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
-                                 float* x_out, void* saved, void* scratch, void* stream);
+                                 float* x_out, void* saved, void* scratch, void* stream, void* kv_cache = nullptr,
+                                 int kv_lmax = 0);
 static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
                                   const void* saved, void* scratch, void* stream);
 
@@ -141,7 +142,7 @@ extern "C" int mmvid_tower_forward(const mmvid_tower_cfg_t* cfg, const mmvid_tow
 }
 
 static int tower_forward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
-                                 float* x_out, void* saved, void* scratch, void* stream) {
+                                 float* x_out, void* saved, void* scratch, void* stream, void* kv_cache, int kv_lmax) {
     const Dims d = dims_of(*cfg);
     const SavedLayer sl = saved_layout(d);
     const Scratch sc = scratch_layout(d);
@@ -172,6 +173,9 @@ static int tower_forward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower
         TRY(mmvid_layernorm_fwd(x, d.E, d.M, d.E, ly.ln1_w, ly.ln1_b, cfg->ln_eps, sv + sl.h1, nullptr, d.E,
                                 (float*)(sv + sl.mean1), (float*)(sv + sl.rstd1), stream));
         TRY(linear_fwd(d.M, 3 * d.E, d.E, sv + sl.h1, ly.in_w, ly.in_b, nullptr, nullptr, 0, nullptr, sv + sl.qkv, stream));
+        if (kv_cache)  // prefill of the incremental decoder: keep this layer's keys and values
+            TRY(mmvid_kv_store(sv + sl.qkv, 3 * d.E, d.B, d.L, d.E, nullptr, 0, kv_lmax,
+                               (char*)kv_cache + (int64_t)i * d.B * kv_lmax * 2 * d.E * 2, stream));
         TRY(mmvid_attention_fwd(sv + sl.qkv, 3 * d.E, d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0, cfg->r1,
                                 cfg->c1, sv + sl.o, d.E, (float*)(sv + sl.lse2), stream));
         TRY(linear_fwd(d.M, d.E, d.E, sv + sl.o, ly.out_w, ly.out_b, x, nullptr, 0, xmid, nullptr, stream));
@@ -303,6 +307,58 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
     if (!hip_ok) {
         mmvid_set_error("tower_backward: stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
         return MMVID_ERR_HIP;
+    }
+    return MMVID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Incremental decoding of the causal tower (decode.hip).  kv_cache: [layers][B][Lmax][2E] bf16.
+extern "C" int mmvid_tower_prefill(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
+                                   float* x_out, void* kv_cache, int Lmax, void* scratch, void* stream) {
+    TRY(check_cfg(cfg));
+    MMVID_REQUIRE(layers && x_in && x_out && kv_cache && scratch, "tower_prefill: null pointer");
+    MMVID_REQUIRE(cfg->mask_mode == 1 && cfg->L <= Lmax, "tower_prefill: needs the causal mask and L (%d) <= Lmax (%d)", cfg->L,
+                  Lmax);
+    return tower_forward_enqueue(cfg, layers, x_in, x_out, nullptr, scratch, stream, kv_cache, Lmax);
+}
+
+// One new position per sequence: x_in / x_out [B, E] fp32; its index comes from the device scalar pos_dev (so a
+// captured step can be replayed for every position) or, when that is NULL, from pos.  cfg->L is ignored.
+extern "C" int mmvid_tower_decode(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
+                                  float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
+                                  void* stream) {
+    TRY(check_cfg(cfg));
+    MMVID_REQUIRE(layers && x_in && x_out && kv_cache && scratch, "tower_decode: null pointer");
+    MMVID_REQUIRE(cfg->mask_mode == 1, "tower_decode: incremental decoding needs the causal mask");
+    const int B = cfg->B, E = cfg->E, F = cfg->F, H = cfg->H;
+    // a few [B, *] rows out of the scratch arena (it is sized for B*L tokens)
+    char* p = (char*)scratch;
+    auto take = [&](int64_t bytes) {
+        char* o = p;
+        p += align256(bytes);
+        return o;
+    };
+    void* h = take((int64_t)B * E * 2);
+    void* qkv = take((int64_t)B * 3 * E * 2);
+    void* o = take((int64_t)B * E * 2);
+    float* xmid = (float*)take((int64_t)B * E * 4);
+    void* act = take((int64_t)B * F * 2);
+    float* xa = (float*)take((int64_t)B * E * 4);
+    float* xb = (float*)take((int64_t)B * E * 4);
+    const float* x = x_in;
+    for (int i = 0; i < cfg->layers; ++i) {
+        const mmvid_tower_layer_t& ly = layers[i];
+        void* cache = (char*)kv_cache + (int64_t)i * B * Lmax * 2 * E * 2;
+        float* xnext = (i == cfg->layers - 1) ? x_out : ((i & 1) ? xb : xa);
+        TRY(mmvid_layernorm_fwd(x, E, B, E, ly.ln1_w, ly.ln1_b, cfg->ln_eps, h, nullptr, E, nullptr, nullptr, stream));
+        TRY(linear_fwd(B, 3 * E, E, h, ly.in_w, ly.in_b, nullptr, nullptr, 0, nullptr, qkv, stream));
+        TRY(mmvid_kv_store(qkv, 3 * E, B, 1, E, pos_dev, pos, Lmax, cache, stream));
+        TRY(mmvid_attention_decode(qkv, 3 * E, cache, B, Lmax, H, E, pos_dev, pos, 0.125f, o, E, stream));
+        TRY(linear_fwd(B, E, E, o, ly.out_w, ly.out_b, x, nullptr, 0, xmid, nullptr, stream));
+        TRY(mmvid_layernorm_fwd(xmid, E, B, E, ly.ln2_w, ly.ln2_b, cfg->ln_eps, h, nullptr, E, nullptr, nullptr, stream));
+        TRY(linear_fwd(B, F, E, h, ly.fc_w, ly.fc_b, nullptr, nullptr, 1, nullptr, act, stream));
+        TRY(linear_fwd(B, E, F, act, ly.pj_w, ly.pj_b, xmid, nullptr, 0, xnext, nullptr, stream));
+        x = xnext;
     }
     return MMVID_OK;
 }

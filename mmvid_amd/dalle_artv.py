@@ -200,10 +200,30 @@ class DALLE(nn.Module):
         zero = torch.tensor(0.0, device=text.device)
         return loss, zero, zero
 
+    def _embed_rows(self, ids, first_pos):
+        """Embedding + positional rows for `ids` [B, n] occupying positions first_pos .. first_pos+n-1."""
+        n = ids.shape[1]
+        pos = torch.cat([self.text_pos_emb.weight, self.visual_pos_emb.table(), self.image_pos_emb.table()], 0)
+        return ops.assemble_sequence([self.text_emb.weight, self.visual_emb.weight, self.image_emb.weight], ids.contiguous(),
+                                     self._seg[first_pos:first_pos + n].contiguous(), pos[first_pos:first_pos + n].contiguous())
+
+    def _sample(self, last_hidden, position, filter_thres, temperature):
+        """dalle_artv.py:282-291: logits of the last position restricted to its allowed block, top-k, multinomial."""
+        last = self._logits_rows(last_hidden.contiguous())
+        c0, c1 = self._allowed_range(position)
+        logits = torch.full_like(last, -torch.finfo(torch.float32).max)
+        logits[:, c0:c1] = last[:, c0:c1]
+        probs = F.softmax(top_k(logits, thres=filter_thres) / temperature, dim=-1)
+        return torch.multinomial(probs, 1) - self.num_control_tokens
+
     @torch.no_grad()
     @eval_decorator
     def generate_images(self, text, *, clip=None, visual=None, mask=None, filter_thres=0.5, temperature=1.,
-                        erase_visual=False, vc_mode=None, face_mode=None, **kwargs):
+                        erase_visual=False, vc_mode=None, face_mode=None, use_cache=True, **kwargs):
+        """dalle_artv.py:236-304.  use_cache=True (default): the prompt is run once and each sampled token then costs
+        one incremental step over the per-layer key/value cache; use_cache=False: the reference's algorithm, the
+        whole transformer over the growing prefix for every token.  Same sampling distribution either way (the
+        two differ in bf16 summation order only; tests/test_models_gpu.py compares the logits step by step)."""
         tsl, total_len = self.text_seq_len, self.text_seq_len + self.target_seq_len
         text = text[:, :tsl]
         out = text
@@ -214,17 +234,38 @@ class DALLE(nn.Module):
             vis_tok = self.get_image_tokens(visual, which_vae='cvae')
             if erase_visual:
                 vis_tok = self.random_erase_codebook(vis_tok, self.eraser, True)
-        neg = -torch.finfo(torch.float32).max
-        for cur_len in range(out.shape[1], total_len):
-            image = out[:, tsl:]
-            hidden, _, _, _ = self._hidden(out[:, :tsl], vis_tok, image, False, False, None, None, None)
-            last = self._logits_rows(hidden[:, -1, :].contiguous())
-            c0, c1 = self._allowed_range(hidden.shape[1] - 1)
-            logits = torch.full_like(last, neg)
-            logits[:, c0:c1] = last[:, c0:c1]
-            probs = F.softmax(top_k(logits, thres=filter_thres) / temperature, dim=-1)
-            sample = torch.multinomial(probs, 1) - self.num_control_tokens
-            out = torch.cat((out, sample), dim=-1)
+        if use_cache:
+            B = text.shape[0]
+            cache = self.transformer.new_kv_cache(B, self.total_seq_len, text.device)
+            # prompt = <bos> text, visual: the same ids _hidden builds (dalle_artv.py:441-477)
+            text_range = torch.arange(tsl, device=text.device) + (self.num_text_tokens - tsl)
+            tx = F.pad(torch.where(text == 0, text_range, text), (1, 0), value=0)
+            vz = vis_tok if vis_tok is not None else -torch.ones(B, self.visual_seq_len, device=text.device).long()
+            visual_range = torch.arange(self.visual_seq_len, device=text.device) + (self.num_visual_tokens - self.visual_seq_len)
+            vz = torch.where(vz == -1, visual_range, vz)
+            prompt = torch.cat((tx, vz), 1)
+            h = self.transformer.prefill(self._embed_rows(prompt, 0), cache)[:, -1, :]
+            if self.stable:
+                h = self.norm_by_max(h)
+            pos = prompt.shape[1]  # index of the position being sampled for
+            toks = []
+            for step in range(self.target_seq_len):
+                sample = self._sample(h, pos - 1, filter_thres, temperature)
+                toks.append(sample)
+                if step == self.target_seq_len - 1:
+                    break
+                x_new = self._embed_rows(sample, pos)[:, 0, :]
+                h = self.transformer.decode_step(x_new, cache, pos)
+                if self.stable:
+                    h = self.norm_by_max(h)
+                pos += 1
+            out = torch.cat([out] + toks, dim=-1)
+        else:
+            for cur_len in range(out.shape[1], total_len):
+                image = out[:, tsl:]
+                hidden, _, _, _ = self._hidden(out[:, :tsl], vis_tok, image, False, False, None, None, None)
+                sample = self._sample(hidden[:, -1, :], hidden.shape[1] - 1, filter_thres, temperature)
+                out = torch.cat((out, sample), dim=-1)
         img_seq = out[:, -self.target_seq_len:].reshape(-1, self.image_seq_len)
         images = self.vae.decode(img_seq)
         if self.num_targets > 1:
