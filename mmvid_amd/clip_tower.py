@@ -77,6 +77,47 @@ class _TowerFn(torch.autograd.Function):
         return (g.view(ctx.shape), None, None) + (None, ) * (len(ctx.needs_input_grad) - 3)
 
 
+class DecodeSession:
+    """See OpenAICLIPTransformer.decode_session.  step(x_new [B, width]) -> hidden [B, width] (a static buffer that
+    the next step overwrites)."""
+
+    def __init__(self, tower, kv_cache, first_pos, graph):
+        self.tower, self.cache = tower, kv_cache
+        B, dev = kv_cache.shape[1], kv_cache.device
+        self.cfg = tower._cfg(B, kv_cache.shape[2])
+        self.layers, self._keep = tower._layer_structs(False)
+        _, self.scratch = tower._workspace(self.cfg, dev, False)
+        self.x = torch.zeros(B, tower.width, device=dev, dtype=torch.float32)
+        self.y = torch.zeros_like(self.x)
+        self.pos = torch.tensor([first_pos], dtype=torch.int32, device=dev)
+        self.graph, self.want_graph, self.calls = None, graph, 0
+
+    def _enqueue(self):
+        _lib.call('mmvid_tower_decode', ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
+                  ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
+        self.pos.add_(1)
+
+    @torch.no_grad()
+    def step(self, x_new):
+        self.x.copy_(x_new)
+        self.calls += 1
+        if self.want_graph and self.graph is None and self.calls == 2:
+            # second step: capture (the first one ran eagerly and warmed every kernel variant up)
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    self._enqueue()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = g
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
+        return self.y
+
+
 class OpenAICLIPTransformer(nn.Module):
     def __init__(self, seq_len=0, which_model='openai_clip_text', model_path=None, causal=True, mask_type='causal',
                  mask_kwargs=None, layers=None, width=None, heads=None):
@@ -95,7 +136,7 @@ class OpenAICLIPTransformer(nn.Module):
         self._shadow = None  # flat bf16 copy of the matrix weights
         self._shadow_key = None
         self._scratch = None
-        self._scratch_key = None
+        self._scratch_retired = []
         self.backward_chunk_layers = 3  # the backward returns to the host every N layers ...
         self.on_layers_done = None      # ... and calls this (first_layer) so gradient exchange can overlap
 
@@ -166,6 +207,11 @@ class OpenAICLIPTransformer(nn.Module):
         _lib.call('mmvid_tower_decode', ctypes.byref(cfg), layers, ops._p(x_new), ops._p(y), ops._p(kv_cache),
                   kv_cache.shape[2], ops._p(pos_dev), int(pos), ops._p(scratch), ops._stream())
         return y
+
+    def decode_session(self, kv_cache, first_pos, graph=True):
+        """A sampling loop's view of decode_step: argument structs and buffers are built once, the position lives in a
+        device scalar that the step itself advances, and (graph=True) the step is captured once and replayed."""
+        return DecodeSession(self, kv_cache, first_pos, graph)
 
     # ---- native plumbing ---------------------------------------------------------------------------
     def _any_trainable(self):
@@ -241,10 +287,11 @@ class OpenAICLIPTransformer(nn.Module):
     def _workspace(self, cfg, device, keep):
         sb, cb = ctypes.c_int64(), ctypes.c_int64()
         _lib.call('mmvid_tower_workspace', ctypes.byref(cfg), ctypes.byref(sb), ctypes.byref(cb))
-        key = (cfg.B, cfg.L, str(device))
-        if self._scratch_key != key:
+        # grow-only scratch: a sampler that calls with a longer sequence every step must not reallocate ~1 GB each time
+        if self._scratch is None or self._scratch.device != torch.device(device) or self._scratch.numel() < cb.value:
+            if self._scratch is not None:
+                self._scratch_retired.append(self._scratch)  # captured graphs / decode sessions may still point into it
             self._scratch = torch.empty(cb.value, device=device, dtype=torch.uint8)
-            self._scratch_key = key
         saved = torch.empty(sb.value, device=device, dtype=torch.uint8) if keep else None
         return saved, self._scratch
 

@@ -248,14 +248,29 @@ class DALLE(nn.Module):
             if self.stable:
                 h = self.norm_by_max(h)
             pos = prompt.shape[1]  # index of the position being sampled for
+            # everything a step needs, prepared once: positional rows, the image block of the logits matrix, the session
+            pos_rows = torch.cat([self.text_pos_emb.weight, self.visual_pos_emb.table(), self.image_pos_emb.table()], 0)
+            c0, c1 = self._allowed_range(pos)
+            lin, ln = self.to_logits[1], self.to_logits[0]
+            w_img, b_img = self._w16()[c0:c1].contiguous(), lin.bias[c0:c1].contiguous()
+            k_keep = max(int((1 - filter_thres) * lin.weight.shape[0]), 1)  # top_k() keeps this many of ALL logits
+            sess = self.transformer.decode_session(cache, pos)
             toks = []
             for step in range(self.target_seq_len):
-                sample = self._sample(h, pos - 1, filter_thres, temperature)
+                # logits of the allowed (image) block only: the other columns are masked to -max by the reference and end
+                # up with probability exactly 0 (dalle_artv.py:285-290), whatever top-k does, as long as k covers the block
+                hn, _, _ = ops.layernorm_fwd(h.contiguous(), ln.weight, ln.bias, 1e-5, save_stats=False)
+                blk = ops.gemm(hn, w_img, bias=b_img, out_dtype=torch.float32)
+                if k_keep < c1 - c0:
+                    blk = top_k(blk, thres=1.0 - k_keep / (c1 - c0))
+                probs = torch.zeros(B, lin.weight.shape[0], device=text.device)
+                probs[:, c0:c1] = F.softmax(blk / temperature, dim=-1)
+                sample = torch.multinomial(probs, 1) - self.num_control_tokens  # same call, same RNG use as the reference
                 toks.append(sample)
                 if step == self.target_seq_len - 1:
                     break
-                x_new = self._embed_rows(sample, pos)[:, 0, :]
-                h = self.transformer.decode_step(x_new, cache, pos)
+                x_new = self.image_emb.weight[sample[:, 0]] + pos_rows[pos]
+                h = sess.step(x_new)
                 if self.stable:
                     h = self.norm_by_max(h)
                 pos += 1

@@ -292,6 +292,14 @@ def test_artv_kv_cache_decode_matches_full_recompute(golden):
         pd = torch.tensor([pos - 1], dtype=torch.int32, device=DEV)
         h2 = m.transformer.decode_step(m._embed_rows(tt[:, 30:31], pos - 1)[:, 0, :], cache, 0, pos_dev=pd)
         assert torch.equal(h2, h)
+        # a decode session (buffers built once, position advanced on the device, step captured and replayed from the
+        # second call on) walks the same positions to the same hidden states
+        cache2 = m.transformer.new_kv_cache(B, m.total_seq_len, DEV)
+        m.transformer.prefill(m._embed_rows(prompt, 0), cache2)
+        sess = m.transformer.decode_session(cache2, prompt.shape[1])
+        for k in range(31):
+            hs = sess.step(m._embed_rows(tt[:, k:k + 1], prompt.shape[1] + k)[:, 0, :])
+        assert sess.graph is not None and torch.equal(hs, h)
 
 
 # --------------------------------------------------------------------------------------------- engine
