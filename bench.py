@@ -21,6 +21,13 @@ import random
 import sys
 import time
 
+# A GPU box shows all of the node's hardware threads (256) but grants a cgroup quota of a few cores.  Thread pools
+# sized by the former (OpenMP, OpenBLAS) overrun the quota the moment they wake up and the kernel then throttles the
+# whole process for the rest of the period -- including the thread that launches GPU work (cpu.stat: throttled 12.7 s
+# over three benchmark runs before this).  Must happen before numpy / torch are imported.
+for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+    os.environ.setdefault(_v, '4')
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -170,6 +177,9 @@ def main():
     ap.add_argument('--layers', type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the model
     args = ap.parse_args()
 
+    # a GPU box exposes all 256 hardware threads but a cgroup quota of a few cores: keep torch's CPU pool small so that
+    # incidental host ops never fan out over hundreds of spinning OpenMP threads (cpu_baseline() sets its own count)
+    torch.set_num_threads(min(4, host_cores()))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -219,7 +229,9 @@ def main():
     lib.mmvid_prof_begin(1)
     lib.mmvid_prof_enable(0)
     t0 = time.perf_counter()
+    host_s = 0.0  # time the host spends issuing the steps (it runs ahead of the GPU; ~= dt means host-bound)
     for i in range(args.steps):
+        th = time.perf_counter()
         timed = i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY and i == args.steps - 1
         if timed or graphed is None:  # per-launch HIP events need direct launches
             lib.mmvid_prof_enable(1 if timed else 0)
@@ -227,6 +239,7 @@ def main():
             lib.mmvid_prof_enable(0)
         else:
             loss = graphed(**host_random_inputs(model, text, frames))
+        host_s += time.perf_counter() - th
     fence()
     dt = time.perf_counter() - t0
     nc = len(CLASS_NAMES)
@@ -243,7 +256,9 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * TOK_PER_SAMPLE / (dt / args.steps)
-        print(f'[bench] {ms_per_step:.2f} ms/step, {value:.0f} video-tokens/s on {world} GPU(s)', file=sys.stderr, flush=True)
+        print(f'[bench] {ms_per_step:.2f} ms/step, {value:.0f} video-tokens/s on {world} GPU(s); host issue time '
+              f'{host_s / args.steps * 1e3:.2f} ms/step, load average {os.getloadavg()[0]:.1f} on {host_cores()} usable cores',
+              file=sys.stderr, flush=True)
         kernels = []
         n_timed_steps = max(1, sum(1 for i in range(args.steps) if i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY and i == args.steps - 1))
         for i in range(nc):
@@ -270,6 +285,7 @@ def main():
                        'per_gpu_batch': B, 'global_batch': world * B, 'seq_len': 579, 'parallelism': f'dp{world}', 'step_launch': 'hipGraph replay' if graphed is not None else 'eager',
                        'layers': args.layers},
             'loss': float(loss.detach()), 'roofline': roofline, 'kernels': kernels, 'graphs': graph_stats,
+            'host_issue_ms_per_step': host_s / args.steps * 1e3, 'host_load_average': os.getloadavg()[0],
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model)

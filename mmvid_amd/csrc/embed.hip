@@ -38,22 +38,60 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(Tables tb, const long
     }
 }
 
+// Scatter-add of dx rows into the table gradients.  A block owns 32 consecutive rows and first merges the rows that
+// hit the SAME table row (the [MASK] id fills most of the target segment, special tokens repeat in every sequence):
+// one burst of atomics per distinct (table, id) of the chunk instead of one per row.  Per-row atomics measured 265 us
+// at 10,422 rows: ~5,000 of them serialised on the 768 addresses of the [MASK] embedding.
+constexpr int SC_ROWS = 32;
 __global__ __launch_bounds__(256) void assemble_bwd_scatter_kernel(GradTables tb, const long long* __restrict__ ids,
                                                                    const int* __restrict__ seg,
                                                                    const float* __restrict__ dx, long nrows, int L,
                                                                    int E) {
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
-    const int lane = threadIdx.x & 63;
-    const int l = (int)(row % L);
-    const int s = seg[l];
-    float* g = tb.t[s];
-    if (!g) return;
-    long id = ids[row];
-    if (id < 0 || id >= tb.rows[s]) return;
-    const float* src = dx + row * E;
-    float* dst = g + id * E;
-    for (int c = lane; c < E; c += 64) unsafeAtomicAdd(dst + c, src[c]);
+    __shared__ long key[SC_ROWS];  // table * 2^40 + id, or -1 when the row has no gradient to deliver
+    __shared__ int lead[SC_ROWS];
+    const long base = (long)blockIdx.x * SC_ROWS;
+    const int tid = threadIdx.x;
+    if (tid < SC_ROWS) {
+        const long row = base + tid;
+        long k = -1;
+        if (row < nrows) {
+            const int s = seg[(int)(row % L)];
+            const long id = ids[row];
+            if (tb.t[s] && id >= 0 && id < tb.rows[s]) k = ((long)s << 40) + id;
+        }
+        key[tid] = k;
+    }
+    __syncthreads();
+    if (tid < SC_ROWS) {
+        int l = tid;
+        const long k = key[tid];
+        if (k < 0) {
+            l = -1;
+        } else {
+            for (int j = 0; j < tid; ++j)
+                if (key[j] == k) {
+                    l = j;
+                    break;
+                }
+        }
+        lead[tid] = l;
+    }
+    __syncthreads();
+    for (int r = 0; r < SC_ROWS; ++r) {
+        if (lead[r] != r) continue;  // block-uniform
+        const long k = key[r];
+        float* dst = tb.t[(int)(k >> 40)] + (k & ((1l << 40) - 1)) * E;
+        for (int c = tid; c < (E >> 2); c += 256) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r2 = r; r2 < SC_ROWS; ++r2) {
+                if (lead[r2] != r) continue;
+                const float4 v = *reinterpret_cast<const float4*>(dx + (base + r2) * E + 4 * c);
+                a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+            }
+            unsafeAtomicAdd(dst + 4 * c, a.x), unsafeAtomicAdd(dst + 4 * c + 1, a.y);
+            unsafeAtomicAdd(dst + 4 * c + 2, a.z), unsafeAtomicAdd(dst + 4 * c + 3, a.w);
+        }
+    }
 }
 
 // dpos[l, e] (+)= sum_b dx[b, l, e]
@@ -206,7 +244,7 @@ extern "C" int mmvid_assemble_sequence_bwd(float* const* grad_tables, const int6
     const long nrows = (long)B * L;
     if (nrows == 0) return MMVID_OK;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(assemble_bwd_scatter_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, s, tb, (const long long*)ids,
+    hipLaunchKernelGGL(assemble_bwd_scatter_kernel, dim3(cdiv(nrows, SC_ROWS)), dim3(256), 0, s, tb, (const long long*)ids,
                        seg, dx, nrows, L, E);
     if (dpos) {
         const long LE = (long)L * E;

@@ -311,7 +311,8 @@ extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x
                   "layernorm_bwd: bad E/strides");
     if (rows == 0) return MMVID_OK;
     int blocks = cdiv(rows, 4);
-    if (blocks > 1024) blocks = 1024;
+    const int cap = mmvid_option(MMVID_OPT_LN_BWD_BLOCKS);
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x,
                        (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16, dw, db,
                        dx_colsum);

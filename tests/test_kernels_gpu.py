@@ -279,6 +279,21 @@ def test_assemble_sequence_and_backward(ops):
             if seg[l] == s:
                 r.index_add_(0, ids[:, l], dx[:, l])
         close(gt, r, 1e-6, f'dtable{s}')
+    # heavy duplication (every target position holds the same id, as [MASK] does) and a table without gradient
+    B = 40
+    ids = torch.stack([torch.randint(0, tabs[s].shape[0], (B, ), device=DEV) for s in seg.tolist()], 1)
+    ids[:, seg == 2] = 7
+    dx = rnd(B, L, E, seed=6)
+    gts = [torch.zeros_like(tabs[0]), None, torch.zeros_like(tabs[2])]
+    ops.assemble_sequence_bwd(gts, [t.shape[0] for t in tabs], ids, seg, dx, None)
+    r = torch.zeros_like(tabs[2])
+    r[7] = dx[:, seg == 2].sum((0, 1))
+    close(gts[2], r, 1e-5, 'dtable2, one hot row')
+    r0 = torch.zeros_like(tabs[0])
+    for l in range(L):
+        if seg[l] == 0:
+            r0.index_add_(0, ids[:, l], dx[:, l])
+    close(gts[0], r0, 1e-5, 'dtable0 next to a frozen table')
 
 
 def test_cross_entropy(ops):

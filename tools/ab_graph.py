@@ -43,6 +43,15 @@ def main():
                 steps[v](**inputs)
             torch.cuda.synchronize()
             res[v].append((time.perf_counter() - t0) / 5 * 1e3)
+    for v in values:  # host cost of ONE replay issued into an idle queue (no back-pressure from earlier work)
+        hs = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            steps[v](**inputs)
+            hs.append((time.perf_counter() - t0) * 1e3)
+            torch.cuda.synchronize()
+        print(f'{opt}={v}: host time of one replay call (copies + hipGraphLaunch) {[round(x, 2) for x in hs]} ms')
     for v in values:
         print(f'{opt}={v}: ms/step per group {[round(x, 2) for x in res[v]]}  median {np.median(res[v]):.2f}')
 
