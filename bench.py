@@ -183,8 +183,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    under_launcher = 'RANK' in os.environ  # torch.distributed.run: join the group even when it has one member
+    if world > 1 or under_launcher:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
     torch.cuda.set_device(local)
@@ -195,7 +197,7 @@ def main():
     from mmvid_amd.engine import FlatTrainer, GraphedStep, backward_order, broadcast_parameters
     if local == 0:
         build()  # a no-op when the in-tree library is current (it is built by __graft_entry__.build())
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     # seed_everything(seed + rank) as train.py:87; identical initial weights come from the rank-0 broadcast
     seed = 42 + rank
@@ -220,7 +222,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -245,7 +247,7 @@ def main():
     nc = len(CLASS_NAMES)
     ms, cnt, fl, tot = (ctypes.c_double * nc)(), (ctypes.c_int64 * nc)(), (ctypes.c_double * nc)(), (ctypes.c_int64 * nc)()
     lib.mmvid_prof_end(ms, cnt, fl, tot, nc)
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -290,7 +292,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

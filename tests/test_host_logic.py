@@ -141,3 +141,28 @@ def test_no_cpu_fallback():
     import subprocess
     out = subprocess.run(['grep', '-rlE', r'^\s*(from|import)\s+oracle', os.path.join(ROOT, 'mmvid_amd')], capture_output=True, text=True)
     assert out.stdout.strip() == ''
+
+
+def test_checkpoint_wire_formats_round_trip(tmp_path):
+    """SURVEY next-row N3: the reference's files load unchanged.  `dalle.pt` is a dict {'iter', 'hparams', 'vae_params',
+    'weights', 'optimizer'} whose 'weights' is the module state_dict (train.py:341-354, loaded with strict=False at
+    test.py:134-150); a VQGAN `.ckpt` is {'state_dict': ...} loaded with strict=False (vae.py:28-30)."""
+    from mmvid_amd.vae import VQGanVAE1024
+    torch.manual_seed(0)
+    a = tiny_bert()
+    opt = torch.optim.Adam([p for p in a.parameters() if p.requires_grad], lr=1e-4)
+    path = tmp_path / 'dalle.pt'
+    torch.save({'iter': 7, 'hparams': {'dim': 768, 'num_targets': 2}, 'vae_params': None, 'weights': a.state_dict(),
+                'optimizer': opt.state_dict()}, path)
+    torch.manual_seed(1)
+    b = tiny_bert()
+    ckpt = torch.load(str(path), weights_only=False)
+    missing, unexpected = b.load_state_dict(ckpt['weights'], strict=False)
+    assert not missing and not unexpected and ckpt['iter'] == 7
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    vpath = tmp_path / 'vae.ckpt'
+    torch.save({'state_dict': a.vae.model.state_dict(), 'global_step': 3}, vpath)
+    v = VQGanVAE1024(str(vpath), 64, ddconfig={'ch': 32}, n_embed=256)
+    for (ka, va), (kb, vb) in zip(a.vae.model.state_dict().items(), v.model.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
