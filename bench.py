@@ -183,14 +183,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
     under_launcher = 'RANK' in os.environ  # torch.distributed.run: join the group even when it has one member
     if world > 1 or under_launcher:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from mmvid_amd import _lib
     from mmvid_amd.build import build
