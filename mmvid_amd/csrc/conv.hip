@@ -139,7 +139,7 @@ struct ConvAStage<false> {
     }
 };
 
-template <int WM, bool FAST>
+template <int WM, bool FAST, bool PP>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(ConvParams p) {
     using S = BlockShape<WM>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -177,6 +177,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
             if (t + 1 < nt) stage_tile(t + 1, nxt);
             compute_tile(cur);
         }
+    } else if constexpr (PP) {  // two-group ping-pong (gemm_core.h)
+        k_loop_pingpong<false, false>(
+            smem, nt, wave, lane, wm, wn, acc, [&](int t, char* buf) { sa.issue(p, t * BK, buf, wave); },
+            [&](int t, char* buf) { sb.issue(t * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); });
     } else {  // 3-stage ring with counted vmcnt (see gemm.hip)
         char* b0 = smem;
         char* b1 = smem + S::STAGE_BYTES;
@@ -336,16 +340,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
-template <int WM, bool FAST>
+template <int WM, bool FAST, bool PP = false>
 void launch_conv(const ConvParams& p, hipStream_t stream) {
     using S = BlockShape<WM>;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<WM, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<WM, FAST, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   S::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, FAST>), dim3(cdiv(p.Cout, BN), cdiv(p.M, S::ROWS)), dim3(S::THREADS), S::LDS_BYTES,
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, FAST, PP>), dim3(cdiv(p.Cout, BN), cdiv(p.M, S::ROWS)), dim3(S::THREADS), S::LDS_BYTES,
                        stream, p);
 }
 
@@ -392,13 +396,17 @@ extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Wi
     bool big = false;
     // with fused GroupNorm statistics the block shape must not depend on the batch size: the order in which a
     // 128-pixel block's partial sums are formed differs between the shapes, and a frame's tokens must not depend on
-    // which other frames share its batch (tests/test_models_gpu.py::test_vqgan_roundtrip_full_size)
+    // which other frames share its batch (tests/test_models_gpu.py::test_vqgan_roundtrip_full_size).  It is therefore
+    // chosen from the layer's own geometry.
     if (gn_partial) {
-        big = false;
-    } else if (tile == 256 || (tile != 128 && (long)cdiv(p.M, 256) * cdiv(Cout, BN) >= 200))
+        big = tile == 256 || (tile != 128 && (long)p.Hout * p.Wout >= 4096);
+    } else if (tile == 256 || (tile != 128 && (long)cdiv(p.M, 256) * cdiv(Cout, BN) >= 200)) {
         big = true;
+    }
     const bool fast = Cin % 64 == 0 && mode != 2;
-    if (big && fast)
+    if (big && fast && mmvid_option(MMVID_OPT_GEMM_SCHED) == 1)
+        launch_conv<4, true, true>(p, (hipStream_t)stream);
+    else if (big && fast)
         launch_conv<4, true>(p, (hipStream_t)stream);
     else if (big)
         launch_conv<4, false>(p, (hipStream_t)stream);

@@ -35,7 +35,8 @@ struct Opt {
 Opt g_opts[MMVID_OPT_COUNT] = {{"gemm_tile", "MMVID_GEMM_TILE", 0, 0, false},
                                {"tower_streams", "MMVID_TOWER_STREAMS", 1, 0, false},
                                {"graphs", "MMVID_GRAPHS", 0, 0, false},
-                               {"ln_bwd_blocks", "MMVID_LN_BWD_BLOCKS", 512, 0, false}};
+                               {"ln_bwd_blocks", "MMVID_LN_BWD_BLOCKS", 512, 0, false},
+                               {"gemm_sched", "MMVID_GEMM_SCHED", 1, 0, false}};
 }  // namespace
 
 int mmvid_option(int which) {
@@ -55,7 +56,7 @@ extern "C" int mmvid_set_option(const char* name, int value) {
             g_opts[i].value = value, g_opts[i].set = true;
             return MMVID_OK;
         }
-    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs, ln_bwd_blocks)", name);
+    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs, ln_bwd_blocks, gemm_sched)", name);
     return MMVID_ERR_ARG;
 }
 

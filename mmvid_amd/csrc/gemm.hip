@@ -55,7 +55,7 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
-template <bool AKM, bool BKM, int WM>
+template <bool AKM, bool BKM, int WM, bool PP>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(GemmParams p) {
     using S = BlockShape<WM>;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSTAGE][A sub-tiles | B tile]
@@ -107,6 +107,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
             if (t + 1 < nt) stage_tile(t + 1, nxt);
             compute_tile(cur);
         }
+    } else if constexpr (PP) {
+        k_loop_pingpong<AKM, BKM>(
+            smem, nt, wave, lane, wm, wn, acc, [&](int t, char* buf) { sa.issue((kt0 + t) * BK, p.K, buf, wave, lane); },
+            [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); });
     } else {
         // 3-stage ring: tile t+2 is requested right after the barrier that ends tile t-1 (its buffer is free then);
         // each wave only waits for ITS OWN pieces of tile t (counted vmcnt: tile t+1's stay in flight).
@@ -218,26 +222,30 @@ bool use_big_tile(long M, long N, long zdim) {
     return M >= 256 && blocks >= 200;
 }
 
-template <bool AKM, bool BKM, int WM>
+template <bool AKM, bool BKM, int WM, bool PP>
 void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     using S = BlockShape<WM>;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   S::LDS_BYTES);
         attr = true;
     }
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, S::ROWS), batch * p.splitk);
-    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM>), grid, dim3(S::THREADS), S::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP>), grid, dim3(S::THREADS), S::LDS_BYTES, stream, p);
 }
 
 template <bool AKM, bool BKM>
 int launch(const GemmParams& p, int batch, hipStream_t stream) {
     MmvidProfScope prof(AKM ? PROF_GEMM_TN : (BKM ? PROF_GEMM_NN : PROF_GEMM_NT), 2.0 * p.M * p.N * (double)p.K * batch, stream);
-    if (use_big_tile(p.M, p.N, (long)batch * p.splitk))
-        launch_shape<AKM, BKM, 4>(p, batch, stream);
-    else
-        launch_shape<AKM, BKM, 2>(p, batch, stream);
+    if (use_big_tile(p.M, p.N, (long)batch * p.splitk)) {
+        if (mmvid_option(MMVID_OPT_GEMM_SCHED) == 1)
+            launch_shape<AKM, BKM, 4, true>(p, batch, stream);
+        else
+            launch_shape<AKM, BKM, 4, false>(p, batch, stream);
+    } else {
+        launch_shape<AKM, BKM, 2, false>(p, batch, stream);
+    }
     return 0;
 }
 

@@ -249,6 +249,89 @@ __device__ __forceinline__ void mma_tile(const char* At, const char* Bt, f32x16 
     mma_step(a1, b1, acc);
 }
 
+// ---- ping-pong K loop for the 256x128 / 3-stage block (option gemm_sched = 1) -----------------------------------
+// The 8 waves form two groups (waves 0-3 and 4-7: one wave of each per SIMD) that run one barrier apart.  A K tile is
+// two phases of two k-steps; in a phase a wave first requests its 8 fragments (and issues its share of the DMA of tile
+// t+2), then, between two barriers, runs its 8 MFMAs at raised priority.  Because the groups are staggered, on every
+// SIMD one wave is in its MFMA cluster while the other is in its load part: the matrix pipe no longer idles while a
+// block waits at the per-tile barrier of the plain loop (PMC: 46 % of wave time in s_waitcnt there).
+//   ordering rules (LDS-DMA is only ordered by the ISSUING wave's vmcnt + a barrier the reader has passed):
+//   * tile t+2 is requested at the START of tile t: the other group is at most one barrier behind, i.e. past the last
+//     ds_read of tile t-1 (whose buffer is being refilled) -- its reads completed before its previous MFMA cluster;
+//   * every wave waits for ITS pieces of tile t+1 before barrier 3 of tile t (vmcnt(6): tile t+2's six may fly); the
+//     leading group first reads tile t+1 after its barrier 4, which the trailing group reaches after that wait.
+template <bool AKM, bool BKM, int H>
+__device__ __forceinline__ void pp_load_half(const char* At, const char* Bt, const uint32_t (&ka)[2], const uint32_t (&kb)[2],
+                                             int wm, int wn, int lane, bf16x8_t (&a)[2][2], bf16x8_t (&b)[2][2]) {
+    load_frags<AKM, 2 * H>(At, ka, wm * 64, lane, a[0]), load_frags<BKM, 2 * H>(Bt, kb, wn * 64, lane, b[0]);
+    load_frags<AKM, 2 * H + 1>(At, ka, wm * 64, lane, a[1]), load_frags<BKM, 2 * H + 1>(Bt, kb, wn * 64, lane, b[1]);
+}
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void pp_compute_half(bf16x8_t (&a)[2][2], bf16x8_t (&b)[2][2], f32x16 (&acc)[2][2]) {
+    constexpr int NASM = (AKM ? 4 : 0) + (BKM ? 4 : 0);
+    __builtin_amdgcn_s_setprio(1);
+    frags_ready<AKM, BKM, NASM>(a[0], b[0]);
+    mma_step(a[0], b[0], acc);
+    frags_ready<AKM, BKM, 0>(a[1], b[1]);
+    mma_step(a[1], b[1], acc);
+    __builtin_amdgcn_s_setprio(0);
+}
+// issueA(t, stage) / issueB(t, stage): request this wave's pieces of the A / B part of tile t into `stage`
+template <bool AKM, bool BKM, class IssueA, class IssueB>
+__device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, int lane, int wm, int wn, f32x16 (&acc)[2][2],
+                                                IssueA issueA, IssueB issueB) {
+    using S = BlockShape<4>;
+    char* b0 = smem;
+    char* b1 = smem + S::STAGE_BYTES;
+    char* b2 = smem + 2 * S::STAGE_BYTES;
+    if (nt <= 0) return;
+    issueA(0, b0), issueB(0, b0);
+    if (nt > 1) {
+        issueA(1, b1), issueB(1, b1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::DMA_PER_TILE) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                 // tile 0 is visible to everyone
+    if (wave >= 4) __builtin_amdgcn_s_barrier();  // the trailing group starts one barrier late
+    for (int t = 0; t < nt; ++t) {
+        const char* At = b0 + (wm >> 1) * TILE_BYTES;
+        const char* Bt = b0 + S::NSUB * TILE_BYTES;
+        uint32_t ka[2] = {0, 0}, kb[2] = {0, 0};
+        if constexpr (AKM) {
+            ka[0] = lds_addr(At) + km_lane_off((wm & 1) * 64, lane), ka[1] = lds_addr(At) + km_lane_off((wm & 1) * 64 + 32, lane);
+        }
+        if constexpr (BKM) {
+            kb[0] = lds_addr(Bt) + km_lane_off(wn * 64, lane), kb[1] = lds_addr(Bt) + km_lane_off(wn * 64 + 32, lane);
+        }
+        bf16x8_t a[2][2], b[2][2];
+        // ---- phase A: k-steps 0, 1
+        pp_load_half<AKM, BKM, 0>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
+        if (t + 2 < nt) issueA(t + 2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // 1
+        pp_compute_half<AKM, BKM>(a, b, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // 2
+        // ---- phase B: k-steps 2, 3
+        pp_load_half<AKM, BKM, 1>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
+        if (t + 2 < nt) {
+            issueB(t + 2, b2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::DMA_PER_TILE) : "memory");  // own pieces of tile t+1 landed
+        } else if (t + 1 < nt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // 3
+        pp_compute_half<AKM, BKM>(a, b, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // 4
+        char* tmp = b0;
+        b0 = b1, b1 = b2, b2 = tmp;
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();  // the leading group waits for the trailing one
+}
+
 // ---- epilogue staging: one 32-row slab of every wave's accumulators -> LDS [64][SLAB_PITCH] fp32, so that the
 // global reads/writes of the epilogue are row-contiguous (512 B per row) instead of 16-B pieces at a row stride.
 constexpr int SLAB_PITCH = 132;  // floats; +4 keeps the 8-lane ds_write_b128 groups on distinct banks
