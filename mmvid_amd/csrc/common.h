@@ -74,8 +74,9 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   gemm_tile      MMVID_GEMM_TILE      0 = block shape by grid fill (default), 128 / 256 = forced
 //   tower_streams  MMVID_TOWER_STREAMS  1 = tower backward on one stream (default), 2 = weight-gradient side stream
 //   graphs         MMVID_GRAPHS         1 = library-level hipGraph replay of the long launch sequences (default 0)
-//   gemm_sched     MMVID_GEMM_SCHED     K loop of the 256x128 block: 1 = two-group ping-pong (default; -2 % step time,
-//                                       tools/ab_graph.py), 0 = one barrier per tile
+//   gemm_sched     MMVID_GEMM_SCHED     K loop of the 256x128 block: 0 = one barrier per tile; 1 = two-group ping-pong with
+//                                       the DMA requests in the load parts (-2 % step time); 2 = ping-pong with the DMA
+//                                       requests inside the MFMA clusters (default; a further -0.5 %, tools/ab_graph.py)
 //   ln_bwd_blocks  MMVID_LN_BWD_BLOCKS  grid cap of the LayerNorm backward (default 512: its dw/db atomics scale with the
 //                                       grid -- measured on the whole step 2048: +0.6 ms, 1024: +0.11 ms, 256: +0.25 ms)
 enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_COUNT = 5 };

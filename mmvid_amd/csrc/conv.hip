@@ -139,7 +139,7 @@ struct ConvAStage<false> {
     }
 };
 
-template <int WM, bool FAST, bool PP>
+template <int WM, bool FAST, int PP>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(ConvParams p) {
     using S = BlockShape<WM>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
             if (t + 1 < nt) stage_tile(t + 1, nxt);
             compute_tile(cur);
         }
-    } else if constexpr (PP) {  // two-group ping-pong (gemm_core.h)
-        k_loop_pingpong<false, false>(
+    } else if constexpr (PP != 0) {  // two-group ping-pong (gemm_core.h)
+        k_loop_pingpong<false, false, PP == 2>(
             smem, nt, wave, lane, wm, wn, acc, [&](int t, char* buf) { sa.issue(p, t * BK, buf, wave); },
             [&](int t, char* buf) { sb.issue(t * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); });
     } else {  // 3-stage ring with counted vmcnt (see gemm.hip)
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
-template <int WM, bool FAST, bool PP = false>
+template <int WM, bool FAST, int PP = 0>
 void launch_conv(const ConvParams& p, hipStream_t stream) {
     using S = BlockShape<WM>;
     static bool attr = false;
@@ -404,8 +404,11 @@ extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Wi
         big = true;
     }
     const bool fast = Cin % 64 == 0 && mode != 2;
-    if (big && fast && mmvid_option(MMVID_OPT_GEMM_SCHED) == 1)
-        launch_conv<4, true, true>(p, (hipStream_t)stream);
+    const int sched = mmvid_option(MMVID_OPT_GEMM_SCHED);
+    if (big && fast && sched == 2)
+        launch_conv<4, true, 2>(p, (hipStream_t)stream);
+    else if (big && fast && sched == 1)
+        launch_conv<4, true, 1>(p, (hipStream_t)stream);
     else if (big && fast)
         launch_conv<4, true>(p, (hipStream_t)stream);
     else if (big)

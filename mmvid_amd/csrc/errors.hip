@@ -36,7 +36,7 @@ Opt g_opts[MMVID_OPT_COUNT] = {{"gemm_tile", "MMVID_GEMM_TILE", 0, 0, false},
                                {"tower_streams", "MMVID_TOWER_STREAMS", 1, 0, false},
                                {"graphs", "MMVID_GRAPHS", 0, 0, false},
                                {"ln_bwd_blocks", "MMVID_LN_BWD_BLOCKS", 512, 0, false},
-                               {"gemm_sched", "MMVID_GEMM_SCHED", 1, 0, false}};
+                               {"gemm_sched", "MMVID_GEMM_SCHED", 2, 0, false}};
 }  // namespace
 
 int mmvid_option(int which) {

@@ -55,7 +55,7 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
-template <bool AKM, bool BKM, int WM, bool PP>
+template <bool AKM, bool BKM, int WM, int PP>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(GemmParams p) {
     using S = BlockShape<WM>;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSTAGE][A sub-tiles | B tile]
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
             if (t + 1 < nt) stage_tile(t + 1, nxt);
             compute_tile(cur);
         }
-    } else if constexpr (PP) {
-        k_loop_pingpong<AKM, BKM>(
+    } else if constexpr (PP != 0) {
+        k_loop_pingpong<AKM, BKM, PP == 2>(
             smem, nt, wave, lane, wm, wn, acc, [&](int t, char* buf) { sa.issue((kt0 + t) * BK, p.K, buf, wave, lane); },
             [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); });
     } else {
@@ -222,7 +222,7 @@ bool use_big_tile(long M, long N, long zdim) {
     return M >= 256 && blocks >= 200;
 }
 
-template <bool AKM, bool BKM, int WM, bool PP>
+template <bool AKM, bool BKM, int WM, int PP>
 void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     using S = BlockShape<WM>;
     static bool attr = false;
@@ -239,12 +239,15 @@ template <bool AKM, bool BKM>
 int launch(const GemmParams& p, int batch, hipStream_t stream) {
     MmvidProfScope prof(AKM ? PROF_GEMM_TN : (BKM ? PROF_GEMM_NN : PROF_GEMM_NT), 2.0 * p.M * p.N * (double)p.K * batch, stream);
     if (use_big_tile(p.M, p.N, (long)batch * p.splitk)) {
-        if (mmvid_option(MMVID_OPT_GEMM_SCHED) == 1)
-            launch_shape<AKM, BKM, 4, true>(p, batch, stream);
+        const int sched = mmvid_option(MMVID_OPT_GEMM_SCHED);
+        if (sched == 2)
+            launch_shape<AKM, BKM, 4, 2>(p, batch, stream);
+        else if (sched == 1)
+            launch_shape<AKM, BKM, 4, 1>(p, batch, stream);
         else
-            launch_shape<AKM, BKM, 4, false>(p, batch, stream);
+            launch_shape<AKM, BKM, 4, 0>(p, batch, stream);
     } else {
-        launch_shape<AKM, BKM, 2, false>(p, batch, stream);
+        launch_shape<AKM, BKM, 2, 0>(p, batch, stream);
     }
     return 0;
 }

@@ -266,21 +266,27 @@ __device__ __forceinline__ void pp_load_half(const char* At, const char* Bt, con
     load_frags<AKM, 2 * H>(At, ka, wm * 64, lane, a[0]), load_frags<BKM, 2 * H>(Bt, kb, wn * 64, lane, b[0]);
     load_frags<AKM, 2 * H + 1>(At, ka, wm * 64, lane, a[1]), load_frags<BKM, 2 * H + 1>(Bt, kb, wn * 64, lane, b[1]);
 }
-template <bool AKM, bool BKM>
-__device__ __forceinline__ void pp_compute_half(bf16x8_t (&a)[2][2], bf16x8_t (&b)[2][2], f32x16 (&acc)[2][2]) {
+template <bool AKM, bool BKM, class Mid>
+__device__ __forceinline__ void pp_compute_half(bf16x8_t (&a)[2][2], bf16x8_t (&b)[2][2], f32x16 (&acc)[2][2], Mid mid) {
     constexpr int NASM = (AKM ? 4 : 0) + (BKM ? 4 : 0);
     __builtin_amdgcn_s_setprio(1);
     frags_ready<AKM, BKM, NASM>(a[0], b[0]);
     mma_step(a[0], b[0], acc);
+    mid();  // DMA requests issued from inside the MFMA cluster ride in the matrix pipe's shadow
     frags_ready<AKM, BKM, 0>(a[1], b[1]);
     mma_step(a[1], b[1], acc);
     __builtin_amdgcn_s_setprio(0);
 }
 // issueA(t, stage) / issueB(t, stage): request this wave's pieces of the A / B part of tile t into `stage`
-template <bool AKM, bool BKM, class IssueA, class IssueB>
+// DMA_IN_CLUSTER = false: the requests of tile t+2 are issued in the load parts (A pieces in phase A, B pieces in phase
+// B); true: from inside the MFMA clusters (after the first four MFMAs of each), which shortens the load part to the
+// eight fragment reads.  Either way the refilled buffer is tile t-1's, which the other group finished reading before
+// its previous cluster, and the wait before barrier 3 lets exactly the already-issued pieces of tile t+2 stay in flight.
+template <bool AKM, bool BKM, bool DMA_IN_CLUSTER, class IssueA, class IssueB>
 __device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, int lane, int wm, int wn, f32x16 (&acc)[2][2],
                                                 IssueA issueA, IssueB issueB) {
     using S = BlockShape<4>;
+    constexpr int PIECES_A = S::NSUB * S::PPW;  // this wave's A pieces of a tile; the B pieces are PPW
     char* b0 = smem;
     char* b1 = smem + S::STAGE_BYTES;
     char* b2 = smem + 2 * S::STAGE_BYTES;
@@ -304,26 +310,30 @@ __device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, in
         if constexpr (BKM) {
             kb[0] = lds_addr(Bt) + km_lane_off(wn * 64, lane), kb[1] = lds_addr(Bt) + km_lane_off(wn * 64 + 32, lane);
         }
+        const bool more = t + 2 < nt;
         bf16x8_t a[2][2], b[2][2];
         // ---- phase A: k-steps 0, 1
         pp_load_half<AKM, BKM, 0>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
-        if (t + 2 < nt) issueA(t + 2, b2);
+        if (!DMA_IN_CLUSTER && more) issueA(t + 2, b2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 1
-        pp_compute_half<AKM, BKM>(a, b, acc);
+        pp_compute_half<AKM, BKM>(a, b, acc, [&]() {
+            if (DMA_IN_CLUSTER && more) issueA(t + 2, b2);
+        });
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 2
         // ---- phase B: k-steps 2, 3
         pp_load_half<AKM, BKM, 1>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
-        if (t + 2 < nt) {
-            issueB(t + 2, b2);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::DMA_PER_TILE) : "memory");  // own pieces of tile t+1 landed
-        } else if (t + 1 < nt) {
+        if (!DMA_IN_CLUSTER && more) issueB(t + 2, b2);
+        if (more)  // own pieces of tile t+1 landed; what has been issued of tile t+2 may stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_IN_CLUSTER ? PIECES_A : S::DMA_PER_TILE) : "memory");
+        else if (t + 1 < nt)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 3
-        pp_compute_half<AKM, BKM>(a, b, acc);
+        pp_compute_half<AKM, BKM>(a, b, acc, [&]() {
+            if (DMA_IN_CLUSTER && more) issueB(t + 2, b2);
+        });
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 4
         char* tmp = b0;
