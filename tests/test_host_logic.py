@@ -166,3 +166,18 @@ def test_checkpoint_wire_formats_round_trip(tmp_path):
     v = VQGanVAE1024(str(vpath), 64, ddconfig={'ch': 32}, n_embed=256)
     for (ka, va), (kb, vb) in zip(a.vae.model.state_dict().items(), v.model.state_dict().items()):
         assert ka == kb and torch.equal(va, vb)
+
+
+def test_library_host_side_policies():
+    """Entry points that need no GPU: the dW split-K policy and the tuning-knob table."""
+    from mmvid_amd import _lib
+    lib = _lib.load()
+    # one wave of 256x128 blocks on 256 CUs, at least 6 K tiles per split, at most 16 splits
+    assert lib.mmvid_gemm_dw_pick_splitk(10422, 2304, 768) == 4    # 54 tiles
+    assert lib.mmvid_gemm_dw_pick_splitk(10422, 768, 768) == 14    # 18 tiles
+    assert lib.mmvid_gemm_dw_pick_splitk(10422, 3072, 768) == 3    # 72 tiles
+    assert lib.mmvid_gemm_dw_pick_splitk(100, 768, 768) == 1       # too few tokens to split
+    assert lib.mmvid_gemm_dw_pick_splitk(10 ** 6, 8192, 8192) == 1  # already more tiles than CUs
+    _lib.call('mmvid_set_option', b'gemm_tile', 0)
+    with pytest.raises(_lib.MMVIDError, match='unknown option'):
+        _lib.call('mmvid_set_option', b'no_such_knob', 1)
