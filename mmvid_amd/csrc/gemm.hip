@@ -12,13 +12,13 @@
 // so neither weights nor activations ever need a transposed copy in HBM: k-major tiles are copied as they
 // are and transposed by the LDS transpose read (ds_read_b64_tr_b16) when fragments are formed (gemm_core.h).
 //
-// Tiling for gfx950: 128x128x64 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 as
-// 2x2 v_mfma_f32_32x32x16_bf16 tiles (fp32 accumulate).  LDS holds A and B tiles as rows of
-// 64 bf16 (128 B) with 16-B chunks XOR-swizzled by ((row>>1)&7): conflict-free for the
-// ds_read_b128 lane groups of the 32x32 fragment read.  Tiles are filled by LDS-DMA
-// (global_load_lds_dwordx4), double buffered: one barrier per K tile.  MFMA operands are swapped (a=B-frag, b=A-frag) so that
-// each lane ends up with 4 consecutive n for one m: 16-B epilogue loads/stores.
-// Roofline: bf16 MFMA (2.5 PFLOP/s dense); algorithmic FLOPs = 2*M*N*K.
+// Tiling for gfx950 (gemm_core.h): every wave computes 64x64 as 2x2 v_mfma_f32_32x32x16_bf16 tiles (fp32
+// accumulate); a block is 128x128 (4 waves, two LDS stages, two blocks per CU) or 256x128 (8 waves, three stages,
+// two-group ping-pong K loop), chosen by grid fill.  LDS tiles are rows of 64 bf16 (128 B) with 16-B chunks
+// XOR-swizzled by ((row>>1)&7): conflict-free for the ds_read_b128 lane groups of the 32x32 fragment read.  Tiles are
+// filled by LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds; ragged edges zero-filled by the range
+// check).  MFMA operands are swapped (a = B-frag, b = A-frag) so that each lane ends up with 4 consecutive n for one
+// m: 16-B epilogue loads/stores.  Roofline: bf16 MFMA (2.5 PFLOP/s dense); algorithmic FLOPs = 2*M*N*K.
 #include "gemm_core.h"
 #include "prof.h"
 
@@ -32,7 +32,7 @@ struct GemmParams {
     int M, N, K;
     long lda, ldb;
     long strideA, strideB, strideC;  // batch strides in elements (0 = shared)
-    int splitk;                       // >1: K split over blockIdx.z % splitk, fp32 atomic accumulate
+    int splitk;                       // >1: K split over blockIdx.z % splitk (partials to `partial`, or fp32 atomics)
     // epilogue
     const float* bias;      // [N] or null
     const float* residual;  // [M][ldr] fp32 or null  (added after activation)
