@@ -14,7 +14,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_INSTS_MFMA" \
            "TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  for tile in 128 256; do
+  for tile in ${TILES:-128 256}; do
     (cd /tmp && MMVID_GEMM_TILE=$tile timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc/${which}_t${tile}_g$i -o p -- python $ROOT/tools/pmc_gemm.py $which > $ROOT/gpurun_out/pmc/${which}_t${tile}_g$i.log 2>&1)
   done
 done
