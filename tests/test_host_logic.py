@@ -181,3 +181,31 @@ def test_library_host_side_policies():
     _lib.call('mmvid_set_option', b'gemm_tile', 0)
     with pytest.raises(_lib.MMVIDError, match='unknown option'):
         _lib.call('mmvid_set_option', b'no_such_knob', 1)
+
+
+def test_vqgan_plan_structure_config2(monkeypatch):
+    """The planned op list of one full-size encode (what mmvid_vqgan_run executes): 45 convolutions, no cast passes
+    (convs store the precisions their consumers read), GroupNorm statistics fused into the producing conv wherever
+    the geometry allows, and a matching stats area on both sides of every fused pair."""
+    from mmvid_amd import vae as V
+    v = V.VQGanVAE1024(None, 128)
+    v.image_size = 128
+    monkeypatch.setattr(v, '_ee', lambda: torch.zeros(1024))  # the codebook norms are a device kernel; not needed here
+    pl = V._Planner(v)
+    v._plan_encode(pl, 4, 128)
+    ops_ = pl.ops
+    kinds = [o.op for o in ops_]
+    assert kinds.count(pl.OP_CONV) == 45 and kinds.count(pl.OP_CAST) == 0
+    assert kinds.count(pl.OP_GN) == 28 and kinds.count(pl.OP_ATTN) == 3 and kinds[-1] == pl.OP_VQ
+    fused_gn = [o for o in ops_ if o.op == pl.OP_GN and o.flags & 2]
+    emitting = [o for o in ops_ if o.op == pl.OP_CONV and o.flags & 4]
+    # every level but 8x8 (64 pixels) fuses: 128^2, 64^2, 32^2, 16^2 have hw % 128 == 0 and >= 128 channels
+    assert len(fused_gn) == sum(1 for o in ops_ if o.op == pl.OP_GN and (o.H * o.W) % 128 == 0 and o.C % 128 == 0)
+    assert len(fused_gn) >= 18 and {o.scratch for o in fused_gn} <= {o.scratch for o in emitting}
+    for o in ops_:
+        if o.op == pl.OP_CONV:
+            assert o.out_bf16 >= 0 or o.out_f32 >= 0
+            assert max(o.in0, o.in1, o.out_bf16, o.out_f32, o.scratch) < pl.top
+    # dual stores only where a 1x1 shortcut reads the stream in bf16 as well (the two channel-widening blocks)
+    both = [o for o in ops_ if o.op == pl.OP_CONV and o.out_bf16 >= 0 and o.out_f32 >= 0]
+    assert len(both) == 2
