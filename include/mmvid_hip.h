@@ -37,12 +37,14 @@ int mmvid_gather_rows(const float* table, int64_t table_rows, const int64_t* idx
  *   C[m][n] = alpha * sum_k A(m,k) B(n,k)   A row-major [M][K] or k-major [K][M]; B row-major [N][K] or k-major [K][N]
  *   then: +bias[n]; save_pre<-bf16; act (1 = QuickGELU, clip_model.py:196-198); *QuickGELU'(dact_pre);
  *         +residual[m][n]; (+= out_f32 if accumulate); store out_f32 and/or out_bf16.
- *   splitk > 1: K is split over blocks, fp32 atomicAdd into out_f32 (which must hold the base value). */
+ *   splitk > 1: K is split over blocks, fp32 atomicAdd into out_f32 (which must hold the base value).  * out_colsum (optional, batch 1, no split-K): [N] += column sums of the stored result -- the bias gradient of the
+ * Linear whose output gradient this GEMM produces (fused instead of a separate pass over the result). */
 int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int64_t lda, const void* B,
                     int64_t ldb, int batch, int64_t strideA, int64_t strideB, int64_t strideC, int splitk,
                     float alpha, const float* bias, const float* residual, int64_t ldr, const void* dact_pre,
                     void* save_pre, int64_t ldp, int act, int accumulate, float* out_f32, void* out_bf16,
-                    int64_t ldc, void* stream);
+                    int64_t ldc, float* out_colsum,
+                    void* stream);
 
 /* Weight gradient dW[N][K] (+)= dY^T X over M tokens (autograd of nn.Linear); split-K through `workspace`
  * ([splitk][N][K] fp32) with a fixed-order reduction: deterministic. */

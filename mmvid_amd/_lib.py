@@ -38,7 +38,7 @@ SIGNATURES = {
     'mmvid_vq_sqnorm': [P, I, I, P, P],
     'mmvid_vq_argmin_l2': [P, P, P, I64, I, I, P, P, P],
     'mmvid_gather_rows': [P, I64, P, I64, I, P, P, P],
-    'mmvid_gemm_bf16': [I, I, I, I, I, P, I64, P, I64, I, I64, I64, I64, I, F, P, P, I64, P, P, I64, I, I, P, P, I64, P],
+    'mmvid_gemm_bf16': [I, I, I, I, I, P, I64, P, I64, I, I64, I64, I64, I, F, P, P, I64, P, P, I64, I, I, P, P, I64, P, P],
     'mmvid_gemm_bf16_dw': [I64, I, I, P, I64, P, I64, I, P, P, I, P],
     'mmvid_gemm_dw_pick_splitk': [I64, I, I],
     'mmvid_layernorm_fwd': [P, I64, I64, I, P, P, F, P, P, I64, P, P, P],

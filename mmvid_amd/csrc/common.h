@@ -77,8 +77,9 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   gemm_sched     MMVID_GEMM_SCHED     K loop of the 256x128 block: 0 = one barrier per tile; 1 = two-group ping-pong with
 //                                       the DMA requests in the load parts (-2 % step time); 2 = ping-pong with the DMA
 //                                       requests inside the MFMA clusters (default; a further -0.5 %, tools/ab_graph.py)
+//   fuse_colsum    MMVID_FUSE_COLSUM    1 = c_fc's bias gradient from the epilogue of the GEMM that produces d_pre (default)
 //   ln_bwd_blocks  MMVID_LN_BWD_BLOCKS  grid cap of the LayerNorm backward (default 512: its dw/db atomics scale with the
 //                                       grid -- measured on the whole step 2048: +0.6 ms, 1024: +0.11 ms, 256: +0.25 ms)
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_COUNT = 5 };
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_COUNT = 6 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

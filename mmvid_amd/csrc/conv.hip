@@ -450,12 +450,12 @@ extern "C" int mmvid_spatial_attention(const void* q, const void* k, const void*
     const long hw2 = (long)HW * HW;
     void* P = (void*)(scores_scratch + (long)N * hw2);
     int rc = mmvid_gemm_bf16(0, 0, HW, HW, C, q, C, k, C, N, (long)HW * C, (long)HW * C, hw2, 1, 1.0f, nullptr, nullptr, 0,
-                             nullptr, nullptr, 0, 0, 0, scores_scratch, nullptr, HW, stream);
+                             nullptr, nullptr, 0, 0, 0, scores_scratch, nullptr, HW, nullptr, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv((long)N * HW, 4)), dim3(256), 0, (hipStream_t)stream,
                        scores_scratch, (long)N * HW, HW, scale, (bf16_t*)P);
     MMVID_LAUNCH_CHECK("spatial_attention.softmax");
     // o[q][c] = sum_key P[q][key] v[key][c] : A = P row-major [HW, HW], B = v k-major [HW(red)][C]
     return mmvid_gemm_bf16(0, 1, HW, C, HW, P, HW, v, C, N, hw2, (long)HW * C, (long)HW * C, 1, 1.0f, nullptr, nullptr, 0,
-                           nullptr, nullptr, 0, 0, 0, nullptr, out_bf16, C, stream);
+                           nullptr, nullptr, 0, 0, 0, nullptr, out_bf16, C, nullptr, stream);
 }

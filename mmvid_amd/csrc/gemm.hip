@@ -47,6 +47,7 @@ struct GemmParams {
     bf16_t* out_bf16;
     long ldc;
     float* partial;  // split-K workspace [splitk][M][N] (plain stores, reduced by splitk_reduce_kernel) or null
+    float* colsum;   // [N] += column sums of the stored result (the bias gradient when the result is a dY), or null
 };
 
 __device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     const float* addbase = p.residual ? p.residual + cb
                                       : ((p.accumulate && !p.partial && p.splitk == 1) ? p.out_f32 + cb : nullptr);
     const long ldadd = p.residual ? p.ldr : p.ldc;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};  // this thread's share of the column sums (p.colsum)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         __syncthreads();
@@ -196,6 +198,20 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
             if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + cb + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             if (p.out_bf16)
                 *reinterpret_cast<uint2*>(p.out_bf16 + cb + (long)m * p.ldc + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            cs[0] += v[0], cs[1] += v[1], cs[2] += v[2], cs[3] += v[3];
+        }
+    }
+    if (p.colsum) {  // block-level column sums -> one atomic per column (as mmvid_colsum_bf16 does per 256 rows)
+        constexpr int RG = S::THREADS / 32;
+        float* red = reinterpret_cast<float*>(smem);  // [RG][128]
+        __syncthreads();
+        *reinterpret_cast<float4*>(red + (tid >> 5) * 128 + 4 * (tid & 31)) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        __syncthreads();
+        if (tid < 128 && bn0 + tid < p.N) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) a += red[r * 128 + tid];
+            unsafeAtomicAdd(p.colsum + bn0 + tid, a);
         }
     }
 }
@@ -259,7 +275,8 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
                                const void* B, int64_t ldb, int batch, int64_t strideA, int64_t strideB,
                                int64_t strideC, int splitk, float alpha, const float* bias, const float* residual,
                                int64_t ldr, const void* dact_pre, void* save_pre, int64_t ldp, int act,
-                               int accumulate, float* out_f32, void* out_bf16, int64_t ldc, void* stream) {
+                               int accumulate, float* out_f32, void* out_bf16, int64_t ldc, float* out_colsum,
+                               void* stream) {
     MMVID_REQUIRE(A && B && (out_f32 || out_bf16), "gemm_bf16: null pointer");
     MMVID_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_bf16: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
     MMVID_REQUIRE(N % 8 == 0 && ldc % 4 == 0, "gemm_bf16: N (%d) must be a multiple of 8 and ldc of 4", N);
@@ -274,8 +291,9 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
         MMVID_REQUIRE(ea * 2 < (1ll << 31) && eb * 2 < (1ll << 31), "gemm_bf16: an operand of 2 GiB or more per batch entry");
     }
     if (splitk > 1)
-        MMVID_REQUIRE(out_f32 && !out_bf16 && !act && !dact_pre && !save_pre && !residual,
+        MMVID_REQUIRE(out_f32 && !out_bf16 && !act && !dact_pre && !save_pre && !residual && !out_colsum,
                       "gemm_bf16: split-K supports only fp32 atomic accumulation (+bias)");
+    MMVID_REQUIRE(!out_colsum || batch == 1, "gemm_bf16: out_colsum needs batch == 1");
     if (dact_pre || save_pre) MMVID_REQUIRE(ldp % 4 == 0, "gemm_bf16: ldp must be a multiple of 4");
     if (residual) MMVID_REQUIRE(ldr % 4 == 0 && !accumulate, "gemm_bf16: ldr must be a multiple of 4; residual and accumulate are exclusive");
     GemmParams p;
@@ -286,7 +304,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.dact_pre = (const bf16_t*)dact_pre, p.save_pre = (bf16_t*)save_pre, p.ldp = ldp;
     p.act = act, p.accumulate = accumulate, p.alpha = alpha;
     p.out_f32 = out_f32, p.out_bf16 = (bf16_t*)out_bf16, p.ldc = ldc;
-    p.partial = nullptr;
+    p.partial = nullptr, p.colsum = out_colsum;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor)
         launch<false, false>(p, batch, s);
@@ -326,6 +344,7 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     p.act = 0, p.accumulate = accumulate, p.alpha = 1.0f;
     p.out_f32 = dW, p.out_bf16 = nullptr, p.ldc = K;
     p.partial = splitk > 1 ? workspace : nullptr;
+    p.colsum = nullptr;
     hipStream_t s = (hipStream_t)stream;
     launch<true, true>(p, 1, s);
     if (splitk > 1) {

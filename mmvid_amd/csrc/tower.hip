@@ -92,13 +92,14 @@ int check_cfg(const mmvid_tower_cfg_t* c) {
 int linear_fwd(int64_t M, int N, int K, const void* X, const void* W, const float* bias, const float* residual,
                void* save_pre, int act, float* out_f32, void* out_bf16, void* st) {
     return mmvid_gemm_bf16(0, 0, (int)M, N, K, X, K, W, K, 1, 0, 0, 0, 1, 1.0f, bias, residual, N, nullptr, save_pre, N,
-                           act, 0, out_f32, out_bf16, N, st);
+                           act, 0, out_f32, out_bf16, N, nullptr, st);
 }
-// dX = dY W (A = dY [M,N] row-major, B = W [N(red)][K(out)] k-major)
+// dX = dY W (A = dY [M,N] row-major, B = W [N(red)][K(out)] k-major); out_colsum: [K] += column sums of dX, i.e. the
+// bias gradient of the Linear that produced this layer's input
 int linear_dx(int64_t M, int N, int K, const void* dY, const void* W, const void* dact_pre, float* out_f32,
-              void* out_bf16, void* st) {
+              void* out_bf16, void* st, float* out_colsum = nullptr) {
     return mmvid_gemm_bf16(0, 1, (int)M, K, N, dY, N, W, K, 1, 0, 0, 0, 1, 1.0f, nullptr, nullptr, 0, dact_pre, nullptr, K,
-                           0, 0, out_f32, out_bf16, K, st);
+                           0, 0, out_f32, out_bf16, K, out_colsum, st);
 }
 // dW[N,K] += dY^T X (both k-major over the token dimension), db[N] += colsum(dY)
 int linear_dw(int64_t M, int N, int K, const void* dY, const void* X, float* dW, float* db, float* ws, void* st) {
@@ -276,9 +277,12 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, i == d.layers - 1 ? ly.g_pj_b : nullptr, ws, wst));
         const hipEvent_t ev_pj = mark();
         wait(ev_fc);  // the previous layer's c_fc dW still reads d_pre
-        TRY(linear_dx(d.M, d.E, d.F, gb, ly.pj_w, sv + sl.pre, nullptr, scr + sc.d_pre, stream));
+        // d_pre = (gb W_proj) * QuickGELU'(pre); its column sums are c_fc's bias gradient: taken in this epilogue
+        const bool fuse_fc_bias = mmvid_option(MMVID_OPT_FUSE_COLSUM) != 0;
+        TRY(linear_dx(d.M, d.E, d.F, gb, ly.pj_w, sv + sl.pre, nullptr, scr + sc.d_pre, stream,
+                      fuse_fc_bias ? ly.g_fc_b : nullptr));
         fork();
-        TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, ly.g_fc_b, ws, wst));
+        TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, fuse_fc_bias ? nullptr : ly.g_fc_b, ws, wst));
         ev_fc = mark();
         TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, d_h, nullptr, stream));
         wait(ev_pj);  // the LayerNorm backward overwrites gb

@@ -67,7 +67,7 @@ def gather_rows(table, idx, out_dtype=f32):
 
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, residual=None, dact_pre=None, save_pre=None, act=0,
-         out_dtype=bf16, out=None, accumulate=False, splitk=1, alpha=1.0):
+         out_dtype=bf16, out=None, accumulate=False, splitk=1, alpha=1.0, colsum=None):
     """C[m,n] = sum_k A(m,k) B(n,k).  A: [M,K] (or [K,M] when a_kmajor), B: [N,K] (or [K,N] when b_kmajor), 2-D
     bf16; or 3-D batched with identical leading batch size."""
     _chk(A, bf16, 'A'), _chk(B, bf16, 'B')
@@ -92,7 +92,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, residual=None, dact
             _chk(t, f32, n)
     call('mmvid_gemm_bf16', int(a_kmajor), int(b_kmajor), M, N, K, _p(A), A2.stride(0), _p(B), B2.stride(0), batch,
          sA, sB, sC, splitk, float(alpha), _p(bias), _p(residual), N, _p(dact_pre), _p(save_pre), N, act,
-         int(accumulate), _p(out) if is32 else None, None if is32 else _p(out), N, _stream())
+         int(accumulate), _p(out) if is32 else None, None if is32 else _p(out), N, _p(colsum), _stream())
     return out
 
 

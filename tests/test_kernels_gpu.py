@@ -132,6 +132,12 @@ def test_gemm_epilogues(ops):
     ref = (dY.float() @ Wp.float()) * (s * (1 + 1.702 * x * (1 - s)))
     out = ops.gemm(dY, Wp, b_kmajor=True, dact_pre=save)
     close(out, ref, 1e-2, 'dgelu')
+    # the same GEMM also delivering the column sums of its result (the bias gradient of the producing Linear)
+    cs = rnd(N, seed=14)
+    cs0 = cs.clone()
+    out2 = ops.gemm(dY, Wp, b_kmajor=True, dact_pre=save, colsum=cs)
+    assert torch.equal(out2, out)
+    close(cs, cs0 + ref.sum(0), 2e-3, 'fused column sums')
     # batched
     Ab, Bb = rnd(3, 256, 64, seed=12, dtype=torch.bfloat16), rnd(3, 256, 64, seed=13, dtype=torch.bfloat16)
     close(ops.gemm(Ab, Bb, out_dtype=torch.float32), Ab.float() @ Bb.float().transpose(1, 2), 1e-4, 'batched')
