@@ -101,7 +101,44 @@ int mmvid_grad_sqnorm(const float* g, int64_t n, float* out_accum, void* stream)
 int mmvid_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int step, const float* step_dev,
                     float max_norm, const float* sqnorm, float grad_scale, void* stream);
+/* deterministic form of mmvid_grad_sqnorm (fixed-order reduction through `partials`, fp32 [2048]); out_accum[0] += sum g^2 */
+int mmvid_grad_sqnorm_det(const float* g, int64_t n, float* partials, float* out_accum, void* stream);
+/* mmvid_adam_step with the learning rate read from the device scalar lr_dev when it is not NULL (see mmvid_lr_schedule). */
+int mmvid_adam_step_lr(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                       const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int step,
+                       const float* step_dev, float max_norm, const float* sqnorm, float grad_scale, void* stream);
+/* utils_train.py:373-385 (deepspeed WarmupLR, restated) evaluated on the device from the optimiser-step counter:
+ * kind 0 constant lr_max | 1 warm-up log schedule stepped every `every` iterations (train.py:373-374). */
+int mmvid_lr_schedule(const float* step_dev, int kind, float lr_min, float lr_max, int warmup_steps, int every,
+                      float* lr_out, void* stream);
+int mmvid_counter_add(float* counter, float value, void* stream);
 int mmvid_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* ---- stochastic front-end of a BERT training step on the device (csrc/frontend.hip).  Every decision is a
+ * function of (seed, *step_dev, sample, purpose) through Philox4x32-10; step_dev may be NULL (step 0).
+ * MSM masks, dalle_bert.py:992-1029: strategy_prob[4] = Bernoulli(p ~ U(bern_lo, bern_hi)) | fully masked | RandomErasing
+ * box hidden | only the box visible; pc_prob: frame preservation (1022-1026).  mask1 [B, T*f*f] (1 = token visible),
+ * not_fully_masked [B]; strategy_out (optional) [B] the strategy drawn (tests). */
+int mmvid_msm_masks(uint64_t seed, const float* step_dev, int B, int T, int f, const float* strategy_prob, float bern_lo,
+                    float bern_hi, float pc_prob, uint8_t* mask1, float* not_fully_masked, int32_t* strategy_out,
+                    void* stream);
+/* VID negative, dalle_bert.py:204-238 (+93-202): x, out [B,T,C,H,W] fp32 in [0,1]; strategy_prob[4] = frame of another
+ * sample | frame shuffle | colour shift | affine warp (affine_grid + bilinear grid_sample, reflection padding).
+ * params_scratch: B * mmvid_warp_params_bytes() bytes; draw_params = 0 applies the parameters already in it (tests). */
+int mmvid_warp_params_bytes(void);
+int mmvid_vid_warp(uint64_t seed, const float* step_dev, const float* x, int B, int T, int C, int H, int W,
+                   const float* strategy_prob, void* params_scratch, int draw_params, float* out, void* stream);
+/* visual-token erasing on token maps tok [B, Tv, f, f] int64, in place.  erase_codebook_face (dalle_bert.py:796-848):
+ * one of `nchoice` (<= 4) alternatives is drawn per call from the cumulative probabilities; modes[i] 0 = untouched,
+ * 1 = keep only boxes[i] = (r0, r1, c0, c1), 2 = erase the box; frame0_full leaves frame 0 untouched. */
+int mmvid_erase_tokens_choice(uint64_t seed, const float* step_dev, int nchoice, const float* cumprob, const int32_t* modes,
+                              const int32_t* boxes, int frame0_full, int B, int Tv, int f, int64_t value, int64_t* tok,
+                              void* stream);
+/* random_erase_codebook (dalle_bert.py:779-794): per sample torchvision-style RandomErasing(p, scale, ratio) box set to
+ * `value` on every frame, or (erase_half) the lower half of every frame. */
+int mmvid_random_erase_tokens(uint64_t seed, const float* step_dev, int B, int Tv, int f, float p, float scale_lo,
+                              float scale_hi, float ratio_lo, float ratio_hi, int erase_half, int64_t value, int64_t* tok,
+                              void* stream);
 
 /* ---- whole CLIP tower (12 x ResidualAttentionBlock), layer loop in native code:
  * clip_model.py:580-584 -> 230-247 -> 224-227.  x is [B*L, E] fp32, batch-first. */
@@ -171,6 +208,68 @@ int mmvid_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int Cuse,
 int mmvid_spatial_attention(const void* q, const void* k, const void* v, int N, int HW, int C, float scale,
                             float* scores_scratch, void* out_bf16, void* stream);
 
+/* ---- device-side samplers (csrc/sample.hip): BERT mask-predict, dalle_bert.py:514-714, and the ART-V token draw,
+ * dalle_artv.py:61-67,274-281.  Randomness enters as tensors of Exp(1) variates E (what torch.multinomial draws
+ * internally): tok = first argmin_c E[c] / P[c] with P = exp(x - max x), x = logits / logit_div (+ temperature *
+ * Gumbel(noise_u) when noise_u != NULL, dalle_bert.py:527-538); y (optional) = softmax probability of the drawn token. */
+int mmvid_sample_race(const float* logits, int64_t ld, const float* E, const float* noise_u, float temperature,
+                      float logit_div, int64_t R, int V, int64_t tok_offset, int64_t* tok, float* y, void* stream);
+/* keep-mask of a refinement step (dalle_bert.py:646-668): of the positions with preserve == 0, the k with the smallest
+ * E / Y stay visible (k outside [1, #non-zero weights] -> 1, the reference's except branch); preserved positions always
+ * stay.  Y [b, TS], E [b, Bm, TS], mask1 out [b, Bm, TS] (1 = keep). */
+int mmvid_mp_select_keep(const float* Y, const float* E, const uint8_t* preserve, int b, int Bm, int TS, int k,
+                         uint8_t* mask1, void* stream);
+/* tower input of the b*Bm candidates: control_emb [b, csl, E] broadcast per candidate, then image_emb[id] + tpos with
+ * id = mask1 ? (mask1[.] ? I_tok : mask_id) : I_tok.  out [b*Bm, csl+TS, E]. */
+int mmvid_mp_build_input(const float* control_emb, const float* image_emb, int64_t table_rows, const float* tpos,
+                         const int64_t* I_tok, const uint8_t* mask1, int b, int Bm, int csl, int TS, int E, int64_t mask_id,
+                         float* out, void* stream);
+/* per video: S_j = (sigmoid(rel_j) + sigmoid(vid_j)) / 2, jmax = first argmax, the sequential where-chain over
+ * candidates 0..jmax (dalle_bert.py:675-692), dynamic stop after 5 steps without a better score (701-707).
+ * State (updated in place, only where active[i]): Y, I_tok [b, TS], Imax [b, TS], Smax [b], tmax [b], active [b]. */
+int mmvid_mp_update(const uint8_t* mask1, const float* Ynew, const int64_t* Inew, const float* rel_logit,
+                    const float* vid_logit, int b, int Bm, int TS, int t, int dynamic, float* Y, int64_t* I_tok,
+                    int64_t* Imax, float* Smax, int32_t* tmax, uint8_t* active, float* S_out, int32_t* jmax_out,
+                    void* stream);
+/* to_logits_rel / to_logits_vid (LayerNorm + Linear(dim,1), dalle_bert.py:418-425) on R gathered rows x[rows[r]] and
+ * binary_cross_entropy_with_logits (1067-1084, 1107-1123): loss = sum_r row_weight[r] * bce(z_r, label_r) / den with
+ * den = den_from ? max(1, sum den_from[0..nden)) : den_const.  label == NULL: logits only (sampling).  The backward
+ * accumulates (+=) dw [E], db [1], dln_w, dln_b [E] and adds each row's input gradient into dx[rows[r]]. */
+int mmvid_head_bce_fwd(const float* x, int64_t ldx, const int64_t* rows, int R, int E, const float* ln_w, const float* ln_b,
+                       float eps, const float* w, const float* b, const float* label, const float* row_weight,
+                       const float* den_from, int nden, float den_const, float* z, float* mean, float* rstd, float* loss,
+                       void* stream);
+int mmvid_head_bce_bwd(const float* x, int64_t ldx, const int64_t* rows, int R, int E, const float* ln_w, const float* ln_b,
+                       const float* w, const float* z, const float* mean, const float* rstd, const float* label,
+                       const float* row_weight, const float* den_from, int nden, float den_const, const float* gloss,
+                       float* dx, int64_t lddx, float* dw, float* db, float* dln_w, float* dln_b, void* stream);
+/* every token id of a BERT training step in one launch (dalle_bert.py:903-973, 1030-1035, 1057, 1094-1100):
+ * ids [(1+rel+vid)*B, L] = MSM | REL negative (control of sample (b+B/2)%B, or text_neg) | VID negative (target_warp);
+ * select_full [B*L] / target_full [B*L] = rows and labels of the MSM cross entropy; select_count = #selected. */
+int mmvid_bert_build_ids(const int64_t* text, const int64_t* text_neg, const int64_t* visual_tok, const int64_t* target,
+                         const int64_t* target_warp, const uint8_t* mask1, int B, int Ttxt, int Nvis, int TS,
+                         int64_t pad_base, int64_t mask_id, int has_rel, int has_vid, int64_t* ids, uint8_t* select_full,
+                         int64_t* target_full, float* select_count, void* stream);
+
+/* ---- strict-parity (fp32-accurate) VQGAN operators: `VQGanVAE1024.strict = True` (csrc/strict.hip).  Same reference
+ * lines as the bf16 entry points above, but every product and accumulate is fp32: convolutions and matmuls are
+ * k-ordered fmaf chains on the f32-input matrix instruction, GroupNorm statistics are fp64, exp is expf.
+ * Used where token indices must equal the reference's exactly (north star: "token-index bit-exact"). */
+/* C[m][n] = alpha * sum_k A[m][k] B(n,k) (+bias[n]) (+residual[m][n]); B row-major [N][ldb] or k-major [K][ldb]. */
+int mmvid_gemm_f32(int b_kmajor, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                   int batch, int64_t strideA, int64_t strideB, int64_t strideC, float alpha, const float* bias,
+                   const float* residual, float* C, int64_t ldc, void* stream);
+/* modes as mmvid_conv2d_nhwc; x [N,Hin,Win,Cin] fp32 (Cin a power of two >= 4), w [Cout][taps][Cin] fp32. */
+int mmvid_conv2d_nhwc_f32(int mode, const float* x, int N, int Hin, int Win, int Cin, const float* w,
+                          const float* bias, int Cout, const float* residual, int clamp01, float* out, void* stream);
+int mmvid_image_to_nhwc4_f32(const float* img, int N, int H, int W, float* out, void* stream);
+/* stats_scratch: fp32 [N][C][2] (mean, rstd per channel). */
+int mmvid_groupnorm_swish_nhwc_f32(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
+                                   int swish, float* stats_scratch, float* y, void* stream);
+/* scratch: 2*N*HW*HW floats. */
+int mmvid_spatial_attention_f32(const float* q, const float* k, const float* v, int N, int HW, int C, float scale,
+                                float* scratch, float* out, void* stream);
+
 /* ---- native op-list executor for the VQGAN encoder / decoder (model.py:439-466, 551-582; vae.py:38-56): the host
  * plans the op sequence once per input shape, every call is then one host->native transition.  Offsets are bytes
  * into `arena` (-1 = unused); w/b/ext_* are device pointers. */
@@ -184,8 +283,12 @@ enum {
     MMVID_VQOP_SPATIAL_ATTN = 4, /* in0,in1,in2 = q,k,v [N,H*W,C] bf16, eps = scale, scratch                        */
     MMVID_VQOP_VQ_ARGMIN = 5, /* in0 z [N*H*W, C] f32, w = codebook [Cout, C], b = ee -> ext_out int64            */
     MMVID_VQOP_GATHER = 6,    /* ext_in idx int64 [N*H*W], w = table [Cout, C] f32 -> out_bf16 [N,H,W,C]           */
-    MMVID_VQOP_NHWC2NCHW = 7  /* in0 [N,H,W,C] f32 -> ext_out [N,Cout,H,W] f32                                    */
+    MMVID_VQOP_NHWC2NCHW = 7, /* in0 [N,H,W,C] f32 -> ext_out [N,Cout,H,W] f32                                    */
+    MMVID_VQOP_EXT_CAST = 8   /* ext_in f32 [N*H*W*C] -> out_bf16 (or out_f32 copy when strict): decode_train's z     */
 };
+/* flags & 16 (IMG2NHWC8, CONV, GROUPNORM, SPATIAL_ATTN, GATHER, EXT_CAST): the strict fp32 operator; every arena
+ * tensor of such a plan is fp32 (out_f32 / in* are fp32), w is fp32 [Cout][taps][Cin]. */
+#define MMVID_VQFLAG_STRICT 16
 typedef struct {
     int32_t op, mode;
     int32_t N, H, W, C;

@@ -5,13 +5,13 @@ first kernel call without the library or without a GPU raises.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libmmvid_hip.so')
 
 P = c_void_p
-I, I64, F = c_int, c_int64, c_float
+I, I64, F, U64 = c_int, c_int64, c_float, c_uint64
 
 
 class TowerLayer(Structure):
@@ -66,6 +66,26 @@ SIGNATURES = {
     'mmvid_nhwc_to_nchw_f32': [P, I, I, I, I, I, P, P],
     'mmvid_spatial_attention': [P, P, P, I, I, I, F, P, P, P],
     'mmvid_vqgan_run': [POINTER(VqganOp), I, P, P],
+    'mmvid_sample_race': [P, I64, P, P, F, F, I64, I, I64, P, P, P],
+    'mmvid_mp_select_keep': [P, P, P, I, I, I, I, P, P],
+    'mmvid_mp_build_input': [P, P, I64, P, P, P, I, I, I, I, I, I64, P, P],
+    'mmvid_mp_update': [P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P],
+    'mmvid_head_bce_fwd': [P, I64, P, I, I, P, P, F, P, P, P, P, P, I, F, P, P, P, P, P],
+    'mmvid_head_bce_bwd': [P, I64, P, I, I, P, P, P, P, P, P, P, P, P, I, F, P, P, I64, P, P, P, P, P],
+    'mmvid_bert_build_ids': [P, P, P, P, P, P, I, I, I, I, I64, I64, I, I, P, P, P, P, P],
+    'mmvid_grad_sqnorm_det': [P, I64, P, P, P],
+    'mmvid_adam_step_lr': [P, P, P, P, P, I64, F, P, F, F, F, F, I, P, F, P, F, P],
+    'mmvid_lr_schedule': [P, I, F, F, I, I, P, P],
+    'mmvid_counter_add': [P, F, P],
+    'mmvid_msm_masks': [U64, P, I, I, I, P, F, F, F, P, P, P, P],
+    'mmvid_vid_warp': [U64, P, P, I, I, I, I, I, P, P, I, P, P],
+    'mmvid_erase_tokens_choice': [U64, P, I, P, P, P, I, I, I, I, I64, P, P],
+    'mmvid_random_erase_tokens': [U64, P, I, I, I, F, F, F, F, F, I, I64, P, P],
+    'mmvid_gemm_f32': [I, I, I, I, P, I64, P, I64, I, I64, I64, I64, F, P, P, P, I64, P],
+    'mmvid_conv2d_nhwc_f32': [I, P, I, I, I, I, P, P, I, P, I, P, P],
+    'mmvid_image_to_nhwc4_f32': [P, I, I, I, P, P],
+    'mmvid_groupnorm_swish_nhwc_f32': [P, I, I64, I, P, P, F, I, P, P, P],
+    'mmvid_spatial_attention_f32': [P, P, P, I, I, I, F, P, P, P],
     'mmvid_probe': [I, P, P, P],
     'mmvid_prof_begin': [I],
     'mmvid_prof_enable': [I],
@@ -73,7 +93,8 @@ SIGNATURES = {
     'mmvid_set_option': [c_char_p, I],
     'mmvid_prof_end': [P, P, P, P, I],
 }
-OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I)}
+OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I),
+         'mmvid_warp_params_bytes': ([], I)}
 
 _lib = None
 

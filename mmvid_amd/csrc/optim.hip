@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ shadow, long n, AdamArgs a,
                                                    const float* __restrict__ sqnorm,
-                                                   const float* __restrict__ step_dev) {
+                                                   const float* __restrict__ step_dev,
+                                                   const float* __restrict__ lr_dev) {
+    if (lr_dev) a.lr = *lr_dev;  // learning rate kept on the device (mmvid_lr_schedule): a captured step follows the schedule
     if (step_dev) {  // step count kept on the device (whole-step graph replay): bias corrections computed here
         const float t = *step_dev;
         a.bc1 = 1.0f - powf(a.beta1, t);
@@ -111,10 +113,64 @@ extern "C" int mmvid_grad_sqnorm(const float* g, int64_t n, float* out_accum, vo
     return MMVID_OK;
 }
 
+// fixed-order version of grad_sqnorm: per-block partial sums, then one block adds them in index order (deterministic:
+// the clip coefficient of a step no longer depends on atomic arrival order)
+__global__ __launch_bounds__(256) void grad_sqnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+    float a = 0.f;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(g + i);
+            a += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        } else {
+            for (long k = i; k < n; ++k) a += g[k] * g[k];
+        }
+    }
+    a = wave_sum(a);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+    __shared__ float sh[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) a += part[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += sh[0];
+}
+
+extern "C" int mmvid_grad_sqnorm_det(const float* g, int64_t n, float* partials, float* out_accum, void* stream) {
+    MMVID_REQUIRE(g && partials && out_accum && n >= 0, "grad_sqnorm_det: bad arguments");
+    MMVID_REQUIRE(((uintptr_t)g & 15) == 0, "grad_sqnorm_det: buffer must be 16-byte aligned");
+    if (n == 0) return MMVID_OK;
+    const int nb = grid_for(n);  // <= 2048: `partials` holds 2048 floats
+    hipLaunchKernelGGL(grad_sqnorm_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (long)n, partials);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, out_accum);
+    MMVID_LAUNCH_CHECK("grad_sqnorm_det");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_adam_step_lr(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int step,
+                                  const float* step_dev, float max_norm, const float* sqnorm, float grad_scale, void* stream);
+
 extern "C" int mmvid_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                                float beta1, float beta2, float eps, float weight_decay, int step,
                                const float* step_dev, float max_norm, const float* sqnorm, float grad_scale,
                                void* stream) {
+    return mmvid_adam_step_lr(p, g, m, v, shadow_bf16, n, lr, nullptr, beta1, beta2, eps, weight_decay, step, step_dev, max_norm,
+                              sqnorm, grad_scale, stream);
+}
+
+extern "C" int mmvid_adam_step_lr(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int step,
+                                  const float* step_dev, float max_norm, const float* sqnorm, float grad_scale, void* stream) {
     MMVID_REQUIRE(p && g && m && v && n >= 0 && (step >= 1 || step_dev), "adam_step: bad arguments");
     MMVID_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)shadow_bf16 & 7) == 0,
                   "adam_step: buffers must be 16-byte aligned");
@@ -125,7 +181,7 @@ extern "C" int mmvid_adam_step(float* p, const float* g, float* m, float* v, voi
     a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)(step >= 1 ? step : 1)));
     a.max_norm = max_norm, a.grad_scale = grad_scale;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16,
-                       (long)n, a, sqnorm, step_dev);
+                       (long)n, a, sqnorm, step_dev, lr_dev);
     MMVID_LAUNCH_CHECK("adam_step");
     return MMVID_OK;
 }

@@ -103,8 +103,10 @@ int linear_dx(int64_t M, int N, int K, const void* dY, const void* W, const void
 }
 // dW[N,K] += dY^T X (both k-major over the token dimension), db[N] += colsum(dY)
 int linear_dw(int64_t M, int N, int K, const void* dY, const void* X, float* dW, float* db, float* ws, void* st) {
-    const int sk = mmvid_gemm_dw_pick_splitk(M, N, K);
-    TRY(mmvid_gemm_bf16_dw(M, N, K, dY, N, X, K, sk, ws, dW, /*accumulate=*/1, st));
+    if (dW) {  // a frozen weight has no gradient buffer: its activations still need dX (a frozen tower under trainable embeddings)
+        const int sk = mmvid_gemm_dw_pick_splitk(M, N, K);
+        TRY(mmvid_gemm_bf16_dw(M, N, K, dY, N, X, K, sk, ws, dW, /*accumulate=*/1, st));
+    }
     if (db) TRY(mmvid_colsum_bf16(dY, N, M, N, db, st));
     return 0;
 }

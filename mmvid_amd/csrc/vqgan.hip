@@ -16,6 +16,45 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
     for (int i = 0; i < nops; ++i) {
         const mmvid_vqgan_op_t& o = ops[i];
         int rc = 0;
+        const bool strict = (o.flags & MMVID_VQFLAG_STRICT) != 0;
+        if (strict) {  // fp32-accurate operators (strict.hip): every arena tensor of the plan is fp32
+            switch (o.op) {
+                case MMVID_VQOP_IMG2NHWC8:
+                    rc = mmvid_image_to_nhwc4_f32((const float*)o.ext_in, o.N, o.H, o.W, (float*)at(arena, o.out_f32), stream);
+                    break;
+                case MMVID_VQOP_CONV:
+                    rc = mmvid_conv2d_nhwc_f32(o.mode, (const float*)at(arena, o.in0), o.N, o.H, o.W, o.C, (const float*)o.w,
+                                               o.b, o.Cout, (const float*)at(arena, o.in1), (o.flags >> 1) & 1,
+                                               (float*)at(arena, o.out_f32), stream);
+                    break;
+                case MMVID_VQOP_GROUPNORM:
+                    rc = mmvid_groupnorm_swish_nhwc_f32((const float*)at(arena, o.in0), o.N, (int64_t)o.H * o.W, o.C,
+                                                        (const float*)o.w, o.b, o.eps, o.mode, (float*)at(arena, o.scratch),
+                                                        (float*)at(arena, o.out_f32), stream);
+                    break;
+                case MMVID_VQOP_SPATIAL_ATTN:
+                    rc = mmvid_spatial_attention_f32((const float*)at(arena, o.in0), (const float*)at(arena, o.in1),
+                                                     (const float*)at(arena, o.in2), o.N, o.H * o.W, o.C, o.eps,
+                                                     (float*)at(arena, o.scratch), (float*)at(arena, o.out_f32), stream);
+                    break;
+                case MMVID_VQOP_GATHER:
+                    rc = mmvid_gather_rows((const float*)o.w, o.Cout, (const int64_t*)o.ext_in, (int64_t)o.N * o.H * o.W, o.C,
+                                           (float*)at(arena, o.out_f32), nullptr, stream);
+                    break;
+                case MMVID_VQOP_EXT_CAST:
+                    if (hipMemcpyAsync(at(arena, o.out_f32), o.ext_in, (size_t)o.N * o.H * o.W * o.C * 4, hipMemcpyDeviceToDevice,
+                                       (hipStream_t)stream) != hipSuccess) {
+                        mmvid_set_error("vqgan_run: memcpy failed");
+                        rc = MMVID_ERR_HIP;
+                    }
+                    break;
+                default:
+                    mmvid_set_error("vqgan_run: op %d at %d has no strict form", o.op, i);
+                    return MMVID_ERR_ARG;
+            }
+            if (rc) return rc;
+            continue;
+        }
         switch (o.op) {
             case MMVID_VQOP_IMG2NHWC8:
                 rc = mmvid_image_to_nhwc8((const float*)o.ext_in, o.N, o.H, o.W, at(arena, o.out_bf16), stream);
@@ -49,6 +88,9 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
             case MMVID_VQOP_GATHER:
                 rc = mmvid_gather_rows((const float*)o.w, o.Cout, (const int64_t*)o.ext_in, (int64_t)o.N * o.H * o.W, o.C,
                                        nullptr, at(arena, o.out_bf16), stream);
+                break;
+            case MMVID_VQOP_EXT_CAST:
+                rc = mmvid_cast_f32_to_bf16((const float*)o.ext_in, at(arena, o.out_bf16), (int64_t)o.N * o.H * o.W * o.C, stream);
                 break;
             case MMVID_VQOP_NHWC2NCHW:
                 rc = mmvid_nhwc_to_nchw_f32((const float*)at(arena, o.in0), o.N, o.H, o.W, o.C, o.Cout, (float*)o.ext_out,

@@ -1,20 +1,26 @@
 """Host-side mirror of mmvid_pytorch/dalle_artv.py::DALLE (103-542), the autoregressive "ART-V" baseline, over
 the HIP kernels: same constructor, state_dict keys, `forward` (logits or (loss, 0, 0)) and `generate_images`
--> (images, [], None).  The tower runs with the causal mask predicate; the 51,584-way `to_logits` is the bf16
-MFMA GEMM.  generate_images follows the reference's loop (one forward per generated token, dalle_artv.py:
-253-281) but evaluates `to_logits` on the last position only -- the only row the loop reads."""
-import random
+-> (images, [], None).
 
+The reference's block-diagonal vocabulary mask (a [1, L, 51584] bool buffer, dalle_artv.py:215-227, applied with
+masked_fill at 509-512) says: text positions predict text ids, visual positions visual ids, image positions image
+ids; every other class gets logit -max, i.e. probability exactly 0.  Here that structure is used instead of
+materialised: each of the three position segments runs `to_logits` against ITS block of the weight only (LayerNorm +
+MFMA GEMM + the fused cross-entropy kernels), which is the same loss with ~14x fewer head FLOPs and no [B, L, 51584]
+tensors.  Sampling keeps a per-layer key/value cache (the reference recomputes the whole prefix per token) and draws
+tokens with the device sampler of csrc/sample.hip."""
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from . import ops
 from .clip_tower import OpenAICLIPTransformer
-from .dalle_bert import (DivideMax, eval_decorator, exists, set_requires_grad, warp_video_with_color)
-from .functional import AssembleSequence, LNLinear
+from .dalle_bert import DivideMax, eval_decorator, exists, set_requires_grad
+from .frontend import Frontend, face_choices
+from .functional import AssembleSequence, LNLinear, LNLinearCrossEntropy
 from .modules import AxialPositionalEmbedding, AxialPositionalEmbeddingList
-from .random_erasing import RandomErasing
+
+NEG = -torch.finfo(torch.float32).max
 
 
 def is_empty(t):
@@ -22,12 +28,11 @@ def is_empty(t):
 
 
 def top_k(logits, thres=0.5):
-    """dalle_artv.py:61-67."""
+    """dalle_artv.py:61-67: keep the k = max(int((1 - thres) * n), 1) largest logits of each row, -inf elsewhere."""
     k = max(int((1 - thres) * logits.shape[-1]), 1)
+    kept = torch.full_like(logits, float('-inf'))
     val, ind = torch.topk(logits, k)
-    probs = torch.full_like(logits, float('-inf'))
-    probs.scatter_(1, ind, val)
-    return probs
+    return kept.scatter_(1, ind, val)
 
 
 class DALLE(nn.Module):
@@ -76,13 +81,22 @@ class DALLE(nn.Module):
         if stable:
             self.norm_by_max = DivideMax(dim=-1)
         self.to_logits = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, self.total_tokens))
-        # block-diagonal vocabulary mask (dalle_artv.py:215-227) kept as three (row range -> column range) segments
         self.loss_vis_weight, self.loss_img_weight = 1., loss_img_weight
-        self.eraser = RandomErasing(p=1, scale=(0.4, 0.8), ratio=(0.5, 2), value=-1)
+        self.eraser = dict(p=1.0, scale=(0.4, 0.8), ratio=(0.5, 2.0))  # RandomErasing(value=-1), dalle_artv.py:229-232
+        self.frontend = Frontend(seed=kwargs.get('frontend_seed', 0))
         self._w16_cache = None
         seg = [0] * (text_seq_len + 1) + [1] * self.visual_seq_len + [2] * self.target_seq_len
         self.register_buffer('_seg', torch.tensor(seg, dtype=torch.int32), persistent=False)
 
+    def half(self):
+        """train.py:194-195 (`--fp16`).  The kernels always compute in bf16 on the MFMA pipe over fp32 master weights
+        (what mixed precision buys is already in place); fp16 parameters would have no kernel to run on."""
+        import warnings
+        warnings.warn('mmvid_amd: .half() ignored -- compute is bf16 MFMA over fp32 master weights (fp16 checkpoints still '
+                      'load: values are widened on copy)', UserWarning)
+        return self
+
+    # ---- the vocabulary blocks --------------------------------------------------------------------------------------
     @property
     def logits_mask(self):
         """The reference's [1, total_seq_len, total_tokens] bool buffer, materialised on demand (tests only)."""
@@ -91,22 +105,46 @@ class DALLE(nn.Module):
                              torch.ones(self.target_seq_len, self.num_image_tokens)) == 0
         return m.unsqueeze(0)
 
-    def _w16(self):
-        w = self.to_logits[1].weight
-        key = (w._version, w.data_ptr())
-        if self._w16_cache is None or self._w16_cache[0] != key:
-            self._w16_cache = (key, ops.cast_bf16(w.detach().contiguous()))
-        return self._w16_cache[1]
+    def _segments(self, L):
+        """[(first position, end position, first class, end class)] of the block-diagonal mask, clipped to L positions."""
+        tl, cl = self.text_seq_len, self.control_seq_len
+        segs = [(0, tl, 0, self.num_text_tokens), (tl, cl, self.num_text_tokens, self.num_control_tokens),
+                (cl, self.total_seq_len, self.num_control_tokens, self.total_tokens)]
+        return [(lo, min(hi, L), c0, c1) for lo, hi, c0, c1 in segs if lo < L]
 
     def _allowed_range(self, pos):
-        """columns of the logits that position `pos` may predict (block diagonal, dalle_artv.py:215-219)."""
-        if pos < self.text_seq_len:
-            return 0, self.num_text_tokens
-        if pos < self.control_seq_len:
-            return self.num_text_tokens, self.num_control_tokens
-        return self.num_control_tokens, self.total_tokens
+        """classes position `pos` may predict (dalle_artv.py:215-219)."""
+        for lo, hi, c0, c1 in self._segments(self.total_seq_len):
+            if lo <= pos < hi:
+                return c0, c1
+        raise IndexError(pos)
 
-    # token helpers shared with BERT's behaviour (dalle_artv.py:306-416)
+    # ---- bf16 copy of the 51,584 x 768 head ----------------------------------------------------------------------------
+    def _w16(self):
+        w = self.to_logits[1].weight
+        c = self._w16_cache
+        if c is not None and c[0] == 'attached':
+            if c[2] == w.data_ptr():
+                if c[3] != w._version:  # written through torch since the attachment: refresh the attached view
+                    ops.cast_bf16(w.detach().contiguous(), c[1])
+                    self._w16_cache = ('attached', c[1], c[2], w._version)
+                return c[1]
+            c = None
+        key = (w._version, w.data_ptr())
+        if c is None or c[0] != key:
+            c = self._w16_cache = (key, ops.cast_bf16(w.detach().contiguous()))
+        return c[1]
+
+    def attach_head_shadow(self, lin, view):
+        """Engine hook (see BERT.attach_head_shadow): a fused optimiser updates parameters through raw pointers, which
+        never bumps `_version`; it keeps `view` == bf16(weight) itself."""
+        assert lin is self.to_logits[1]
+        self._w16_cache = ('attached', view, lin.weight.data_ptr(), lin.weight._version)
+
+    def head_shadow_targets(self):
+        return [self.to_logits[1]]
+
+    # ---- token helpers (dalle_artv.py:306-416) --------------------------------------------------------------------------
     def get_image_tokens(self, image, reshape=True, insert_sep=False, which_vae='vae'):
         vae = self.cvae if (which_vae == 'cvae' and self.cvae is not None) else self.vae
         if isinstance(image, list):
@@ -124,34 +162,52 @@ class DALLE(nn.Module):
 
     def random_erase_codebook(self, image, eraser, erase_half=False):
         f = self.image_fmap_size
-        image = image.view(image.shape[0], -1, f, f)
-        if erase_half:
-            image[:, :, f // 2:, :] = -1
-        else:
-            image = torch.stack([eraser(c) for c in image], dim=0)
-        return image.reshape(image.shape[0], -1)
+        image = image.contiguous()
+        return self.frontend.random_erase(image, image.shape[1] // (f * f), f, -1, eraser['p'], eraser['scale'],
+                                          eraser['ratio'], erase_half)
 
-    def _hidden(self, text, visual, image, erase_visual, erase_visual_half, vc_mode, face_mode, visual_aug_mode):
-        """dalle_artv.py:431-500: ids -> assembled sequence -> causal tower.  Returns (out, labels parts)."""
+    def erase_codebook_face(self, image, vc_mode, face_mode=None):
+        """dalle_artv.py:356-416; erased positions become -1 (later replaced by per-position pad ids, 473-477)."""
+        f = self.image_fmap_size
+        image = image.contiguous()
+        if vc_mode == 'face3_8x8':
+            raise NotImplementedError(vc_mode)  # BERT-only mode
+        choices, frame0 = face_choices(vc_mode, face_mode)
+        if vc_mode in ('mask_8x8', 'mask2_8x8') and face_mode is None:
+            # the reference builds strategy 2's masked copy but never assigns it (dalle_artv.py:401-404): unchanged
+            choices = [(choices[0][0] + choices[1][0], 0, (0, 0, 0, 0)), choices[2]]
+        return self.frontend.erase_choice(image, image.shape[1] // (f * f), f, -1, choices, frame0)
+
+    def _visual_tokens(self, visual, erase_visual, erase_visual_half, vc_mode, face_mode, visual_aug_mode):
+        if not (exists(visual) and not is_empty(visual)):
+            return None
+        if visual_aug_mode == 'motion_color':
+            raise NotImplementedError("visual_aug_mode='motion_color' is not used by any recipe in scripts/ and is not built")
+        tok = self.get_image_tokens(visual, which_vae='cvae')
+        if erase_visual:
+            tok = self.random_erase_codebook(tok, self.eraser, erase_visual_half)
+        if vc_mode is not None:
+            tok = self.erase_codebook_face(tok, vc_mode, face_mode)
+        return tok
+
+    # ---- sequence -> hidden states ---------------------------------------------------------------------------------------
+    def _prompt_ids(self, text, vis_tok):
+        """<bos> + text (0 -> per-position pad id) + visual tokens (-1 -> per-position pad id): dalle_artv.py:441-477."""
+        device, B = text.device, text.shape[0]
         assert text.shape[-1] == self.text_seq_len, \
             f'the length {text.shape[-1]} of the text tokens you passed in does not have the correct length ({self.text_seq_len})'
-        device, B = text.device, text.shape[0]
-        text_range = torch.arange(self.text_seq_len, device=device) + (self.num_text_tokens - self.text_seq_len)
-        text = F.pad(torch.where(text == 0, text_range, text), (1, 0), value=0)  # <bos>
-        if exists(visual) and not is_empty(visual):
-            if visual_aug_mode == 'motion_color' and random.random() < 0.9:
-                visual_ = visual.detach().clone()
-                visual_[:, 1:, ...] = warp_video_with_color(visual[:, 1:, ...])
-                visual = visual_
-            visual = self.get_image_tokens(visual, which_vae='cvae')
-            if erase_visual:
-                visual = self.random_erase_codebook(visual, self.eraser, erase_visual_half)
-            if vc_mode is not None:
-                raise NotImplementedError('erase_codebook_face for ART-V (dalle_artv.py:356-416) is not on the benchmarked path')
-        else:
-            visual = -torch.ones(B, self.visual_seq_len, device=device).long()
-        visual_range = torch.arange(self.visual_seq_len, device=device) + (self.num_visual_tokens - self.visual_seq_len)
-        visual = torch.where(visual == -1, visual_range, visual)
+        text_pad = torch.arange(self.text_seq_len, device=device) + (self.num_text_tokens - self.text_seq_len)
+        text = F.pad(torch.where(text == 0, text_pad, text), (1, 0), value=0)
+        if vis_tok is None:
+            vis_tok = torch.full((B, self.visual_seq_len), -1, dtype=torch.long, device=device)
+        vis_pad = torch.arange(self.visual_seq_len, device=device) + (self.num_visual_tokens - self.visual_seq_len)
+        return text, torch.where(vis_tok == -1, vis_pad, vis_tok)
+
+    def _pos_rows(self):
+        return torch.cat([self.text_pos_emb.weight, self.visual_pos_emb.table(), self.image_pos_emb.table()], 0)
+
+    def _hidden(self, text, vis_tok, image):
+        text, visual = self._prompt_ids(text, vis_tok)
         parts = [text, visual]
         if exists(image) and not is_empty(image):
             image = self.get_image_tokens(image)
@@ -160,131 +216,121 @@ class DALLE(nn.Module):
         if ids.shape[1] > self.total_seq_len:  # drop the last token when training (dalle_artv.py:496-498)
             ids = ids[:, :-1]
         L = ids.shape[1]
-        pos = torch.cat([self.text_pos_emb.weight, self.visual_pos_emb.table(), self.image_pos_emb.table()], 0)[:L]
-        x = AssembleSequence.apply(pos, ids.contiguous(), self._seg[:L].contiguous(), self.text_emb.weight,
+        x = AssembleSequence.apply(self._pos_rows()[:L], ids.contiguous(), self._seg[:L].contiguous(), self.text_emb.weight,
                                    self.visual_emb.weight, self.image_emb.weight)
         out = self.transformer(x)
         if self.stable:
             out = self.norm_by_max(out)
         return out, text, visual, image
 
-    def _logits_rows(self, rows):
+    def _logits_rows(self, rows, cols=None):
         lin = self.to_logits[1]
-        return LNLinear.apply(rows, self.to_logits[0].weight, self.to_logits[0].bias, lin.weight, lin.bias, self._w16())
+        if cols is None:
+            return LNLinear.apply(rows, self.to_logits[0].weight, self.to_logits[0].bias, lin.weight, lin.bias, self._w16())
+        with torch.no_grad():  # one class block: inference only (training goes through LNLinearCrossEntropy)
+            hn = ops.layernorm_fwd(rows.contiguous(), self.to_logits[0].weight, self.to_logits[0].bias, 1e-5, save_stats=False)[0]
+            return ops.gemm(hn, self._w16()[cols[0]:cols[1]], bias=lin.bias.detach()[cols[0]:cols[1]], out_dtype=torch.float32)
 
     def forward(self, text, visual=None, target=None, return_loss=False, erase_visual=False, erase_visual_half=False,
                 vc_mode=None, face_mode=None, visual_aug_mode=None, **kwargs):
-        out, text, visual, image = self._hidden(text, visual, target, erase_visual, erase_visual_half, vc_mode,
-                                                face_mode, visual_aug_mode)
-        B, L, _ = out.shape
-        logits = self._logits_rows(out.reshape(B * L, self.dim)).view(B, L, -1)
-        neg = -torch.finfo(logits.dtype).max
-        # block-diagonal mask (dalle_artv.py:509-512), applied per segment instead of through a [L, V] bool buffer
-        masked = torch.full_like(logits, neg)
-        for lo, hi in ((0, self.text_seq_len), (self.text_seq_len, self.control_seq_len), (self.control_seq_len, L)):
-            if lo < min(hi, L):
-                c0, c1 = self._allowed_range(lo)
-                masked[:, lo:min(hi, L), c0:c1] = logits[:, lo:min(hi, L), c0:c1]
-        logits = masked
+        vis_tok = self._visual_tokens(visual, erase_visual, erase_visual_half, vc_mode, face_mode, visual_aug_mode)
+        out, text, visual, image = self._hidden(text, vis_tok, target)
+        B, L, E = out.shape
         if not return_loss:
+            with torch.no_grad():  # the reference's dense [B, L, total_tokens] tensor, -max outside each position's block
+                logits = torch.full((B, L, self.total_tokens), NEG, device=out.device, dtype=torch.float32)
+                for lo, hi, c0, c1 in self._segments(L):
+                    logits[:, lo:hi, c0:c1] = self._logits_rows(out[:, lo:hi].reshape(-1, E), (c0, c1)).view(B, hi - lo, c1 - c0)
             return logits
         assert exists(image), 'when training, image must be supplied'
-        labels = torch.cat((text[:, 1:], visual + self.num_text_tokens, image + self.num_control_tokens), dim=1)
-        lg = logits.permute(0, 2, 1)
-        tl, cl = self.text_seq_len, self.control_seq_len
-        loss_text = F.cross_entropy(lg[:, :, :tl], labels[:, :tl])
-        loss_vis = F.cross_entropy(lg[:, :, tl:cl], labels[:, tl:cl])
-        loss_img = F.cross_entropy(lg[:, :, cl:], labels[:, cl:])
-        loss = (loss_text + self.loss_vis_weight * loss_vis + self.loss_img_weight * loss_img) / \
+        # labels (dalle_artv.py:519-524) relative to each segment's class block: text[1:], visual ids, image ids
+        labels = (text[:, 1:], visual, image)
+        lin, ln = self.to_logits[1], self.to_logits[0]
+        losses = []
+        for (lo, hi, c0, c1), lab in zip(self._segments(L), labels):
+            rows = out[:, lo:hi].reshape(B * (hi - lo), E)
+            loss, _ = LNLinearCrossEntropy.apply(rows, lab[:, :hi - lo].reshape(-1).contiguous(), None, ln.weight, ln.bias,
+                                                 lin.weight, lin.bias, self._w16(), (c0, c1))
+            losses.append(loss)
+        loss = (losses[0] + self.loss_vis_weight * losses[1] + self.loss_img_weight * losses[2]) / \
             (self.loss_img_weight + self.loss_vis_weight + 1)
         zero = torch.tensor(0.0, device=text.device)
         return loss, zero, zero
 
+    # ---- sampling ---------------------------------------------------------------------------------------------------------
     def _embed_rows(self, ids, first_pos):
         """Embedding + positional rows for `ids` [B, n] occupying positions first_pos .. first_pos+n-1."""
         n = ids.shape[1]
-        pos = torch.cat([self.text_pos_emb.weight, self.visual_pos_emb.table(), self.image_pos_emb.table()], 0)
         return ops.assemble_sequence([self.text_emb.weight, self.visual_emb.weight, self.image_emb.weight], ids.contiguous(),
-                                     self._seg[first_pos:first_pos + n].contiguous(), pos[first_pos:first_pos + n].contiguous())
+                                     self._seg[first_pos:first_pos + n].contiguous(),
+                                     self._pos_rows()[first_pos:first_pos + n].contiguous())
 
-    def _sample(self, last_hidden, position, filter_thres, temperature):
-        """dalle_artv.py:282-291: logits of the last position restricted to its allowed block, top-k, multinomial."""
-        last = self._logits_rows(last_hidden.contiguous())
-        c0, c1 = self._allowed_range(position)
-        logits = torch.full_like(last, -torch.finfo(torch.float32).max)
-        logits[:, c0:c1] = last[:, c0:c1]
-        probs = F.softmax(top_k(logits, thres=filter_thres) / temperature, dim=-1)
-        return torch.multinomial(probs, 1) - self.num_control_tokens
+    def _draw(self, block_logits, filter_thres, temperature, race, name):
+        """One token per row from the logits of the position's class block (dalle_artv.py:274-276): top_k over ALL
+        total_tokens classes keeps k = int((1 - thres) * total_tokens) of them; the classes outside the block sit at -max,
+        so the filter only ever removes block classes when k is smaller than the block."""
+        B, n = block_logits.shape
+        k_keep = max(int((1 - filter_thres) * self.total_tokens), 1)
+        if k_keep < n:
+            kept = torch.full_like(block_logits, float('-inf'))
+            val, ind = torch.topk(block_logits, k_keep)
+            block_logits = kept.scatter_(1, ind, val)
+        E = race(name, (B, n)) if race is not None else ops.exponential_like((B, n), block_logits.device)
+        tok, _ = ops.sample_race(block_logits.contiguous(), E, None, 0.0, logit_div=temperature, want_y=False)
+        return tok.view(B, 1)
+
+    def sampling_probs(self, block_logits, filter_thres=0.5, temperature=1.0):
+        """The probability vector `_draw` samples from (tests compare it with the reference's full-width expression)."""
+        k_keep = max(int((1 - filter_thres) * self.total_tokens), 1)
+        if k_keep < block_logits.shape[1]:
+            val, ind = torch.topk(block_logits, k_keep)
+            block_logits = torch.full_like(block_logits, float('-inf')).scatter_(1, ind, val)
+        return F.softmax(block_logits / temperature, dim=-1)
 
     @torch.no_grad()
     @eval_decorator
     def generate_images(self, text, *, clip=None, visual=None, mask=None, filter_thres=0.5, temperature=1.,
-                        erase_visual=False, vc_mode=None, face_mode=None, use_cache=True, **kwargs):
-        """dalle_artv.py:236-304.  use_cache=True (default): the prompt is run once and each sampled token then costs
-        one incremental step over the per-layer key/value cache; use_cache=False: the reference's algorithm, the
-        whole transformer over the growing prefix for every token.  Same sampling distribution either way (the
-        two differ in bf16 summation order only; tests/test_models_gpu.py compares the logits step by step)."""
-        tsl, total_len = self.text_seq_len, self.text_seq_len + self.target_seq_len
+                        erase_visual=False, vc_mode=None, face_mode=None, use_cache=True, _race=None, **kwargs):
+        """dalle_artv.py:236-304.  use_cache=True (default): the prompt runs once and every sampled token costs one
+        incremental step over the per-layer key/value cache; use_cache=False: the reference's algorithm (the whole
+        transformer over the growing prefix per token).  Both draw from the same distribution: softmax over the image
+        block of the last position's logits (tests/test_parity_gpu.py compares it with the reference's expression)."""
+        tsl = self.text_seq_len
         text = text[:, :tsl]
-        out = text
-        # the visual control tokens do not change during sampling: tokenise once (the reference re-encodes them
-        # every step, dalle_artv.py:464-466, with identical results)
-        vis_tok = None
-        if exists(visual) and not is_empty(visual):
-            vis_tok = self.get_image_tokens(visual, which_vae='cvae')
-            if erase_visual:
-                vis_tok = self.random_erase_codebook(vis_tok, self.eraser, True)
+        B = text.shape[0]
+        # visual control tokens (with the erasing the reference applies on every step, dalle_artv.py:464-472) are fixed
+        # during sampling: tokenise once
+        vis_tok = self._visual_tokens(visual, erase_visual, True, vc_mode, face_mode, None)
+        cl = self.control_seq_len
+        c0, c1 = self._allowed_range(cl)
+        toks = []
         if use_cache:
-            B = text.shape[0]
             cache = self.transformer.new_kv_cache(B, self.total_seq_len, text.device)
-            # prompt = <bos> text, visual: the same ids _hidden builds (dalle_artv.py:441-477)
-            text_range = torch.arange(tsl, device=text.device) + (self.num_text_tokens - tsl)
-            tx = F.pad(torch.where(text == 0, text_range, text), (1, 0), value=0)
-            vz = vis_tok if vis_tok is not None else -torch.ones(B, self.visual_seq_len, device=text.device).long()
-            visual_range = torch.arange(self.visual_seq_len, device=text.device) + (self.num_visual_tokens - self.visual_seq_len)
-            vz = torch.where(vz == -1, visual_range, vz)
-            prompt = torch.cat((tx, vz), 1)
+            prompt = torch.cat(self._prompt_ids(text, vis_tok), 1)  # <bos> text visual: positions 0 .. cl
             h = self.transformer.prefill(self._embed_rows(prompt, 0), cache)[:, -1, :]
-            if self.stable:
-                h = self.norm_by_max(h)
-            pos = prompt.shape[1]  # index of the position being sampled for
-            # everything a step needs, prepared once: positional rows, the image block of the logits matrix, the session
-            pos_rows = torch.cat([self.text_pos_emb.weight, self.visual_pos_emb.table(), self.image_pos_emb.table()], 0)
-            c0, c1 = self._allowed_range(pos)
-            lin, ln = self.to_logits[1], self.to_logits[0]
-            w_img, b_img = self._w16()[c0:c1].contiguous(), lin.bias[c0:c1].contiguous()
-            k_keep = max(int((1 - filter_thres) * lin.weight.shape[0]), 1)  # top_k() keeps this many of ALL logits
-            sess = self.transformer.decode_session(cache, pos)
-            toks = []
+            pos_rows = self._pos_rows()
+            sess = self.transformer.decode_session(cache, prompt.shape[1])
             for step in range(self.target_seq_len):
-                # logits of the allowed (image) block only: the other columns are masked to -max by the reference and end
-                # up with probability exactly 0 (dalle_artv.py:285-290), whatever top-k does, as long as k covers the block
-                hn, _, _ = ops.layernorm_fwd(h.contiguous(), ln.weight, ln.bias, 1e-5, save_stats=False)
-                blk = ops.gemm(hn, w_img, bias=b_img, out_dtype=torch.float32)
-                if k_keep < c1 - c0:
-                    blk = top_k(blk, thres=1.0 - k_keep / (c1 - c0))
-                probs = torch.zeros(B, lin.weight.shape[0], device=text.device)
-                probs[:, c0:c1] = F.softmax(blk / temperature, dim=-1)
-                sample = torch.multinomial(probs, 1) - self.num_control_tokens  # same call, same RNG use as the reference
+                if self.stable:
+                    h = self.norm_by_max(h)
+                sample = self._draw(self._logits_rows(h.contiguous(), (c0, c1)), filter_thres, temperature, _race, f'tok{step}')
                 toks.append(sample)
                 if step == self.target_seq_len - 1:
                     break
-                x_new = self.image_emb.weight[sample[:, 0]] + pos_rows[pos]
-                h = sess.step(x_new)
-                if self.stable:
-                    h = self.norm_by_max(h)
-                pos += 1
-            out = torch.cat([out] + toks, dim=-1)
+                h = sess.step(self.image_emb.weight[sample[:, 0]] + pos_rows[prompt.shape[1] + step])
         else:
-            for cur_len in range(out.shape[1], total_len):
-                image = out[:, tsl:]
-                hidden, _, _, _ = self._hidden(out[:, :tsl], vis_tok, image, False, False, None, None, None)
-                sample = self._sample(hidden[:, -1, :], hidden.shape[1] - 1, filter_thres, temperature)
-                out = torch.cat((out, sample), dim=-1)
-        img_seq = out[:, -self.target_seq_len:].reshape(-1, self.image_seq_len)
+            image = torch.empty(B, 0, dtype=torch.long, device=text.device)
+            for step in range(self.target_seq_len):
+                hidden = self._hidden(text, vis_tok, image)[0]
+                sample = self._draw(self._logits_rows(hidden[:, -1, :].contiguous(), (c0, c1)), filter_thres, temperature,
+                                    _race, f'tok{step}')
+                toks.append(sample)
+                image = torch.cat((image, sample), dim=-1)
+        img_seq = torch.cat(toks, dim=-1).reshape(-1, self.image_seq_len)
         images = self.vae.decode(img_seq)
         if self.num_targets > 1:
             images = images.view(-1, self.num_targets, *images.shape[1:])
         if exists(clip):
+            out = torch.cat((text, torch.cat(toks, dim=-1) + self.num_control_tokens), dim=-1)
             return images, clip(out[:, :tsl], images, return_loss=False)
         return images, [], None

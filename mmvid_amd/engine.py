@@ -23,10 +23,33 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class WarmupLR:
+    """The reference's default schedule (utils_train.py:373-385 -> deepspeed.runtime.lr_schedules.WarmupLR; third-party,
+    restated from its published semantics: parity unpinned): lr = min + (max - min) * gamma, gamma = log(k + 1) /
+    log(warmup) for scheduler step k < warmup, else 1.  train.py:373-374 steps it after every `every`-th iteration;
+    before its first step the optimiser runs at its construction lr.  `lr_at(i)` is the host view; the training step
+    evaluates the same closed form on the device (mmvid_lr_schedule) so that a captured step follows it."""
+
+    def __init__(self, warmup_min_lr=1e-6, warmup_max_lr=1e-4, warmup_num_steps=5000, every=1):
+        self.min_lr, self.max_lr = float(warmup_min_lr), float(warmup_max_lr)
+        self.warmup = max(2, int(warmup_num_steps))
+        self.every = max(1, int(every))
+
+    def lr_at(self, iteration):
+        import math
+        ns = iteration // self.every
+        if ns == 0:
+            return self.max_lr
+        k = ns - 1
+        gamma = math.log(k + 1) / math.log(self.warmup) if k < self.warmup else 1.0
+        return self.min_lr + (self.max_lr - self.min_lr) * gamma
+
+
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 process_group=None, bucket_mb=64, order=None):
+                 process_group=None, bucket_mb=64, order=None, lr_schedule=None):
         self.model = model
+        self.lr_schedule = lr_schedule
         params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if order is not None:
             params = order(params)
@@ -57,9 +80,11 @@ class FlatTrainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.bucket_elems = max(ALIGN, int(bucket_mb * (1 << 20) / 4) // ALIGN * ALIGN)
         self._sq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._sq_partials = torch.zeros(2048, device=dev, dtype=torch.float32) if dev.type == 'cuda' else None
         # the step count also lives on the device, advanced by a device op: a captured step (GraphedStep) replays with
-        # the right Adam bias corrections without the host passing a new scalar
+        # the right Adam bias corrections and learning rate without the host passing new scalars
         self._step_dev = torch.zeros(1, device=dev, dtype=torch.float32) if dev.type == 'cuda' else None
+        self._lr_dev = torch.full((1, ), float(lr), device=dev, dtype=torch.float32) if dev.type == 'cuda' else None
         self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self._works = []
         self._sent_from = tot  # gradients at flat offsets >= this are already on the wire this step
@@ -79,12 +104,71 @@ class FlatTrainer:
         return self.S[o:o + p.numel()].view(p.shape)
 
     def _attach_shadows(self):
+        """Hand the model views of the flat bf16 shadow for every weight its MFMA kernels read in bf16: the tower's
+        matrices and each head listed by `model.head_shadow_targets()` (BERT: to_logits; ART-V: the 51,584-way to_logits).
+        A weight that is frozen (not in the flat buffer) keeps the model's own cast-on-change copy."""
         m = self.model
+        self._tower_shadow_attached = False
         tw = getattr(m, 'transformer', None)
         if tw is not None and hasattr(tw, 'attach_shadow') and all(p.requires_grad for p in tw._matrix_params()):
             tw.attach_shadow([self._shadow_view(p) for p in tw._matrix_params()])
-        if hasattr(m, 'attach_head_shadow') and m.to_logits[1].weight.requires_grad:
-            m.attach_head_shadow(m.to_logits[1], self._shadow_view(m.to_logits[1].weight))
+            self._tower_shadow_attached = True
+        if hasattr(m, 'attach_head_shadow') and hasattr(m, 'head_shadow_targets'):
+            for lin in m.head_shadow_targets():
+                if lin.weight.requires_grad:
+                    m.attach_head_shadow(lin, self._shadow_view(lin.weight))
+
+    def _check_bindings(self):
+        """`p.data` / `p.grad` must still be the views into P / G the kernels update: `model.zero_grad()` (set_to_none),
+        `load_state_dict(assign=True)` or `.to()` would silently detach them.  Re-bind gradients, refuse moved params."""
+        for p, o in zip(self.params, self.offsets):
+            if p.data_ptr() != self.P.data_ptr() + 4 * o:
+                raise RuntimeError('a parameter no longer lives in FlatTrainer.P (moved by .to() / load_state_dict(assign=True)); '
+                                   'rebuild the trainer after moving the model')
+            if p.grad is None or p.grad.data_ptr() != self.G.data_ptr() + 4 * o:
+                stray = p.grad
+                p.grad = self.G[o:o + p.numel()].view(p.shape)
+                if stray is not None:  # gradients were accumulated into a detached tensor this step: fold them in
+                    p.grad.add_(stray)
+
+    # --------------------------------------------------------------------------------------------- checkpoint
+    def state_dict(self):
+        """Optimiser state in torch.optim.Adam's layout (train.py:202-203, 352, 387 save / restore `optimizer`): per
+        parameter exp_avg / exp_avg_sq / step, keyed by position in `self.names` order."""
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': self.M[o:o + n].view(p.shape).clone(),
+                        'exp_avg_sq': self.V[o:o + n].view(p.shape).clone()}
+        group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.wd, 'amsgrad': False,
+                 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group], 'names': list(self.names)}
+
+    def load_state_dict(self, sd):
+        names = sd.get('names', self.names)
+        assert list(names) == list(self.names), 'optimizer state was saved for a different parameter order'
+        steps = set()
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            st = sd['state'].get(i, sd['state'].get(str(i)))
+            if st is None:
+                continue
+            n = p.numel()
+            self.M[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self.V[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(float(st['step'])))
+        if steps:
+            assert len(steps) == 1, 'per-parameter step counts differ'
+            self.step_count = steps.pop()
+            if self._step_dev is not None:
+                self._step_dev.fill_(float(self.step_count))
+        g = sd['param_groups'][0]
+        self.lr, self.betas, self.eps, self.wd = g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']
+
+    def refresh_shadows(self):
+        """Call after writing parameters behind the trainer's back (model.load_state_dict): re-cast the bf16 shadow."""
+        if self.S is not None:
+            ops.cast_bf16(self.P, self.S)
+            self._attach_shadows()
 
     # ---------------------------------------------------------------------------------------------
     def zero_grad(self):
@@ -126,19 +210,25 @@ class FlatTrainer:
 
     def step(self):
         """clip_grad_norm_(max_norm) + Adam (train.py:324-325) on the averaged gradients."""
+        self._check_bindings()
         self.allreduce_grads()
         self.step_count += 1
         gscale = 1.0 / self.world
         # the update itself is the HIP kernel; on a host tensor ops.adam_step raises (there is no CPU path)
         self._sq.zero_()
+        lr_dev = None
         if self._step_dev is not None:
-            self._step_dev.add_(1.0)
-        ops.grad_sqnorm(self.G, self._sq)
+            if self.lr_schedule is not None:  # lr of THIS iteration from the count of finished steps, on the device
+                sc = self.lr_schedule
+                ops.lr_schedule(self._step_dev, 1, sc.min_lr, sc.max_lr, sc.warmup, sc.every, self._lr_dev)
+                lr_dev = self._lr_dev
+            ops.counter_add(self._step_dev, 1.0)
+        ops.grad_sqnorm(self.G, self._sq, partials=self._sq_partials)
         ops.adam_step(self.P, self.G, self.M, self.V, self.S, self.step_count, self.lr, self.betas, self.eps, self.wd,
-                      self.max_norm, self._sq, gscale, step_dev=self._step_dev)
+                      self.max_norm, self._sq, gscale, step_dev=self._step_dev, lr_dev=lr_dev)
         tw = getattr(self.model, 'transformer', None)
-        if tw is not None and hasattr(tw, 'mark_shadow_fresh'):
-            tw.mark_shadow_fresh()
+        if tw is not None and hasattr(tw, 'mark_shadow_fresh') and getattr(self, '_tower_shadow_attached', False):
+            tw.mark_shadow_fresh()  # the Adam kernel wrote the attached bf16 views; an un-attached tower recasts itself
 
     def grad_norm(self):
         return float(self.G.norm()) / self.world

@@ -55,14 +55,15 @@ class LNLinear(torch.autograd.Function):
         return LNLinear._backward_bf16(d16, x, mean, rstd, h, ln_w, ln_b, w, b, w_bf16)
 
     @staticmethod
-    def _backward_bf16(d16, x, mean, rstd, h, ln_w, ln_b, w, b, w_bf16):
+    def _backward_bf16(d16, x, mean, rstd, h, ln_w, ln_b, w, b, w_bf16, cols=None):
         R, N = d16.shape
         E = x.shape[1]
+        c0, c1 = cols if cols is not None else (0, w.shape[0])
         if w.requires_grad:
-            ops.gemm_dw(d16, h, _grad_buf(w), accumulate=True)
+            ops.gemm_dw(d16, h, _grad_buf(w)[c0:c1], accumulate=True)
         if b.requires_grad:
-            ops.colsum_bf16(d16, _grad_buf(b))
-        dh = ops.gemm(d16, w_bf16, b_kmajor=True, out_dtype=f32)  # [R, E]
+            ops.colsum_bf16(d16, _grad_buf(b)[c0:c1])
+        dh = ops.gemm(d16, w_bf16[c0:c1], b_kmajor=True, out_dtype=f32)  # [R, E]
         dx = ops.layernorm_bwd(dh, x, mean, rstd, ln_w.detach(), dw=_grad_buf(ln_w) if ln_w.requires_grad else None,
                                db=_grad_buf(ln_b) if ln_b.requires_grad else None)
         return dx, None, None, None, None, None
@@ -70,13 +71,20 @@ class LNLinear(torch.autograd.Function):
 
 class LNLinearCrossEntropy(torch.autograd.Function):
     """to_logits + F.cross_entropy(logits[select], target[select]) (dalle_bert.py:1038-1040) fused at the autograd
-    level: the bf16 dlogits go straight into the backward GEMMs.  Returns (loss, logits)."""
+    level: the bf16 dlogits go straight into the backward GEMMs.  Returns (loss, logits).
+    cols = (c0, c1): only that block of output classes exists for these rows (ART-V's block-diagonal vocabulary mask,
+    dalle_artv.py:215-227, 509-512: every other class has logit -max, i.e. probability exactly 0); `target` is then
+    relative to c0 and the weight / bias gradients go to rows c0:c1 of the full parameters."""
 
     @staticmethod
-    def forward(ctx, x, target, select, ln_w, ln_b, w, b, w_bf16):
+    def forward(ctx, x, target, select, ln_w, ln_b, w, b, w_bf16, cols=None):
         x = x.contiguous()
         h, mean, rstd = ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), 1e-5)
-        logits = ops.gemm(h, w_bf16, bias=b.detach(), out_dtype=f32)
+        ctx.cols = cols
+        if cols is not None:
+            w_bf16 = w_bf16[cols[0]:cols[1]]
+        bias = b.detach() if cols is None else b.detach()[cols[0]:cols[1]].contiguous()
+        logits = ops.gemm(h, w_bf16, bias=bias, out_dtype=f32)
         sel8 = select.to(torch.uint8).contiguous() if select is not None else None
         lse, loss_sum = ops.cross_entropy_fwd(logits, target, sel8)
         cnt = (select.sum() if select is not None else torch.tensor(logits.shape[0], device=x.device)).to(f32)
@@ -90,5 +98,82 @@ class LNLinearCrossEntropy(torch.autograd.Function):
         x, mean, rstd, h, logits, target, sel8, lse, cnt = ctx.saved_tensors
         gs = (gloss.to(f32) / cnt).reshape(1).contiguous()
         d16 = ops.cross_entropy_bwd(logits, target, sel8, lse, gs)
-        dx = LNLinear._backward_bf16(d16, x, mean, rstd, h, *ctx.params)[0]
-        return (dx, ) + (None, ) * 7
+        dx = LNLinear._backward_bf16(d16, x, mean, rstd, h, *ctx.params, cols=ctx.cols)[0]
+        return (dx, ) + (None, ) * 8
+
+
+class BertHeads(torch.autograd.Function):
+    """All three heads and losses of a BERT training step (dalle_bert.py:1038-1040, 1062-1084, 1103-1123) on the tower
+    output y [nseq*B, L, E], forward and backward as HIP launches:
+      MSM   to_logits (LayerNorm + MFMA GEMM) on the B*L rows of the first pass and cross entropy over the rows
+            `select` marks (the masked target positions; control rows are never selected, so their logits cost ~13 %
+            of a small GEMM and buy a copy-free, uniformly strided row set);
+      REL / VID   LayerNorm + 768->1 dot + BCE-with-logits on 2*B gathered rows each (csrc/sample.hip).
+    The backward writes ONE gradient tensor for y: the MSM LayerNorm backward fills the first pass's rows, the other
+    passes are zero-filled, the small heads add their rows.  Returns (loss_msm, loss_rel, loss_vid, logits [B*L, V])."""
+
+    @staticmethod
+    def forward(ctx, y, target_full, select_full, count, nfm, labels, rel_rows, vid_rows, weight_by_nfm, B, w_bf16, ln_w,
+                ln_b, w, b, rel_ln_w, rel_ln_b, rel_w, rel_b, vid_ln_w, vid_ln_b, vid_w, vid_b):
+        nB, L, E = y.shape
+        y2d = y.contiguous().view(nB * L, E)
+        rows = B * L
+        h, mean, rstd = ops.layernorm_fwd(y2d[:rows], ln_w.detach(), ln_b.detach(), 1e-5)
+        logits = ops.gemm(h, w_bf16, bias=b.detach(), out_dtype=f32)
+        lse, loss_sum = ops.cross_entropy_fwd(logits, target_full, select_full)
+        loss_msm = (loss_sum / count).squeeze(0)
+        zero = torch.zeros((), device=y.device, dtype=f32)
+        den_from = nfm if weight_by_nfm else None
+        saved_small = []
+        losses = []
+        for rws, lw, lb, hw, hb, per_row in ((rel_rows, rel_ln_w, rel_ln_b, rel_w, rel_b, True),
+                                             (vid_rows, vid_ln_w, vid_ln_b, vid_w, vid_b, False)):
+            if rws is None:
+                losses.append(zero)
+                saved_small.append(None)
+                continue
+            # REL weights each sample's two terms by not_fully_masked (1067-1079); VID only divides by its sum (1107-1116)
+            rw = nfm.repeat(2) if (weight_by_nfm and per_row) else None
+            z, mu, rs, loss = ops.head_rows_fwd(y2d, rws, lw.detach(), lb.detach(), hw.detach().view(-1), hb.detach(), 1e-5,
+                                                label=labels, row_weight=rw, den_from=den_from, den_const=float(B))
+            losses.append(loss.squeeze(0))
+            saved_small.append((rws, z, mu, rs, rw))
+        ctx.save_for_backward(y2d, mean, rstd, h, logits, target_full, select_full, lse, count, labels)
+        ctx.small = saved_small
+        ctx.den_from, ctx.B = den_from, B
+        ctx.params = (w_bf16, ln_w, ln_b, w, b, rel_ln_w, rel_ln_b, rel_w, rel_b, vid_ln_w, vid_ln_b, vid_w, vid_b)
+        ctx.shape = (nB, L, E)
+        ctx.mark_non_differentiable(logits)
+        return loss_msm, losses[0], losses[1], logits
+
+    @staticmethod
+    def backward(ctx, g_msm, g_rel, g_vid, _g_logits):
+        y2d, mean, rstd, h, logits, target_full, select_full, lse, count, labels = ctx.saved_tensors
+        w_bf16, ln_w, ln_b, w, b, rel_ln_w, rel_ln_b, rel_w, rel_b, vid_ln_w, vid_ln_b, vid_w, vid_b = ctx.params
+        nB, L, E = ctx.shape
+        rows = ctx.B * L
+        gy = torch.empty_like(y2d)
+        # ---- MSM: dlogits (bf16) -> dW, db, dh -> LayerNorm backward straight into gy's first rows
+        gs = (g_msm.to(f32) / count).reshape(1).contiguous()
+        d16 = ops.cross_entropy_bwd(logits, target_full, select_full, lse, gs)
+        if w.requires_grad:
+            ops.gemm_dw(d16, h, _grad_buf(w), accumulate=True)
+        if b.requires_grad:
+            ops.colsum_bf16(d16, _grad_buf(b))
+        dh = ops.gemm(d16, w_bf16, b_kmajor=True, out_dtype=f32)
+        ops.layernorm_bwd(dh, y2d[:rows], mean, rstd, ln_w.detach(), dx=gy[:rows],
+                          dw=_grad_buf(ln_w) if ln_w.requires_grad else None,
+                          db=_grad_buf(ln_b) if ln_b.requires_grad else None)
+        if nB * L > rows:
+            gy[rows:].zero_()
+        # ---- REL / VID rows (added on top)
+        for saved, g, (lw, lb, hw, hb), per_row in ((ctx.small[0], g_rel, (rel_ln_w, rel_ln_b, rel_w, rel_b), True),
+                                                    (ctx.small[1], g_vid, (vid_ln_w, vid_ln_b, vid_w, vid_b), False)):
+            if saved is None or g is None:
+                continue
+            rws, z, mu, rs, rw = saved
+            ops.head_rows_bwd(y2d, rws, lw.detach(), lb.detach(), hw.detach().view(-1), z, mu, rs, labels, rw, ctx.den_from,
+                              float(ctx.B), g.to(f32).reshape(1).contiguous(), gy,
+                              _grad_buf(hw).view(-1) if hw.requires_grad else None, _grad_buf(hb) if hb.requires_grad else None,
+                              _grad_buf(lw) if lw.requires_grad else None, _grad_buf(lb) if lb.requires_grad else None)
+        return (gy.view(nB, L, E), ) + (None, ) * 22

@@ -108,6 +108,18 @@ def gemm_dw(dY, X, dW, accumulate=True, splitk=None):
     return dW
 
 
+def gemm_f32(A, B, *, b_kmajor=False, bias=None, residual=None, alpha=1.0):
+    """Exact-fp32 GEMM (k-ordered fmaf chains on the f32 matrix pipe): C = alpha * A @ (B if b_kmajor else B^T).
+    A [M,K] f32; B [N,K] (row-major) or [K,N] (b_kmajor)."""
+    _chk(A, f32, 'A'), _chk(B, f32, 'B')
+    M, K = A.shape
+    N = B.shape[1] if b_kmajor else B.shape[0]
+    out = torch.empty(M, N, device=A.device, dtype=f32)
+    call('mmvid_gemm_f32', int(b_kmajor), M, N, K, _p(A), K, _p(B), B.shape[1], 1, 0, 0, 0, float(alpha), _p(bias),
+         _p(residual), _p(out), N, _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- norms
 def layernorm_fwd(x, w, b, eps=1e-5, out_dtype=bf16, save_stats=True):
     _chk(x, f32, 'x')
@@ -242,18 +254,31 @@ def colsum_bf16(dy, db):
 
 
 # ------------------------------------------------------------------------------------------ optimiser
-def grad_sqnorm(g, out):
+def grad_sqnorm(g, out, partials=None):
+    """out[0] += sum g^2.  With `partials` (fp32 [2048] scratch) the reduction order is fixed (deterministic)."""
     _chk(g, f32, 'g'), _chk(out, f32, 'out')
-    call('mmvid_grad_sqnorm', _p(g), g.numel(), _p(out), _stream())
+    if partials is not None:
+        call('mmvid_grad_sqnorm_det', _p(g), g.numel(), _p(partials), _p(out), _stream())
+    else:
+        call('mmvid_grad_sqnorm', _p(g), g.numel(), _p(out), _stream())
 
 
 def adam_step(p, g, m, v, shadow, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0,
-              sqnorm=None, grad_scale=1.0, step_dev=None):
+              sqnorm=None, grad_scale=1.0, step_dev=None, lr_dev=None):
     for t, n in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
         _chk(t, f32, n)
-    call('mmvid_adam_step', _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(betas[0]),
+    call('mmvid_adam_step_lr', _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), _p(lr_dev), float(betas[0]),
          float(betas[1]), float(eps), float(weight_decay), int(step), _p(step_dev), float(max_norm), _p(sqnorm),
          float(grad_scale), _stream())
+
+
+def lr_schedule(step_dev, kind, lr_min, lr_max, warmup, every, lr_out):
+    call('mmvid_lr_schedule', _p(step_dev), int(kind), float(lr_min), float(lr_max), int(warmup), int(every), _p(lr_out),
+         _stream())
+
+
+def counter_add(counter, value=1.0):
+    call('mmvid_counter_add', _p(counter), float(value), _stream())
 
 
 def cast_bf16(x, out=None):
@@ -308,3 +333,96 @@ def spatial_attention(q, k, v):
     out = torch.empty_like(q)
     call('mmvid_spatial_attention', _p(q), _p(k), _p(v), N, HW, C, float(C)**-0.5, _p(scratch), _p(out), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------- samplers
+u8 = torch.uint8
+
+
+def exponential_like(shape, device):
+    """Exp(1) race variates for the samplers (what torch.multinomial draws internally), from torch's device generator."""
+    return torch.empty(shape, device=device, dtype=f32).exponential_()
+
+
+def sample_race(logits, E, noise_u=None, temperature=0.0, logit_div=1.0, tok_offset=0, want_y=True):
+    """logits [R, V] f32 (row stride = logits.stride(0)), E [R, V] f32 Exp(1) variates -> (tok int64 [R], y f32 [R])."""
+    _chk(E, f32, 'E')
+    assert logits.dtype == f32 and logits.is_cuda and logits.stride(1) == 1
+    R, V = logits.shape
+    assert E.shape == (R, V)
+    tok = torch.empty(R, device=logits.device, dtype=i64)
+    y = torch.empty(R, device=logits.device, dtype=f32) if want_y else None
+    if noise_u is not None:
+        _chk(noise_u, f32, 'noise_u')
+    call('mmvid_sample_race', _p(logits), logits.stride(0), _p(E), _p(noise_u), float(temperature), float(logit_div), R, V,
+         int(tok_offset), _p(tok), _p(y), _stream())
+    return tok, y
+
+
+def mp_select_keep(Y, E, preserve, k):
+    """Y [b, TS], E [b, Bm, TS], preserve [TS] uint8 or None -> mask1 [b, Bm, TS] uint8 (1 = position stays visible)."""
+    _chk(Y, f32, 'Y'), _chk(E, f32, 'E')
+    b, Bm, TS = E.shape
+    mask1 = torch.empty(b, Bm, TS, device=Y.device, dtype=u8)
+    call('mmvid_mp_select_keep', _p(Y), _p(E), _p(preserve), b, Bm, TS, int(k), _p(mask1), _stream())
+    return mask1
+
+
+def mp_build_input(control_emb, image_emb, tpos, I_tok, mask1, Bm, mask_id):
+    _chk(control_emb, f32, 'control_emb'), _chk(image_emb, f32, 'image_emb'), _chk(tpos, f32, 'tpos'), _chk(I_tok, i64, 'I_tok')
+    b, csl, E = control_emb.shape
+    TS = I_tok.shape[1]
+    out = torch.empty(b * Bm, csl + TS, E, device=control_emb.device, dtype=f32)
+    call('mmvid_mp_build_input', _p(control_emb), _p(image_emb), image_emb.shape[0], _p(tpos), _p(I_tok), _p(mask1), b, Bm, csl,
+         TS, E, int(mask_id), _p(out), _stream())
+    return out
+
+
+def mp_update(mask1, Ynew, Inew, rel_logit, vid_logit, t, dynamic, Y, I_tok, Imax, Smax, tmax, active, S_out=None,
+              jmax_out=None):
+    b, Bm, TS = mask1.shape
+    call('mmvid_mp_update', _p(mask1), _p(Ynew), _p(Inew), _p(rel_logit), _p(vid_logit), b, Bm, TS, int(t), int(dynamic),
+         _p(Y), _p(I_tok), _p(Imax), _p(Smax), _p(tmax), _p(active), _p(S_out), _p(jmax_out), _stream())
+
+
+def head_rows_fwd(x2d, rows, ln_w, ln_b, w, b, eps=1e-5, label=None, row_weight=None, den_from=None, den_const=1.0):
+    """z[r] = LN(x2d[rows[r]]) . w + b (the 768 -> 1 heads); with `label` also the BCE loss [1].  Returns
+    (z, mean, rstd, loss|None)."""
+    _chk(x2d, f32, 'x'), _chk(rows, i64, 'rows')
+    R, E = rows.numel(), x2d.shape[1]
+    dev = x2d.device
+    z, mean, rstd = (torch.empty(R, device=dev, dtype=f32) for _ in range(3))
+    loss = torch.empty(1, device=dev, dtype=f32) if label is not None else None
+    call('mmvid_head_bce_fwd', _p(x2d), x2d.stride(0), _p(rows), R, E, _p(ln_w), _p(ln_b), float(eps), _p(w), _p(b),
+         _p(label), _p(row_weight), _p(den_from), den_from.numel() if den_from is not None else 0, float(den_const), _p(z),
+         _p(mean), _p(rstd), _p(loss), _stream())
+    return z, mean, rstd, loss
+
+
+def head_rows_bwd(x2d, rows, ln_w, ln_b, w, z, mean, rstd, label, row_weight, den_from, den_const, gloss, dx2d, dw, db,
+                  dln_w, dln_b):
+    R, E = rows.numel(), x2d.shape[1]
+    call('mmvid_head_bce_bwd', _p(x2d), x2d.stride(0), _p(rows), R, E, _p(ln_w), _p(ln_b), _p(w), _p(z), _p(mean), _p(rstd),
+         _p(label), _p(row_weight), _p(den_from), den_from.numel() if den_from is not None else 0, float(den_const),
+         _p(gloss), _p(dx2d), dx2d.stride(0), _p(dw), _p(db), _p(dln_w), _p(dln_b), _stream())
+
+
+def bert_build_ids(text, visual_tok, nvis, target, target_warp, mask1, pad_base, mask_id, has_rel, has_vid, text_neg=None):
+    """-> (ids [(1+rel+vid)*B, L] int64, select_full [B*L] uint8, target_full [B*L] int64, select_count [1] f32)."""
+    _chk(text, i64, 'text'), _chk(target, i64, 'target')
+    B, Ttxt = text.shape
+    TS = target.shape[1]
+    Nvis = int(nvis)  # visual_tok None with nvis > 0: the visual segment is all [MASK] (dalle_bert.py:954-957)
+    assert visual_tok is None or visual_tok.shape == (B, Nvis)
+    L = 1 + Ttxt + Nvis + 2 + TS
+    nseq = 1 + int(has_rel) + int(has_vid)
+    dev = text.device
+    ids = torch.empty(nseq * B, L, device=dev, dtype=i64)
+    sel = torch.empty(B * L, device=dev, dtype=u8)
+    tfull = torch.empty(B * L, device=dev, dtype=i64)
+    cnt = torch.empty(1, device=dev, dtype=f32)
+    m1 = mask1 if mask1.dtype == u8 else mask1.to(u8)
+    call('mmvid_bert_build_ids', _p(text), _p(text_neg), _p(visual_tok), _p(target), _p(target_warp), _p(m1.contiguous()), B,
+         Ttxt, Nvis, TS, int(pad_base), int(mask_id), int(has_rel), int(has_vid), _p(ids), _p(sel), _p(tfull), _p(cnt),
+         _stream())
+    return ids, sel, tfull, cnt

@@ -168,11 +168,13 @@ class _Plan:
 
 
 class _Planner:
-    OP_IMG, OP_CONV, OP_GN, OP_CAST, OP_ATTN, OP_VQ, OP_GATHER, OP_NCHW = range(8)
+    OP_IMG, OP_CONV, OP_GN, OP_CAST, OP_ATTN, OP_VQ, OP_GATHER, OP_NCHW, OP_EXT = range(9)
+    STRICT = 16  # MMVID_VQFLAG_STRICT: the fp32-accurate operator (csrc/strict.hip); all planned tensors are fp32
 
-    def __init__(self, vae):
+    def __init__(self, vae, strict=False):
         self.vae, self.ops, self.free, self.top, self.recording = vae, [], [], 0, True
         self.patches, self.kept = [], {}
+        self.strict = strict
 
     # arena allocation: first fit in the free list, else bump
     def alloc(self, shape, dtype):
@@ -200,6 +202,11 @@ class _Planner:
         return len(self.ops) - 1
 
     def image(self, n, s):
+        if self.strict:
+            out = self.alloc((n, s, s, 4), f32)
+            i = self._op(op=self.OP_IMG, N=n, H=s, W=s, C=3, out_f32=out.off, flags=self.STRICT)
+            self.patches.append((i, 'ext_in', 'img'))
+            return out
         out = self.alloc((n, s, s, 8), bf16)
         i = self._op(op=self.OP_IMG, N=n, H=s, W=s, C=3, out_bf16=out.off)
         self.patches.append((i, 'ext_in', 'img'))
@@ -209,11 +216,17 @@ class _Planner:
         """feeds_gn: a GroupNorm reads this output next -> the epilogue also emits its partial statistics (when the
         shape allows), into a stats area that lives as long as the output buffer.
         also_bf16 (with out32): the epilogue stores a bf16 copy too (`out.bf16`), instead of a later cast pass."""
-        w, b, _ = self.vae._cw(holder)
+        w, b, _ = self.vae._cw(holder, self.strict)
         n, h, wd, cin = x.shape
-        assert x.dtype == bf16 and cin == w.shape[2], (x.shape, w.shape)
+        assert x.dtype == (f32 if self.strict else bf16) and cin == w.shape[2], (x.shape, w.shape)
         ho, wo = (h // 2, wd // 2) if mode == 1 else ((2 * h, 2 * wd) if mode == 2 else (h, wd))
         cout = w.shape[0]
+        if self.strict:
+            out = self.alloc((n, ho, wo, cout), f32)
+            self._op(op=self.OP_CONV, mode=mode, N=n, H=h, W=wd, C=cin, Cout=cout,
+                     flags=self.STRICT | (2 if clamp01 else 0), in0=x.off,
+                     in1=residual.off if residual is not None else -1, out_f32=out.off, w=w.data_ptr(), b=b.data_ptr())
+            return out
         out = self.alloc((n, ho, wo, cout), f32 if out32 else bf16)
         flags = (1 if (residual is not None and residual.dtype == f32) else 0) | (2 if clamp01 else 0)
         scratch = -1
@@ -235,6 +248,12 @@ class _Planner:
 
     def gn(self, x, holder, swish=True):
         n, h, wd, c = x.shape
+        if self.strict:
+            out = self.alloc(x.shape, f32)
+            st = self.alloc((n * 2 * c, ), f32)
+            self._op(op=self.OP_GN, mode=int(swish), N=n, H=h, W=wd, C=c, flags=self.STRICT, in0=x.off, out_f32=out.off,
+                     scratch=st.off, w=holder.weight.data_ptr(), b=holder.bias.data_ptr(), eps=1e-6)
+            return out
         out = self.alloc(x.shape, bf16)
         st = getattr(x, 'gn_stats', None)
         flags = (1 if x.dtype == f32 else 0) | (2 if st is not None else 0)
@@ -245,7 +264,7 @@ class _Planner:
         return out
 
     def cast(self, x):
-        if x.dtype == bf16:
+        if x.dtype == bf16 or self.strict:
             return x
         if getattr(x, 'bf16', None) is not None:  # the producing conv already stored the bf16 copy
             return x.bf16
@@ -257,6 +276,12 @@ class _Planner:
     def spatial_attention(self, q, k, v):
         n, h, wd, c = q.shape
         hw = h * wd
+        if self.strict:
+            out = self.alloc(q.shape, f32)
+            sc = self.alloc((2 * n * hw * hw, ), f32)
+            self._op(op=self.OP_ATTN, N=n, H=h, W=wd, C=c, flags=self.STRICT, in0=q.off, in1=k.off, in2=v.off,
+                     out_f32=out.off, scratch=sc.off, eps=float(c)**-0.5)
+            return out
         out = self.alloc(q.shape, bf16)
         sc = self.alloc((n * hw * hw * 3 // 2 + 64, ), f32)
         self._op(op=self.OP_ATTN, N=n, H=h, W=wd, C=c, in0=q.off, in1=k.off, in2=v.off, out_bf16=out.off,
@@ -272,10 +297,18 @@ class _Planner:
 
     def gather(self, n, hw):
         cb = self.vae.model.quantize.embedding.weight
-        out = self.alloc((n, hw, hw, cb.shape[1]), bf16)
-        i = self._op(op=self.OP_GATHER, N=n, H=hw, W=hw, C=cb.shape[1], Cout=cb.shape[0], out_bf16=out.off,
-                     w=cb.data_ptr())
+        out = self.alloc((n, hw, hw, cb.shape[1]), f32 if self.strict else bf16)
+        i = self._op(op=self.OP_GATHER, N=n, H=hw, W=hw, C=cb.shape[1], Cout=cb.shape[0], w=cb.data_ptr(),
+                     flags=self.STRICT if self.strict else 0, **{'out_f32' if self.strict else 'out_bf16': out.off})
         self.patches.append((i, 'ext_in', 'idx'))
+        return out
+
+    def external_z(self, n, hw, c):
+        """decode_train: z [n*hw*hw, c] fp32 computed outside the plan (probs @ codebook) enters here."""
+        out = self.alloc((n, hw, hw, c), f32 if self.strict else bf16)
+        i = self._op(op=self.OP_EXT, N=n, H=hw, W=hw, C=c, flags=self.STRICT if self.strict else 0,
+                     **{'out_f32' if self.strict else 'out_bf16': out.off})
+        self.patches.append((i, 'ext_in', 'z'))
         return out
 
     def to_nchw(self, x, cuse):
@@ -309,6 +342,9 @@ class VQGanVAE1024(nn.Module):
         self.num_layers = 4
         self.image_size = 256
         self.num_tokens = 1024
+        # strict = True: fp32-accurate encoder / decoder (csrc/strict.hip) -- token indices equal the reference's; the
+        # default bf16 MFMA path is ~20x faster and differs on near-ties of the codebook distances
+        self.strict = False
         self._prep = {}
         self._prep_key = None
 
@@ -320,10 +356,17 @@ class VQGanVAE1024(nn.Module):
             self._prep_key = key
         return self._prep
 
-    def _cw(self, holder):
-        """conv holder -> (w bf16 [Cout_p, taps, Cin_p], bias f32 [Cout_p], Cout)."""
+    def _cw(self, holder, strict=False):
+        """conv holder -> (w bf16 [Cout_p, taps, Cin_p], bias f32 [Cout_p], Cout); strict: w fp32 [Cout, taps, Cin_p4]."""
         prep = self._prepared()
-        k = id(holder)
+        k = (id(holder), strict)
+        if strict and k not in prep:
+            w, b = holder.weight.detach().float(), holder.bias.detach().float()
+            cout, cin, kh, kw = w.shape
+            cin_p = max(4, _pow2_at_least8(cin) if cin > 4 else 4)
+            wp = torch.zeros(cout, kh * kw, cin_p, device=w.device, dtype=f32)
+            wp[:, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+            prep[k] = (wp.contiguous(), b.contiguous(), cout)
         if k not in prep:
             w, b = holder.weight.detach(), holder.bias.detach()
             cout, cin, kh, kw = w.shape
@@ -344,11 +387,13 @@ class VQGanVAE1024(nn.Module):
     # ---- planning: the op sequence of one encode / decode for a given batch shape ------------------------------
     def _plan(self, kind, n, size_or_hw):
         prep = self._prepared()
-        key = ('plan', kind, n, size_or_hw)
+        key = ('plan', kind, n, size_or_hw, bool(self.strict))
         if key not in prep:
-            pl = _Planner(self)
+            pl = _Planner(self, strict=bool(self.strict))
             if kind == 'enc':
                 self._plan_encode(pl, n, size_or_hw)
+            elif kind == 'dec_z':
+                self._plan_decode(pl, n, size_or_hw, from_z=True)
             else:
                 self._plan_decode(pl, n, size_or_hw)
             prep[key] = pl.finish(next(self.model.parameters()).device)
@@ -404,10 +449,12 @@ class VQGanVAE1024(nn.Module):
         pl.keep('z', z)
         pl.vq_argmin(z)
 
-    def _plan_decode(self, pl, n, hw):
-        """codebook gather (vae.py:50) + post_quant_conv + Decoder.forward (model.py:551-582) + vae.py:55."""
+    def _plan_decode(self, pl, n, hw, from_z=False):
+        """codebook gather (vae.py:50) + post_quant_conv + Decoder.forward (model.py:551-582) + vae.py:55.
+        from_z: the quantised map arrives as an external fp32 tensor instead (decode_train, vae.py:58-68)."""
         dec = self.model.decoder
-        h = pl.conv(pl.gather(n, hw), self.model.post_quant_conv, 3)
+        z0 = pl.external_z(n, hw, self.model.quantize.embedding.weight.shape[1]) if from_z else pl.gather(n, hw)
+        h = pl.conv(z0, self.model.post_quant_conv, 3)
         h = pl.conv(h, dec.conv_in, 0, out32=True, feeds_gn=True)
         h = self._plan_resblock(pl, h, dec.mid.block_1)
         h = self._plan_attn(pl, h, dec.mid.attn_1)
@@ -459,9 +506,20 @@ class VQGanVAE1024(nn.Module):
             return out
 
     def decode_train(self, probs):
-        """vae.py:58-68 (soft one-hot @ codebook -> decoder).  Not on the benchmarked path and never called by the
-        reference's drivers; the hard-index `decode` is the supported entry point."""
-        raise NotImplementedError('decode_train (vae.py:58-68) is not part of the hot path; use decode(img_seq)')
+        """vae.py:58-68: probs [B, N, num_tokens] (soft one-hot) @ codebook -> decoder -> [B,3,S,S] in [0,1].
+        The soft lookup is the exact-fp32 matrix kernel; the decoder is the planned op list of `decode`.  The VQGAN is
+        frozen and no caller of the reference differentiates through it, so this is a forward-only entry point."""
+        with torch.no_grad():
+            probs = ops._chk(probs.contiguous().float(), f32, 'probs')
+            b, n, d = probs.shape
+            cb = self.model.quantize.embedding.weight.detach()
+            assert d == cb.shape[0], f'probs last dim {d} != codebook size {cb.shape[0]}'
+            hw = int(sqrt(n))
+            z = ops.gemm_f32(probs.view(b * n, d), cb, b_kmajor=True)  # [b*n, embed_dim] = probs @ codebook
+            plan = self._plan('dec_z', b, hw)
+            out = torch.empty(b, 3, hw * 16, hw * 16, device=probs.device, dtype=f32)
+            plan.run(ext_in={'z': z}, ext_out={'img': out})
+            return out
 
     def forward(self, img):
         raise NotImplementedError  # as the reference (vae.py:70-71)

@@ -141,3 +141,31 @@ def test_artv_logits_loss_and_sampling(golden):
         random.seed(5), np.random.seed(5), torch.manual_seed(5)
         imgs, _ = artv.generate_images(sd, cfg, text[:1], vt[:1])
         assert relerr(imgs[:, :, :, ::8, ::8], g['gen_images_s']) <= TOL
+
+
+def test_race_sampler_matches_multinomial_distributions():
+    """oracle/sampling.py (randomness injected as Exp(1) race variates) draws from the distributions torch.multinomial
+    draws from -- the form oracle/bert.py::mask_predict uses and the reference golden trajectory pins."""
+    from oracle import sampling as S
+    rng = np.random.RandomState(0)
+    p = np.array([0.45, 0.25, 0.15, 0.1, 0.05], np.float32)
+    n = 40000
+    tok, Y, P = S.token_race(np.log(p)[None].repeat(n, 0), rng.exponential(size=(n, 5)).astype(np.float32))
+    freq = np.bincount(tok, minlength=5) / n
+    assert np.abs(freq - p).max() < 4 * np.sqrt(0.25 / n)
+    assert np.allclose(Y, p[tok], rtol=1e-5)
+    w = np.array([0.4, 0.3, 0.2, 0.1, 0.0, 0.25], np.float32)
+    inc = np.zeros(6)
+    for _ in range(6000):
+        inc += S.keep_race(w, rng.exponential(size=6).astype(np.float32), None, 3)
+    ref = torch.zeros(6)
+    torch.manual_seed(0)
+    for _ in range(6000):
+        ref[torch.multinomial(torch.from_numpy(w), 3, replacement=False)] += 1
+    assert np.abs(inc / 6000 - ref.numpy() / 6000).max() < 0.03 and inc[4] == 0
+    # the reference's except-branch: an impossible request degrades to ONE kept position
+    assert S.keep_race(w, rng.exponential(size=6).astype(np.float32), None, 0).sum() == 1
+    assert S.keep_race(w, rng.exponential(size=6).astype(np.float32), None, 6).sum() == 1
+    pres = np.array([1, 0, 0, 0, 0, 0], bool)
+    k = S.keep_race(w, rng.exponential(size=6).astype(np.float32), pres, 2)
+    assert k[0] and k.sum() == 3
