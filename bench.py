@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: video-tokens/sec of one full MMVID training step on MI355X.
 
-Workload (BASELINE.json configs[1]): text_to_video, 8 frames of 128x128, 64 text tokens
-(L = 579), full BERT (CLIP ViT-B/32-shaped tower, 12 layers) + full VQGAN (encoder runs inside the step: 16
-frames per sample), bf16 MFMA compute with fp32 accumulation / fp32 master weights, losses 7*MSM + 0.5*REL +
-0.5*VID (three transformer passes), backward, clip_grad_norm_(1.0) and Adam -- i.e. everything train.py:298-325
-of the reference does per iteration.  Synthetic inputs, random-init weights, per-GPU batch 6 (= the recipe's 48/8).
+Default workload (--config 2 = BASELINE.json configs[1]): text_to_video, 8 frames of 128x128, 64 text
+tokens (L = 579), full BERT (CLIP ViT-B/32-shaped tower, 12 layers) + full VQGAN (the encoder runs inside the step: 16
+frames per sample), bf16 MFMA compute with fp32 accumulation / fp32 master weights, losses 7*MSM + 0.5*REL + 0.5*VID
+(three transformer passes), backward, clip_grad_norm_(1.0) and Adam under the WarmupLR schedule -- everything
+train.py:298-325 of the reference does per iteration, including the stochastic front-end (masking strategies, VID warp),
+which is drawn on the device.  Synthetic inputs, random-init weights, per-GPU batch 6 (= the recipe's 48 / 8).
+Other BASELINE configs, for driver-visible numbers next to the headline:
+  --config 4   text_and_mask (one visual control frame through the cvae, vc_mode mask_8x8, L = 643), per-GPU batch 2
+  --config 5   dalle_artv generate_images, 16 frames (1,024 sampled tokens per video, L = 1152), batch 4: a "step" is one
+               call; value = sampled video tokens / s.  Also reports the ART-V training step.
 
   python bench.py --gpus N --steps K --warmup W        (N > 1 via `python -m torch.distributed.run ...`)
 
-Prints ONE JSON line on rank 0: value = whole-job video tokens / second (512 per sample), a `roofline` object for
-the dominant kernel (HIP-event timed inside the timed region) and, at N = 1, a `cpu_baseline` object (the fp32
-CPU oracle timed on the host cores on a bounded sample of the same workload).
+Prints ONE JSON line on rank 0: value = whole-job video tokens / second, a `roofline` object for the dominant kernel
+(HIP-event timed inside the timed region) and, at N = 1 / config 2, a `cpu_baseline` object (the fp32 CPU oracle timed on
+the host cores on a bounded sample of the same workload).  The step is ONE hipGraph replay at every N: with
+torch.distributed the bucketed RCCL all-reduces are captured inside it, overlapped with the backward.
 """
 import argparse
 import ctypes
@@ -23,8 +29,8 @@ import time
 
 # A GPU box shows all of the node's hardware threads (256) but grants a cgroup quota of a few cores.  Thread pools
 # sized by the former (OpenMP, OpenBLAS) overrun the quota the moment they wake up and the kernel then throttles the
-# whole process for the rest of the period -- including the thread that launches GPU work (cpu.stat: throttled 12.7 s
-# over three benchmark runs before this).  Must happen before numpy / torch are imported.
+# whole process for the rest of the period -- including the thread that launches GPU work.  Must happen before numpy /
+# torch are imported.
 for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
     os.environ.setdefault(_v, '4')
 
@@ -35,81 +41,98 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TEXT_LEN, FRAMES, SIZE, TOK_PER_SAMPLE = 64, 8, 128, 512
+TEXT_LEN, SIZE = 64, 128
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PROF_EVERY = 10  # every 10th timed step (at least the last one) runs eagerly with per-launch HIP events; the others are graph replays
 CLASS_NAMES = ['gemm_bf16_kernel<A.B^T> (forward)', 'gemm_bf16_kernel<dX>', 'gemm_bf16_kernel<dW>',
                'conv_igemm_kernel (VQGAN)', 'attn_fwd_kernel', 'attn_bwd (dq+dkv)']
+MSM_PROB, MSM_BERN, VID_PROB = [0.7, 0.1, 0.1, 0.1], [0.2, 0.2], [0.25, 0.25, 0.25, 0.25]
+WORKLOADS = {
+    2: ('text_to_video 8-frame 128x128, 64 text tokens (L=579), full dalle_bert (12-layer CLIP ViT-B/32 tower) + VQGAN '
+        'encode in-step, device front-end, MSM+REL+VID, backward, clip+Adam (WarmupLR)'),
+    4: ('text_and_mask 8-frame 128x128 + 1 visual control frame through the cvae (vc_mode mask_8x8), 64 text tokens (L=643), '
+        'full dalle_bert + 2 VQGANs in-step, MSM+REL+VID, backward, clip+Adam'),
+    5: ('dalle_artv generate_images 16-frame 128x128 (1,024 sampled tokens per video over a KV cache, L=1152, 51,584 '
+        'classes) + VQGAN decode'),
+}
 
 
-def build_model(device, layers=12):
-    from mmvid_amd.dalle_bert import BERT
+def build_model(cfg, device, layers=12):
     from mmvid_amd.vae import VQGanVAE1024
     vae = VQGanVAE1024(None, SIZE)
     vae.image_size = SIZE
-    model = BERT(dim=768, vae=vae, cvae=None, num_text_tokens=49408, text_seq_len=TEXT_LEN,
-                 which_transformer='openai_clip_visual', num_visuals=0, num_targets=FRAMES, transformer_layers=layers)
+    if cfg == 5:
+        from mmvid_amd.dalle_artv import DALLE
+        m = DALLE(dim=768, vae=vae, cvae=None, num_text_tokens=49408, text_seq_len=TEXT_LEN, which_transformer='openai_clip_visual',
+                  num_visuals=1, num_targets=16, transformer_layers=layers)
+        return m.to(device)
+    from mmvid_amd.dalle_bert import BERT
+    cvae = None
+    if cfg == 4:
+        cvae = VQGanVAE1024(None, SIZE)
+        cvae.image_size = SIZE
+    model = BERT(dim=768, vae=vae, cvae=cvae, num_text_tokens=49408, text_seq_len=TEXT_LEN,
+                 which_transformer='openai_clip_visual', num_visuals=1 if cfg == 4 else 0, num_targets=8, transformer_layers=layers)
     return model.to(device)
 
 
-def synth_batch(B, device, gen):
+def synth_batch(B, frames, device, gen, visuals=0):
     text = torch.randint(1, 49408, (B, TEXT_LEN), generator=gen)
     lens = torch.randint(8, TEXT_LEN + 1, (B, ), generator=gen)
     text[torch.arange(TEXT_LEN)[None, :] >= lens[:, None]] = 0  # padded tail
-    frames = torch.rand(B, FRAMES, 3, SIZE, SIZE, generator=gen)
-    return text.to(device), frames.to(device)
+    out = {'text': text.to(device), 'frames': torch.rand(B, frames, 3, SIZE, SIZE, generator=gen).to(device)}
+    if visuals:
+        out['visual'] = torch.rand(B, visuals, 3, SIZE, SIZE, generator=gen).to(device)
+    return out
 
 
-def train_step(model, trainer, text, frames):
-    trainer.zero_grad()
-    lm, lr, lv = model(text, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
-                       msm_strategy_prob=MSM_PROB, msm_bernoulli_prob=MSM_BERN, vid_strategy_prob=VID_PROB)
-    loss = 7.0 * lm + 0.5 * lr + 0.5 * lv
-    loss.backward()
-    trainer.step()
-    return loss
+def loss_fn(model, cfg):
+    """The step's forward as a capture-safe function of the data tensors: every random choice is drawn on the device."""
+    if cfg == 4:
+        def fn(text, frames, visual):
+            lm, lr, lv = model(text, visual=visual, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
+                               vc_mode='mask_8x8', msm_strategy_prob=MSM_PROB, msm_bernoulli_prob=MSM_BERN, vid_strategy_prob=VID_PROB)
+            return 7.0 * lm + 0.5 * lr + 0.5 * lv
+        return fn
 
-
-MSM_PROB, MSM_BERN, VID_PROB = np.array([0.7, 0.1, 0.1, 0.1]), [0.2, 0.2], np.array([0.25, 0.25, 0.25, 0.25])
-
-
-def loss_fn(model):
-    """The device part of the step as a capture-safe function of tensors (engine.GraphedStep): the host-side random
-    choices -- masking strategies and the VID warp (dalle_bert.py:992-1029, 1094) -- arrive as inputs."""
-    def fn(text, frames, mask1, nfm, warped):
+    def fn(text, frames):
         lm, lr, lv = model(text, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
-                           _mask1=mask1, _not_fully_masked=nfm, _target_warp=warped)
+                           msm_strategy_prob=MSM_PROB, msm_bernoulli_prob=MSM_BERN, vid_strategy_prob=VID_PROB)
         return 7.0 * lm + 0.5 * lr + 0.5 * lv
     return fn
 
 
-def host_random_inputs(model, text, frames):
-    """Same RNG call order as BERT.forward (mask strategies first, then the warp)."""
-    from mmvid_amd.dalle_bert import warp
-    mask1, nfm = model._msm_mask(text.shape[0], text.device, MSM_PROB, MSM_BERN, 0)
-    warped = warp(frames.detach(), VID_PROB).to(text.device)
-    return {'text': text, 'frames': frames, 'mask1': mask1, 'nfm': nfm, 'warped': warped}
+def eager_step(trainer, fn, batch):
+    trainer.zero_grad()
+    loss = fn(**batch)
+    loss.backward()
+    trainer.step()
+    return loss.detach()
 
 
 def pmc_traffic(prefix):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_{fetch,write}_size.csv: `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate runs, kernel-trace only).
-    Units are KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads, so it is doubled
-    (MI355X_MICROARCH.md, HBM; cross-checked on adam_kernel: 2 x FETCH = 16.0 B, WRITE = 14.0 B per parameter)."""
+    (profiles/rNN_pmc_{fetch,write}_size.csv: `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate runs, kernel-trace only;
+    the newest round present is used).  Units are KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
+    reads, so it is doubled (MI355X_MICROARCH.md, HBM; cross-checked on adam_kernel: 2 x FETCH = 16.0 B, WRITE = 14.0 B per
+    parameter)."""
     import csv
-    tot, disp = 0.0, 0
-    try:
-        for name, mult in (('fetch', 2.0), ('write', 1.0)):
-            d = 0
-            with open(os.path.join(ROOT, 'profiles', f'r01_pmc_{name}_size.csv')) as fh:
-                for r in csv.DictReader(fh):
-                    if r['kernel'].startswith(prefix):
-                        tot += mult * float(r['total']) * 1024.0
-                        d += int(r['dispatches'])
-            disp = d
-        return tot / disp if disp else None
-    except OSError:
-        return None
+    for rnd in ('r02', 'r01'):
+        tot, disp = 0.0, 0
+        try:
+            for name, mult in (('fetch', 2.0), ('write', 1.0)):
+                d = 0
+                with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{name}_size.csv')) as fh:
+                    for r in csv.DictReader(fh):
+                        if r['kernel'].startswith(prefix):
+                            tot += mult * float(r['total']) * 1024.0
+                            d += int(r['dispatches'])
+                disp = d
+            if disp:
+                return tot / disp
+        except OSError:
+            continue
+    return None
 
 
 def host_cores():
@@ -136,10 +159,11 @@ def cpu_baseline(model, B=2, budget_s=60.0):
     train_keys = [k for k in sd if not k.startswith(('vae.', 'cvae.'))]
     for k in train_keys:
         sd[k].requires_grad_(True)
-    cfg = ob.Cfg(sd, TEXT_LEN, 0, FRAMES, SIZE)
+    cfg = ob.Cfg(sd, TEXT_LEN, 0, 8, SIZE)
     opt = torch.optim.Adam([sd[k] for k in train_keys], lr=1e-4)
     gen = torch.Generator().manual_seed(1)
-    text, frames = synth_batch(B, 'cpu', gen)
+    batch = synth_batch(B, 8, 'cpu', gen)
+    text, frames = batch['text'], batch['frames']
 
     def step():
         t0 = time.time()
@@ -162,20 +186,113 @@ def cpu_baseline(model, B=2, budget_s=60.0):
         used += times[-1]
     t = float(np.mean(times)) if times else warm
     note = f'{len(times)} timed' if times else 'warm-up only (budget exceeded)'
-    return {'value': B * TOK_PER_SAMPLE / t, 'unit': 'video-tokens/s', 'cores': cores, 'kind': 'port',
+    return {'value': B * 512 / t, 'unit': 'video-tokens/s', 'cores': cores, 'kind': 'port',
             'sample': f'full training step at batch {B} (config 2 shapes, fp32 torch-CPU oracle): {note} step(s), {t:.2f} s/step'}
+
+
+def fence():
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def comm_report(trainer, step_ms, world):
+    """Gradient exchange on its own (whole flat buffer, same bucketing), for the bus-bandwidth / overlap figures."""
+    if world == 1 or not dist.is_initialized():
+        return None
+    try:
+        fence()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            trainer._send(0, trainer.numel)
+            for w in trainer._works:
+                w.wait()
+            trainer._works = []
+            torch.cuda.current_stream().wait_stream(trainer._comm_stream)
+        fence()
+        ar_ms = (time.perf_counter() - t0) / reps * 1e3
+        wire = 2.0 * (world - 1) / world * 4.0 * trainer.numel  # bytes per GPU on the links, ring-equivalent
+        return {'allreduce_alone_ms': ar_ms, 'bytes_per_gpu_on_wire': wire, 'bus_bandwidth_GBps': wire / (ar_ms * 1e-3) / 1e9,
+                'gradient_bytes': 4.0 * trainer.numel, 'note': 'overlap = 1 - (step - step_without_exchange) / allreduce_alone'}
+    except Exception as e:  # never lose the headline line to a diagnostics failure
+        return {'error': repr(e)}
+
+
+def run_artv_sampling(args, device, rank, world):
+    """--config 5: a 'step' = one DALLE.generate_images call (b videos x 1,024 sampled tokens + VQGAN decode)."""
+    model = build_model(5, device, args.layers).eval()
+    b = args.batch or 4
+    gen = torch.Generator().manual_seed(42 + rank)
+    batch = synth_batch(b, 1, device, gen, visuals=1)
+    vis_tok = torch.randint(0, 1024, (b, 64), generator=gen).to(device)
+    call = lambda: model.generate_images(batch['text'], visual=vis_tok)
+    for _ in range(max(1, args.warmup)):
+        call()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        images = call()[0]
+    fence()
+    dt = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    # ART-V training step (dalle_artv.py:418-542) on the same model: tokens in, loss, backward, Adam
+    from mmvid_amd.engine import FlatTrainer, backward_order
+    model.train()
+    tr = FlatTrainer(model, lr=1e-4, max_grad_norm=1.0, order=backward_order)
+    tt = torch.randint(0, 1024, (b, 1024), generator=gen).to(device)
+    def tstep():
+        tr.zero_grad()
+        loss = model(batch['text'], visual=vis_tok, target=tt, return_loss=True)[0]
+        loss.backward()
+        tr.step()
+        return loss
+    tstep(), tstep()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        loss = tstep()
+    fence()
+    train_ms = (time.perf_counter() - t1) / 3 * 1e3
+    if rank != 0:
+        return
+    per_call = dt / args.steps
+    tokens = world * b * 1024
+    # a decode step streams every tower weight once: 12 layers x 7.08 M matrix params x 2 B (bf16) + the image block of the head
+    stream_bytes = args.layers * (4 * 768 * 768 + 2 * 768 * 3072) * 2 + 1024 * 768 * 2
+    step_s = per_call / 1024
+    out = {'metric': 'video-tokens/sec training step, 8-frame 128px text-to-video', 'value': tokens / per_call, 'unit': 'video-tokens/s',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': per_call * 1e3, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+           'config': {'workload': WORKLOADS[5], 'config_id': 5, 'per_gpu_batch': b, 'seq_len': 1152, 'parallelism': f'replicas{world}',
+                      'layers': args.layers, 'note': 'value counts SAMPLED tokens (inference), not training tokens'},
+           'roofline': {'bound': 'hbm', 'kernel': 'decode step (weight streaming, batch %d)' % b, 'achieved': stream_bytes / step_s / 1e9,
+                        'peak': 8000.0, 'unit': 'GB/s', 'frac': stream_bytes / step_s / 1e9 / 8000.0, 'traffic': None,
+                        'ms_per_token_step': step_s * 1e3, 'algorithmic_bytes_per_step': stream_bytes},
+           'artv_train_step': {'ms_per_step': train_ms, 'video_tokens_per_s': b * 1024 / (train_ms * 1e-3), 'per_gpu_batch': b,
+                               'loss': float(loss.detach())},
+           'image_checksum': float(images.float().mean())}
+    print(json.dumps(out))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=6, help='per-GPU batch (even; the recipe is 48 / 8 GPUs)')
+    ap.add_argument('--config', type=int, default=2, choices=sorted(WORKLOADS), help='BASELINE.json config (1-based): 2 headline, 4, 5')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (even; config 2: the recipe is 48 / 8 GPUs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='launch every step from Python instead of replaying the captured step graph')
+    ap.add_argument('--force-exchange', action='store_true', help='run the gradient all-reduce path even with one rank (tests)')
     ap.add_argument('--layers', type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the model
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 2 if args.config == 5 else 10
 
     # a GPU box exposes all 256 hardware threads but a cgroup quota of a few cores: keep torch's CPU pool small so that
     # incidental host ops never fan out over hundreds of spinning OpenMP threads (cpu_baseline() sets its own count)
@@ -194,7 +311,7 @@ def main():
 
     from mmvid_amd import _lib
     from mmvid_amd.build import build
-    from mmvid_amd.engine import FlatTrainer, GraphedStep, backward_order, broadcast_parameters
+    from mmvid_amd.engine import FlatTrainer, GraphedStep, WarmupLR, backward_order, broadcast_parameters
     if local == 0:
         build()  # a no-op when the in-tree library is current (it is built by __graft_entry__.build())
     if dist.is_initialized():
@@ -202,45 +319,49 @@ def main():
     # seed_everything(seed + rank) as train.py:87; identical initial weights come from the rank-0 broadcast
     seed = 42 + rank
     random.seed(seed), np.random.seed(seed), torch.manual_seed(seed)
-    model = build_model(device, args.layers)
+    if args.config == 5:
+        run_artv_sampling(args, device, rank, world)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
+    model = build_model(args.config, device, args.layers)
+    model.frontend.seed = seed  # every rank draws its own masks / warps
     broadcast_parameters(model)
     model.train()
-    trainer = FlatTrainer(model, lr=1e-4, max_grad_norm=1.0, order=backward_order)
+    trainer = FlatTrainer(model, lr=1e-4, max_grad_norm=1.0, order=backward_order, force_exchange=args.force_exchange,
+                          lr_schedule=WarmupLR(1e-6, 1e-4, 5000, every=1))
     gen = torch.Generator().manual_seed(seed)
-    B = args.batch
-    text, frames = synth_batch(B, device, gen)
+    B = args.batch or (6 if args.config == 2 else 2)
+    batch = synth_batch(B, 8, device, gen, visuals=1 if args.config == 4 else 0)
+    fn = loss_fn(model, args.config)
+    tok_per_sample = 512
 
-    # Single process: the step is replayed as ONE hipGraph (the host then only draws the random masks / warp and
-    # copies them in); with torch.distributed the eager step keeps the overlapped bucketed all-reduce.
-    use_graph = world == 1 and not args.eager
+    # The step is replayed as ONE hipGraph at every world size (with torch.distributed the bucketed all-reduces are captured
+    # inside it, between the backward chunks they overlap with).  The host only calls replay.
+    use_graph = not args.eager
     graph_warm = min(2, args.warmup) if use_graph else 0
     for _ in range(args.warmup - graph_warm):
-        train_step(model, trainer, text, frames)
-    graphed = None
+        eager_step(trainer, fn, batch)
+    graphed, step_launch = None, 'eager'
     if use_graph:
-        graphed = GraphedStep(trainer, loss_fn(model), host_random_inputs(model, text, frames), warmup=graph_warm)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
+        graphed = GraphedStep(trainer, fn, batch, warmup=graph_warm)
+        step_launch = 'hipGraph replay' if graphed.graph is not None else f'eager (capture failed: {graphed.capture_error})'
 
     lib = _lib.load()
     fence()
     lib.mmvid_prof_begin(1)
     lib.mmvid_prof_enable(0)
     t0 = time.perf_counter()
-    host_s = 0.0  # time the host spends issuing the steps (it runs ahead of the GPU; ~= dt means host-bound)
+    host_s = 0.0  # time the host spends issuing the steps (it runs ahead of the GPU; ~= dt would mean host-bound)
     for i in range(args.steps):
         th = time.perf_counter()
         timed = i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY and i == args.steps - 1
-        if timed or graphed is None:  # per-launch HIP events need direct launches
+        if timed or graphed is None or graphed.graph is None:  # per-launch HIP events need direct launches
             lib.mmvid_prof_enable(1 if timed else 0)
-            loss = train_step(model, trainer, text, frames)
+            loss = eager_step(trainer, fn, batch)
             lib.mmvid_prof_enable(0)
         else:
-            loss = graphed(**host_random_inputs(model, text, frames))
+            loss = graphed()
         host_s += time.perf_counter() - th
     fence()
     dt = time.perf_counter() - t0
@@ -251,13 +372,27 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    comm = comm_report(trainer, dt / args.steps * 1e3, world)
+    if comm and 'error' not in comm and graphed is not None and graphed.graph is not None:
+        try:  # the same captured step without the exchange -> how much of the all-reduce is hidden behind the backward
+            trainer.exchange_enabled = False
+            nocomm = GraphedStep(trainer, fn, batch, warmup=0)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                nocomm()
+            fence()
+            base_ms = (time.perf_counter() - t1) / 5 * 1e3
+            trainer.exchange_enabled = True
+            exposed = max(0.0, dt / args.steps * 1e3 - base_ms)
+            comm.update(step_without_exchange_ms=base_ms, exposed_ms=exposed,
+                        overlap_frac=max(0.0, 1.0 - exposed / comm['allreduce_alone_ms']))
+        except Exception as e:
+            comm['overlap_error'] = repr(e)
 
-    gs = (ctypes.c_int64 * 3)()
-    lib.mmvid_graph_stats(gs)
-    graph_stats = {'direct': int(gs[0]), 'captured': int(gs[1]), 'replayed': int(gs[2])}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * B * TOK_PER_SAMPLE / (dt / args.steps)
+        value = world * B * tok_per_sample / (dt / args.steps)
         print(f'[bench] {ms_per_step:.2f} ms/step, {value:.0f} video-tokens/s on {world} GPU(s); host issue time '
               f'{host_s / args.steps * 1e3:.2f} ms/step, load average {os.getloadavg()[0]:.1f} on {host_cores()} usable cores',
               file=sys.stderr, flush=True)
@@ -277,19 +412,21 @@ def main():
                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes committed under profiles/)',
                         'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches_per_step'],
                         'timed_steps': n_timed_steps}
+        L = model.total_seq_len
         out = {
             'metric': 'video-tokens/sec training step, 8-frame 128px text-to-video', 'value': value,
             'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'text_to_video 8-frame 128x128, 64 text tokens (L=579), full dalle_bert (12-layer '
-                                   'CLIP ViT-B/32 tower) + VQGAN encode in-step, MSM+REL+VID, backward, clip+Adam',
-                       'per_gpu_batch': B, 'global_batch': world * B, 'seq_len': 579, 'parallelism': f'dp{world}', 'step_launch': 'hipGraph replay' if graphed is not None else 'eager',
-                       'layers': args.layers},
-            'loss': float(loss.detach()), 'roofline': roofline, 'kernels': kernels, 'graphs': graph_stats,
+            'config': {'workload': WORKLOADS[args.config], 'config_id': args.config, 'per_gpu_batch': B, 'global_batch': world * B,
+                       'seq_len': L, 'parallelism': f'dp{world}', 'step_launch': step_launch, 'layers': args.layers},
+            'loss': float(loss.detach()), 'roofline': roofline, 'kernels': kernels,
             'host_issue_ms_per_step': host_s / args.steps * 1e3, 'host_load_average': os.getloadavg()[0],
+            'lr_device_scalar': float(trainer._lr_dev), 'optimizer_steps': trainer.step_count,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if comm:
+            out['gradient_exchange'] = comm
+        if world == 1 and args.config == 2 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model)
         print(json.dumps(out))
     if dist.is_initialized():

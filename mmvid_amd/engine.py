@@ -47,9 +47,12 @@ class WarmupLR:
 
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 process_group=None, bucket_mb=64, order=None, lr_schedule=None):
+                 process_group=None, bucket_mb=64, order=None, lr_schedule=None, force_exchange=False):
         self.model = model
         self.lr_schedule = lr_schedule
+        # force_exchange: run the all-reduce path even in a group of one (exercises RCCL + graph capture on a 1-GPU box)
+        self.force_exchange = bool(force_exchange) and dist.is_available() and dist.is_initialized()
+        self.exchange_enabled = True
         params = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if order is not None:
             params = order(params)
@@ -176,7 +179,7 @@ class FlatTrainer:
 
     def _send(self, lo, hi):
         """All-reduce G[lo:hi] (SUM) on the side stream, in messages of at most bucket_elems."""
-        if self.world == 1 or hi <= lo:
+        if (self.world == 1 and not self.force_exchange) or hi <= lo or not self.exchange_enabled:
             return
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
@@ -199,7 +202,7 @@ class FlatTrainer:
 
     def allreduce_grads(self):
         """Send whatever is still local (embedding tables, or everything when no callback fired) and wait."""
-        if self.world > 1:
+        if self.world > 1 or self.force_exchange:
             self._send(0, self._sent_from)
             for w in self._works:
                 w.wait()
@@ -235,32 +238,58 @@ class FlatTrainer:
 
 
 class GraphedStep:
-    """One training step -- zero_grad, forward, backward, clip + Adam -- as ONE hipGraph (torch.cuda.CUDAGraph).
+    """One training step -- zero_grad, forward, backward, gradient exchange, clip + Adam -- as ONE hipGraph
+    (torch.cuda.CUDAGraph).
 
-    The step is ~700 kernel launches issued from Python and from the native layer loops; replayed as a graph it costs
-    the host one call, so a slow or contended host can no longer stall the GPU.  `fn(**inputs)` returns the loss and
-    must be capture-safe: device work only (no host reads, no host-to-device uploads), fixed shapes, every random
-    choice made by the caller BEFORE the call and passed in as a tensor.  Single process only: with world_size > 1
-    the eager path keeps the overlapped bucketed all-reduce.
+    The step is several hundred kernel launches issued from Python and from the native layer loops; replayed as a graph
+    it costs the host one call, so a slow or contended host (8 ranks sharing a 16-core quota) can no longer stall the GPU.
+    `fn(**inputs)` returns the loss and must be capture-safe: device work only, fixed shapes; the stochastic front-end
+    draws on the device from a device step counter, so replays need no host input at all.
+
+    With torch.distributed the bucketed all-reduces are captured too: the tower backward returns to the host every few
+    layers DURING CAPTURE, `FlatTrainer.layers_done` enqueues the finished range on the communication stream (which
+    joins the capture through an event), and the replayed graph carries the same fork / join dependencies -- RCCL
+    kernels overlapping the remaining backward.  If the runtime refuses to capture a collective, the step falls back to
+    eager launches (`graph is None`, `capture_error` says why).
 
         step = GraphedStep(trainer, fn, example_inputs)      # runs `warmup` real steps, then captures
-        loss = step(text=..., frames=..., ...)               # copies into the static inputs, replays
+        loss = step()                                        # replay on the static inputs
+        loss = step(text=..., frames=...)                    # copy new data into the static inputs, then replay
     """
 
     def __init__(self, trainer, fn, example_inputs, warmup=2):
-        assert trainer.world == 1, 'GraphedStep is single-process; use the eager step with torch.distributed'
         self.trainer, self.fn = trainer, fn
         self.static = {k: v.clone() for k, v in example_inputs.items()}
+        self.graph, self.capture_error = None, None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires (real training steps)
             for _ in range(warmup):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._step()
-        trainer.step_count -= 1  # the capture pass enqueued nothing: it was not a step
+        torch.cuda.synchronize()
+        saved = (trainer.step_count, trainer._step_dev.clone(), self._frontend_steps())
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                self.loss = self._step()
+            self.graph = graph
+        except Exception as e:  # e.g. a collective that cannot be captured: keep training, eagerly
+            self.capture_error = f'{type(e).__name__}: {e}'.splitlines()[0][:200]
+            torch.cuda.synchronize()
+        # the capture pass enqueued nothing: it was not a step
+        trainer.step_count = saved[0]
+        trainer._step_dev.copy_(saved[1])
+        self._frontend_steps(saved[2])
+
+    def _frontend_steps(self, restore=None):
+        fe = getattr(self.trainer.model, 'frontend', None)
+        if fe is None or fe.step is None:
+            return None
+        if restore is not None:
+            fe.step.copy_(restore)
+            return None
+        return fe.step.clone()
 
     def _step(self):
         self.trainer.zero_grad()
@@ -272,6 +301,8 @@ class GraphedStep:
     def __call__(self, **inputs):
         for k, v in inputs.items():
             self.static[k].copy_(v, non_blocking=True)
+        if self.graph is None:
+            return self._step()
         self.graph.replay()
         self.trainer.step_count += 1
         return self.loss
