@@ -128,6 +128,16 @@ int mmvid_msm_masks(uint64_t seed, const float* step_dev, int B, int T, int f, c
 int mmvid_warp_params_bytes(void);
 int mmvid_vid_warp(uint64_t seed, const float* step_dev, const float* x, int B, int T, int C, int H, int W,
                    const float* strategy_prob, void* params_scratch, int draw_params, float* out, void* stream);
+/* The same negative without re-encoding what did not change: the VQGAN tokenises frames independently and the warp
+ * changes the pixels of at most one frame per sample, so only that frame (new_frames [B,C,H,W]) goes through the
+ * encoder again; mmvid_vid_warp_tokens then assembles the negative's tokens [B, T*n] from the target's tokens
+ * [B, T*n], the new frames' tokens [B, n] and the drawn parameters (frame permutation, frame of another sample,
+ * replaced frame).  Bit-identical to tokenising mmvid_vid_warp's output. */
+int mmvid_vid_warp_new_frames(uint64_t seed, const float* step_dev, const float* x, int B, int T, int C, int H, int W,
+                              const float* strategy_prob, void* params_scratch, int draw_params, float* new_frames,
+                              void* stream);
+int mmvid_vid_warp_tokens(const int64_t* target_tok, const int64_t* new_frame_tok, const void* params, int B, int T, int n,
+                          int64_t* out, void* stream);
 /* visual-token erasing on token maps tok [B, Tv, f, f] int64, in place.  erase_codebook_face (dalle_bert.py:796-848):
  * one of `nchoice` (<= 4) alternatives is drawn per call from the cumulative probabilities; modes[i] 0 = untouched,
  * 1 = keep only boxes[i] = (r0, r1, c0, c1), 2 = erase the box; frame0_full leaves frame 0 untouched. */

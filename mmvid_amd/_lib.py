@@ -79,6 +79,8 @@ SIGNATURES = {
     'mmvid_counter_add': [P, F, P],
     'mmvid_msm_masks': [U64, P, I, I, I, P, F, F, F, P, P, P, P],
     'mmvid_vid_warp': [U64, P, P, I, I, I, I, I, P, P, I, P, P],
+    'mmvid_vid_warp_new_frames': [U64, P, P, I, I, I, I, I, P, P, I, P, P],
+    'mmvid_vid_warp_tokens': [P, P, P, I, I, I, P, P],
     'mmvid_erase_tokens_choice': [U64, P, I, P, P, P, I, I, I, I, I64, P, P],
     'mmvid_random_erase_tokens': [U64, P, I, I, I, F, F, F, F, F, I, I64, P, P],
     'mmvid_gemm_f32': [I, I, I, I, P, I64, P, I64, I, I64, I64, I64, F, P, P, P, I64, P],

@@ -244,6 +244,54 @@ __global__ __launch_bounds__(256) void warp_apply_kernel(const float* __restrict
     out[idx] = v;
 }
 
+// The VID negative differs from the target in ONE frame per sample (modes 0, 2, 3) or is a permutation of its frames
+// (mode 1), and the VQGAN encodes frames independently.  So only the frames that are NEW pixels need encoding: one per
+// sample (the colour-shifted / affine-warped frame; for modes 0 and 1 the slot is filled with frame j1 and its tokens
+// are not used).  new_frames: [B, C, H, W].
+__global__ __launch_bounds__(256) void warp_new_frame_kernel(const float* __restrict__ x, const WarpParams* __restrict__ wp, int B,
+                                                             int T, int C, int H, int W, float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long hw = (long)H * W;
+    if (idx >= (long)B * C * hw) return;
+    const int b = (int)(idx / (C * hw));
+    const long r = idx - (long)b * C * hw;
+    const int c = (int)(r / hw);
+    const int pix = (int)(r - (long)c * hw);
+    const WarpParams& w = wp[b];
+    const float* src = x + (((long)b * T + w.j1) * C + c) * hw;
+    float v;
+    if (w.mode == 2) {
+        const float m = (w.chan == 0 || w.chan - 1 == c) ? w.shift : 0.f;
+        v = fminf(fmaxf(src[pix] + m, 0.f), 1.f);
+    } else if (w.mode == 3) {
+        v = affine_sample(src, H, W, w.th, pix / W, pix % W);
+    } else {
+        v = src[pix];
+    }
+    out[idx] = v;
+}
+// tokens of the VID negative from the target's tokens [B, T*n] and the new frames' tokens [B, n]
+__global__ __launch_bounds__(256) void warp_tokens_kernel(const long long* __restrict__ tok, const long long* __restrict__ extra,
+                                                          const WarpParams* __restrict__ wp, int B, int T, int n,
+                                                          long long* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * T * n) return;
+    const int b = (int)(idx / ((long)T * n));
+    const int r = (int)(idx - (long)b * T * n);
+    const int t = r / n, p = r - t * n;
+    const WarpParams& w = wp[b];
+    long long v;
+    if (w.mode == 1)
+        v = tok[((long)b * T + w.perm[t]) * n + p];
+    else if (t != w.j1)
+        v = tok[idx];
+    else if (w.mode == 0)
+        v = tok[((long)w.src_b * T + w.src_t) * n + p];
+    else
+        v = extra[(long)b * n + p];
+    out[idx] = v;
+}
+
 // ---- visual-token erasing on [B, Tv, f, f] int64 token maps
 // choice c (drawn once per call, as the reference's single random draw per forward): mode 0 = untouched, 1 = keep only
 // the box (everything else -> value), 2 = erase the box.  frame0_full: frame 0 is never touched (face2 / face3 modes).
@@ -352,6 +400,32 @@ extern "C" int mmvid_vid_warp(uint64_t seed, const float* step_dev, const float*
     hipLaunchKernelGGL(warp_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, (const WarpParams*)params_scratch, B, T, C, H,
                        W, out);
     MMVID_LAUNCH_CHECK("vid_warp");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_vid_warp_new_frames(uint64_t seed, const float* step_dev, const float* x, int B, int T, int C, int H, int W,
+                                         const float* strategy_prob, void* params_scratch, int draw_params, float* new_frames,
+                                         void* stream) {
+    MMVID_REQUIRE(x && strategy_prob && params_scratch && new_frames, "vid_warp_new_frames: null pointer");
+    MMVID_REQUIRE(B > 0 && T > 0 && T <= 32, "vid_warp_new_frames: B=%d T=%d (T <= 32)", B, T);
+    hipStream_t s = (hipStream_t)stream;
+    if (draw_params)
+        hipLaunchKernelGGL(warp_params_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, seed, step_dev, B, T, strategy_prob[0],
+                           strategy_prob[1], strategy_prob[2], (WarpParams*)params_scratch);
+    const long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(warp_new_frame_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, (const WarpParams*)params_scratch, B, T, C,
+                       H, W, new_frames);
+    MMVID_LAUNCH_CHECK("vid_warp_new_frames");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_vid_warp_tokens(const int64_t* target_tok, const int64_t* new_frame_tok, const void* params, int B, int T,
+                                     int n, int64_t* out, void* stream) {
+    MMVID_REQUIRE(target_tok && new_frame_tok && params && out && B > 0 && T > 0 && n > 0, "vid_warp_tokens: bad arguments");
+    const long total = (long)B * T * n;
+    hipLaunchKernelGGL(warp_tokens_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const long long*)target_tok,
+                       (const long long*)new_frame_tok, (const WarpParams*)params, B, T, n, (long long*)out);
+    MMVID_LAUNCH_CHECK("vid_warp_tokens");
     return MMVID_OK;
 }
 

@@ -325,13 +325,23 @@ class BERT(nn.Module):
             not_fully_masked = kwargs.get('_not_fully_masked', torch.ones(B, device=device))
         # ---- tokens: the target and its warped negative go through the VQGAN as one batch (983, 1095)
         target_warp = None
-        if do_vid and torch.is_tensor(target) and target.dim() == 5:
+        if do_vid and torch.is_tensor(target) and target.dim() == 5 and _target_warp is None:
+            # The negative is the target with ONE frame's pixels changed (or its frames permuted), and the VQGAN tokenises
+            # frames independently: encode the B*T target frames plus the B new frames as one batch, then assemble the
+            # negative's tokens from them.  Bit-identical to tokenising the warped video (984-985 + 1094-1095), 44 % fewer
+            # encoder frames (tests/test_parity_gpu.py::test_vid_negative_tokens_without_reencoding).
+            frames = ops._chk(target.contiguous().float(), torch.float32, 'target')
+            _, _, C, H, W = frames.shape
+            both = torch.empty(B * T + B, C, H, W, device=device, dtype=torch.float32)
+            both[:B * T].copy_(frames.view(B * T, C, H, W))
+            self.frontend.vid_warp_new_frames(frames, vid_strategy_prob, both[B * T:])
+            toks = self.vae.get_codebook_indices(both)
+            target = toks[:B * T].reshape(B, -1).contiguous()
+            target_warp = self.frontend.vid_warp_tokens(target, toks[B * T:], T)
+        elif do_vid and torch.is_tensor(target) and target.dim() == 5:
             both = torch.empty((2 * B, ) + tuple(target.shape[1:]), device=device, dtype=torch.float32)
             both[:B].copy_(target)
-            if _target_warp is None:
-                self.frontend.vid_warp(both[:B], vid_strategy_prob, out=both[B:])
-            else:
-                both[B:].copy_(_target_warp)
+            both[B:].copy_(_target_warp)
             toks = self.get_image_tokens(both)
             target, target_warp = toks[:B].contiguous(), toks[B:].contiguous()
         else:

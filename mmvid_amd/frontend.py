@@ -25,8 +25,11 @@ class Frontend:
         self._warp_scratch = None
 
     def _step(self, device):
-        if self.step is None or self.step.device != torch.device(device):
-            self.step = torch.zeros(1, device=device, dtype=f32)
+        dev = torch.device(device)
+        if dev.type == 'cuda' and dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        if self.step is None or self.step.device != dev:
+            self.step = torch.zeros(1, device=dev, dtype=f32)
         return self.step
 
     def advance(self, device):
@@ -59,6 +62,30 @@ class Frontend:
             out = torch.empty_like(x)
         _lib.call('mmvid_vid_warp', self.seed, _p(self._step(x.device)), _p(x), B, T, C, H, W, _farr(list(strategy_prob)),
                   _p(scratch), draw, _p(out), _stream())
+        return out
+
+    def _scratch(self, B, device):
+        nbytes = B * _lib.load().mmvid_warp_params_bytes()
+        if self._warp_scratch is None or self._warp_scratch.numel() < nbytes or self._warp_scratch.device != torch.device(device):
+            self._warp_scratch = torch.empty(nbytes, device=device, dtype=u8)
+        return self._warp_scratch
+
+    def vid_warp_new_frames(self, x, strategy_prob, out):
+        """Draw the warp parameters and write the ONE frame per sample whose pixels are new into out [B,C,H,W] (the rest
+        of the negative is frames the VQGAN has already tokenised: vid_warp_tokens)."""
+        ops._chk(x, f32, 'x')
+        B, T, C, H, W = x.shape
+        assert out.shape == (B, C, H, W) and out.is_contiguous() and out.dtype == f32
+        _lib.call('mmvid_vid_warp_new_frames', self.seed, _p(self._step(x.device)), _p(x), B, T, C, H, W,
+                  _farr(list(strategy_prob)), _p(self._scratch(B, x.device)), 1, _p(out), _stream())
+        return out
+
+    def vid_warp_tokens(self, target_tok, new_tok, T):
+        """target_tok [B, T*n], new_tok [B, n] -> tokens of the negative drawn by the last vid_warp_new_frames call."""
+        B, n = new_tok.shape
+        out = torch.empty_like(target_tok)
+        _lib.call('mmvid_vid_warp_tokens', _p(target_tok), _p(new_tok.contiguous()), _p(self._warp_scratch), B, T, n, _p(out),
+                  _stream())
         return out
 
     def erase_choice(self, tok, Tv, fmap, value, choices, frame0_full=False):

@@ -81,10 +81,9 @@ class LNLinearCrossEntropy(torch.autograd.Function):
         x = x.contiguous()
         h, mean, rstd = ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), 1e-5)
         ctx.cols = cols
-        if cols is not None:
-            w_bf16 = w_bf16[cols[0]:cols[1]]
+        w_blk = w_bf16 if cols is None else w_bf16[cols[0]:cols[1]]
         bias = b.detach() if cols is None else b.detach()[cols[0]:cols[1]].contiguous()
-        logits = ops.gemm(h, w_bf16, bias=bias, out_dtype=f32)
+        logits = ops.gemm(h, w_blk, bias=bias, out_dtype=f32)
         sel8 = select.to(torch.uint8).contiguous() if select is not None else None
         lse, loss_sum = ops.cross_entropy_fwd(logits, target, sel8)
         cnt = (select.sum() if select is not None else torch.tensor(logits.shape[0], device=x.device)).to(f32)

@@ -444,6 +444,33 @@ def test_frontend_vid_warp_matches_oracle():
     assert not torch.equal(a, fe.vid_warp(x.to(DEV), [0.25] * 4))
 
 
+def test_vid_negative_tokens_without_reencoding():
+    """BERT.forward encodes the B*T target frames plus ONE new frame per sample and assembles the VID negative's tokens
+    (frontend.vid_warp_tokens) instead of tokenising the whole warped video again.  Must be bit-identical to the
+    reference's order of operations: warp the pixels (dalle_bert.py:1094), then tokenise all of them (1095)."""
+    from mmvid_amd.frontend import Frontend
+    torch.manual_seed(0)
+    vae = tiny_vae().to(DEV)
+    with torch.no_grad():
+        vae.model.quantize.embedding.weight.normal_(0, 0.5)
+    fe = Frontend(seed=5)
+    B, T = 8, 4
+    x = torch.rand(B, T, 3, 64, 64, device=DEV)
+    seen = set()
+    for rep in range(6):
+        full = fe.vid_warp(x, [0.25] * 4)  # draws the parameters of this step
+        ref = vae.get_codebook_indices(full.view(B * T, 3, 64, 64)).view(B, -1)
+        both = torch.empty(B * T + B, 3, 64, 64, device=DEV)
+        both[:B * T].copy_(x.view(B * T, 3, 64, 64))
+        fe.vid_warp_new_frames(x, [0.25] * 4, both[B * T:])  # same (seed, step): the same parameters
+        toks = vae.get_codebook_indices(both)
+        got = fe.vid_warp_tokens(toks[:B * T].reshape(B, -1).contiguous(), toks[B * T:], T)
+        assert torch.equal(got, ref), f'draw {rep}: {(got != ref).sum().item()} tokens differ'
+        seen |= {p['mode'] for p in _read_warp_params(fe._warp_scratch[:B * 176], B)}
+        fe.advance(DEV)
+    assert seen == {0, 1, 2, 3}
+
+
 def test_frontend_msm_masks_distribution():
     """MSM masking strategies on the device (dalle_bert.py:992-1029) against oracle/frontend.py: strategy frequencies,
     Bernoulli keep rate, erased-box area / shape statistics, frame preservation."""
