@@ -192,6 +192,18 @@ int mmvid_tower_prefill(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t*
                         float* x_out, void* kv_cache, int Lmax, void* scratch, void* stream);
 int mmvid_tower_decode(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in, float* x_out,
                        void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch, void* stream);
+/* The same step as five matrix-vector launches per layer (weights streamed once, rows in LDS, 256 CUs busy) instead of
+ * the M = B corner of the training GEMM: ~10x less time per token.  B <= 8.  scratch: B * (7E + F) floats.
+ * mmvid_gemv_rows is the building block (y = act(LN?(x) W^T + b) (+ residual), x / y fp32 [NB, *], W bf16 [N, K]);
+ * mmvid_decode_embed writes the embedding row of the token just sampled (table[tok] + pos_rows[*pos_dev + pos_off]). */
+int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
+                             float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
+                             void* stream);
+int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const float* ln_w, const float* ln_b, float eps, const void* W,
+                    const float* bias, int N, int act, const float* residual, int64_t ldr, int round_in, int round_out,
+                    float* out, int64_t ldo, void* stream);
+int mmvid_decode_embed(const int64_t* tok, const float* table, int64_t table_rows, const float* pos_rows,
+                       const int32_t* pos_dev, int pos_off, int B, int E, float* x, void* stream);
 /* building blocks: append K|V rows of qkv [B*L, ldq] at positions pos..pos+L-1, and one-query attention over the
  * cached positions 0..pos (head_dim 64, Lmax <= 4096). */
 int mmvid_kv_store(const void* qkv, int64_t ldq, int B, int L, int E, const int32_t* pos_dev, int pos0, int Lmax,

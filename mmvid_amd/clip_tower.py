@@ -81,8 +81,8 @@ class DecodeSession:
     """See OpenAICLIPTransformer.decode_session.  step(x_new [B, width]) -> hidden [B, width] (a static buffer that
     the next step overwrites)."""
 
-    def __init__(self, tower, kv_cache, first_pos, graph):
-        self.tower, self.cache = tower, kv_cache
+    def __init__(self, tower, kv_cache, first_pos, graph, fused=True):
+        self.tower, self.cache, self.fused = tower, kv_cache, fused
         B, dev = kv_cache.shape[1], kv_cache.device
         self.cfg = tower._cfg(B, kv_cache.shape[2])
         self.layers, self._keep = tower._layer_structs(False)
@@ -93,7 +93,10 @@ class DecodeSession:
         self.graph, self.want_graph, self.calls = None, graph, 0
 
     def _enqueue(self):
-        _lib.call('mmvid_tower_decode', ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
+        # batches of up to 8 sequences take the matrix-vector path (five launches per layer, csrc/decode.hip); larger
+        # ones the M = B corner of the MFMA GEMM
+        fn = 'mmvid_tower_decode_fused' if (self.fused and self.x.shape[0] <= 8) else 'mmvid_tower_decode'
+        _lib.call(fn, ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
                   ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
         self.pos.add_(1)
 
@@ -208,10 +211,10 @@ class OpenAICLIPTransformer(nn.Module):
                   kv_cache.shape[2], ops._p(pos_dev), int(pos), ops._p(scratch), ops._stream())
         return y
 
-    def decode_session(self, kv_cache, first_pos, graph=True):
+    def decode_session(self, kv_cache, first_pos, graph=True, fused=True):
         """A sampling loop's view of decode_step: argument structs and buffers are built once, the position lives in a
         device scalar that the step itself advances, and (graph=True) the step is captured once and replayed."""
-        return DecodeSession(self, kv_cache, first_pos, graph)
+        return DecodeSession(self, kv_cache, first_pos, graph, fused)
 
     # ---- native plumbing ---------------------------------------------------------------------------
     def _any_trainable(self):

@@ -103,3 +103,286 @@ extern "C" int mmvid_attention_decode(const void* qkv, int64_t ldq, const void* 
     MMVID_LAUNCH_CHECK("attention_decode");
     return MMVID_OK;
 }
+
+// =====================================================================================================================
+// Fused decode step (round 2).  The first version of mmvid_tower_decode reused the training GEMM (128x128 MFMA tiles) at
+// M = B <= 8: ~13 launches per layer, each a handful of blocks -- 1.5 ms per token, 50x above the weight-streaming floor
+// (12 layers x 14.2 MB of bf16 weights / 6.3 TB/s = 27 us).  A decode step is a chain of matrix-VECTOR products: every
+// weight byte is used once per sequence of the batch, so the right kernel streams weight rows straight into registers
+// (16 B per lane, several rows in flight), keeps the B input rows in LDS, and spreads the N output features over all
+// 256 CUs.  Five launches per layer:
+//   gemv<LN>   q,k,v = LN1(x) W_in^T + b          (+ K|V appended to the cache, q kept for the attention)
+//   attn       o = softmax(q K^T / 8) V over the cached positions
+//   gemv       x_mid = x + o W_out^T + b
+//   gemv<LN>   a = QuickGELU(LN2(x_mid) W_fc^T + b)
+//   gemv       x' = x_mid + a W_proj^T + b
+// Operands are rounded to bf16 exactly where the full forward stores them in bf16 (LayerNorm output, q, o, the GELU
+// output), so cached and recomputed logits differ only by fp32 summation order.  HBM/latency-bound.
+namespace {
+
+constexpr int GV_MAXB = 8;    // sequences per decode batch
+constexpr int GV_COLS = 8;    // output features per block (2 per wave)
+__device__ __forceinline__ float round_bf16(float v) { return bf2f(f2bf(v)); }
+
+struct GemvArgs {
+    const float* x;      // [NB][ldx] fp32
+    long ldx;
+    const float *ln_w, *ln_b;  // LayerNorm applied to the rows first, or null
+    float eps;
+    const bf16_t* W;     // [N][K] row-major
+    const float* bias;   // [N] or null
+    const float* residual;  // [NB][ldr] or null
+    long ldr;
+    float* out;          // [NB][ldo] fp32
+    long ldo;
+    int NB, N, K, act, round_in, round_out;
+    // K|V append: features n in [kv_lo, kv_lo + 2E) are also written as bf16 to cache[b][pos][n - kv_lo]
+    bf16_t* kv_cache;
+    int kv_lo, kv_width, Lmax;
+    const int* pos_dev;
+    int pos0;
+};
+
+__global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][K]
+    __shared__ float stats[GV_MAXB][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, NB = a.NB;
+    // ---- stage the input rows (LayerNorm + bf16 rounding where the full forward has them)
+    for (int b = wave; b < NB; b += 4) {  // one wave per row: statistics
+        if (a.ln_w) {
+            float s = 0.f;
+            for (int k = lane; k < K; k += 64) s += a.x[b * a.ldx + k];
+            const float mean = wave_sum(s) / (float)K;
+            float q = 0.f;
+            for (int k = lane; k < K; k += 64) {
+                const float d = a.x[b * a.ldx + k] - mean;
+                q += d * d;
+            }
+            const float rstd = rsqrtf(wave_sum(q) / (float)K + a.eps);
+            if (lane == 0) stats[b][0] = mean, stats[b][1] = rstd;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < NB * K; i += 256) {
+        const int b = i / K, k = i - b * K;
+        float v = a.x[b * a.ldx + k];
+        if (a.ln_w) v = (v - stats[b][0]) * stats[b][1] * a.ln_w[k] + a.ln_b[k];
+        if (a.round_in) v = round_bf16(v);
+        xs[i] = v;
+    }
+    __syncthreads();
+    // ---- each wave: two output features, all NB rows; weights streamed 16 B per lane
+    const int n0 = blockIdx.x * GV_COLS + wave * 2;
+    if (n0 >= a.N) return;
+    const bool two = n0 + 1 < a.N;
+    float acc[2][GV_MAXB];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int b = 0; b < GV_MAXB; ++b) acc[c][b] = 0.f;
+    const bf16_t* w0 = a.W + (long)n0 * K;
+    const bf16_t* w1 = a.W + (long)(two ? n0 + 1 : n0) * K;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        const uint4 u0 = *reinterpret_cast<const uint4*>(w0 + k0);
+        const uint4 u1 = *reinterpret_cast<const uint4*>(w1 + k0);
+        const float f0[8] = {bf_lo(u0.x), bf_hi(u0.x), bf_lo(u0.y), bf_hi(u0.y), bf_lo(u0.z), bf_hi(u0.z), bf_lo(u0.w), bf_hi(u0.w)};
+        const float f1[8] = {bf_lo(u1.x), bf_hi(u1.x), bf_lo(u1.y), bf_hi(u1.y), bf_lo(u1.z), bf_hi(u1.z), bf_lo(u1.w), bf_hi(u1.w)};
+#pragma unroll
+        for (int b = 0; b < GV_MAXB; ++b) {
+            if (b < NB) {
+                const float4 xa = *reinterpret_cast<const float4*>(xs + b * K + k0);
+                const float4 xb = *reinterpret_cast<const float4*>(xs + b * K + k0 + 4);
+                acc[0][b] += (f0[0] * xa.x + f0[1] * xa.y) + (f0[2] * xa.z + f0[3] * xa.w) + (f0[4] * xb.x + f0[5] * xb.y) +
+                             (f0[6] * xb.z + f0[7] * xb.w);
+                acc[1][b] += (f1[0] * xa.x + f1[1] * xa.y) + (f1[2] * xa.z + f1[3] * xa.w) + (f1[4] * xb.x + f1[5] * xb.y) +
+                             (f1[6] * xb.z + f1[7] * xb.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int b = 0; b < GV_MAXB; ++b)
+            if (b < NB) acc[c][b] = wave_sum(acc[c][b]);
+    if (lane == 0) {
+        const int pos = a.pos_dev ? *a.pos_dev : a.pos0;
+        for (int c = 0; c < (two ? 2 : 1); ++c) {
+            const int n = n0 + c;
+            const float bias = a.bias ? a.bias[n] : 0.f;
+            for (int b = 0; b < NB; ++b) {
+                float v = acc[c][b] + bias;
+                if (a.act == 1) v = v * sigmoidf_(1.702f * v);  // QuickGELU (clip_model.py:196-198)
+                if (a.residual) v += a.residual[b * a.ldr + n];
+                if (a.round_out) v = round_bf16(v);
+                a.out[b * a.ldo + n] = v;
+                if (a.kv_cache && n >= a.kv_lo && n < a.kv_lo + a.kv_width && pos < a.Lmax)
+                    a.kv_cache[((long)b * a.Lmax + pos) * a.kv_width + (n - a.kv_lo)] = f2bf(v);
+            }
+        }
+    }
+}
+
+// One block per (head, batch): q fp32 [B][ldq] (already bf16-rounded), K|V rows from the cache (position `pos` included).
+__global__ __launch_bounds__(256) void attn_decode2_kernel(const float* __restrict__ q, long ldq, const bf16_t* __restrict__ cache,
+                                                           int Lmax, int E, const int* __restrict__ pos_dev, int pos0,
+                                                           float scale_log2, float* __restrict__ out, long ldo) {
+    __shared__ float sc[DEC_MAXL];
+    __shared__ float qs[64];
+    __shared__ float red[32][64];
+    __shared__ float stat[8];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = (pos_dev ? *pos_dev : pos0) + 1;
+    if (tid < 64) qs[tid] = q[(long)b * ldq + h * 64 + tid];
+    __syncthreads();
+    const bf16_t* kv = cache + (long)b * Lmax * 2 * E + h * 64;
+    float mx = -INFINITY;
+    for (int k = tid; k < n; k += 256) {
+        const uint4* kr = reinterpret_cast<const uint4*>(kv + (long)k * 2 * E);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint4 u = kr[c];
+            const float* qq = qs + 8 * c;
+            d += (bf_lo(u.x) * qq[0] + bf_hi(u.x) * qq[1]) + (bf_lo(u.y) * qq[2] + bf_hi(u.y) * qq[3]) +
+                 (bf_lo(u.z) * qq[4] + bf_hi(u.z) * qq[5]) + (bf_lo(u.w) * qq[6] + bf_hi(u.w) * qq[7]);
+        }
+        d *= scale_log2;
+        sc[k] = d;
+        mx = fmaxf(mx, d);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) stat[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(stat[0], stat[1]), fmaxf(stat[2], stat[3]));
+    float sum = 0.f;
+    for (int k = tid; k < n; k += 256) {
+        const float p = __builtin_amdgcn_exp2f(sc[k] - mx);
+        sc[k] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) stat[4 + wave] = sum;
+    __syncthreads();
+    sum = (stat[4] + stat[5]) + (stat[6] + stat[7]);
+    // o[d] = sum_k p[k] V[k][d]: thread (kg = tid>>3, dc = tid&7) owns 8 dims of every 32nd key: 16-B loads, 8 accumulators
+    const int kg = tid >> 3, dc = tid & 7;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = kg; k < n; k += 32) {
+        const uint4 u = *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E + dc * 8);
+        const float p = sc[k];
+        acc[0] += p * bf_lo(u.x), acc[1] += p * bf_hi(u.x), acc[2] += p * bf_lo(u.y), acc[3] += p * bf_hi(u.y);
+        acc[4] += p * bf_lo(u.z), acc[5] += p * bf_hi(u.z), acc[6] += p * bf_lo(u.w), acc[7] += p * bf_hi(u.w);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[kg][dc * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) s += red[g][tid];
+        out[(long)b * ldo + h * 64 + tid] = round_bf16(s / sum);  // the full forward stores the attention output in bf16
+    }
+}
+
+// x[b, :] = table[tok[b]] + pos_rows[*pos_dev + pos_off]: the embedding of the token just sampled (dalle_artv.py:484-491)
+__global__ __launch_bounds__(256) void dec_embed_kernel(const long long* __restrict__ tok, const float* __restrict__ table,
+                                                        long table_rows, const float* __restrict__ pos_rows,
+                                                        const int* __restrict__ pos_dev, int pos_off, int E, float* __restrict__ x) {
+    const int b = blockIdx.x;
+    long long id = tok[b];
+    if (id < 0 || id >= table_rows) id = 0;
+    const long p = (long)(*pos_dev) + pos_off;
+    for (int e = threadIdx.x; e < E; e += 256) x[(long)b * E + e] = table[id * E + e] + pos_rows[p * E + e];
+}
+
+int gemv_launch(GemvArgs a, hipStream_t s) {
+    if (a.NB > GV_MAXB || a.K % 8 != 0 || (long)a.NB * a.K * 4 > 64 * 1024) {
+        mmvid_set_error("decode gemv: NB=%d (<= %d), K=%d (multiple of 8, NB*K*4 <= 64 KiB)", a.NB, GV_MAXB, a.K);
+        return MMVID_ERR_ARG;
+    }
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(cdiv(a.N, GV_COLS)), dim3(256), (size_t)a.NB * a.K * 4, s, a);
+    return MMVID_OK;
+}
+
+}  // namespace
+
+extern "C" int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const float* ln_w, const float* ln_b, float eps,
+                               const void* W, const float* bias, int N, int act, const float* residual, int64_t ldr,
+                               int round_in, int round_out, float* out, int64_t ldo, void* stream) {
+    MMVID_REQUIRE(x && W && out && NB > 0 && N > 0 && K > 0, "gemv_rows: bad arguments");
+    GemvArgs a = {};
+    a.x = x, a.ldx = ldx, a.ln_w = ln_w, a.ln_b = ln_b, a.eps = eps, a.W = (const bf16_t*)W, a.bias = bias;
+    a.residual = residual, a.ldr = ldr, a.out = out, a.ldo = ldo, a.NB = NB, a.N = N, a.K = K, a.act = act;
+    a.round_in = round_in, a.round_out = round_out;
+    int rc = gemv_launch(a, (hipStream_t)stream);
+    if (rc) return rc;
+    MMVID_LAUNCH_CHECK("gemv_rows");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_decode_embed(const int64_t* tok, const float* table, int64_t table_rows, const float* pos_rows,
+                                  const int32_t* pos_dev, int pos_off, int B, int E, float* x, void* stream) {
+    MMVID_REQUIRE(tok && table && pos_rows && pos_dev && x && B > 0, "decode_embed: bad arguments");
+    hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)tok, table, (long)table_rows,
+                       pos_rows, pos_dev, pos_off, E, x);
+    MMVID_LAUNCH_CHECK("decode_embed");
+    return MMVID_OK;
+}
+
+// One new position per sequence through all layers, five launches per layer (see above).  scratch: >= B*(3E+E+E+F+2E)*4 B.
+extern "C" int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
+                                        float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
+                                        void* stream) {
+    MMVID_REQUIRE(cfg && layers && x_in && x_out && kv_cache && scratch, "tower_decode_fused: null pointer");
+    MMVID_REQUIRE(cfg->mask_mode == 1 && cfg->E == cfg->H * 64 && cfg->B <= GV_MAXB && Lmax <= DEC_MAXL,
+                  "tower_decode_fused: causal tower, head_dim 64, batch <= %d, Lmax <= %d", GV_MAXB, DEC_MAXL);
+    const int B = cfg->B, E = cfg->E, F = cfg->F, H = cfg->H;
+    hipStream_t s = (hipStream_t)stream;
+    float* p = (float*)scratch;
+    float* qkv = p;
+    p += (long)B * 3 * E;
+    float* o = p;
+    p += (long)B * E;
+    float* xmid = p;
+    p += (long)B * E;
+    float* act = p;
+    p += (long)B * F;
+    float* xa = p;
+    p += (long)B * E;
+    float* xb = p;
+    const float* x = x_in;
+    for (int i = 0; i < cfg->layers; ++i) {
+        const mmvid_tower_layer_t& ly = layers[i];
+        bf16_t* cache = (bf16_t*)kv_cache + (long)i * B * Lmax * 2 * E;
+        float* xnext = (i == cfg->layers - 1) ? x_out : ((i & 1) ? xb : xa);
+        GemvArgs g = {};
+        g.NB = B, g.eps = cfg->ln_eps;
+        // q,k,v (+ cache append)
+        g.x = x, g.ldx = E, g.ln_w = ly.ln1_w, g.ln_b = ly.ln1_b, g.W = (const bf16_t*)ly.in_w, g.bias = ly.in_b, g.N = 3 * E, g.K = E;
+        g.out = qkv, g.ldo = 3 * E, g.round_in = 1, g.round_out = 1, g.kv_cache = cache, g.kv_lo = E, g.kv_width = 2 * E, g.Lmax = Lmax;
+        g.pos_dev = pos_dev, g.pos0 = pos;
+        int rc = gemv_launch(g, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(attn_decode2_kernel, dim3(H, B), dim3(256), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
+                           0.125f * 1.4426950408889634f, o, (long)E);
+        GemvArgs g2 = {};
+        g2.NB = B, g2.x = o, g2.ldx = E, g2.W = (const bf16_t*)ly.out_w, g2.bias = ly.out_b, g2.N = E, g2.K = E, g2.residual = x,
+        g2.ldr = E, g2.out = xmid, g2.ldo = E;
+        rc = gemv_launch(g2, s);
+        if (rc) return rc;
+        GemvArgs g3 = {};
+        g3.NB = B, g3.eps = cfg->ln_eps, g3.x = xmid, g3.ldx = E, g3.ln_w = ly.ln2_w, g3.ln_b = ly.ln2_b, g3.W = (const bf16_t*)ly.fc_w,
+        g3.bias = ly.fc_b, g3.N = F, g3.K = E, g3.act = 1, g3.out = act, g3.ldo = F, g3.round_in = 1, g3.round_out = 1;
+        rc = gemv_launch(g3, s);
+        if (rc) return rc;
+        GemvArgs g4 = {};
+        g4.NB = B, g4.x = act, g4.ldx = F, g4.W = (const bf16_t*)ly.pj_w, g4.bias = ly.pj_b, g4.N = E, g4.K = F, g4.residual = xmid,
+        g4.ldr = E, g4.out = xnext, g4.ldo = E;
+        rc = gemv_launch(g4, s);
+        if (rc) return rc;
+        x = xnext;
+    }
+    MMVID_LAUNCH_CHECK("tower_decode_fused");
+    return MMVID_OK;
+}

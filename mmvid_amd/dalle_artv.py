@@ -279,6 +279,72 @@ class DALLE(nn.Module):
         tok, _ = ops.sample_race(block_logits.contiguous(), E, None, 0.0, logit_div=temperature, want_y=False)
         return tok.view(B, 1)
 
+    def _sample_cached(self, h, cache, first_pos, filter_thres, temperature, race):
+        """The sampling loop over the key/value cache.  One token = [head logits of the image block -> draw -> embedding
+        row of the drawn token -> one decode step through the tower]; that chain is captured once (hipGraph) and replayed
+        per token: the position lives in a device scalar the step advances, the race variates come from torch's
+        graph-safe device generator.  Injected variates (`race`, tests) or a top-k that actually filters run the same
+        kernels eagerly."""
+        B, dev = h.shape[0], h.device
+        c0, c1 = self._allowed_range(self.control_seq_len)
+        V = c1 - c0
+        lin, ln = self.to_logits[1], self.to_logits[0]
+        w_blk, b_blk = self._w16()[c0:c1], lin.bias.detach()[c0:c1].contiguous()
+        pos_rows = self._pos_rows().detach().contiguous()
+        iemb = self.image_emb.weight.detach()
+        sess = self.transformer.decode_session(cache, first_pos, graph=False)
+        k_keep = max(int((1 - filter_thres) * self.total_tokens), 1)
+        steps = self.target_seq_len
+        out = torch.empty(B, steps, dtype=torch.long, device=dev)
+        hbuf, logits = h.clone(), torch.empty(B, V, device=dev)
+        tok, E = torch.empty(B, dtype=torch.long, device=dev), torch.empty(B, V, device=dev)
+
+        def draw(step):
+            if self.stable:
+                hbuf.copy_(self.norm_by_max(hbuf))
+            ops.gemv_rows(hbuf, w_blk, b_blk, ln=(ln.weight, ln.bias, ln.eps), round_in=True, out=logits)  # LN + head block
+            lg = logits
+            if k_keep < V:
+                val, ind = torch.topk(lg, k_keep)
+                lg = torch.full_like(lg, float('-inf')).scatter_(1, ind, val)
+            if race is not None:
+                E.copy_(race(f'tok{step}', (B, V)))
+            else:
+                E.exponential_()
+            t, _ = ops.sample_race(lg, E, None, 0.0, logit_div=temperature, want_y=False)
+            tok.copy_(t)
+
+        def advance():
+            ops.decode_embed(tok, iemb, pos_rows, sess.pos, sess.x)
+            sess._enqueue()  # one position through the tower; advances sess.pos
+            hbuf.copy_(sess.y)
+
+        graph = None
+        use_graph = race is None and k_keep >= V and not self.stable and steps > 4
+        for step in range(steps - 1):  # every token but the last: draw it, then run it through the tower
+            if graph is not None:
+                graph.replay()
+                continue
+            draw(step)
+            out[:, step].copy_(tok)
+            advance()
+            if use_graph and step == 1:
+                # two eager steps have warmed every kernel; capture [draw -> record -> advance] once and replay it
+                idx = torch.full((1, ), step + 1, dtype=torch.long, device=dev)  # the column of `out` the next token goes to
+                graph = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(graph, stream=side):
+                        draw(-1)
+                        out.scatter_(1, idx.expand(B, 1), tok.view(B, 1))
+                        idx.add_(1)
+                        advance()
+                torch.cuda.current_stream().wait_stream(side)
+        draw(steps - 1)
+        out[:, steps - 1].copy_(tok)
+        return [out[:, i:i + 1] for i in range(steps)]
+
     def sampling_probs(self, block_logits, filter_thres=0.5, temperature=1.0):
         """The probability vector `_draw` samples from (tests compare it with the reference's full-width expression)."""
         k_keep = max(int((1 - filter_thres) * self.total_tokens), 1)
@@ -307,17 +373,8 @@ class DALLE(nn.Module):
         if use_cache:
             cache = self.transformer.new_kv_cache(B, self.total_seq_len, text.device)
             prompt = torch.cat(self._prompt_ids(text, vis_tok), 1)  # <bos> text visual: positions 0 .. cl
-            h = self.transformer.prefill(self._embed_rows(prompt, 0), cache)[:, -1, :]
-            pos_rows = self._pos_rows()
-            sess = self.transformer.decode_session(cache, prompt.shape[1])
-            for step in range(self.target_seq_len):
-                if self.stable:
-                    h = self.norm_by_max(h)
-                sample = self._draw(self._logits_rows(h.contiguous(), (c0, c1)), filter_thres, temperature, _race, f'tok{step}')
-                toks.append(sample)
-                if step == self.target_seq_len - 1:
-                    break
-                h = sess.step(self.image_emb.weight[sample[:, 0]] + pos_rows[prompt.shape[1] + step])
+            h = self.transformer.prefill(self._embed_rows(prompt, 0), cache)[:, -1, :].contiguous()
+            toks = self._sample_cached(h, cache, prompt.shape[1], filter_thres, temperature, _race)
         else:
             image = torch.empty(B, 0, dtype=torch.long, device=text.device)
             for step in range(self.target_seq_len):

@@ -426,3 +426,25 @@ def bert_build_ids(text, visual_tok, nvis, target, target_warp, mask1, pad_base,
          Ttxt, Nvis, TS, int(pad_base), int(mask_id), int(has_rel), int(has_vid), _p(ids), _p(sel), _p(tfull), _p(cnt),
          _stream())
     return ids, sel, tfull, cnt
+
+
+def gemv_rows(x, W, bias=None, ln=None, act=0, residual=None, round_in=False, round_out=False, out=None):
+    """Decode-time linear layer on a few rows: y = act(LN?(x) @ W^T + bias) (+ residual).  x [NB <= 8, K] f32, W [N, K] bf16."""
+    _chk(x, f32, 'x'), _chk(W, bf16, 'W')
+    NB, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(NB, N, device=x.device, dtype=f32)
+    lw, lb, eps = (ln[0], ln[1], ln[2]) if ln is not None else (None, None, 0.0)
+    call('mmvid_gemv_rows', _p(x), K, NB, K, _p(lw), _p(lb), float(eps), _p(W), _p(bias), N, int(act), _p(residual), N,
+         int(round_in), int(round_out), _p(out), N, _stream())
+    return out
+
+
+def decode_embed(tok, table, pos_rows, pos_dev, out, pos_off=0):
+    """out[b] = table[tok[b]] + pos_rows[pos_dev + pos_off] (the embedding row of a freshly sampled token)."""
+    _chk(tok, i64, 'tok'), _chk(table, f32, 'table'), _chk(pos_rows, f32, 'pos_rows')
+    B, E = out.shape
+    call('mmvid_decode_embed', _p(tok), _p(table), table.shape[0], _p(pos_rows), _p(pos_dev), int(pos_off), B, E, _p(out),
+         _stream())
+    return out

@@ -296,10 +296,19 @@ def test_artv_kv_cache_decode_matches_full_recompute(golden):
         # second call on) walks the same positions to the same hidden states
         cache2 = m.transformer.new_kv_cache(B, m.total_seq_len, DEV)
         m.transformer.prefill(m._embed_rows(prompt, 0), cache2)
-        sess = m.transformer.decode_session(cache2, prompt.shape[1])
+        sess = m.transformer.decode_session(cache2, prompt.shape[1], fused=False)
         for k in range(31):
             hs = sess.step(m._embed_rows(tt[:, k:k + 1], prompt.shape[1] + k)[:, 0, :])
         assert sess.graph is not None and torch.equal(hs, h)
+        # the matrix-vector decode step (five launches per layer, the default for batches <= 8): same hidden states up to
+        # fp32 summation order, since it rounds to bf16 exactly where the MFMA path stores bf16
+        cache3 = m.transformer.new_kv_cache(B, m.total_seq_len, DEV)
+        m.transformer.prefill(m._embed_rows(prompt, 0), cache3)
+        sess3 = m.transformer.decode_session(cache3, prompt.shape[1])
+        for k in range(31):
+            hf = sess3.step(m._embed_rows(tt[:, k:k + 1], prompt.shape[1] + k)[:, 0, :])
+        close(hf, h, 1e-2, 'fused decode step vs GEMM decode step (hidden state after 31 tokens)')
+        close(cache3[:, :, :prompt.shape[1] + 31], cache2[:, :, :prompt.shape[1] + 31], 1e-2, 'key/value cache')
 
 
 # --------------------------------------------------------------------------------------------- engine

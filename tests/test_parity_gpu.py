@@ -301,6 +301,27 @@ def test_artv_sampler_distribution_and_cache_agreement(golden):
     print('cached vs recomputed sampling: identical videos', (a == b).flatten(1).all(1).float().mean().item())
 
 
+def test_gemv_rows_kernel_vs_torch():
+    """The decode-time linear layer (csrc/decode.hip): LN + bf16 weights streamed once + bias + QuickGELU + residual."""
+    from mmvid_amd import ops
+    torch.manual_seed(0)
+    for NB, K, N, act, ln, res in ((1, 768, 2304, 0, True, False), (4, 768, 3072, 1, True, False), (3, 3072, 768, 0, False, True),
+                                   (8, 768, 1024, 0, True, False), (2, 768, 770, 0, False, True)):
+        x = torch.randn(NB, K, device=DEV)
+        W = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+        b = torch.randn(N, device=DEV) * 0.1
+        lw, lb = 1 + 0.1 * torch.randn(K, device=DEV), 0.1 * torch.randn(K, device=DEV)
+        r = torch.randn(NB, N, device=DEV) if res else None
+        y = ops.gemv_rows(x, W, b, ln=(lw, lb, 1e-5) if ln else None, act=act, residual=r, round_in=True)
+        h = F.layer_norm(x, (K, ), lw, lb, 1e-5) if ln else x
+        ref = h.bfloat16().float() @ W.float().t() + b
+        if act:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        if res:
+            ref = ref + r
+        close(y, ref, 2e-5, f'gemv NB={NB} K={K} N={N}')
+
+
 # ------------------------------------------------------------------------------------------- heads, ids
 def test_bert_build_ids_matches_torch(golden):
     from mmvid_amd import ops
