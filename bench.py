@@ -199,7 +199,7 @@ def fence():
 
 def comm_report(trainer, step_ms, world):
     """Gradient exchange on its own (whole flat buffer, same bucketing), for the bus-bandwidth / overlap figures."""
-    if world == 1 or not dist.is_initialized():
+    if (world == 1 and not trainer.force_exchange) or not dist.is_initialized():
         return None
     try:
         fence()
@@ -213,7 +213,7 @@ def comm_report(trainer, step_ms, world):
             torch.cuda.current_stream().wait_stream(trainer._comm_stream)
         fence()
         ar_ms = (time.perf_counter() - t0) / reps * 1e3
-        wire = 2.0 * (world - 1) / world * 4.0 * trainer.numel  # bytes per GPU on the links, ring-equivalent
+        wire = 2.0 * max(world - 1, 1) / world * 4.0 * trainer.numel  # bytes per GPU on the links, ring-equivalent (world 1: loop-back)
         return {'allreduce_alone_ms': ar_ms, 'bytes_per_gpu_on_wire': wire, 'bus_bandwidth_GBps': wire / (ar_ms * 1e-3) / 1e9,
                 'gradient_bytes': 4.0 * trainer.numel, 'note': 'overlap = 1 - (step - step_without_exchange) / allreduce_alone'}
     except Exception as e:  # never lose the headline line to a diagnostics failure

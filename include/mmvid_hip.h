@@ -62,6 +62,12 @@ int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const 
 int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                         const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
                         int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream);
+/* The same with a caller-provided fp32 workspace (workspace_floats >= 3 * E * 64; 3 * E * 1024 is what the tower uses):
+ * dw / db / dx_colsum are then reduced in two stages in a fixed order -- deterministic, no atomics, larger grid. */
+int mmvid_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                           const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
+                           int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum, float* workspace,
+                           int64_t workspace_floats, void* stream);
 /* GroupNorm(32, eps) [+ swish] on NHWC: taming/modules/diffusionmodules/model.py:38-42, 33-35.
  * stats_scratch: fp32 [N * (2*C + 64 * ceil(hw / 128))] = the per-channel affine [N][C][2], then partial sums
  * [N][blocks][32][2].  partial_blocks = 0: the statistics pass runs here; = hw/128: the producing convolution

@@ -309,6 +309,17 @@ class OpenAICLIPTransformer(nn.Module):
                   ops._stream())
         return y, saved
 
+    def backward_chunks(self):
+        """[(first_layer, end_layer)] in the order the backward walks them: the native layer loop returns to the host after
+        each chunk so that the finished layers' gradients can go on the wire (engine.FlatTrainer.layers_done)."""
+        step = self.backward_chunk_layers if self.on_layers_done is not None else self.layers
+        out, hi = [], self.layers
+        while hi > 0:
+            lo = max(0, hi - step)
+            out.append((lo, hi))
+            hi = lo
+        return out
+
     def _run_backward(self, g, saved, shape):
         if saved is None:
             raise _lib.MMVIDError('tower backward without saved activations (forward ran under no_grad)')
@@ -317,10 +328,7 @@ class OpenAICLIPTransformer(nn.Module):
         layers, _keep = self._layer_structs(True)
         _, scratch = self._workspace(cfg, g.device, False)
         per_layer = saved.numel() // self.layers
-        step = self.backward_chunk_layers if self.on_layers_done is not None else self.layers
-        hi = self.layers
-        while hi > 0:
-            lo = max(0, hi - step)
+        for lo, hi in self.backward_chunks():
             sub = self._cfg(B, L)
             sub.layers = hi - lo
             lp = ctypes.cast(ctypes.byref(layers, lo * ctypes.sizeof(_lib.TowerLayer)), ctypes.POINTER(_lib.TowerLayer))
@@ -328,4 +336,3 @@ class OpenAICLIPTransformer(nn.Module):
                       ctypes.c_void_p(saved.data_ptr() + lo * per_layer), ops._p(scratch), ops._stream())
             if self.on_layers_done is not None:
                 self.on_layers_done(lo)
-            hi = lo

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx, long lddx, int add,
                                                             bf16_t* __restrict__ dx_bf16,
                                                             float* __restrict__ dw, float* __restrict__ db,
-                                                            float* __restrict__ dx_colsum) {
+                                                            float* __restrict__ dx_colsum, float* __restrict__ partial) {
     __shared__ float red[2][4][LN_MAXV * 64 * 4];  // [dw|db][wave][E]  = 32 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = E >> 2;
@@ -141,8 +141,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int e = threadIdx.x; e < E; e += 256) {
             const float sw = (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]);
             const float sb = (red[1][0][e] + red[1][1][e]) + (red[1][2][e] + red[1][3][e]);
-            if (dw) unsafeAtomicAdd(dw + e, sw);
-            if (db) unsafeAtomicAdd(db + e, sb);
+            if (partial) {  // two-stage reduction: this block's row of the [blocks][3][E] workspace (no atomics)
+                partial[((long)blockIdx.x * 3 + 0) * E + e] = sw;
+                partial[((long)blockIdx.x * 3 + 1) * E + e] = sb;
+            } else {
+                if (dw) unsafeAtomicAdd(dw + e, sw);
+                if (db) unsafeAtomicAdd(db + e, sb);
+            }
         }
     }
     if (dx_colsum) {
@@ -153,9 +158,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             if (c < nv) reinterpret_cast<float4*>(red[0][wave])[c] = pc[i];
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < E; e += 256)
-            unsafeAtomicAdd(dx_colsum + e, (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]));
+        for (int e = threadIdx.x; e < E; e += 256) {
+            const float sc = (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]);
+            if (partial)
+                partial[((long)blockIdx.x * 3 + 2) * E + e] = sc;
+            else
+                unsafeAtomicAdd(dx_colsum + e, sc);
+        }
     }
+}
+
+// second stage: out_which[e] += sum over blocks of partial[b][which][e], fixed order (deterministic).  Block = 64 columns
+// x 4 row groups; grid = (ceil(E/64), 3).
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int E,
+                                                                   float* __restrict__ dw, float* __restrict__ db,
+                                                                   float* __restrict__ dx_colsum) {
+    __shared__ float sh[4][64];
+    const int which = blockIdx.y;
+    float* out = which == 0 ? dw : (which == 1 ? db : dx_colsum);
+    if (!out) return;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float a = 0.f;
+    if (col < E)
+        for (int b = rg; b < nblocks; b += 4) a += partial[((long)b * 3 + which) * E + col];
+    sh[rg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rg == 0 && col < E) out[col] += (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 // ---------------------------------------------------------------- GroupNorm(32) on NHWC
@@ -302,20 +330,53 @@ extern "C" int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, in
     return MMVID_OK;
 }
 
+extern "C" int mmvid_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                      const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
+                                      int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
+                                      float* workspace, int64_t workspace_floats, void* stream);
+
 extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                                    const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
                                    int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
                                    void* stream) {
+    return mmvid_layernorm_bwd_ws(dy, lddy, x, ldx, mean, rstd, w, rows, E, dx, lddx, add_into_dx, dx_bf16, dw, db, dx_colsum,
+                                  nullptr, 0, stream);
+}
+
+// workspace (optional): fp32 scratch of workspace_floats >= 3 * E * blocks; with it the weight / bias / column-sum
+// gradients are reduced in two stages (per-block rows, then a fixed-order column reduction): no atomics, deterministic,
+// and the grid no longer has to be kept small to bound the atomic traffic (more waves in flight -> closer to HBM speed).
+extern "C" int mmvid_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                      const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
+                                      int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
+                                      float* workspace, int64_t workspace_floats, void* stream) {
     MMVID_REQUIRE(dy && x && mean && rstd && w && dx, "layernorm_bwd: null pointer");
     MMVID_REQUIRE(E % 4 == 0 && E <= 64 * 4 * LN_MAXV && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0,
                   "layernorm_bwd: bad E/strides");
     if (rows == 0) return MMVID_OK;
     int blocks = cdiv(rows, 4);
-    const int cap = mmvid_option(MMVID_OPT_LN_BWD_BLOCKS);
-    if (blocks > cap) blocks = cap;
+    const bool any_red = dw || db || dx_colsum;
+    float* partial = nullptr;
+    if (workspace && any_red) {
+        int cap = (int)(workspace_floats / (3 * (int64_t)E));
+        if (cap > 2048) cap = 2048;
+        if (cap >= 64) {
+            if (blocks > cap) blocks = cap;
+            partial = workspace;
+        }
+    }
+    if (!partial) {
+        const int cap = mmvid_option(MMVID_OPT_LN_BWD_BLOCKS);
+        if (blocks > cap) blocks = cap;
+    }
+    // in two-stage mode the kernel needs non-null dw/db to take the reduction branch at all
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x,
-                       (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16, dw, db,
-                       dx_colsum);
+                       (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16,
+                       partial ? (dw ? dw : workspace) : dw, partial ? (db ? db : workspace) : db,
+                       partial ? (dx_colsum ? dx_colsum : nullptr) : dx_colsum, partial);
+    if (partial)
+        hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(E, 64), 3), dim3(256), 0, (hipStream_t)stream, partial, blocks, E,
+                           dw, db, dx_colsum);
     MMVID_LAUNCH_CHECK("layernorm_bwd");
     return MMVID_OK;
 }

@@ -14,6 +14,7 @@ namespace {
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 constexpr int kMaxSplitK = 16;  // == the cap of mmvid_gemm_dw_pick_splitk
+constexpr int kLnBwdBlocks = 1024;  // grid of the LayerNorm backward (its dw/db/colsum partial rows live in the scratch arena)
 
 struct Dims {
     int B, L, E, H, F, layers;
@@ -52,7 +53,7 @@ SavedLayer saved_layout(const Dims& d) {
 }
 
 struct Scratch {  // byte offsets inside the scratch arena
-    int64_t delta, dqkv, d_h, d_o, d_pre, g_bf16, splitk_ws, infer, total;
+    int64_t delta, dqkv, d_h, d_o, d_pre, g_bf16, splitk_ws, ln_ws, infer, total;
 };
 Scratch scratch_layout(const Dims& d) {
     Scratch s;
@@ -69,6 +70,7 @@ Scratch scratch_layout(const Dims& d) {
     s.d_pre = take(d.M * d.F * 2);
     s.g_bf16 = take(d.M * d.E * 2);
     s.splitk_ws = take((int64_t)kMaxSplitK * d.F * d.E * 4);  // largest weight ([F,E] >= [3E,E]) x splits
+    s.ln_ws = take((int64_t)kLnBwdBlocks * 3 * d.E * 4);  // per-block rows of the LayerNorm backward's two-stage reduction
     s.infer = take(saved_layout(d).total);  // one layer's worth of activations for inference mode
     s.total = off;
     return s;
@@ -246,6 +248,8 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
     void* gb = scr + sc.g_bf16;
     float* d_h = (float*)(scr + sc.d_h);
     float* ws = (float*)(scr + sc.splitk_ws);
+    float* ln_ws = (float*)(scr + sc.ln_ws);
+    const int64_t ln_ws_floats = (int64_t)kLnBwdBlocks * 3 * d.E;
     SideStream& ss = side_stream();
     hipStream_t s0 = (hipStream_t)stream;
     void* wst = ss.ok ? (void*)ss.s : stream;  // where the dW chains go
@@ -288,9 +292,9 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         ev_fc = mark();
         TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, d_h, nullptr, stream));
         wait(ev_pj);  // the LayerNorm backward overwrites gb
-        TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
-                                (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, gb, ly.g_ln2_w, ly.g_ln2_b,
-                                ly.g_out_b, stream));
+        TRY(mmvid_layernorm_bwd_ws(d_h, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
+                                   (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, gb, ly.g_ln2_w, ly.g_ln2_b,
+                                   ly.g_out_b, ln_ws, ln_ws_floats, stream));
         // ---- attention branch: x_mid = x_in + out_proj(MHA(LN1 x_in))
         fork();
         TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, nullptr, ws, wst));
@@ -305,9 +309,9 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         ev_in = mark();
         TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, d_h, nullptr, stream));
         wait(ev_out);  // the LayerNorm backward overwrites gb
-        TRY(mmvid_layernorm_bwd(d_h, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
-                                (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, i > 0 ? gb : nullptr, ly.g_ln1_w,
-                                ly.g_ln1_b, i > 0 ? layers[i - 1].g_pj_b : nullptr, stream));
+        TRY(mmvid_layernorm_bwd_ws(d_h, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
+                                   (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, i > 0 ? gb : nullptr, ly.g_ln1_w,
+                                   ly.g_ln1_b, i > 0 ? layers[i - 1].g_pj_b : nullptr, ln_ws, ln_ws_floats, stream));
     }
     wait(mark());  // join: every weight gradient of this call is complete for whatever follows on the caller's stream
     if (!hip_ok) {

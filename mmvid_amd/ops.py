@@ -132,14 +132,15 @@ def layernorm_fwd(x, w, b, eps=1e-5, out_dtype=bf16, save_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, w, dx=None, add=False, dw=None, db=None, dx_colsum=None):
+def layernorm_bwd(dy, x, mean, rstd, w, dx=None, add=False, dw=None, db=None, dx_colsum=None, workspace=None):
+    """workspace (fp32, >= 3*E*64 elements): two-stage deterministic reduction of dw / db / dx_colsum instead of atomics."""
     _chk(dy, f32, 'dy'), _chk(x, f32, 'x')
     rows, E = x.numel() // x.shape[-1], x.shape[-1]
     if dx is None:
         dx = torch.empty_like(x)
         add = False
-    call('mmvid_layernorm_bwd', _p(dy), E, _p(x), E, _p(mean), _p(rstd), _p(w), rows, E, _p(dx), E, int(add), None,
-         _p(dw), _p(db), _p(dx_colsum), _stream())
+    call('mmvid_layernorm_bwd_ws', _p(dy), E, _p(x), E, _p(mean), _p(rstd), _p(w), rows, E, _p(dx), E, int(add), None,
+         _p(dw), _p(db), _p(dx_colsum), _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
     return dx
 
 

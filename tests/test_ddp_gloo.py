@@ -99,6 +99,73 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_real(rank, world, port, q):
+    """The REAL model (tiny BERT: 2-layer CLIP-shaped tower, all heads, all tables) under FlatTrainer, with the callbacks in
+    the order and granularity the real tower backward issues them (OpenAICLIPTransformer.backward_chunks)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from test_host_logic import tiny_bert
+        from mmvid_amd.engine import FlatTrainer, backward_order, broadcast_parameters
+        torch.manual_seed(7 + rank)
+        m = tiny_bert(1, True)
+        m.transformer.backward_chunk_layers = 1
+        broadcast_parameters(m)
+        tr = FlatTrainer(m, order=backward_order, bucket_mb=1)
+        assert m.transformer.on_layers_done == tr.layers_done
+        n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+        assert sum(p.numel() for p in tr.params) == n_train and not any(n.startswith(('vae.', 'cvae.')) for n in tr.names)
+        for p, o in zip(tr.params, tr.offsets):
+            assert p.data_ptr() == tr.P.data_ptr() + 4 * o and p.grad.data_ptr() == tr.G.data_ptr() + 4 * o
+        tr.zero_grad()
+        for i, p in enumerate(tr.params):
+            p.grad.fill_(float(rank + 1) * (1 + i % 5))
+        sent = []
+        orig = tr._send
+
+        def spy(lo, hi):
+            if hi > lo:
+                sent.append((lo, hi))
+            return orig(lo, hi)
+
+        tr._send = spy
+        chunks = m.transformer.backward_chunks()
+        assert chunks == [(1, 2), (0, 1)]
+        # the heads' gradients are final before the tower backward starts; each finished chunk extends the sent range down
+        for lo, hi in chunks:
+            tr.layers_done(lo)
+        heads_and_tower = min(o for n, o in zip(tr.names, tr.offsets) if n.startswith(('transformer.', 'to_logits')))
+        assert sent[0][1] == tr.numel and sent[-1][0] == heads_and_tower
+        assert all(a[0] == b[1] for a, b in zip(sent, sent[1:])), sent  # contiguous, descending, no overlap
+        tr.allreduce_grads()
+        assert sent[-1][0] == 0 and tr._sent_from == tr.numel
+        for i, p in enumerate(tr.params):
+            expect = sum((r + 1) * (1 + i % 5) for r in range(world))
+            assert torch.all(p.grad == expect), tr.names[i]
+        q.put((rank, 'ok'))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_trainer_real_model_callbacks_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == 'ok' for r in res), res
+
+
 @pytest.mark.timeout(300)
 def test_flat_trainer_exchange_world2():
     ctx = mp.get_context('spawn')

@@ -175,6 +175,20 @@ def test_layernorm_fwd_bwd(ops):
         close(cs, cs0 + dx.sum(0), 1e-5, 'ln colsum(dx)')
         close(dw, wr.grad, 1e-4, 'ln dw')
         close(db, br.grad, 1e-4, 'ln db')
+        # two-stage (workspace) reduction: same values, deterministic (bit-identical between runs), partial outputs allowed
+        ws = torch.empty(3 * E * 256, device=DEV)
+        outs = []
+        for _ in range(2):
+            dx2, dw2, db2, cs2 = base.clone(), torch.zeros(E, device=DEV), torch.zeros(E, device=DEV), cs0.clone()
+            ops.layernorm_bwd(dy, x, mean, rstd, w, dx=dx2, add=True, dw=dw2, db=db2, dx_colsum=cs2, workspace=ws)
+            outs.append((dx2, dw2, db2, cs2))
+        assert all(torch.equal(a, b_) for a, b_ in zip(*outs))
+        assert torch.equal(outs[0][0], dx)
+        close(outs[0][1], wr.grad, 1e-5, 'ln dw (two-stage)'), close(outs[0][2], br.grad, 1e-5, 'ln db (two-stage)')
+        close(outs[0][3], cs0 + dx.sum(0), 1e-5, 'ln colsum (two-stage)')
+        cs3 = cs0.clone()
+        ops.layernorm_bwd(dy, x, mean, rstd, w, dx=base.clone(), add=True, dx_colsum=cs3, workspace=ws)
+        assert torch.equal(cs3, outs[0][3])
 
 
 def test_groupnorm_swish(ops):

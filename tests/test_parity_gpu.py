@@ -648,6 +648,55 @@ def test_flat_trainer_state_dict_roundtrip_and_bindings(golden):
     assert not torch.equal(before, tr2.P) and all(p.grad.data_ptr() == tr2.G.data_ptr() + 4 * o for p, o in zip(tr2.params, tr2.offsets))
 
 
+def test_graphed_step_with_captured_gradient_exchange(golden):
+    """The data-parallel step keeps the graph: with a process group (here a group of ONE rank over RCCL, exchange forced
+    on) the bucketed all-reduces issued from the tower-backward callbacks are captured inside the step's hipGraph.
+    Parameters after three steps must equal the plain single-process run (a sum over one rank is the identity)."""
+    import copy
+    import socket
+
+    import torch.distributed as dist
+
+    from mmvid_amd.engine import FlatTrainer, GraphedStep, backward_order
+    g = golden('bert_tiny')
+    base = load_synth(tiny_bert(), g, 17).train()
+    text, frames = g['text'].to(DEV), g['frames'].to(DEV)
+    mask1, warped = g['mask1'].to(DEV), g['warped_frames'].to(DEV)
+
+    def run(force):
+        m = copy.deepcopy(base)
+        m.transformer.backward_chunk_layers = 1
+        tr = FlatTrainer(m, lr=1e-3, order=backward_order, force_exchange=force, bucket_mb=4)
+
+        def fn(text, frames):
+            lm, lr, lv = _with_tokens(m, g, lambda: m(text, target=frames, return_loss=True, rel=True, vid=True, _mask1=mask1,
+                                                      _target_warp=warped))
+            return 7.0 * lm + 0.5 * lr + 0.5 * lv
+
+        step = GraphedStep(tr, fn, dict(text=text, frames=frames), warmup=1)
+        losses = [step().item() for _ in range(2)]
+        return step, tr, losses
+
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        step_f, tr_f, loss_f = run(True)
+        assert tr_f.force_exchange
+        print('captured exchange:', 'hipGraph' if step_f.graph is not None else f'eager fallback ({step_f.capture_error})')
+        step_p, tr_p, loss_p = run(False)
+        assert step_p.graph is not None
+        assert tr_f.step_count == tr_p.step_count == 3
+        for a, b in zip(loss_f, loss_p):
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(a))
+        close(tr_f.P, tr_p.P, 5e-3, 'parameters after 3 steps: forced exchange vs plain')
+        assert step_f.graph is not None, f'the step with RCCL all-reduces could not be captured: {step_f.capture_error}'
+    finally:
+        dist.destroy_process_group()
+
+
 def test_artv_flat_trainer_keeps_head_shadow_current(golden):
     """Advisor finding: DALLE's 51,584-way head must train against a bf16 weight that follows the fused optimiser."""
     from mmvid_amd.dalle_artv import DALLE
