@@ -143,49 +143,125 @@ struct GemvArgs {
     int pos0;
 };
 
+// KIT = ceil(K / 512): 16-byte weight loads per lane and output feature.  The kernel is latency-bound (a decode step is a
+// chain of ~60 of these), so the two global round trips it needs are overlapped: every weight load of the wave is issued
+// FIRST, into registers, and the input rows are fetched / normalised / staged in LDS while those are in flight.
+template <int KIT>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][K]
+    __shared__ float red[4][GV_MAXB];
     __shared__ float stats[GV_MAXB][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, NB = a.NB;
-    // ---- stage the input rows (LayerNorm + bf16 rounding where the full forward has them)
-    for (int b = wave; b < NB; b += 4) {  // one wave per row: statistics
-        if (a.ln_w) {
-            float s = 0.f;
-            for (int k = lane; k < K; k += 64) s += a.x[b * a.ldx + k];
-            const float mean = wave_sum(s) / (float)K;
-            float q = 0.f;
-            for (int k = lane; k < K; k += 64) {
-                const float d = a.x[b * a.ldx + k] - mean;
-                q += d * d;
-            }
-            const float rstd = rsqrtf(wave_sum(q) / (float)K + a.eps);
-            if (lane == 0) stats[b][0] = mean, stats[b][1] = rstd;
+    const int n0 = blockIdx.x * GV_COLS + wave * 2;
+    const bool have = n0 < a.N, two = n0 + 1 < a.N;
+    // ---- 1. weights of this wave's two output features -> registers
+    uint4 w[2][KIT];
+    {
+        const bf16_t* w0 = a.W + (long)(have ? n0 : 0) * K;
+        const bf16_t* w1 = a.W + (long)(two ? n0 + 1 : (have ? n0 : 0)) * K;
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int k0 = (it * 64 + lane) * 8;
+            w[0][it] = k0 < K ? *reinterpret_cast<const uint4*>(w0 + k0) : make_uint4(0u, 0u, 0u, 0u);
+            w[1][it] = k0 < K ? *reinterpret_cast<const uint4*>(w1 + k0) : make_uint4(0u, 0u, 0u, 0u);
         }
     }
-    __syncthreads();
-    for (int i = tid; i < NB * K; i += 256) {
-        const int b = i / K, k = i - b * K;
-        float v = a.x[b * a.ldx + k];
-        if (a.ln_w) v = (v - stats[b][0]) * stats[b][1] * a.ln_w[k] + a.ln_b[k];
-        if (a.round_in) v = round_bf16(v);
-        xs[i] = v;
+    // epilogue operands of lane l = (feature c = l >> 3, row b = l & 7): requested now, consumed at the very end
+    const int ec = lane >> 3, eb = lane & 7;
+    const bool elane = lane < 16 && eb < NB && n0 + ec < a.N;
+    const int en = n0 + ec;
+    const float ebias = (elane && a.bias) ? a.bias[en] : 0.f;
+    const float eres = (elane && a.residual) ? a.residual[eb * a.ldr + en] : 0.f;
+    const int epos = a.kv_cache ? (a.pos_dev ? *a.pos_dev : a.pos0) : 0;
+    // ---- 2. input rows: one pass of 16-byte loads into registers, LayerNorm statistics by block reduction, then LDS
+    const int kq = K >> 2, total4 = NB * kq;  // float4 per row / in all rows
+    constexpr int XV = 12;                    // float4 per thread: NB * K <= 12288 floats
+    float4 xv[XV];
+    int xrow[XV];
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+        const int i = tid + 256 * j;
+        xrow[j] = i < total4 ? i / kq : -1;
+        xv[j] = i < total4 ? *reinterpret_cast<const float4*>(a.x + (long)xrow[j] * a.ldx + (i - xrow[j] * kq) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    constexpr int XL = 6;  // with LayerNorm NB * K <= 6144: gain / bias of this thread's elements, requested with the rows
+    float4 lg[XL], lb[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        const bool on = a.ln_w && xrow[j] >= 0;
+        const int k = on ? (tid + 256 * j - xrow[j] * kq) * 4 : 0;
+        lg[j] = on ? *reinterpret_cast<const float4*>(a.ln_w + k) : make_float4(1.f, 1.f, 1.f, 1.f);
+        lb[j] = on ? *reinterpret_cast<const float4*>(a.ln_b + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (a.ln_w) {
+        for (int pass = 0; pass < 2; ++pass) {
+            float part[GV_MAXB];
+#pragma unroll
+            for (int b = 0; b < GV_MAXB; ++b) part[b] = 0.f;
+#pragma unroll
+            for (int j = 0; j < XV; ++j) {
+                if (xrow[j] < 0) continue;
+                float v;
+                if (pass == 0) {
+                    v = (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+                } else {
+                    const float mu = stats[xrow[j]][0];
+                    const float d0 = xv[j].x - mu, d1 = xv[j].y - mu, d2 = xv[j].z - mu, d3 = xv[j].w - mu;
+                    v = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+#pragma unroll
+                for (int b = 0; b < GV_MAXB; ++b) part[b] += (xrow[j] == b) ? v : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < GV_MAXB; ++b) {
+                if (b < NB) {
+                    const float sw = wave_sum(part[b]);
+                    if (lane == 0) red[wave][b] = sw;
+                }
+            }
+            __syncthreads();
+            if (tid < NB) {
+                const float t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+                if (pass == 0)
+                    stats[tid][0] = t / (float)K;
+                else
+                    stats[tid][1] = rsqrtf(t / (float)K + a.eps);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+        if (xrow[j] < 0) continue;
+        const int i = tid + 256 * j;
+        const int k = (i - xrow[j] * kq) * 4;
+        float v[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+        if (a.ln_w && j < XL) {
+            const float mu = stats[xrow[j]][0], rs = stats[xrow[j]][1];
+            const float4 g4 = lg[j < XL ? j : 0], b4 = lb[j < XL ? j : 0];
+            v[0] = (v[0] - mu) * rs * g4.x + b4.x, v[1] = (v[1] - mu) * rs * g4.y + b4.y;
+            v[2] = (v[2] - mu) * rs * g4.z + b4.z, v[3] = (v[3] - mu) * rs * g4.w + b4.w;
+        }
+        if (a.round_in) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]);
+        }
+        *reinterpret_cast<float4*>(xs + (long)xrow[j] * K + k) = make_float4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
-    // ---- each wave: two output features, all NB rows; weights streamed 16 B per lane
-    const int n0 = blockIdx.x * GV_COLS + wave * 2;
-    if (n0 >= a.N) return;
-    const bool two = n0 + 1 < a.N;
+    if (!have) return;
+    // ---- 3. dot products: weights from registers, rows from LDS
     float acc[2][GV_MAXB];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int b = 0; b < GV_MAXB; ++b) acc[c][b] = 0.f;
-    const bf16_t* w0 = a.W + (long)n0 * K;
-    const bf16_t* w1 = a.W + (long)(two ? n0 + 1 : n0) * K;
-    for (int k0 = lane * 8; k0 < K; k0 += 512) {
-        const uint4 u0 = *reinterpret_cast<const uint4*>(w0 + k0);
-        const uint4 u1 = *reinterpret_cast<const uint4*>(w1 + k0);
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+        const int k0 = (it * 64 + lane) * 8;
+        if (k0 >= K) continue;
+        const uint4 u0 = w[0][it], u1 = w[1][it];
         const float f0[8] = {bf_lo(u0.x), bf_hi(u0.x), bf_lo(u0.y), bf_hi(u0.y), bf_lo(u0.z), bf_hi(u0.z), bf_lo(u0.w), bf_hi(u0.w)};
         const float f1[8] = {bf_lo(u1.x), bf_hi(u1.x), bf_lo(u1.y), bf_hi(u1.y), bf_lo(u1.z), bf_hi(u1.z), bf_lo(u1.w), bf_hi(u1.w)};
 #pragma unroll
@@ -205,21 +281,21 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a) {
 #pragma unroll
         for (int b = 0; b < GV_MAXB; ++b)
             if (b < NB) acc[c][b] = wave_sum(acc[c][b]);
-    if (lane == 0) {
-        const int pos = a.pos_dev ? *a.pos_dev : a.pos0;
-        for (int c = 0; c < (two ? 2 : 1); ++c) {
-            const int n = n0 + c;
-            const float bias = a.bias ? a.bias[n] : 0.f;
-            for (int b = 0; b < NB; ++b) {
-                float v = acc[c][b] + bias;
-                if (a.act == 1) v = v * sigmoidf_(1.702f * v);  // QuickGELU (clip_model.py:196-198)
-                if (a.residual) v += a.residual[b * a.ldr + n];
-                if (a.round_out) v = round_bf16(v);
-                a.out[b * a.ldo + n] = v;
-                if (a.kv_cache && n >= a.kv_lo && n < a.kv_lo + a.kv_width && pos < a.Lmax)
-                    a.kv_cache[((long)b * a.Lmax + pos) * a.kv_width + (n - a.kv_lo)] = f2bf(v);
-            }
-        }
+    // every lane holds every sum: lane (c, b) finishes its own output (one parallel round of stores)
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int b = 0; b < GV_MAXB; ++b)
+            if (lane == c * 8 + b) v = acc[c][b];
+    if (elane) {
+        v += ebias;
+        if (a.act == 1) v = v * sigmoidf_(1.702f * v);  // QuickGELU (clip_model.py:196-198)
+        v += eres;
+        if (a.round_out) v = round_bf16(v);
+        a.out[eb * a.ldo + en] = v;
+        if (a.kv_cache && en >= a.kv_lo && en < a.kv_lo + a.kv_width && epos < a.Lmax)
+            a.kv_cache[((long)eb * a.Lmax + epos) * a.kv_width + (en - a.kv_lo)] = f2bf(v);
     }
 }
 
@@ -237,19 +313,35 @@ __global__ __launch_bounds__(256) void attn_decode2_kernel(const float* __restri
     __syncthreads();
     const bf16_t* kv = cache + (long)b * Lmax * 2 * E + h * 64;
     float mx = -INFINITY;
-    for (int k = tid; k < n; k += 256) {
-        const uint4* kr = reinterpret_cast<const uint4*>(kv + (long)k * 2 * E);
-        float d = 0.f;
+    for (int k0 = tid; k0 < n; k0 += 512) {  // two keys (16 loads) in flight per thread
+        uint4 ua[8], ub[8];
+        const int k1 = k0 + 256;
+        const uint4* ka = reinterpret_cast<const uint4*>(kv + (long)k0 * 2 * E);
+        const uint4* kb = reinterpret_cast<const uint4*>(kv + (long)(k1 < n ? k1 : k0) * 2 * E);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ua[c] = ka[c], ub[c] = kb[c];
+        float da = 0.f, db = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const uint4 u = kr[c];
             const float* qq = qs + 8 * c;
-            d += (bf_lo(u.x) * qq[0] + bf_hi(u.x) * qq[1]) + (bf_lo(u.y) * qq[2] + bf_hi(u.y) * qq[3]) +
-                 (bf_lo(u.z) * qq[4] + bf_hi(u.z) * qq[5]) + (bf_lo(u.w) * qq[6] + bf_hi(u.w) * qq[7]);
+            da += (bf_lo(ua[c].x) * qq[0] + bf_hi(ua[c].x) * qq[1]) + (bf_lo(ua[c].y) * qq[2] + bf_hi(ua[c].y) * qq[3]) +
+                  (bf_lo(ua[c].z) * qq[4] + bf_hi(ua[c].z) * qq[5]) + (bf_lo(ua[c].w) * qq[6] + bf_hi(ua[c].w) * qq[7]);
+            db += (bf_lo(ub[c].x) * qq[0] + bf_hi(ub[c].x) * qq[1]) + (bf_lo(ub[c].y) * qq[2] + bf_hi(ub[c].y) * qq[3]) +
+                  (bf_lo(ub[c].z) * qq[4] + bf_hi(ub[c].z) * qq[5]) + (bf_lo(ub[c].w) * qq[6] + bf_hi(ub[c].w) * qq[7]);
         }
-        d *= scale_log2;
-        sc[k] = d;
-        mx = fmaxf(mx, d);
+        da *= scale_log2, db *= scale_log2;
+        sc[k0] = da;
+        mx = fmaxf(mx, da);
+        if (k1 < n) sc[k1] = db, mx = fmaxf(mx, db);
+    }
+    // the values do not depend on the scores: request the first batch of V rows now, under the softmax statistics
+    // o[d] = sum_k p[k] V[k][d]: thread (kg = tid>>3, dc = tid&7) owns 8 dims of every 32nd key: 16-B loads, 8 accumulators
+    const int kg = tid >> 3, dc = tid & 7;
+    uint4 u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kg + 32 * j;
+        u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E + dc * 8) : make_uint4(0u, 0u, 0u, 0u);
     }
     mx = wave_max(mx);
     if (lane == 0) stat[wave] = mx;
@@ -265,14 +357,22 @@ __global__ __launch_bounds__(256) void attn_decode2_kernel(const float* __restri
     if (lane == 0) stat[4 + wave] = sum;
     __syncthreads();
     sum = (stat[4] + stat[5]) + (stat[6] + stat[7]);
-    // o[d] = sum_k p[k] V[k][d]: thread (kg = tid>>3, dc = tid&7) owns 8 dims of every 32nd key: 16-B loads, 8 accumulators
-    const int kg = tid >> 3, dc = tid & 7;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = kg; k < n; k += 32) {
-        const uint4 u = *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E + dc * 8);
-        const float p = sc[k];
-        acc[0] += p * bf_lo(u.x), acc[1] += p * bf_hi(u.x), acc[2] += p * bf_lo(u.y), acc[3] += p * bf_hi(u.y);
-        acc[4] += p * bf_lo(u.z), acc[5] += p * bf_hi(u.z), acc[6] += p * bf_lo(u.w), acc[7] += p * bf_hi(u.w);
+    for (int k0 = kg; k0 < n; k0 += 32 * 8) {  // 8 independent 16-byte loads per round trip (the first batch is already here)
+        if (k0 != kg) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + 32 * j;
+                u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E + dc * 8) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + 32 * j;
+            const float p = k < n ? sc[k] : 0.f;
+            acc[0] += p * bf_lo(u[j].x), acc[1] += p * bf_hi(u[j].x), acc[2] += p * bf_lo(u[j].y), acc[3] += p * bf_hi(u[j].y);
+            acc[4] += p * bf_lo(u[j].z), acc[5] += p * bf_hi(u[j].z), acc[6] += p * bf_lo(u[j].w), acc[7] += p * bf_hi(u[j].w);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[kg][dc * 8 + e] = acc[e];
@@ -297,11 +397,20 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const long long* __restr
 }
 
 int gemv_launch(GemvArgs a, hipStream_t s) {
-    if (a.NB > GV_MAXB || a.K % 8 != 0 || (long)a.NB * a.K * 4 > 64 * 1024) {
-        mmvid_set_error("decode gemv: NB=%d (<= %d), K=%d (multiple of 8, NB*K*4 <= 64 KiB)", a.NB, GV_MAXB, a.K);
+    if (a.NB > GV_MAXB || a.K % 8 != 0 || (long)a.NB * a.K > 12288 || a.K > 3072 || a.ldx % 4 != 0 ||
+        (a.ln_w && (long)a.NB * a.K > 6144)) {
+        mmvid_set_error("decode gemv: NB=%d (<= %d), K=%d (multiple of 8, <= 3072, NB*K <= 12288), ldx %% 4 == 0", a.NB, GV_MAXB, a.K);
         return MMVID_ERR_ARG;
     }
-    hipLaunchKernelGGL(gemv_rows_kernel, dim3(cdiv(a.N, GV_COLS)), dim3(256), (size_t)a.NB * a.K * 4, s, a);
+    const dim3 grid(cdiv(a.N, GV_COLS));
+    const size_t lds = (size_t)a.NB * a.K * 4;
+    const int kit = cdiv(a.K, 512);
+    if (kit <= 2)
+        hipLaunchKernelGGL(gemv_rows_kernel<2>, grid, dim3(256), lds, s, a);
+    else if (kit <= 4)
+        hipLaunchKernelGGL(gemv_rows_kernel<4>, grid, dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(gemv_rows_kernel<6>, grid, dim3(256), lds, s, a);
     return MMVID_OK;
 }
 

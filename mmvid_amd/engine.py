@@ -270,8 +270,11 @@ class GraphedStep:
         torch.cuda.synchronize()
         saved = (trainer.step_count, trainer._step_dev.clone(), self._frontend_steps())
         graph = torch.cuda.CUDAGraph()
+        # with a process group alive, its watchdog thread polls events while we capture: only THIS thread's calls may be
+        # policed (the default "global" mode turns the watchdog's hipEventQuery into a capture violation)
+        mode = 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=mode):
                 self.loss = self._step()
             self.graph = graph
         except Exception as e:  # e.g. a collective that cannot be captured: keep training, eagerly

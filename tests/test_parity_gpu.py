@@ -662,15 +662,16 @@ def test_graphed_step_with_captured_gradient_exchange(golden):
     base = load_synth(tiny_bert(), g, 17).train()
     text, frames = g['text'].to(DEV), g['frames'].to(DEV)
     mask1, warped = g['mask1'].to(DEV), g['warped_frames'].to(DEV)
+    nfm = torch.ones(text.shape[0], device=DEV)
 
     def run(force):
         m = copy.deepcopy(base)
         m.transformer.backward_chunk_layers = 1
         tr = FlatTrainer(m, lr=1e-3, order=backward_order, force_exchange=force, bucket_mb=4)
 
-        def fn(text, frames):
-            lm, lr, lv = _with_tokens(m, g, lambda: m(text, target=frames, return_loss=True, rel=True, vid=True, _mask1=mask1,
-                                                      _target_warp=warped))
+        def fn(text, frames):  # capture-safe: device work only (the model's own encoder, injected mask / warp tensors)
+            lm, lr, lv = m(text, target=frames, return_loss=True, rel=True, vid=True, _mask1=mask1, _target_warp=warped,
+                           _not_fully_masked=nfm)
             return 7.0 * lm + 0.5 * lr + 0.5 * lv
 
         step = GraphedStep(tr, fn, dict(text=text, frames=frames), warmup=1)
