@@ -228,6 +228,15 @@ int mmvid_attention_decode(const void* qkv, int64_t ldq, const void* cache, int 
 int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w, const float* bias,
                       int Cout, const void* residual_bf16, const float* residual_f32, int clamp01, void* out_bf16,
                       float* out_f32, float* gn_partial, void* stream);
+/* The ResnetBlock convolutions (mode 0: 3x3, stride 1, pad 1; model.py:102-115) at 32x32 and above in "strip" form
+ * (csrc/conv_strip.hip): a K tile is (kernel row, 32 input channels), the input strip is staged once for the three kx
+ * taps, the block is 512 pixels x 128 channels.  Same contract as mmvid_conv2d_nhwc(mode 0) except that the GroupNorm
+ * partial sums are per 64-pixel block: gn_partial64 [N][H*W/64][32][2].  mmvid_conv3x3_strip_supported: geometry test
+ * (W a power of two in 8..128, Cin a power of two >= 32, Cout % 128 == 0, H*W >= 1024); independent of N by design. */
+int mmvid_conv3x3_strip_supported(int H, int W, int Cin, int Cout);
+int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
+                             const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32,
+                             float* gn_partial64, void* stream);
 /* img NCHW fp32 [N,3,H,W] in [0,1] -> NHWC bf16 [N,H,W,8] of 2x-1 (vae.py:41), channels 3..7 zero. */
 int mmvid_image_to_nhwc8(const float* img, int N, int H, int W, void* out_bf16, void* stream);
 /* NHWC fp32 [N,H,W,C] -> NCHW fp32 (first Cuse channels). */
@@ -304,9 +313,11 @@ int mmvid_spatial_attention_f32(const float* q, const float* k, const float* v, 
 enum {
     MMVID_VQOP_IMG2NHWC8 = 0, /* ext_in img [N,3,H,W] f32 -> out_bf16 [N,H,W,8]                                  */
     MMVID_VQOP_CONV = 1,      /* in0 x [N,H,W,C] bf16, w, b, Cout, mode; in1 residual (flags&1: f32); flags&2 clamp01;
-                                 flags&4: write GroupNorm partial sums of the output into `scratch` (a GN stats area) */
+                                 flags&4: write GroupNorm partial sums of the output into `scratch` (a GN stats area);
+                                 flags&8: the strip kernel (mmvid_conv3x3_strip_nhwc; partial sums per 64 pixels)           */
     MMVID_VQOP_GROUPNORM = 2, /* in0 [N,H,W,C] (flags&1: f32), w, b, eps, mode = swish, scratch = stats;
-                                 flags&2: the partial sums in `scratch` were written by the producing CONV          */
+                                 flags&2: the partial sums in `scratch` were written by the producing CONV (flags&8: per
+                                 64-pixel block instead of per 128)                                                  */
     MMVID_VQOP_CAST = 3,      /* in0 f32 -> out_bf16, N*H*W*C elements                                           */
     MMVID_VQOP_SPATIAL_ATTN = 4, /* in0,in1,in2 = q,k,v [N,H*W,C] bf16, eps = scale, scratch                        */
     MMVID_VQOP_VQ_ARGMIN = 5, /* in0 z [N*H*W, C] f32, w = codebook [Cout, C], b = ee -> ext_out int64            */

@@ -1,0 +1,259 @@
+// 3x3 / stride-1 / pad-1 convolution on NHWC bf16 for gfx950, "strip" form -- the VQGAN ResnetBlock convolutions
+// (taming/modules/diffusionmodules/model.py:102-115) at the resolutions that dominate the encoder (128^2, 64^2, 32^2).
+//
+// Why a second kernel.  conv_igemm_kernel (conv.hip) treats the convolution as a GEMM whose A tile is gathered per TAP:
+// every input pixel goes through the global->LDS path nine times, 48 one-KiB LDS-DMA pieces per 128 MFMAs, and the PMC
+// passes showed that path -- not HBM, not the matrix pipe -- bounding the kernel.  Here a K tile is
+// (kernel row ky, 32 input channels): the A operand is a STRIP of the input -- the tile's image rows shifted by ky-1, with
+// one zero pixel of padding left and right -- staged ONCE and read three times (kx = 0,1,2 are the same strip, one pixel
+// apart), and the block covers 512 output pixels x 128 output channels, so the weights are amortised over twice the
+// pixels:
+//                         conv_igemm 256x128      conv_strip 512x128
+//   LDS-DMA pieces / MFMA        0.375                  0.15
+//   ds_read_b128   / MFMA        1.0                    0.75
+//   barriers       / MFMA        1/32 (4 per 128)       1/384
+// 8 waves, each 64 pixels x 128 channels (2 x 4 v_mfma_f32_32x32x16_bf16 tiles, 128 accumulator VGPRs); two LDS stages of
+// 72 KiB (A strip 40 KiB + B 32 KiB); operands reach LDS by buffer_load ... lds with the swizzle on the source address
+// (gemm_core.h), zero padding and ragged edges by the descriptor's range check.  Epilogue as conv.hip: bias, residual
+// (fp32 / bf16), fp32 and/or bf16 stores, GroupNorm partial sums of the output (per 64-pixel block, fixed order).
+// Roofline: bf16 MFMA; algorithmic FLOPs = 2 * M * Cout * 9 * Cin.
+#include "../../include/mmvid_hip.h"
+#include "gemm_core.h"
+#include "prof.h"
+
+namespace {
+using namespace mmvid_core;
+
+constexpr int ST_M = 512, ST_N = 128;
+constexpr int A_STAGE = 40 * 1024, B_STAGE = 32 * 1024, STAGE = A_STAGE + B_STAGE;
+constexpr int PA = 5, PB = 4;  // LDS-DMA pieces per wave and K tile (A strip: 40, B: 32)
+constexpr int ST_LDS = 2 * STAGE;
+
+struct StripParams {
+    const bf16_t* x;
+    const bf16_t* w;  // [Cout][9][Cin]
+    int N, H, W, Cin, Cout, w_log2;
+    long M;
+    const float* bias;
+    const bf16_t* res_bf16;
+    const float* res_f32;
+    bf16_t* out_bf16;
+    float* out_f32;
+    float* gn_partial;  // [N][H*W/64][32][2] or null
+};
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk_n = p.Cout / ST_N;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int cout0 = (wg % nblk_n) * ST_N;
+    const long m0 = (long)(wg / nblk_n) * ST_M;
+    const int W = p.W, H = p.H, Cin = p.Cin, WP = W + 2;
+    const int R = ST_M >> p.w_log2;            // image rows per tile
+    const long grow0 = m0 >> p.w_log2;         // first global image-row index (over all images)
+    const long grows = (long)p.N * H;
+
+    // ---- LDS-DMA descriptors of this lane: A strip (centre row, channel chunk 0) and B
+    uint32_t avoff[PA], amask[PA];
+#pragma unroll
+    for (int jj = 0; jj < PA; ++jj) {
+        const int slot = (wave * PA + jj) * 64 + lane;
+        const int sp = slot >> 2, pc = slot & 3;
+        const int c = pc ^ ((sp >> 2) & 3);
+        const int rr = sp / WP, xx = sp - rr * WP - 1;
+        const long g = grow0 + rr;
+        avoff[jj] = 0, amask[jj] = 0;
+        if (rr < R && g < grows && xx >= 0 && xx < W) {
+            const int y = (int)(g % H);
+            avoff[jj] = (uint32_t)(((g * W + xx) * Cin + c * 8) * 2);
+            amask[jj] = (y >= 1 ? 1u : 0u) | 2u | (y + 1 < H ? 4u : 0u);
+        }
+    }
+    uint32_t bvoff[PB];
+#pragma unroll
+    for (int jj = 0; jj < PB; ++jj) {
+        const int row = (wave * PB + jj) * 4 + (lane >> 4), ps = lane & 15;
+        const int q = ps ^ (row & 15);
+        bvoff[jj] = (q < 12 && cout0 + row < p.Cout) ? (uint32_t)((((long)(cout0 + row) * 9 + (q >> 2)) * Cin + (q & 3) * 8) * 2) : OOB;
+    }
+    const rsrc_t brsrc = make_rsrc(p.w, (uint32_t)((long)p.Cout * 9 * Cin * 2));
+    const int chunks = Cin >> 5, nt = 3 * chunks;
+    auto stage_tile = [&](int t, char* buf) {
+        const int ky = t / chunks, ch = t - ky * chunks;  // wave-uniform
+        const long disp = ((long)(ky - 1) * W * Cin + ch * 32) * 2;
+        const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + disp, 0x7fffffffu);
+        const uint32_t bit = 1u << ky;
+#pragma unroll
+        for (int jj = 0; jj < PA; ++jj)
+            blds16(arsrc, (amask[jj] & bit) ? avoff[jj] : OOB, 0, buf + (wave * PA + jj) * 1024);
+        const uint32_t bsoff = (uint32_t)((ky * 3 * Cin + ch * 32) * 2);
+#pragma unroll
+        for (int jj = 0; jj < PB; ++jj) blds16(brsrc, bvoff[jj], bsoff, buf + A_STAGE + (wave * PB + jj) * 1024);
+    };
+
+    // ---- fragment addresses (byte offsets inside a stage)
+    const int h8 = lane >> 5;
+    uint32_t aaddr[2][3], baddr[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 64 + i * 32 + (lane & 31);
+        const int rr = r >> p.w_log2, x = r & (W - 1);
+        const int sp = rr * WP + x;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int spk = sp + kx;
+            aaddr[i][kx] = (uint32_t)(spk * 64 + ((h8 ^ ((spk >> 2) & 3)) << 4));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = j * 32 + (lane & 31);
+        baddr[j] = (uint32_t)(A_STAGE + row * 256 + ((h8 ^ (row & 15)) << 4));
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    stage_tile(0, smem);
+    for (int t = 0; t < nt; ++t) {
+        char* cur = smem + (t & 1) * STAGE;
+        __syncthreads();  // tile t has landed for every wave (the compiler's vmcnt(0) precedes it); buffer (t+1)&1 is free
+        if (t + 1 < nt) stage_tile(t + 1, smem + ((t + 1) & 1) * STAGE);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t af[2], bfr[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(cur + (aaddr[i][kx] ^ (uint32_t)(s << 5)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(cur + (baddr[j] ^ (uint32_t)((kx << 6) | (s << 5))));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: per wave a private [32][132] fp32 slab, two passes (i = 0, 1); global traffic is row-contiguous
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma_settle(acc[i][j]);
+    __syncthreads();  // every wave is done reading the stages
+    float* slab = reinterpret_cast<float*>(smem) + wave * (32 * SLAB_PITCH);
+    const int cg = lane & 31, n = cout0 + 4 * cg;
+    const bool n_ok = n < p.Cout;
+    const float4 bias4 = (p.bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float gs = 0.f, gq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(slab + (lane & 31) * SLAB_PITCH + j * 32 + 8 * q + 4 * h8) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS write -> read
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // 8 rows at a time: every load of a batch is issued before any is consumed
+            float4 v4[8], rf[8];
+            uint2 rb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = h8 + 2 * (half * 8 + k);
+                const long m = m0 + wave * 64 + i * 32 + r;
+                const bool ok = n_ok && m < p.M;
+                const long o = m * p.Cout + n;
+                v4[k] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + 4 * cg);
+                rf[k] = (p.res_f32 && ok) ? *reinterpret_cast<const float4*>(p.res_f32 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[k] = (p.res_bf16 && ok) ? *reinterpret_cast<const uint2*>(p.res_bf16 + o) : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = h8 + 2 * (half * 8 + k);
+                const long m = m0 + wave * 64 + i * 32 + r;
+                if (!n_ok || m >= p.M) continue;
+                const float v[4] = {v4[k].x + bias4.x + rf[k].x + bf_lo(rb[k].x), v4[k].y + bias4.y + rf[k].y + bf_hi(rb[k].x),
+                                    v4[k].z + bias4.z + rf[k].z + bf_lo(rb[k].y), v4[k].w + bias4.w + rf[k].w + bf_hi(rb[k].y)};
+                const long o = m * p.Cout + n;
+                if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+                const uint2 packed = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                if (p.out_bf16) *reinterpret_cast<uint2*>(p.out_bf16 + o) = packed;
+                if (p.gn_partial) {  // statistics of the values the GroupNorm will read (bf16-rounded unless fp32 is stored)
+                    const float u[4] = {p.out_f32 ? v[0] : bf_lo(packed.x), p.out_f32 ? v[1] : bf_hi(packed.x),
+                                        p.out_f32 ? v[2] : bf_lo(packed.y), p.out_f32 ? v[3] : bf_hi(packed.y)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gs += u[e], gq += u[e] * u[e];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next pass overwrites it
+    }
+    // ---- GroupNorm partial sums of this wave's 64 pixels (one image: H*W % 64 == 0), fixed order: lane -> half-wave pair ->
+    // the lanes of a group.  cpg = Cout/32 channels per group = cpg/4 adjacent lanes.
+    if (p.gn_partial) {
+        gs += __shfl_xor(gs, 32, 64), gq += __shfl_xor(gq, 32, 64);
+        const int lpg = (p.Cout >> 5) >> 2;  // lanes per group: 1, 2, 4
+        for (int o = 1; o < lpg; o <<= 1) gs += __shfl_xor(gs, o, 64), gq += __shfl_xor(gq, o, 64);
+        const long mw = m0 + wave * 64;
+        if (lane < 32 && (cg & (lpg - 1)) == 0 && n_ok && mw < p.M) {
+            const long hw = (long)H * W;
+            const long img = mw / hw;
+            const int blk = (int)((mw - img * hw) >> 6);
+            const int grp = n / (p.Cout >> 5);
+            *reinterpret_cast<float2*>(p.gn_partial + ((img * (hw >> 6) + blk) * 32 + grp) * 2) = make_float2(gs, gq);
+        }
+    }
+}
+
+}  // namespace
+
+// 1 when mmvid_conv3x3_strip_nhwc takes this geometry (the caller falls back to mmvid_conv2d_nhwc otherwise)
+// The choice must NOT depend on the batch size: the two kernels add in a different order, and a frame's tokens may not depend
+// on which other frames share its batch (tests/test_models_gpu.py::test_vqgan_roundtrip_full_size; the VID negative reuses the
+// target's tokens).  So it is made from the layer's own geometry: 32x32 maps and larger, where a training batch fills the chip
+// with 512-pixel tiles.
+extern "C" int mmvid_conv3x3_strip_supported(int H, int W, int Cin, int Cout) {
+    if (H <= 0 || W < 8 || W > 128 || (W & (W - 1)) != 0) return 0;
+    if (Cin < 32 || (Cin & (Cin - 1)) != 0 || Cout % 128 != 0) return 0;
+    if (((long)H * W) % 64 != 0) return 0;
+    return (long)H * W >= 1024 ? 1 : 0;
+}
+
+extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
+                                        const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32,
+                                        float* gn_partial64, void* stream) {
+    MMVID_REQUIRE(x && w && (out_bf16 || out_f32), "conv3x3_strip: null pointer");
+    MMVID_REQUIRE(W >= 8 && W <= 128 && (W & (W - 1)) == 0 && Cin >= 32 && (Cin & (Cin - 1)) == 0 && Cout % 128 == 0 &&
+                      ((long)H * W) % 64 == 0,
+                  "conv3x3_strip: unsupported geometry H=%d W=%d Cin=%d Cout=%d", H, W, Cin, Cout);
+    MMVID_REQUIRE((long)N * H * W * Cin * 2 < (1ll << 31) && (long)Cout * 9 * Cin * 2 < (1ll << 31),
+                  "conv3x3_strip: input or weight of 2 GiB or more (32-bit buffer offsets)");
+    StripParams p;
+    p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.N = N, p.H = H, p.W = W, p.Cin = Cin, p.Cout = Cout;
+    p.w_log2 = 0;
+    while ((1 << p.w_log2) < W) ++p.w_log2;
+    p.M = (long)N * H * W;
+    p.bias = bias, p.res_bf16 = (const bf16_t*)residual_bf16, p.res_f32 = residual_f32;
+    p.out_bf16 = (bf16_t*)out_bf16, p.out_f32 = out_f32, p.gn_partial = gn_partial64;
+    if (p.M == 0) return MMVID_OK;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_strip_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+        attr = true;
+    }
+    MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * 9 * Cin, (hipStream_t)stream);
+    const int blocks = cdiv(p.M, ST_M) * (Cout / ST_N);
+    hipLaunchKernelGGL(conv_strip_kernel<0>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
+    MMVID_LAUNCH_CHECK("conv3x3_strip");
+    return MMVID_OK;
+}

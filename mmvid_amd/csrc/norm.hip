@@ -389,7 +389,7 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
                                           int partial_blocks, void* y_bf16, float* y_f32, void* stream) {
     MMVID_REQUIRE(x && w && b && stats_scratch && (y_bf16 || y_f32), "groupnorm: null pointer");
     MMVID_REQUIRE(C % 32 == 0 && C <= 512 && 256 % (C / 8) == 0, "groupnorm: C=%d unsupported", C);
-    MMVID_REQUIRE(partial_blocks >= 0 && partial_blocks <= cdiv(hw, 128), "groupnorm: partial_blocks %d", partial_blocks);
+    MMVID_REQUIRE(partial_blocks >= 0 && partial_blocks <= cdiv(hw, 64), "groupnorm: partial_blocks %d", partial_blocks);
     if (N == 0 || hw == 0) return MMVID_OK;
     hipStream_t s = (hipStream_t)stream;
     const int pix_per_block = 256;

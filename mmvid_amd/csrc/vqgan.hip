@@ -60,6 +60,15 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
                 rc = mmvid_image_to_nhwc8((const float*)o.ext_in, o.N, o.H, o.W, at(arena, o.out_bf16), stream);
                 break;
             case MMVID_VQOP_CONV:
+                if (o.flags & 8) {  // 3x3 stride-1 convolution in strip form (the planner checked the geometry)
+                    rc = mmvid_conv3x3_strip_nhwc(at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
+                                                  (o.flags & 1) ? nullptr : at(arena, o.in1),
+                                                  (o.flags & 1) ? (const float*)at(arena, o.in1) : nullptr, at(arena, o.out_bf16),
+                                                  (float*)at(arena, o.out_f32),
+                                                  (o.flags & 4) ? (float*)at(arena, o.scratch) + (int64_t)o.N * o.Cout * 2 : nullptr,
+                                                  stream);
+                    break;
+                }
                 rc = mmvid_conv2d_nhwc(o.mode, at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
                                        (o.flags & 1) ? nullptr : at(arena, o.in1),
                                        (o.flags & 1) ? (const float*)at(arena, o.in1) : nullptr, (o.flags >> 1) & 1,
@@ -70,7 +79,7 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
             case MMVID_VQOP_GROUPNORM:
                 rc = mmvid_groupnorm_swish_nhwc(at(arena, o.in0), (o.flags & 1) ? 0 : 1, o.N, (int64_t)o.H * o.W, o.C,
                                                 (const float*)o.w, o.b, o.eps, o.mode, (float*)at(arena, o.scratch),
-                                                (o.flags & 2) ? (o.H * o.W) / 128 : 0, at(arena, o.out_bf16),
+                                                (o.flags & 2) ? (o.H * o.W) / ((o.flags & 8) ? 64 : 128) : 0, at(arena, o.out_bf16),
                                                 (float*)at(arena, o.out_f32), stream);
                 break;
             case MMVID_VQOP_CAST:

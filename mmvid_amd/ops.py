@@ -145,11 +145,28 @@ def layernorm_bwd(dy, x, mean, rstd, w, dx=None, add=False, dw=None, db=None, dx
 
 
 def gn_stats_buffer(N, hw, C, device):
-    """fp32 scratch of mmvid_groupnorm_swish_nhwc: [N][C][2] affine, then [N][ceil(hw/128)][32][2] partial sums."""
-    return torch.empty(N * (2 * C + 64 * ((hw + 127) // 128)), device=device, dtype=f32)
+    """fp32 scratch of mmvid_groupnorm_swish_nhwc: [N][C][2] affine, then partial sums [N][blocks][32][2] (blocks of 128
+    pixels, or of 64 for the strip convolution: sized for the finer one)."""
+    return torch.empty(N * (2 * C + 64 * ((hw + 63) // 64)), device=device, dtype=f32)
 
 
-def groupnorm_swish(x, w, b, eps=1e-6, swish=True, out_dtype=bf16, stats=None):
+def conv3x3_strip(x, w, bias, residual=None, out_dtype=bf16, also_bf16=False, gn_stats=None):
+    """3x3 / stride 1 / pad 1 on NHWC bf16 in strip form (csrc/conv_strip.hip).  x [N,H,W,Cin], w [Cout,9,Cin] bf16.
+    Returns out (and a bf16 copy when out is fp32 and also_bf16).  gn_stats: a gn_stats_buffer (partials per 64 pixels)."""
+    _chk(x, bf16, 'x'), _chk(w, bf16, 'w')
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    out = torch.empty(N, H, W, Cout, device=x.device, dtype=out_dtype)
+    o16 = torch.empty(N, H, W, Cout, device=x.device, dtype=bf16) if (also_bf16 and out_dtype == f32) else None
+    rb = residual if (residual is not None and residual.dtype == bf16) else None
+    rf = residual if (residual is not None and residual.dtype == f32) else None
+    gp = ctypes.c_void_p(gn_stats.data_ptr() + N * Cout * 2 * 4) if gn_stats is not None else None
+    call('mmvid_conv3x3_strip_nhwc', _p(x), N, H, W, Cin, _p(w), _p(bias), Cout, _p(rb), _p(rf),
+         _p(out) if out_dtype == bf16 else _p(o16), _p(out) if out_dtype == f32 else None, gp, _stream())
+    return (out, o16) if o16 is not None else out
+
+
+def groupnorm_swish(x, w, b, eps=1e-6, swish=True, out_dtype=bf16, stats=None, stats_block=128):
     """x NHWC [N,H,W,C] bf16 or f32 -> same shape.  `stats`: a gn_stats_buffer whose partial sums were already
     written by the convolution that produced x (conv2d_nhwc(..., gn_stats=...))."""
     N, H, W, C = x.shape
@@ -158,8 +175,8 @@ def groupnorm_swish(x, w, b, eps=1e-6, swish=True, out_dtype=bf16, stats=None):
     if stats is None:
         stats = gn_stats_buffer(N, H * W, C, x.device)
     else:
-        assert (H * W) % 128 == 0
-        blocks = H * W // 128
+        assert (H * W) % stats_block == 0
+        blocks = H * W // stats_block
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     call('mmvid_groupnorm_swish_nhwc', _p(x), int(x.dtype == bf16), N, H * W, C, _p(w), _p(b), float(eps), int(swish),
          _p(stats), blocks, _p(y) if out_dtype == bf16 else None, _p(y) if out_dtype == f32 else None, _stream())

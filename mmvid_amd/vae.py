@@ -135,6 +135,7 @@ class VQModel(_H):  # vqgan.py:16-53
 # A/B switches for the planner's fusions (diagnostics; both on by default)
 _FUSE_GN = os.environ.get('MMVID_FUSE_GN', '1') != '0'
 _DUAL_OUT = os.environ.get('MMVID_DUAL_OUT', '1') != '0'
+_STRIP = os.environ.get('MMVID_CONV_STRIP', '1') != '0'
 
 
 def _pow2_at_least8(c):
@@ -229,9 +230,14 @@ class _Planner:
             return out
         out = self.alloc((n, ho, wo, cout), f32 if out32 else bf16)
         flags = (1 if (residual is not None and residual.dtype == f32) else 0) | (2 if clamp01 else 0)
+        # 3x3 stride-1 layers at 32x32 and above run in strip form (csrc/conv_strip.hip); the rule is geometry only
+        strip = _STRIP and mode == 0 and not clamp01 and bool(_lib.load().mmvid_conv3x3_strip_supported(h, wd, cin, cout))
+        if strip:
+            flags |= 8
         scratch = -1
         if feeds_gn and _FUSE_GN and (ho * wo) % 128 == 0 and cout % 128 == 0:
             out.gn_stats = self._gn_stats(n, ho * wo, cout)
+            out.gn_stats.blocks64 = strip
             flags |= 4
             scratch = out.gn_stats.off
         o16 = out.off if not out32 else -1
@@ -244,7 +250,9 @@ class _Planner:
         return out
 
     def _gn_stats(self, n, hw, c):
-        return self.alloc((n * (2 * c + 64 * ((hw + 127) // 128)), ), f32)
+        # per image: the per-channel affine [C][2], then partial sums [blocks][32][2] for blocks of 64 pixels (the strip
+        # convolution's granularity; 128-pixel producers use the first half)
+        return self.alloc((n * (2 * c + 64 * ((hw + 63) // 64)), ), f32)
 
     def gn(self, x, holder, swish=True):
         n, h, wd, c = x.shape
@@ -256,7 +264,7 @@ class _Planner:
             return out
         out = self.alloc(x.shape, bf16)
         st = getattr(x, 'gn_stats', None)
-        flags = (1 if x.dtype == f32 else 0) | (2 if st is not None else 0)
+        flags = (1 if x.dtype == f32 else 0) | (2 if st is not None else 0) | (8 if getattr(st, 'blocks64', False) else 0)
         if st is None:
             st = self._gn_stats(n, h * wd, c)
         self._op(op=self.OP_GN, mode=int(swish), N=n, H=h, W=wd, C=c, flags=flags, in0=x.off,

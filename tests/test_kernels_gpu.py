@@ -410,6 +410,39 @@ def test_conv_fused_groupnorm_statistics(ops, mode, N, H, Cin, Cout, out32):
     assert torch.equal(st[off:], st2[off:])  # deterministic partial sums
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 32, 32, 128, 128), (1, 64, 64, 128, 128), (3, 32, 32, 256, 256), (1, 128, 128, 128, 128),
+                                            (2, 32, 32, 128, 256), (5, 16, 16, 256, 256), (3, 16, 16, 64, 128), (7, 8, 8, 512, 512),
+                                            (1, 64, 32, 32, 128)])
+def test_conv3x3_strip_vs_torch(ops, N, H, W, Cin, Cout):
+    """csrc/conv_strip.hip: the (kernel row, 32 channels) K tiling with the input strip staged once per three taps.  Covers
+    every strip geometry (image rows per 512-pixel tile: 4 ... 64, tiles spanning several images, ragged last tile),
+    zero padding at all four borders, both residual precisions, dual stores and the 64-pixel GroupNorm partial sums."""
+    x = rnd(N, H, W, Cin, seed=1, dtype=torch.bfloat16)
+    w = rnd(Cout, 9, Cin, seed=2, scale=1 / math.sqrt(9 * Cin), dtype=torch.bfloat16)
+    b = rnd(Cout, seed=3) * 0.1
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    out = ops.conv3x3_strip(x, w, b, out_dtype=torch.float32)
+    close(out, ref, 2e-4, f'strip conv {H}x{W} {Cin}->{Cout}')
+    old = ops.conv2d_nhwc(x, w, b, 0, out_dtype=torch.float32)
+    close(out, old, 1e-5, 'strip vs per-tap kernel (same bf16 products, different fp32 summation order)')
+    r32, r16 = rnd(N, H, W, Cout, seed=4), rnd(N, H, W, Cout, seed=5, dtype=torch.bfloat16)
+    st = ops.gn_stats_buffer(N, H * W, Cout, x.device)
+    o32, o16 = ops.conv3x3_strip(x, w, b, residual=r32, out_dtype=torch.float32, also_bf16=True, gn_stats=st)
+    close(o32, ref + r32, 2e-4, 'strip + fp32 residual')
+    assert torch.equal(o16, o32.bfloat16())
+    gw, gb = rnd(Cout, seed=6) * 0.1 + 1, rnd(Cout, seed=7) * 0.1
+    fused = ops.groupnorm_swish(o32, gw, gb, out_dtype=torch.float32, stats=st, stats_block=64)
+    close(fused, ops.groupnorm_swish(o32, gw, gb, out_dtype=torch.float32), 1e-5, 'gn(strip partial sums) vs gn(own stats)')
+    st16 = ops.gn_stats_buffer(N, H * W, Cout, x.device)
+    y16 = ops.conv3x3_strip(x, w, b, residual=r16, gn_stats=st16)
+    close(y16, ref + r16.float(), 1e-2, 'strip + bf16 residual, bf16 out')
+    close(ops.groupnorm_swish(y16, gw, gb, out_dtype=torch.float32, stats=st16, stats_block=64),
+          ops.groupnorm_swish(y16, gw, gb, out_dtype=torch.float32), 1e-5, 'gn on the bf16 output')
+    # batch independence and determinism
+    assert torch.equal(ops.conv3x3_strip(x[:1].contiguous(), w, b, out_dtype=torch.float32), out[:1])
+    assert torch.equal(ops.conv3x3_strip(x, w, b, out_dtype=torch.float32), out)
+
+
 def test_image_layout_kernels(ops):
     img = torch.rand(2, 3, 16, 16, device=DEV)
     o = ops.image_to_nhwc8(img)

@@ -76,3 +76,22 @@ m.generate_images(text, visual=vt)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f'generate_images: {dt * 1e3:.1f} ms per call = {dt / 1024 * 1e6:.1f} us per token step (incl. prefill + VQGAN decode of {16 * B} frames)')
+
+# ---- platform floor: a dependent chain of 60 trivial kernels (one 64-thread block each), eager and as a graph replay
+c = torch.zeros(1, device=dev)
+
+
+def chain():
+    for _ in range(60):
+        ops.counter_add(c, 1.0)
+
+
+print('60 dependent trivial kernels, eager: %.1f us' % timeit(chain, 20))
+g = torch.cuda.CUDAGraph()
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    with torch.cuda.graph(g, stream=s):
+        chain()
+torch.cuda.current_stream().wait_stream(s)
+print('60 dependent trivial kernels, graph replay: %.1f us  (= the floor of a 60-launch decode step on this box)' % timeit(g.replay, 20))
