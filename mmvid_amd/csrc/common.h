@@ -80,6 +80,8 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   fuse_colsum    MMVID_FUSE_COLSUM    1 = c_fc's bias gradient from the epilogue of the GEMM that produces d_pre (default)
 //   ln_bwd_blocks  MMVID_LN_BWD_BLOCKS  grid cap of the LayerNorm backward (default 512: its dw/db atomics scale with the
 //                                       grid -- measured on the whole step 2048: +0.6 ms, 1024: +0.11 ms, 256: +0.25 ms)
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_COUNT = 6 };
+//   strip_sched    MMVID_STRIP_SCHED    strip convolution: 0 = LDS-DMA requests right after the tile barrier, 1 = spread over the
+//                                       first three k-steps of the tile (tools/bench_gemm.py strip)
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_COUNT = 7 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

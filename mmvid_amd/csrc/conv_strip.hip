@@ -42,7 +42,10 @@ struct StripParams {
     float* gn_partial;  // [N][H*W/64][32][2] or null
 };
 
-template <int DUMMY>
+// SCHED 0: the LDS-DMA requests of tile t+1 are issued right after the barrier that starts tile t (all eight waves at once);
+// SCHED 1: they are spread over the first three k-steps of tile t (three pieces behind each group of eight MFMAs), so that a
+//          wave's DMA issue stalls fall into its SIMD partner's MFMA time instead of lining up across the block.
+template <int SCHED>
 __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,24 +124,48 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // Fragments of k-step q = kx*2 + s (compile-time) of the stage at LDS byte offset `st` (a multiple of 8 KiB, so the XOR
+    // on address bits 4..7 commutes with adding it).
+    auto load_frags = [&](uint32_t st, int q, bf16x8_t (&fa)[2], bf16x8_t (&fb)[4]) {
+        const int kx = q >> 1, sx = q & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(smem + ((st + aaddr[i][kx]) ^ (uint32_t)(sx << 5)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(smem + ((st + baddr[j]) ^ (uint32_t)((kx << 6) | (sx << 5))));
+    };
+    auto mma8 = [&](const bf16x8_t (&fa)[2], const bf16x8_t (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    };
     stage_tile(0, smem);
+    int ky_n = 0, ch_n = 0;  // (kernel row, channel chunk) of the NEXT tile, advanced without a division
     for (int t = 0; t < nt; ++t) {
-        char* cur = smem + (t & 1) * STAGE;
+        const uint32_t st = (uint32_t)(t & 1) * STAGE;
+        char* nxt = smem + ((t + 1) & 1) * STAGE;
+        if (++ch_n == chunks) ch_n = 0, ++ky_n;
+        const bool more = t + 1 < nt;
         __syncthreads();  // tile t has landed for every wave (the compiler's vmcnt(0) precedes it); buffer (t+1)&1 is free
-        if (t + 1 < nt) stage_tile(t + 1, smem + ((t + 1) & 1) * STAGE);
+        if (SCHED == 0 && more) stage_tile(t + 1, nxt);
+        // descriptor / offsets of the next tile's requests: scalar work, once per tile
+        const long disp = ((long)(ky_n - 1) * W * Cin + ch_n * 32) * 2;
+        const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + (more ? disp : 0), 0x7fffffffu);
+        const uint32_t bit = 1u << ky_n;
+        const uint32_t bsoff = (uint32_t)((ky_n * 3 * Cin + ch_n * 32) * 2);
+        bf16x8_t fa[2][2], fb[2][4];
+        load_frags(st, 0, fa[0], fb[0]);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        for (int q = 0; q < 6; ++q) {
+            if (q < 5) load_frags(st, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);  // next k-step's operands fly under these MFMAs
+            mma8(fa[q & 1], fb[q & 1]);
+            if (SCHED == 1 && q < 3 && more) {  // one third of the next tile's LDS-DMA requests behind each of the first three groups
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8_t af[2], bfr[4];
+                for (int jj = 0; jj < PA; ++jj)
+                    if (jj / 2 == q) blds16(arsrc, (amask[jj] & bit) ? avoff[jj] : OOB, 0, nxt + (wave * PA + jj) * 1024);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(cur + (aaddr[i][kx] ^ (uint32_t)(s << 5)));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(cur + (baddr[j] ^ (uint32_t)((kx << 6) | (s << 5))));
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                for (int jj = 0; jj < PB; ++jj)
+                    if (jj == q || (q == 2 && jj == 3)) blds16(brsrc, bvoff[jj], bsoff, nxt + A_STAGE + (wave * PB + jj) * 1024);
             }
         }
     }
@@ -249,11 +276,15 @@ extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int 
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_strip_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_strip_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
         attr = true;
     }
     MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * 9 * Cin, (hipStream_t)stream);
     const int blocks = cdiv(p.M, ST_M) * (Cout / ST_N);
-    hipLaunchKernelGGL(conv_strip_kernel<0>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
+    if (mmvid_option(MMVID_OPT_STRIP_SCHED) == 1)
+        hipLaunchKernelGGL(conv_strip_kernel<1>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_strip_kernel<0>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
     MMVID_LAUNCH_CHECK("conv3x3_strip");
     return MMVID_OK;
 }

@@ -406,8 +406,8 @@ def test_conv_fused_groupnorm_statistics(ops, mode, N, H, Cin, Cout, out32):
     close(fused, plain, 1e-5, 'gn(fused stats) vs gn(own stats)')
     st2 = ops.gn_stats_buffer(N, Ho * Ho, Cout, x.device)
     ops.conv2d_nhwc(x, w, b, mode, residual=res, out_dtype=dt, gn_stats=st2)
-    off = N * Cout * 2
-    assert torch.equal(st[off:], st2[off:])  # deterministic partial sums
+    off, used = N * Cout * 2, N * ((Ho * Ho + 127) // 128) * 64  # the buffer is sized for 64-pixel blocks; 128-pixel producers fill half
+    assert torch.equal(st[off:off + used], st2[off:off + used])  # deterministic partial sums
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 32, 32, 128, 128), (1, 64, 64, 128, 128), (3, 32, 32, 256, 256), (1, 128, 128, 128, 128),

@@ -25,7 +25,29 @@ def timeit(fn, iters=20):
     return a.elapsed_time(b) / iters
 
 
+def strip():
+    """The strip convolution on the encoder's mode-0 layers (54 frames), both DMA schedules, against the per-tap kernel."""
+    from mmvid_amd import _lib
+    for name, N, H, Cin, Cout in (('c128@128', 54, 128, 128, 128), ('c128@64', 54, 64, 128, 128), ('c256@32', 54, 32, 256, 256),
+                                  ('c128->256@32', 54, 32, 128, 256)):
+        x = torch.randn(N, H, H, Cin, device=dev).to(bf)
+        w = (torch.randn(Cout, 9, Cin, device=dev) * 0.03).to(bf)
+        b = torch.zeros(Cout, device=dev)
+        r32 = torch.randn(N, H, H, Cout, device=dev)
+        fl = 2.0 * N * H * H * Cout * 9 * Cin
+        t = timeit(lambda: ops.conv2d_nhwc(x, w, b, 0), 5)
+        line = f'{name:13s} per-tap {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF |'
+        for sched in (0, 1):
+            _lib.call('mmvid_set_option', b'strip_sched', sched)
+            t = timeit(lambda: ops.conv3x3_strip(x, w, b), 5)
+            t2 = timeit(lambda: ops.conv3x3_strip(x, w, b, residual=r32, out_dtype=torch.float32), 5)
+            line += f' strip sched {sched}: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF, +res f32: {t2*1e3:7.1f} us {fl/t2/1e9:7.1f} TF |'
+        print(line)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'strip':
+        return strip()
     M = 10422
     for name, N, K in (('qkv', 2304, 768), ('out', 768, 768), ('fc', 3072, 768), ('proj', 768, 3072)):
         X = torch.randn(M, K, device=dev).to(bf)

@@ -11,7 +11,12 @@ from mmvid_amd import ops
 dev, bf = 'cuda', torch.bfloat16
 which = sys.argv[1] if len(sys.argv) > 1 else 'fc'
 M = 10422
-if which == 'conv':
+if which == 'strip':
+    x = torch.randn(54, 128, 128, 128, device=dev).to(bf)
+    w = (torch.randn(128, 9, 128, device=dev) * 0.03).to(bf)
+    b = torch.zeros(128, device=dev)
+    fn = lambda: ops.conv3x3_strip(x, w, b)
+elif which == 'conv':
     x = torch.randn(96, 128, 128, 128, device=dev).to(bf)
     w = (torch.randn(128, 9, 128, device=dev) * 0.03).to(bf)
     b = torch.zeros(128, device=dev)
