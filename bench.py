@@ -22,6 +22,7 @@ torch.distributed the bucketed RCCL all-reduces are captured inside it, overlapp
 import argparse
 import ctypes
 import json
+import math
 import os
 import random
 import sys
@@ -413,6 +414,9 @@ def main():
                         'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches_per_step'],
                         'timed_steps': n_timed_steps}
         L = model.total_seq_len
+        loss_value = float(loss.detach())
+        if not math.isfinite(loss_value):  # a step that produced NaN/Inf measured nothing: fail loudly instead of reporting it
+            raise SystemExit(f'[bench] non-finite loss {loss_value} after {trainer.step_count} optimizer steps: the run is invalid')
         out = {
             'metric': 'video-tokens/sec training step, 8-frame 128px text-to-video', 'value': value,
             'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -420,7 +424,7 @@ def main():
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': WORKLOADS[args.config], 'config_id': args.config, 'per_gpu_batch': B, 'global_batch': world * B,
                        'seq_len': L, 'parallelism': f'dp{world}', 'step_launch': step_launch, 'layers': args.layers},
-            'loss': float(loss.detach()), 'roofline': roofline, 'kernels': kernels,
+            'loss': loss_value, 'roofline': roofline, 'kernels': kernels,
             'host_issue_ms_per_step': host_s / args.steps * 1e3, 'host_load_average': os.getloadavg()[0],
             'lr_device_scalar': float(trainer._lr_dev), 'optimizer_steps': trainer.step_count,
         }

@@ -307,6 +307,7 @@ class OpenAICLIPTransformer(nn.Module):
         y = torch.empty_like(x)
         _lib.call('mmvid_tower_forward', ctypes.byref(cfg), layers, ops._p(x), ops._p(y), ops._p(saved), ops._p(scratch),
                   ops._stream())
+        self._last_saved = saved  # the activation arena of the latest forward (layout: csrc/tower.hip saved_layout; debugging aid)
         return y, saved
 
     def backward_chunks(self):

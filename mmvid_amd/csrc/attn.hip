@@ -22,6 +22,7 @@
 
 namespace {
 using mmvid_core::blds16;
+using mmvid_core::dma_publish_barrier;
 using mmvid_core::make_rsrc;
 using mmvid_core::rsrc_t;
 using mmvid_core::bf16x4_t;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     for (int t = 0; t < ntiles; ++t) {
         const char* Kt = smem[t & 1];
         const char* Vt = Kt + TILE;
-        __syncthreads();  // tile t has landed (the barrier's release drains vmcnt); everyone is done with tile t-1
+        dma_publish_barrier();  // tile t has landed for every wave; everyone is done with tile t-1
         if (t + 1 < ntiles) {
             sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
         }
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     for (int t = 0; t < ntiles; ++t) {
         const char* Kt = smem[t & 1];
         const char* Vt = Kt + TILE;
-        __syncthreads();
+        dma_publish_barrier();
         if (t + 1 < ntiles) {
             sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
         }
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         const float* st_del = st_nlse + 64;
         char* nx = dsm + (bi ^ 1) * DKV_BUF;
         const bool more = t + 1 < nq_tiles;
-        __syncthreads();
+        dma_publish_barrier();
         if (more) {
             sq.issue((t + 1) * 64, nx, wave), sdo.issue((t + 1) * 64, nx + TILE, wave);
             stat = load_stat(t + 1);

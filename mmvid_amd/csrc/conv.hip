@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
         for (int t = 0; t < nt; ++t) {
             char* cur = smem + (t & 1) * S::STAGE_BYTES;
             char* nxt = smem + ((t + 1) & 1) * S::STAGE_BYTES;
-            __syncthreads();
+            dma_publish_barrier();
             if (t + 1 < nt) stage_tile(t + 1, nxt);
             compute_tile(cur);
         }

@@ -44,7 +44,8 @@ struct StripParams {
 
 // SCHED 0: the LDS-DMA requests of tile t+1 are issued right after the barrier that starts tile t (all eight waves at once);
 // SCHED 1: they are spread over the first three k-steps of tile t (three pieces behind each group of eight MFMAs), so that a
-//          wave's DMA issue stalls fall into its SIMD partner's MFMA time instead of lining up across the block.
+//          wave's DMA issue stalls fall into its SIMD partner's MFMA time instead of lining up across the block;
+// SCHED 2: two-group ping-pong: the block's halves alternate between a load part and a 16-MFMA cluster, one barrier apart.
 template <int SCHED>
 __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,37 +140,94 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     };
-    stage_tile(0, smem);
-    int ky_n = 0, ch_n = 0;  // (kernel row, channel chunk) of the NEXT tile, advanced without a division
-    for (int t = 0; t < nt; ++t) {
-        const uint32_t st = (uint32_t)(t & 1) * STAGE;
-        char* nxt = smem + ((t + 1) & 1) * STAGE;
-        if (++ch_n == chunks) ch_n = 0, ++ky_n;
-        const bool more = t + 1 < nt;
-        __syncthreads();  // tile t has landed for every wave (the compiler's vmcnt(0) precedes it); buffer (t+1)&1 is free
-        if (SCHED == 0 && more) stage_tile(t + 1, nxt);
-        // descriptor / offsets of the next tile's requests: scalar work, once per tile
-        const long disp = ((long)(ky_n - 1) * W * Cin + ch_n * 32) * 2;
-        const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + (more ? disp : 0), 0x7fffffffu);
-        const uint32_t bit = 1u << ky_n;
-        const uint32_t bsoff = (uint32_t)((ky_n * 3 * Cin + ch_n * 32) * 2);
-        bf16x8_t fa[2][2], fb[2][4];
-        load_frags(st, 0, fa[0], fb[0]);
+    if constexpr (SCHED == 2) {
+        // ---- two-group ping-pong (MI355X_MICROARCH.md "Two waves per SIMD"): waves 0-3 and 4-7 -- one of each per SIMD -- run one
+        // barrier apart, so that on every SIMD one wave is in its MFMA cluster while the other requests operands.  A phase is one
+        // kx (two k-steps): LOAD part = 12 fragment reads (+ this wave's LDS-DMA requests of the next tile), COMPUTE part = 16
+        // MFMAs at raised priority, a barrier after each.
+        //   WAR (the next tile overwrites the buffer tile t-1 was read from): every wave drains its fragment reads (lgkmcnt(0))
+        //   BEFORE the barrier that ends its load part; a wave issuing DMA in L(t,0) has passed the barrier the trailing group
+        //   passed into C(t-1,2), i.e. after that group's last read of tile t-1 completed.
+        //   RAW: A pieces are requested in L(t,0), B pieces in L(t,1); every wave waits for its own pieces (vmcnt(0)) at the end
+        //   of L(t,2) and then passes a barrier the other group must also pass before its first read of tile t+1.
+        stage_tile(0, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave >= 4) __builtin_amdgcn_s_barrier();  // the trailing group starts one barrier late
+        int ky_n = 0, ch_n = 0;
+        for (int t = 0; t < nt; ++t) {
+            const uint32_t st = (uint32_t)(t & 1) * STAGE;
+            char* nxt = smem + ((t + 1) & 1) * STAGE;
+            if (++ch_n == chunks) ch_n = 0, ++ky_n;
+            const bool more = t + 1 < nt;
+            const long disp = ((long)(ky_n - 1) * W * Cin + ch_n * 32) * 2;
+            const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + (more ? disp : 0), 0x7fffffffu);
+            const uint32_t bit = 1u << ky_n;
+            const uint32_t bsoff = (uint32_t)((ky_n * 3 * Cin + ch_n * 32) * 2);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            if (q < 5) load_frags(st, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);  // next k-step's operands fly under these MFMAs
-            mma8(fa[q & 1], fb[q & 1]);
-            if (SCHED == 1 && q < 3 && more) {  // one third of the next tile's LDS-DMA requests behind each of the first three groups
+            for (int kx = 0; kx < 3; ++kx) {
+                bf16x8_t fa[2][2], fb[2][4];
+                load_frags(st, 2 * kx, fa[0], fb[0]);
+                load_frags(st, 2 * kx + 1, fa[1], fb[1]);
+                if (kx == 0 && more) {
 #pragma unroll
-                for (int jj = 0; jj < PA; ++jj)
-                    if (jj / 2 == q) blds16(arsrc, (amask[jj] & bit) ? avoff[jj] : OOB, 0, nxt + (wave * PA + jj) * 1024);
+                    for (int jj = 0; jj < PA; ++jj) blds16(arsrc, (amask[jj] & bit) ? avoff[jj] : OOB, 0, nxt + (wave * PA + jj) * 1024);
+                }
+                if (kx == 1 && more) {
 #pragma unroll
-                for (int jj = 0; jj < PB; ++jj)
-                    if (jj == q || (q == 2 && jj == 3)) blds16(brsrc, bvoff[jj], bsoff, nxt + A_STAGE + (wave * PB + jj) * 1024);
+                    for (int jj = 0; jj < PB; ++jj) blds16(brsrc, bvoff[jj], bsoff, nxt + A_STAGE + (wave * PB + jj) * 1024);
+                }
+                // fragments complete before the barrier (WAR rule above); the registers are tied so no MFMA moves above the wait
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]),
+                               "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3])
+                             :
+                             : "memory");
+                if (kx == 2 && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+                mma8(fa[0], fb[0]);
+                mma8(fa[1], fb[1]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
             }
         }
-    }
-
+        if (wave < 4) __builtin_amdgcn_s_barrier();  // the leading group waits for the trailing one
+    } else {
+    stage_tile(0, smem);
+        int ky_n = 0, ch_n = 0;  // (kernel row, channel chunk) of the NEXT tile, advanced without a division
+        for (int t = 0; t < nt; ++t) {
+            const uint32_t st = (uint32_t)(t & 1) * STAGE;
+            char* nxt = smem + ((t + 1) & 1) * STAGE;
+            if (++ch_n == chunks) ch_n = 0, ++ky_n;
+            const bool more = t + 1 < nt;
+            dma_publish_barrier();  // tile t has landed for every wave; buffer (t+1)&1 is free
+            if (SCHED == 0 && more) stage_tile(t + 1, nxt);
+            // descriptor / offsets of the next tile's requests: scalar work, once per tile
+            const long disp = ((long)(ky_n - 1) * W * Cin + ch_n * 32) * 2;
+            const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + (more ? disp : 0), 0x7fffffffu);
+            const uint32_t bit = 1u << ky_n;
+            const uint32_t bsoff = (uint32_t)((ky_n * 3 * Cin + ch_n * 32) * 2);
+            bf16x8_t fa[2][2], fb[2][4];
+            load_frags(st, 0, fa[0], fb[0]);
+    #pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (q < 5) load_frags(st, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);  // next k-step's operands fly under these MFMAs
+                mma8(fa[q & 1], fb[q & 1]);
+                if (SCHED == 1 && q < 3 && more) {  // one third of the next tile's LDS-DMA requests behind each of the first three groups
+    #pragma unroll
+                    for (int jj = 0; jj < PA; ++jj)
+                        if (jj / 2 == q) blds16(arsrc, (amask[jj] & bit) ? avoff[jj] : OOB, 0, nxt + (wave * PA + jj) * 1024);
+    #pragma unroll
+                    for (int jj = 0; jj < PB; ++jj)
+                        if (jj == q || (q == 2 && jj == 3)) blds16(brsrc, bvoff[jj], bsoff, nxt + A_STAGE + (wave * PB + jj) * 1024);
+                }
+            }
+        }
+    
+}
     // ---- epilogue: per wave a private [32][132] fp32 slab, two passes (i = 0, 1); global traffic is row-contiguous
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -277,11 +335,14 @@ extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int 
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_strip_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
         (void)hipFuncSetAttribute((const void*)conv_strip_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_strip_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
         attr = true;
     }
     MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * 9 * Cin, (hipStream_t)stream);
     const int blocks = cdiv(p.M, ST_M) * (Cout / ST_N);
-    if (mmvid_option(MMVID_OPT_STRIP_SCHED) == 1)
+    if (mmvid_option(MMVID_OPT_STRIP_SCHED) == 2)
+        hipLaunchKernelGGL(conv_strip_kernel<2>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
+    else if (mmvid_option(MMVID_OPT_STRIP_SCHED) == 1)
         hipLaunchKernelGGL(conv_strip_kernel<1>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(conv_strip_kernel<0>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);

@@ -98,13 +98,13 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
         mma_tile<AKM, BKM>(buf + (wm >> 1) * TILE_BYTES, buf + S::NSUB * TILE_BYTES, acc, wm & 1, wn, lane);
     };
     if constexpr (S::NSTAGE == 2) {
-        // 2 stages, one barrier per K tile: the barrier (with the compiler's vmcnt(0) in front of it) makes tile t
+        // 2 stages, one barrier per K tile: the barrier (behind an explicit vmcnt(0)) makes tile t
         // visible to every wave and proves everyone is done reading the buffer tile t+1 overwrites.
         if (nt > 0) stage_tile(0, smem);
         for (int t = 0; t < nt; ++t) {
             char* cur = smem + (t & 1) * S::STAGE_BYTES;
             char* nxt = smem + ((t + 1) & 1) * S::STAGE_BYTES;
-            __syncthreads();
+            dma_publish_barrier();
             if (t + 1 < nt) stage_tile(t + 1, nxt);
             compute_tile(cur);
         }

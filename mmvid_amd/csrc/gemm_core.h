@@ -60,6 +60,16 @@ __device__ __forceinline__ void blds16(rsrc_t r, uint32_t voff, uint32_t soff, c
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)lds_dst_wave_uniform, 16, voff, soff, 0, 0);
 }
 
+// The barrier that publishes LDS-DMA'd tiles.  A buffer_load ... lds is complete for OTHER waves only after the ISSUING
+// wave's vmcnt has counted it down and both waves have passed a barrier.  hipcc (ROCm 7.2) usually puts an s_waitcnt
+// vmcnt(0) in front of __syncthreads() while LDS-DMA is in flight, but not always: attn_fwd_kernel's K/V loop was compiled
+// with lgkmcnt(0) only, and under hipGraph replay (kernels back to back, busier memory system) a late piece was read as
+// stale LDS once in a few hundred launches -> NaN rows (tools/stress_nan2.py).  So the wait is written out.
+__device__ __forceinline__ void dma_publish_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 __device__ __forceinline__ int rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ bf16x8_t frag_rowmajor(const char* tile, int row, int s, int fh) {
     return *reinterpret_cast<const bf16x8_t*>(tile + rm_off(row, 2 * s + fh));

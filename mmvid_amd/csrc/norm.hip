@@ -168,22 +168,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-// second stage: out_which[e] += sum over blocks of partial[b][which][e], fixed order (deterministic).  Block = 64 columns
-// x 4 row groups; grid = (ceil(E/64), 3).
-__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int E,
-                                                                   float* __restrict__ dw, float* __restrict__ db,
-                                                                   float* __restrict__ dx_colsum) {
-    __shared__ float sh[4][64];
+// second stage: out_which[e] += sum over blocks of partial[b][which][e], fixed order (deterministic).  The sum is latency
+// bound (a few MB, one dependent chain per thread), so the block is wide and shallow: 32 columns x 32 row groups, every
+// thread keeps 16 independent loads in flight; grid = (ceil(E/32), 3).  (36 blocks of 4 row groups took 66 us per call.)
+__global__ __launch_bounds__(1024) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int E,
+                                                                    float* __restrict__ dw, float* __restrict__ db,
+                                                                    float* __restrict__ dx_colsum) {
+    __shared__ float sh[32][33];
     const int which = blockIdx.y;
     float* out = which == 0 ? dw : (which == 1 ? db : dx_colsum);
     if (!out) return;
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + lane;
     float a = 0.f;
-    if (col < E)
-        for (int b = rg; b < nblocks; b += 4) a += partial[((long)b * 3 + which) * E + col];
-    sh[rg][threadIdx.x & 63] = a;
+    if (col < E) {
+        const float* src = partial + (long)which * E + col;
+        int b = rg;
+        for (; b + 15 * 32 < nblocks; b += 16 * 32) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = src[(long)(b + i * 32) * 3 * E];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a += v[i];
+        }
+        for (; b < nblocks; b += 32) a += src[(long)b * 3 * E];
+    }
+    sh[rg][lane] = a;
     __syncthreads();
-    if (rg == 0 && col < E) out[col] += (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (rg == 0 && col < E) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += sh[i][lane];
+        out[col] += t;
+    }
 }
 
 // ---------------------------------------------------------------- GroupNorm(32) on NHWC
@@ -375,7 +392,7 @@ extern "C" int mmvid_layernorm_bwd_ws(const float* dy, int64_t lddy, const float
                        partial ? (dw ? dw : workspace) : dw, partial ? (db ? db : workspace) : db,
                        partial ? (dx_colsum ? dx_colsum : nullptr) : dx_colsum, partial);
     if (partial)
-        hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(E, 64), 3), dim3(256), 0, (hipStream_t)stream, partial, blocks, E,
+        hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(E, 32), 3), dim3(1024), 0, (hipStream_t)stream, partial, blocks, E,
                            dw, db, dx_colsum);
     MMVID_LAUNCH_CHECK("layernorm_bwd");
     return MMVID_OK;

@@ -131,6 +131,7 @@ class BERT(nn.Module):
         self.frontend = Frontend(seed=kwargs.get('frontend_seed', 0))  # reseed per rank: frontend.seed = seed + rank
         self._w16_cache = {}
         self._row_cache = {}
+        self._debug_keep = None
         # segment table: which embedding table each position reads (0 special, 1 text, 2 visual, 3 image)
         seg = [0] + [1] * self.text_seq_len + [2] * self.visual_seq_len + [0, 0] + [3] * self.target_seq_len
         self.register_buffer('_seg', torch.tensor(seg, dtype=torch.int32), persistent=False)
@@ -362,7 +363,11 @@ class BERT(nn.Module):
             text_neg_ids = ops._chk(text_neg.contiguous(), torch.int64, 'text_neg')
         ids, sel, tfull, cnt = ops.bert_build_ids(text, vis_tok, self.visual_seq_len, target, target_warp, mask1, pad_base, MASK,
                                                   bool(rel), bool(do_vid), text_neg=text_neg_ids)
-        y = self.transformer_forward(self._assemble(ids, self.total_seq_len))  # [nseq*B, L, dim]
+        x_seq = self._assemble(ids, self.total_seq_len)
+        y = self.transformer_forward(x_seq)  # [nseq*B, L, dim]
+        if self._debug_keep is not None:  # tools/stress_nan2.py: the stage tensors of the last (replayed) forward
+            self._debug_keep.update(mask1=mask1, nfm=not_fully_masked, target=target, target_warp=target_warp, ids=ids, sel=sel,
+                                    tfull=tfull, cnt=cnt, x_seq=x_seq, y=y)
         nseq = 1 + int(bool(rel)) + int(bool(do_vid))
         rows, labels = self._head_rows(B, nseq, device)
         lin = self.to_logits[1]

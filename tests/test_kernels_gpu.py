@@ -278,6 +278,36 @@ def test_attention_deterministic(ops):
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
 
 
+def test_attention_reproducible_in_graph_replay_under_memory_pressure(ops):
+    """Regression test of an LDS-DMA race: attn_fwd_kernel's tile loop ran without an s_waitcnt vmcnt before its barrier, so
+    a K/V piece that landed late was read as stale LDS -- never seen with eager launches, once in a few hundred launches when
+    the step was replayed as a hipGraph (kernels back to back, copies in flight): NaN rows in one layer, every parameter NaN
+    after the clip.  The kernels have no atomics, so every replay must reproduce the first result bit for bit."""
+    B, L, H = 18, 579, 12  # BASELINE config 2: three passes of six sequences
+    qkv = rnd(B * L, 3 * H * 64, seed=91, dtype=torch.bfloat16)
+    dout = rnd(B * L, H * 64, seed=92, dtype=torch.bfloat16)
+    spec = ('rows', [(65, 65), (66, 66)])
+    big_a, big_b = torch.empty(64 << 20, device=DEV), torch.empty(64 << 20, device=DEV)
+    ref_out, ref_lse = ops.attention_fwd(qkv, B, L, H, spec)
+    ref_dqkv = ops.attention_bwd(qkv, ref_out, dout, ref_lse, B, L, H, spec)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        res = []
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(12):
+                big_b.copy_(big_a)  # keeps the memory system busy right in front of the attention kernels
+                out, lse2 = ops.attention_fwd(qkv, B, L, H, spec)
+                res.append((out, lse2, ops.attention_bwd(qkv, out, dout, lse2, B, L, H, spec)))
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(40):
+        g.replay()
+        torch.cuda.synchronize()
+        for i, (out, lse2, dqkv) in enumerate(res):
+            assert torch.equal(out, ref_out) and torch.equal(lse2, ref_lse) and torch.equal(dqkv, ref_dqkv), (rep, i)
+
+
 # ------------------------------------------------------------------------------------- embed / losses
 def test_assemble_sequence_and_backward(ops):
     B, L, E = 3, 37, 768

@@ -37,7 +37,7 @@ def strip():
         fl = 2.0 * N * H * H * Cout * 9 * Cin
         t = timeit(lambda: ops.conv2d_nhwc(x, w, b, 0), 5)
         line = f'{name:13s} per-tap {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF |'
-        for sched in (0, 1):
+        for sched in (0, 1, 2):
             _lib.call('mmvid_set_option', b'strip_sched', sched)
             t = timeit(lambda: ops.conv3x3_strip(x, w, b), 5)
             t2 = timeit(lambda: ops.conv3x3_strip(x, w, b, residual=r32, out_dtype=torch.float32), 5)
