@@ -414,6 +414,7 @@ def main():
                         'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches_per_step'],
                         'timed_steps': n_timed_steps}
         L = model.total_seq_len
+        _lib.check_device_faults()  # an out-of-range token id / CE target anywhere in the run is an error, not a silent row 0
         loss_value = float(loss.detach())
         if not math.isfinite(loss_value):  # a step that produced NaN/Inf measured nothing: fail loudly instead of reporting it
             raise SystemExit(f'[bench] non-finite loss {loss_value} after {trainer.step_count} optimizer steps: the run is invalid')

@@ -99,6 +99,11 @@ int mmvid_cross_entropy_bwd(const float* logits, int64_t ldl, const int64_t* tar
                             const float* lse, const float* gscale, int64_t rows, int V, void* dlogits_bf16,
                             int64_t ldd, void* stream);
 int mmvid_colsum_bf16(const void* dy, int64_t ld, int64_t M, int N, float* db, void* stream);
+/* Kernels never fault on a bad index: an embedding id outside its table reads row 0, a cross-entropy target outside [0, V)
+ * counts as class 0 -- and both are COUNTED on the device (the reference's nn.Embedding / F.cross_entropy raise a device-side
+ * assert instead).  counts[0] = bad embedding ids, counts[1] = bad CE targets, [2..3] reserved; reset != 0 clears them.
+ * Synchronises the device: call between steps, never during stream capture. */
+int mmvid_device_faults(int64_t* counts, int reset);
 
 /* ---- optimiser: train.py:322-325 (clip_grad_norm_ 1.0 + Adam), utils_train.py:167-172. */
 int mmvid_grad_sqnorm(const float* g, int64_t n, float* out_accum, void* stream);

@@ -99,6 +99,7 @@ SIGNATURES = {
     'mmvid_prof_enable': [I],
     'mmvid_graph_stats': [P],
     'mmvid_set_option': [c_char_p, I],
+    'mmvid_device_faults': [P, I],
     'mmvid_prof_end': [P, P, P, P, I],
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I),
@@ -138,3 +139,23 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise MMVIDError(f'{name} failed (rc={rc}): {lib.mmvid_last_error().decode()}')
+
+
+FAULT_NAMES = ('embedding id outside its table', 'cross-entropy target outside [0, V)', 'reserved', 'reserved')
+
+
+def device_faults(reset=True):
+    """Counts of bad indices the kernels met since the last reset (they read row 0 / class 0 instead of faulting).
+    Synchronises the device."""
+    arr = (ctypes.c_int64 * 4)()
+    call('mmvid_device_faults', arr, int(reset))
+    return list(arr)
+
+
+def check_device_faults():
+    """Raise if any kernel met an out-of-range index since the last check (the reference's nn.Embedding / cross_entropy
+    would have hit a device-side assert).  Call at a point where a device sync is acceptable: between steps, after a bench."""
+    counts = device_faults(reset=True)
+    bad = [f'{n} x {FAULT_NAMES[i]}' for i, n in enumerate(counts) if n]
+    if bad:
+        raise MMVIDError('kernels met out-of-range indices: ' + '; '.join(bad))

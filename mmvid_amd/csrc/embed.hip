@@ -17,6 +17,11 @@ struct GradTables {
     long rows[MAX_TABLES];
 };
 
+// Device-side fault counters: kernels never fault on bad indices (an out-of-range id reads row 0), they COUNT them;
+// mmvid_device_faults() reads and optionally clears the counters (a synchronising call: between steps, not during capture).
+//   [0] embedding id outside its table (assemble_sequence), [1] cross-entropy target outside [0, V)
+__device__ unsigned long long g_faults[4];
+
 // one wave per (b,l) row; E % 4 == 0
 __global__ __launch_bounds__(256) void assemble_fwd_kernel(Tables tb, const long long* __restrict__ ids,
                                                            const int* __restrict__ seg,
@@ -28,7 +33,10 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(Tables tb, const long
     const int l = (int)(row % L);
     const int s = seg[l];
     long id = ids[row];
-    if (id < 0 || id >= tb.rows[s]) id = 0;  // host validates; never fault
+    if (id < 0 || id >= tb.rows[s]) {  // never fault; counted (mmvid_device_faults)
+        if (lane == 0) atomicAdd(&g_faults[0], 1ull);
+        id = 0;
+    }
     const float4* src = reinterpret_cast<const float4*>(tb.t[s] + id * E);
     const float4* pp = reinterpret_cast<const float4*>(pos + (long)l * E);
     float4* dst = reinterpret_cast<float4*>(out + row * E);
@@ -142,7 +150,10 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         const float l = mx + __logf(s);
         lse[row] = l;
         long t = target[row];
-        if (t < 0 || t >= V) t = 0;
+        if (t < 0 || t >= V) {
+            atomicAdd(&g_faults[1], 1ull);
+            t = 0;
+        }
         unsafeAtomicAdd(loss_sum, l - logits[row * ldl + t]);
     }
 }
@@ -286,5 +297,24 @@ extern "C" int mmvid_colsum_bf16(const void* dy, int64_t ld, int64_t M, int N, f
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N, 256), cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dy, (long)ld, (long)M, N, db);
     MMVID_LAUNCH_CHECK("colsum_bf16");
+    return MMVID_OK;
+}
+
+// counts[4] <- the device fault counters (see g_faults); reset != 0 clears them.  Waits for the device.
+extern "C" int mmvid_device_faults(int64_t* counts, int reset) {
+    MMVID_REQUIRE(counts, "device_faults: null pointer");
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_faults), sizeof(h)) != hipSuccess) {
+        mmvid_set_error("device_faults: %s", hipGetErrorString(hipGetLastError()));
+        return MMVID_ERR_HIP;
+    }
+    for (int i = 0; i < 4; ++i) counts[i] = (int64_t)h[i];
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_faults), z, sizeof(z)) != hipSuccess) {
+            mmvid_set_error("device_faults: reset failed: %s", hipGetErrorString(hipGetLastError()));
+            return MMVID_ERR_HIP;
+        }
+    }
     return MMVID_OK;
 }

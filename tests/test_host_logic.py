@@ -212,6 +212,16 @@ def test_clip_torchscript_archive_loads(tmp_path):
     assert torch.equal(tw2.transformer.resblocks[1].mlp.c_fc.weight, src['transformer.resblocks.1.mlp.c_fc.weight'].float())
 
 
+def test_divide_max_stable_option():
+    """utils/utils.py:18-25 (x / amax over the last dim), wired into both models only under stable=True
+    (dalle_bert.py:1000-1001, dalle_artv.py:496-497)."""
+    from mmvid_amd.dalle_bert import DivideMax
+    x = torch.tensor([[1.0, -4.0, 2.0], [3.0, 0.5, -2.0]])
+    y = DivideMax(dim=-1)(x)
+    assert torch.equal(y, x / x.amax(dim=-1, keepdim=True)) and torch.equal(y.amax(-1), torch.ones(2))
+    assert tiny_bert(0, False).stable is False and not hasattr(tiny_bert(0, False), 'norm_by_max')
+
+
 def test_half_keeps_fp32_master_weights():
     """train.py:194-195 calls `.half()` under --fp16.  Compute here is always bf16 MFMA over fp32 master weights; `.half()`
     must not strand the kernels with fp16 parameters: it warns and leaves the module as it is."""

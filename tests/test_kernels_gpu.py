@@ -309,6 +309,25 @@ def test_attention_reproducible_in_graph_replay_under_memory_pressure(ops):
 
 
 # ------------------------------------------------------------------------------------- embed / losses
+def test_out_of_range_ids_are_counted_not_silent(ops):
+    """An embedding id outside its table reads row 0 and a CE target outside [0, V) counts as class 0 (a kernel must never
+    fault), but both are counted on the device and _lib.check_device_faults() raises (the reference hits a device assert)."""
+    from mmvid_amd import _lib
+    _lib.device_faults(reset=True)
+    E = 64
+    tabs = [rnd(5, E, seed=1), rnd(7, E, seed=2)]
+    seg = torch.tensor([0, 1, 1], dtype=torch.int32, device=DEV)
+    ids = torch.tensor([[1, 6, 2], [4, 7, -1]], device=DEV)  # 7 and -1 are outside table 1 (7 rows)
+    x = ops.assemble_sequence(tabs, ids, seg, torch.zeros(3, E, device=DEV))
+    assert torch.equal(x[1, 1], tabs[1][0]) and torch.equal(x[1, 2], tabs[1][0]) and torch.equal(x[0, 1], tabs[1][6])
+    logits = rnd(4, 16, seed=3)
+    ops.cross_entropy_fwd(logits, torch.tensor([0, 15, 16, 3], device=DEV), None)
+    assert _lib.device_faults(reset=False)[:2] == [2, 1]
+    with pytest.raises(_lib.MMVIDError, match='out-of-range'):
+        _lib.check_device_faults()
+    assert _lib.device_faults() == [0, 0, 0, 0]  # the check cleared them
+
+
 def test_assemble_sequence_and_backward(ops):
     B, L, E = 3, 37, 768
     tabs = [rnd(5, E, seed=1), rnd(200, E, seed=2), rnd(258, E, seed=3)]
