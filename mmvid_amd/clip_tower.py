@@ -129,6 +129,7 @@ class OpenAICLIPTransformer(nn.Module):
             raise NotImplementedError(which_model)  # as dalle_bert.py:406-407
         w, l, h = TOWER_SHAPES[which_model]
         self.width, self.layers, self.heads = width or w, layers or l, heads or h
+        self.debug_keep_saved = False
         assert self.width == 64 * self.heads, 'head_dim must be 64 (CLIP towers)'
         self.context_length = seq_len
         self.causal = causal
@@ -307,7 +308,8 @@ class OpenAICLIPTransformer(nn.Module):
         y = torch.empty_like(x)
         _lib.call('mmvid_tower_forward', ctypes.byref(cfg), layers, ops._p(x), ops._p(y), ops._p(saved), ops._p(scratch),
                   ops._stream())
-        self._last_saved = saved  # the activation arena of the latest forward (layout: csrc/tower.hip saved_layout; debugging aid)
+        if self.debug_keep_saved:  # debugging aid (tools/stress_nan2.py): the activation arena of the latest forward
+            self._last_saved = saved  # (layout: csrc/tower.hip saved_layout); holding it changes the allocation pattern
         return y, saved
 
     def backward_chunks(self):

@@ -48,12 +48,119 @@ struct GemmParams {
     long ldc;
     float* partial;  // split-K workspace [splitk][M][N] (plain stores, reduced by splitk_reduce_kernel) or null
     float* colsum;   // [N] += column sums of the stored result (the bias gradient when the result is a dY), or null
+    int debug;       // option gemm_debug (measurement only): 1 = no global stores, 2 = no K loop
 };
 
 __device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
 __device__ __forceinline__ float quick_gelu_grad(float x) {
     float s = sigmoidf_(1.702f * x);
     return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+// ---- epilogue through LDS, shared by both block shapes.  NI = 32-row fragments per wave (2: 64-row wave tiles, 4: 128-row),
+// WAVE_ROWS = rows of a wave tile; the block's wave grid is (THREADS/128) x 2.  Pass i stages fragment i of every wave.
+__device__ __forceinline__ void slab_write_row(const f32x16 (&acc_i)[2], float* slab, int wm, int wn, int lane) {
+    const int frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(slab + (wm * 32 + frow) * SLAB_PITCH + wn * 64 + j * 32 + 8 * q + 4 * fh) =
+                make_float4(acc_i[j][4 * q], acc_i[j][4 * q + 1], acc_i[j][4 * q + 2], acc_i[j][4 * q + 3]);
+}
+template <int NT, int WAVE_ROWS>
+__device__ __forceinline__ void slab_piece_wr(int tid, int k, int i, int& r, int& m_local, int& c) {
+    const int idx = tid + NT * k;
+    r = idx >> 5;
+    c = (idx & 31) * 4;
+    m_local = (r >> 5) * WAVE_ROWS + i * 32 + (r & 31);
+}
+template <int THREADS, int WAVE_ROWS, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, char* smem, f32x16 (&acc)[NI][2], int bm0, int bn0, int batch,
+                                              int ks, int tid, int wm, int wn, int lane) {
+    // ---- epilogue through LDS: every global read/write below is row-contiguous (16 B per lane, 512 B per row).
+    // Thread t owns column n = bn0 + 4*(t&31) of rows (t>>5)+8k of each 64-row slab; all its reads are issued
+    // before any is consumed.
+#pragma unroll
+    for (int i = 0; i < NI; ++i) mfma_settle(acc[i][0]), mfma_settle(acc[i][1]);
+    float* slab = reinterpret_cast<float*>(smem);
+    const long cb = (long)batch * p.strideC;
+    const int n = bn0 + 4 * (tid & 31);
+    const bool n_ok = n < p.N;
+    const bool use_bias = p.bias && (p.splitk == 1 || ks == 0);
+    const float4 bias4 = (use_bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* addbase = p.residual ? p.residual + cb
+                                      : ((p.accumulate && !p.partial && p.splitk == 1) ? p.out_f32 + cb : nullptr);
+    const long ldadd = p.residual ? p.ldr : p.ldc;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};  // this thread's share of the column sums (p.colsum)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        __syncthreads();
+        slab_write_row(acc[i], slab, wm, wn, lane);
+        __syncthreads();
+        float4 v4[8], add4[8];
+        uint2 pre2[8];
+        int mrow[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int r, ml, c;
+            slab_piece_wr<THREADS, WAVE_ROWS>(tid, k, i, r, ml, c);
+            mrow[k] = bm0 + ml;
+            const bool ok = n_ok && mrow[k] < p.M;
+            v4[k] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + c);
+            add4[k] = (addbase && ok) ? *reinterpret_cast<const float4*>(addbase + (long)mrow[k] * ldadd + n)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre2[k] = (p.dact_pre && ok) ? *reinterpret_cast<const uint2*>(p.dact_pre + cb + (long)mrow[k] * p.ldp + n)
+                                         : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = mrow[k];
+            if (!n_ok || m >= p.M || p.debug == 1) continue;
+            float v[4] = {v4[k].x * p.alpha + bias4.x, v4[k].y * p.alpha + bias4.y, v4[k].z * p.alpha + bias4.z,
+                          v4[k].w * p.alpha + bias4.w};
+            if (p.partial) {
+                *reinterpret_cast<float4*>(p.partial + ((long)ks * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                continue;
+            }
+            if (p.splitk > 1) {
+                float* o = p.out_f32 + cb + (long)m * p.ldc + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, v[e]);
+                continue;
+            }
+            if (p.save_pre)
+                *reinterpret_cast<uint2*>(p.save_pre + cb + (long)m * p.ldp + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            }
+            if (p.dact_pre) {
+                v[0] *= quick_gelu_grad(bf_lo(pre2[k].x));
+                v[1] *= quick_gelu_grad(bf_hi(pre2[k].x));
+                v[2] *= quick_gelu_grad(bf_lo(pre2[k].y));
+                v[3] *= quick_gelu_grad(bf_hi(pre2[k].y));
+            }
+            v[0] += add4[k].x, v[1] += add4[k].y, v[2] += add4[k].z, v[3] += add4[k].w;
+            if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + cb + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.out_bf16)
+                *reinterpret_cast<uint2*>(p.out_bf16 + cb + (long)m * p.ldc + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            cs[0] += v[0], cs[1] += v[1], cs[2] += v[2], cs[3] += v[3];
+        }
+    }
+    if (p.colsum) {  // block-level column sums -> one atomic per column (as mmvid_colsum_bf16 does per 256 rows)
+        constexpr int RG = THREADS / 32;
+        float* red = reinterpret_cast<float*>(smem);  // [RG][128]
+        __syncthreads();
+        *reinterpret_cast<float4*>(red + (tid >> 5) * 128 + 4 * (tid & 31)) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        __syncthreads();
+        if (tid < 128 && bn0 + tid < p.N) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) a += red[r * 128 + tid];
+            unsafeAtomicAdd(p.colsum + bn0 + tid, a);
+        }
+    }
 }
 
 template <bool AKM, bool BKM, int WM, int PP>
@@ -75,7 +182,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     const int kt0 = ks * per;
     int kt1 = kt0 + per;
     if (kt1 > ktiles_total) kt1 = ktiles_total;
-    const int nt = kt1 - kt0;
+    const int nt = p.debug == 2 ? 0 : kt1 - kt0;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -132,88 +239,169 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
         }
     }
 
-    // ---- epilogue through LDS: every global read/write below is row-contiguous (16 B per lane, 512 B per row).
-    // Thread t owns column n = bn0 + 4*(t&31) of rows (t>>5)+8k of each 64-row slab; all its reads are issued
-    // before any is consumed.
-    mfma_settle(acc[0][0]), mfma_settle(acc[0][1]), mfma_settle(acc[1][0]), mfma_settle(acc[1][1]);
-    float* slab = reinterpret_cast<float*>(smem);
-    const long cb = (long)batch * p.strideC;
-    const int n = bn0 + 4 * (tid & 31);
-    const bool n_ok = n < p.N;
-    const bool use_bias = p.bias && (p.splitk == 1 || ks == 0);
-    const float4 bias4 = (use_bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* addbase = p.residual ? p.residual + cb
-                                      : ((p.accumulate && !p.partial && p.splitk == 1) ? p.out_f32 + cb : nullptr);
-    const long ldadd = p.residual ? p.ldr : p.ldc;
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};  // this thread's share of the column sums (p.colsum)
+    gemm_epilogue<S::THREADS, 64, 2>(p, smem, acc, bm0, bn0, batch, ks, tid, wm, wn, lane);
+}
+
+// ================================================================================================================
+// Block shape "W": 256x128 output tile computed by FOUR waves (2x2), each 128x64 = 4x2 MFMA tiles; K tile 32; three
+// 24-KiB LDS stages (72 KiB) and __launch_bounds__(256, 2): TWO blocks per CU.
+//
+// Why it was built (tools/bench_gemm.py anatomy, profiles/r02_gemm_anatomy.log): the 8-wave 256x128 kernel above multiplies
+// at ~1,000 TFLOP/s inside its K loop, but at K = 768 the loop is only 12 tiles long and what surrounds it (first-tile
+// latency, accumulators -> LDS -> bias / activation / residual -> stores, block turnover) costs about as much: 36 + 29 us
+// for the qkv projection, strictly one after the other because the block owns its CU (144 KiB of LDS).  Here a wave's tile
+// is twice as tall, so the same 256x128 block needs half the waves and, with 32-deep K tiles, half the LDS: two blocks share
+// a CU, and the taller wave tile reads less LDS per MFMA (6 fragments per 8 MFMAs instead of 4 per 4).
+// What it measured: bit-identical results, but 5-25 % SLOWER (K loop 850 instead of 1,030 TFLOP/s; no overlap gained).  Two
+// co-resident blocks start together and stay in phase for the ~3 tiles a CU gets at these sizes, so their epilogues coincide
+// instead of hiding under each other's K loops.  Kept behind option gemm_wshape (default 0) as the measured record of that
+// design; the 8-wave ping-pong shape stays the default.
+//
+//   LDS stage (24 KiB): A [256 rows][32 k] as 64-B rows, 16-B chunk ^= (row>>2)&3 (conflict-free for the ds_read_b128
+//   lane groups: rows r, r+4, r+8, r+12 of a group land in different chunk columns), then B: row-major [128 rows][32 k] in
+//   the same layout, or k-major [32 k][128 rows] exactly as in gemm_core.h (first half of its 64-deep tile).
+//   Staging: 24 one-KiB LDS-DMA pieces per tile, 6 per wave; three stages with counted vmcnt as in the 8-wave kernel.
+namespace wshape {
+constexpr int WBK = 32;
+constexpr int A_BYTES = 256 * 64, B_BYTES = 128 * 64;  // 16 KiB + 8 KiB
+constexpr int STAGE = A_BYTES + B_BYTES, NSTAGE = 3, LDS = NSTAGE * STAGE;
+constexpr int PA = 4, PB = 2;  // DMA pieces per wave and tile
+
+// row-major operand with 64-B LDS rows: this wave's PPW pieces (16 rows each) of an NROWS-row tile
+template <int PPW>
+struct RowStage32 {
+    rsrc_t rsrc;
+    uint32_t voff[PPW];
+    __device__ __forceinline__ void init(const bf16_t* base, long ld, int rows, int K, int r0, int wave, int lane) {
+        rsrc = make_rsrc(base, (uint32_t)(((long)(rows - 1) * ld + K) * 2));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        __syncthreads();
-        slab_write(acc, i, slab, wm, wn, lane);
-        __syncthreads();
-        float4 v4[8], add4[8];
-        uint2 pre2[8];
-        int mrow[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            int r, ml, c;
-            slab_piece<S::THREADS>(tid, k, i, r, ml, c);
-            mrow[k] = bm0 + ml;
-            const bool ok = n_ok && mrow[k] < p.M;
-            v4[k] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + c);
-            add4[k] = (addbase && ok) ? *reinterpret_cast<const float4*>(addbase + (long)mrow[k] * ldadd + n)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-            pre2[k] = (p.dact_pre && ok) ? *reinterpret_cast<const uint2*>(p.dact_pre + cb + (long)mrow[k] * p.ldp + n)
-                                         : make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int m = mrow[k];
-            if (!n_ok || m >= p.M) continue;
-            float v[4] = {v4[k].x * p.alpha + bias4.x, v4[k].y * p.alpha + bias4.y, v4[k].z * p.alpha + bias4.z,
-                          v4[k].w * p.alpha + bias4.w};
-            if (p.partial) {
-                *reinterpret_cast<float4*>(p.partial + ((long)ks * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-                continue;
-            }
-            if (p.splitk > 1) {
-                float* o = p.out_f32 + cb + (long)m * p.ldc + n;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(o + e, v[e]);
-                continue;
-            }
-            if (p.save_pre)
-                *reinterpret_cast<uint2*>(p.save_pre + cb + (long)m * p.ldp + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-            }
-            if (p.dact_pre) {
-                v[0] *= quick_gelu_grad(bf_lo(pre2[k].x));
-                v[1] *= quick_gelu_grad(bf_hi(pre2[k].x));
-                v[2] *= quick_gelu_grad(bf_lo(pre2[k].y));
-                v[3] *= quick_gelu_grad(bf_hi(pre2[k].y));
-            }
-            v[0] += add4[k].x, v[1] += add4[k].y, v[2] += add4[k].z, v[3] += add4[k].w;
-            if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + cb + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.out_bf16)
-                *reinterpret_cast<uint2*>(p.out_bf16 + cb + (long)m * p.ldc + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            cs[0] += v[0], cs[1] += v[1], cs[2] += v[2], cs[3] += v[3];
+        for (int jj = 0; jj < PPW; ++jj) {
+            const int row = (wave * PPW + jj) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int gr = r0 + row;
+            voff[jj] = gr < rows ? (uint32_t)(((long)gr * ld + c * 8) * 2) : OOB;
         }
     }
-    if (p.colsum) {  // block-level column sums -> one atomic per column (as mmvid_colsum_bf16 does per 256 rows)
-        constexpr int RG = S::THREADS / 32;
-        float* red = reinterpret_cast<float*>(smem);  // [RG][128]
-        __syncthreads();
-        *reinterpret_cast<float4*>(red + (tid >> 5) * 128 + 4 * (tid & 31)) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-        __syncthreads();
-        if (tid < 128 && bn0 + tid < p.N) {
-            float a = 0.f;
+    __device__ __forceinline__ void issue(int k0, int K, char* tile, int wave, int lane) const {
+        const uint32_t soff = (uint32_t)k0 * 2;
+        if (k0 + WBK > K) {  // K tail: chunks at or beyond K must read as zeros (they would be the next row's data)
+            asm volatile("; K-tail tile" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < RG; ++r) a += red[r * 128 + tid];
-            unsafeAtomicAdd(p.colsum + bn0 + tid, a);
+            for (int jj = 0; jj < PPW; ++jj) {
+                const int row = (wave * PPW + jj) * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                blds16(rsrc, k0 + c * 8 < K ? voff[jj] : OOB, soff, tile + (wave * PPW + jj) * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < PPW; ++jj) blds16(rsrc, voff[jj], soff, tile + (wave * PPW + jj) * 1024);
         }
     }
+};
+}  // namespace wshape
+
+template <bool BKM>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_w_kernel(GemmParams p) {
+    using namespace wshape;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wg = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int bn0 = (wg % gridDim.x) * BN, bm0 = (wg / gridDim.x) * 256;
+    const int batch = blockIdx.z;
+    const bf16_t* A = p.A + (long)batch * p.strideA;
+    const bf16_t* B = p.B + (long)batch * p.strideB;
+    const int nt = p.debug == 2 ? 0 : (p.K + WBK - 1) / WBK;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    RowStage32<PA> sa;
+    sa.init(A, p.lda, p.M, p.K, bm0, wave, lane);
+    RowStage32<PB> sbr;
+    OperandStage<true, 1, PB> sbk;
+    if constexpr (BKM)
+        sbk.init(B, p.ldb, p.N, p.K, bn0, wave, lane);
+    else
+        sbr.init(B, p.ldb, p.N, p.K, bn0, wave, lane);
+    auto stage_tile = [&](int t, char* buf) {
+        sa.issue(t * WBK, p.K, buf, wave, lane);
+        if constexpr (BKM)
+            sbk.issue(t * WBK, p.K, buf + A_BYTES, wave, lane);
+        else
+            sbr.issue(t * WBK, p.K, buf + A_BYTES, wave, lane);
+    };
+
+    // fragment addresses inside a stage: row-major chunk (2 ks + h) ^ swz(row); swz(row) = (row >> 2) & 3 depends on the lane
+    // only (the row bases are multiples of 32), so one lane constant e = h ^ swz and k-step 1 is address ^ 32
+    const int l32 = lane & 31, e = (lane >> 5) ^ ((l32 >> 2) & 3);
+    uint32_t aoff[4], boff[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoff[i] = (uint32_t)((wm * 128 + i * 32 + l32) * 64 + (e << 4));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if constexpr (BKM)
+            boff[j] = (uint32_t)(A_BYTES + km_lane_off(wn * 64 + j * 32, lane));
+        else
+            boff[j] = (uint32_t)(A_BYTES + (wn * 64 + j * 32 + l32) * 64 + (e << 4));
+    }
+    const uint32_t lds0 = lds_addr(smem);
+
+    auto compute_tile = [&](uint32_t st) {  // st = byte offset of the stage (a multiple of 64)
+        bf16x8_t a0[4], b0[2], a1[4], b1[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a0[i] = *reinterpret_cast<const bf16x8_t*>(smem + st + aoff[i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (BKM)
+                b0[j] = frag_kmajor<0>(lds0 + st + boff[j]);
+            else
+                b0[j] = *reinterpret_cast<const bf16x8_t*>(smem + st + boff[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a1[i] = *reinterpret_cast<const bf16x8_t*>(smem + st + (aoff[i] ^ 32u));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (BKM)
+                b1[j] = frag_kmajor<1>(lds0 + st + boff[j]);
+            else
+                b1[j] = *reinterpret_cast<const bf16x8_t*>(smem + st + (boff[j] ^ 32u));
+        }
+        // the transpose reads are asm (untracked by the compiler): 8 younger LDS operations (a1: 4, b1: 2 x 2) may be in flight
+        if constexpr (BKM) lgkm_wait_tied<8>(b0[0], b0[1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+        if constexpr (BKM) lgkm_wait_tied<0>(b1[0], b1[1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+    };
+
+    // 3-stage ring: tile t+2 is requested right after the barrier that starts tile t (its buffer held tile t-1, which every
+    // wave finished reading before that barrier); a wave waits for ITS OWN pieces of tile t (tile t+1's six may stay in flight)
+    if (nt > 0) stage_tile(0, smem);
+    if (nt > 1) stage_tile(1, smem + STAGE);
+    uint32_t s0 = 0, s1 = STAGE, s2 = 2 * STAGE;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt)
+            wait_dma_and_barrier<PA + PB>();
+        else
+            wait_dma_and_barrier<0>();
+        if (t + 2 < nt) stage_tile(t + 2, smem + s2);
+        compute_tile(s0);
+        const uint32_t tmp = s0;
+        s0 = s1, s1 = s2, s2 = tmp;
+    }
+    gemm_epilogue<256, 128, 4>(p, smem, acc, bm0, bn0, batch, 0, tid, wm, wn, lane);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s partial[s][i]   (fixed order: deterministic)
@@ -251,9 +439,28 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP>), grid, dim3(S::THREADS), S::LDS_BYTES, stream, p);
 }
 
+template <bool BKM>
+void launch_w(const GemmParams& p, int batch, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_w_kernel<BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, wshape::LDS);
+        attr = true;
+    }
+    dim3 grid(cdiv(p.N, BN), cdiv(p.M, 256), batch);
+    hipLaunchKernelGGL((gemm_bf16_w_kernel<BKM>), grid, dim3(256), wshape::LDS, stream, p);
+}
+
 template <bool AKM, bool BKM>
 int launch(const GemmParams& p, int batch, hipStream_t stream) {
     MmvidProfScope prof(AKM ? PROF_GEMM_TN : (BKM ? PROF_GEMM_NN : PROF_GEMM_NT), 2.0 * p.M * p.N * (double)p.K * batch, stream);
+    if constexpr (!AKM) {
+        // the 4-wave / two-blocks-per-CU shape: row-major A, no split-K, enough tiles that two blocks per CU exist
+        const int w = mmvid_option(MMVID_OPT_GEMM_WSHAPE);
+        if (w && p.splitk == 1 && p.M >= 256 && (w == 2 || (long)cdiv(p.M, 256) * cdiv(p.N, BN) * batch >= 200)) {  // default: off
+            launch_w<BKM>(p, batch, stream);
+            return 0;
+        }
+    }
     if (use_big_tile(p.M, p.N, (long)batch * p.splitk)) {
         const int sched = mmvid_option(MMVID_OPT_GEMM_SCHED);
         if (sched == 2)
@@ -305,6 +512,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.act = act, p.accumulate = accumulate, p.alpha = alpha;
     p.out_f32 = out_f32, p.out_bf16 = (bf16_t*)out_bf16, p.ldc = ldc;
     p.partial = nullptr, p.colsum = out_colsum;
+    p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor)
         launch<false, false>(p, batch, s);
@@ -345,6 +553,7 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     p.out_f32 = dW, p.out_bf16 = nullptr, p.ldc = K;
     p.partial = splitk > 1 ? workspace : nullptr;
     p.colsum = nullptr;
+    p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
     hipStream_t s = (hipStream_t)stream;
     launch<true, true>(p, 1, s);
     if (splitk > 1) {

@@ -35,10 +35,59 @@ __global__ void probe_buffer_lds_kernel(const int* __restrict__ in, unsigned* __
     __syncthreads();
     for (int i = lane; i < 256; i += 64) out[i] = lds[i];
 }
+// which = 2: store-pattern bandwidth.  Writes a bf16 [M][N] matrix (values irrelevant) the way a GEMM epilogue would.
+//   variant 0: 256x128 tiles, 512 threads, 8 B per lane, 256-B row segments, rows in the epilogue's slab order
+//   variant 1: 256x128 tiles, 16 B per lane (16 lanes per 256-B segment), rows in natural order
+//   variant 2: as 0 but rows in natural order
+//   variant 3: 128x256 tiles, 16 B per lane (512-B segments)
+//   variant 4: linear (every block writes one contiguous 64-KiB run)
+__global__ __launch_bounds__(512) void probe_store_kernel(int M, int N, int variant, unsigned short* __restrict__ out) {
+    const int t = threadIdx.x;
+    const uint2 v2 = make_uint2(0x3f803f80u, 0x3f803f80u);
+    const uint4 v4 = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    if (variant == 4) {
+        const long base = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 32768;  // elements per block
+        for (int k = 0; k < 8; ++k) {
+            const long e = base + ((long)k * 512 + t) * 8;
+            if (e + 8 <= (long)M * N) *reinterpret_cast<uint4*>(out + e) = v4;
+        }
+        return;
+    }
+    if (variant == 3) {
+        const int bn0 = blockIdx.x * 256, bm0 = blockIdx.y * 128;
+        for (int k = 0; k < 8; ++k) {
+            const int idx = t + 512 * k, r = idx >> 5, c = (idx & 31) * 8;
+            if (bm0 + r < M && bn0 + c < N) *reinterpret_cast<uint4*>(out + (long)(bm0 + r) * N + bn0 + c) = v4;
+        }
+        return;
+    }
+    const int bn0 = blockIdx.x * 128, bm0 = blockIdx.y * 256;
+    if (variant == 1) {
+        for (int k = 0; k < 8; ++k) {
+            const int idx = t + 512 * k, r = idx >> 4, c = (idx & 15) * 8;
+            if (bm0 + r < M && bn0 + c < N) *reinterpret_cast<uint4*>(out + (long)(bm0 + r) * N + bn0 + c) = v4;
+        }
+        return;
+    }
+    for (int i = 0; i < 2; ++i)
+        for (int k = 0; k < 8; ++k) {
+            const int idx = t + 512 * k, r = idx >> 5, c = (idx & 31) * 4;
+            const int ml = variant == 0 ? (r >> 5) * 64 + i * 32 + (r & 31) : i * 128 + r;
+            if (bm0 + ml < M && bn0 + c < N) *reinterpret_cast<uint2*>(out + (long)(bm0 + ml) * N + bn0 + c) = v2;
+        }
+}
 }  // namespace
 
 extern "C" int mmvid_probe(int which, const void* in, void* out, void* stream) {
-    MMVID_REQUIRE((which == 0 || which == 1) && in && out, "probe: bad arguments");
+    MMVID_REQUIRE((which >= 0 && which <= 2) && in && out, "probe: bad arguments");
+    if (which == 2) {  // in = HOST int32[3]: M, N, variant
+        const int* a = (const int*)in;
+        const int M = a[0], N = a[1], variant = a[2];
+        dim3 grid = variant == 3 ? dim3(cdiv(N, 256), cdiv(M, 128)) : dim3(cdiv(N, 128), cdiv(M, 256));
+        hipLaunchKernelGGL(probe_store_kernel, grid, dim3(512), 0, (hipStream_t)stream, M, N, variant, (unsigned short*)out);
+        MMVID_LAUNCH_CHECK("probe");
+        return MMVID_OK;
+    }
     if (which == 1) {
         hipLaunchKernelGGL(probe_buffer_lds_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)in, (unsigned*)out);
         MMVID_LAUNCH_CHECK("probe");

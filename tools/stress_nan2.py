@@ -23,6 +23,7 @@ gen = torch.Generator().manual_seed(seed)
 batch = bench.synth_batch(6, 8, dev, gen)
 parts = torch.zeros(3, device=dev)
 model._debug_keep = {}
+model.transformer.debug_keep_saved = True
 
 
 def fb():
