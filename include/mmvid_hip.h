@@ -233,6 +233,12 @@ int mmvid_attention_decode(const void* qkv, int64_t ldq, const void* cache, int 
 int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w, const float* bias,
                       int Cout, const void* residual_bf16, const float* residual_f32, int clamp01, void* out_bf16,
                       float* out_f32, float* gn_partial, void* stream);
+/* The same convolution with the reduction (taps x input channels) cut into `splitk` ranges computed by separate blocks and
+ * added in a fixed order (deterministic): for deep layers on small maps whose output tiles alone cannot fill the chip.
+ * workspace: fp32 [splitk][N*Hout*Wout][Cout]; gn_partial must be null when splitk > 1. */
+int mmvid_conv2d_nhwc_splitk(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w, const float* bias,
+                             int Cout, const void* residual_bf16, const float* residual_f32, int clamp01, void* out_bf16,
+                             float* out_f32, float* gn_partial, int splitk, float* workspace, void* stream);
 /* The ResnetBlock convolutions (mode 0: 3x3, stride 1, pad 1; model.py:102-115) at 32x32 and above in "strip" form
  * (csrc/conv_strip.hip): a K tile is (kernel row, 32 input channels), the input strip is staged once for the three kx
  * taps, the block is 512 pixels x 128 channels.  Same contract as mmvid_conv2d_nhwc(mode 0) except that the GroupNorm
@@ -319,7 +325,8 @@ enum {
     MMVID_VQOP_IMG2NHWC8 = 0, /* ext_in img [N,3,H,W] f32 -> out_bf16 [N,H,W,8]                                  */
     MMVID_VQOP_CONV = 1,      /* in0 x [N,H,W,C] bf16, w, b, Cout, mode; in1 residual (flags&1: f32); flags&2 clamp01;
                                  flags&4: write GroupNorm partial sums of the output into `scratch` (a GN stats area);
-                                 flags&8: the strip kernel (mmvid_conv3x3_strip_nhwc; partial sums per 64 pixels)           */
+                                 flags&8: the strip kernel (mmvid_conv3x3_strip_nhwc; partial sums per 64 pixels);
+                                 flags&32: split-K by 4 through the fp32 workspace at `scratch` (mmvid_conv2d_nhwc_splitk)   */
     MMVID_VQOP_GROUPNORM = 2, /* in0 [N,H,W,C] (flags&1: f32), w, b, eps, mode = swish, scratch = stats;
                                  flags&2: the partial sums in `scratch` were written by the producing CONV (flags&8: per
                                  64-pixel block instead of per 128)                                                  */

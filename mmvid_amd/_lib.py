@@ -66,6 +66,7 @@ SIGNATURES = {
     'mmvid_kv_store': [P, I64, I, I, I, P, I, I, P, P],
     'mmvid_attention_decode': [P, I64, P, I, I, I, I, P, I, F, P, I64, P],
     'mmvid_conv2d_nhwc': [I, P, I, I, I, I, P, P, I, P, P, I, P, P, P, P],
+    'mmvid_conv2d_nhwc_splitk': [I, P, I, I, I, I, P, P, I, P, P, I, P, P, P, I, P, P],
     'mmvid_conv3x3_strip_supported': [I, I, I, I],
     'mmvid_conv3x3_strip_nhwc': [P, I, I, I, I, P, P, I, P, P, P, P, P, P],
     'mmvid_image_to_nhwc8': [P, I, I, I, P, P],

@@ -30,6 +30,8 @@ struct ConvParams {
     bf16_t* out_bf16;
     float* out_f32;
     float* gn_partial;  // GroupNorm partial sums of the OUTPUT: [N][Hout*Wout/128][32 groups][sum, sumsq], or null
+    int splitk;         // > 1: blockIdx.z owns a K range; raw accumulators go to `partial`, conv_splitk_reduce_kernel finishes
+    float* partial;     // [splitk][M][Cout] fp32
 };
 
 // A-operand gather by LDS-DMA: this lane owns, in each of its wave's 4 DMA pieces, LDS slot (lane&7) of tile row
@@ -160,16 +162,19 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
     sa.init(p, bm0, wave, lane);
     OperandStage<false, 1, S::PPW> sb;  // weights [Cout][K] row-major
     sb.init(p.w, p.K, p.Cout, p.K, bn0, wave, lane);
-    const int nt = (p.K + BK - 1) / BK;
+    const int ktiles = (p.K + BK - 1) / BK, per = (ktiles + p.splitk - 1) / p.splitk;
+    const int kt0 = (int)blockIdx.z * per;
+    int nt = (kt0 + per > ktiles ? ktiles : kt0 + per) - kt0;  // this split's K tiles (all of them when splitk == 1)
+    if (nt < 0) nt = 0;                                            // a trailing split may be empty: it writes zeros
     auto stage_tile = [&](int t, char* buf) {
-        sa.issue(p, t * BK, buf, wave);
-        sb.issue(t * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane);
+        sa.issue(p, (kt0 + t) * BK, buf, wave);
+        sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane);
     };
     auto compute_tile = [&](const char* buf) {
         mma_tile<false, false>(buf + (wm >> 1) * TILE_BYTES, buf + S::NSUB * TILE_BYTES, acc, wm & 1, wn, lane);
     };
     if constexpr (S::NSTAGE == 2) {
-        stage_tile(0, smem);
+        if (nt > 0) stage_tile(0, smem);
         for (int t = 0; t < nt; ++t) {
             char* cur = smem + (t & 1) * S::STAGE_BYTES;
             char* nxt = smem + ((t + 1) & 1) * S::STAGE_BYTES;
@@ -179,13 +184,13 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
         }
     } else if constexpr (PP != 0) {  // two-group ping-pong (gemm_core.h)
         k_loop_pingpong<false, false, PP == 2>(
-            smem, nt, wave, lane, wm, wn, acc, [&](int t, char* buf) { sa.issue(p, t * BK, buf, wave); },
-            [&](int t, char* buf) { sb.issue(t * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); });
+            smem, nt, wave, lane, wm, wn, acc, [&](int t, char* buf) { sa.issue(p, (kt0 + t) * BK, buf, wave); },
+            [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); });
     } else {  // 3-stage ring with counted vmcnt (see gemm.hip)
         char* b0 = smem;
         char* b1 = smem + S::STAGE_BYTES;
         char* b2 = smem + 2 * S::STAGE_BYTES;
-        stage_tile(0, b0);
+        if (nt > 0) stage_tile(0, b0);
         if (nt > 1) stage_tile(1, b1);
         for (int t = 0; t < nt; ++t) {
             if (t + 1 < nt)
@@ -232,6 +237,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (!n_ok || mrow[k] >= p.M) continue;
+            if (p.partial) {  // split-K: the raw partial sums; bias, residual and stores happen in the fixed-order reduce
+                *reinterpret_cast<float4*>(p.partial + ((long)blockIdx.z * p.M + mrow[k]) * p.Cout + n) = v4[k];
+                continue;
+            }
             float v[4] = {v4[k].x + bias4.x + rf[k].x + bf_lo(rb[k].x), v4[k].y + bias4.y + rf[k].y + bf_hi(rb[k].x),
                           v4[k].z + bias4.z + rf[k].z + bf_lo(rb[k].y), v4[k].w + bias4.w + rf[k].w + bf_hi(rb[k].y)};
             if (p.clamp01) {
@@ -288,6 +297,41 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
             p.gn_partial[((img * nblk + blk) * 32 + bn0 / cpg + g) * 2 + which] = a;
         }
     }
+}
+
+// out = bias + residual + sum_s partial[s]  (s in order: deterministic), both output precisions; 4 channels per thread
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ partial, int splitk, long M, int Cout,
+                                                                 const float* __restrict__ bias,
+                                                                 const bf16_t* __restrict__ res_bf16,
+                                                                 const float* __restrict__ res_f32, int clamp01,
+                                                                 bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long mn = M * Cout;
+    if (i >= mn) return;
+    const int n = (int)(i % Cout);
+    float4 a = *reinterpret_cast<const float4*>(partial + i);
+    for (int s = 1; s < splitk; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + (long)s * mn + i);
+        a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+    }
+    if (res_f32) {
+        const float4 r = *reinterpret_cast<const float4*>(res_f32 + i);
+        a.x += r.x, a.y += r.y, a.z += r.z, a.w += r.w;
+    }
+    if (res_bf16) {
+        const uint2 r = *reinterpret_cast<const uint2*>(res_bf16 + i);
+        a.x += bf_lo(r.x), a.y += bf_hi(r.x), a.z += bf_lo(r.y), a.w += bf_hi(r.y);
+    }
+    if (clamp01) {
+        a.x = (fminf(fmaxf(a.x, -1.f), 1.f) + 1.f) * 0.5f, a.y = (fminf(fmaxf(a.y, -1.f), 1.f) + 1.f) * 0.5f;
+        a.z = (fminf(fmaxf(a.z, -1.f), 1.f) + 1.f) * 0.5f, a.w = (fminf(fmaxf(a.w, -1.f), 1.f) + 1.f) * 0.5f;
+    }
+    if (out_f32) *reinterpret_cast<float4*>(out_f32 + i) = a;
+    if (out_bf16) *reinterpret_cast<uint2*>(out_bf16 + i) = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
 }
 
 // img NCHW f32 [N,3,H,W] in [0,1] -> NHWC bf16 [N,H,W,8] holding 2x-1 (vae.py:41), channels 3..7 = 0
@@ -349,8 +393,8 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
                                   S::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, FAST, PP>), dim3(cdiv(p.Cout, BN), cdiv(p.M, S::ROWS)), dim3(S::THREADS), S::LDS_BYTES,
-                       stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, FAST, PP>), dim3(cdiv(p.Cout, BN), cdiv(p.M, S::ROWS), p.splitk), dim3(S::THREADS),
+                       S::LDS_BYTES, stream, p);
 }
 
 int ilog2_exact(int v) {
@@ -364,7 +408,20 @@ int ilog2_exact(int v) {
 extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w,
                                  const float* bias, int Cout, const void* residual_bf16, const float* residual_f32,
                                  int clamp01, void* out_bf16, float* out_f32, float* gn_partial, void* stream) {
+    return mmvid_conv2d_nhwc_splitk(mode, x, N, Hin, Win, Cin, w, bias, Cout, residual_bf16, residual_f32, clamp01, out_bf16,
+                                    out_f32, gn_partial, 1, nullptr, stream);
+}
+
+// splitk > 1: the reduction (taps x input channels) is cut into `splitk` ranges computed by separate blocks into
+// workspace [splitk][M][Cout] fp32, then added in order by conv_splitk_reduce_kernel together with bias / residual.  For the
+// deep, small-map layers (8x8 maps: M = 64 N rows, K = 4,608) whose 128x128 tiles would fill a fraction of the chip.
+extern "C" int mmvid_conv2d_nhwc_splitk(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w,
+                                        const float* bias, int Cout, const void* residual_bf16, const float* residual_f32,
+                                        int clamp01, void* out_bf16, float* out_f32, float* gn_partial, int splitk,
+                                        float* workspace, void* stream) {
     MMVID_REQUIRE(x && w && (out_bf16 || out_f32), "conv2d_nhwc: null pointer");
+    MMVID_REQUIRE(splitk >= 1 && splitk <= 16 && (splitk == 1 || (workspace && !gn_partial && Cout % 4 == 0)),
+                  "conv2d_nhwc: split-K (%d) needs a workspace and cannot emit GroupNorm statistics", splitk);
     MMVID_REQUIRE(mode >= 0 && mode <= 3, "conv2d_nhwc: mode %d", mode);
     const int l2 = ilog2_exact(Cin);
     MMVID_REQUIRE(l2 >= 3, "conv2d_nhwc: Cin=%d must be a power of two >= 8", Cin);
@@ -385,6 +442,7 @@ extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Wi
     p.K = p.taps * Cin;
     p.bias = bias, p.res_bf16 = (const bf16_t*)residual_bf16, p.res_f32 = residual_f32, p.clamp01 = clamp01;
     p.out_bf16 = (bf16_t*)out_bf16, p.out_f32 = out_f32, p.gn_partial = gn_partial;
+    p.splitk = splitk, p.partial = splitk > 1 ? workspace : nullptr;
     if (gn_partial)
         MMVID_REQUIRE(((long)p.Hout * p.Wout) % 128 == 0 && Cout % 128 == 0,
                       "conv2d_nhwc: fused GroupNorm statistics need Hout*Wout %% 128 == 0 and Cout %% 128 == 0");
@@ -400,7 +458,7 @@ extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Wi
     // chosen from the layer's own geometry.
     if (gn_partial) {
         big = tile == 256 || (tile != 128 && (long)p.Hout * p.Wout >= 4096);
-    } else if (tile == 256 || (tile != 128 && (long)cdiv(p.M, 256) * cdiv(Cout, BN) >= 200)) {
+    } else if (splitk == 1 && (tile == 256 || (tile != 128 && (long)cdiv(p.M, 256) * cdiv(Cout, BN) >= 200))) {
         big = true;
     }
     const bool fast = Cin % 64 == 0 && mode != 2;
@@ -417,6 +475,9 @@ extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Wi
         launch_conv<2, true>(p, (hipStream_t)stream);
     else
         launch_conv<2, false>(p, (hipStream_t)stream);
+    if (splitk > 1)
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(cdiv(p.M * Cout / 4, 256)), dim3(256), 0, (hipStream_t)stream, workspace,
+                           splitk, p.M, Cout, bias, (const bf16_t*)residual_bf16, residual_f32, clamp01, (bf16_t*)out_bf16, out_f32);
     MMVID_LAUNCH_CHECK("conv2d_nhwc");
     return MMVID_OK;
 }

@@ -69,6 +69,14 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
                                                   stream);
                     break;
                 }
+                if (o.flags & 32) {  // deep layer on a small map: split-K by 4, fixed-order reduce (workspace at scratch)
+                    rc = mmvid_conv2d_nhwc_splitk(o.mode, at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
+                                                  (o.flags & 1) ? nullptr : at(arena, o.in1),
+                                                  (o.flags & 1) ? (const float*)at(arena, o.in1) : nullptr, (o.flags >> 1) & 1,
+                                                  at(arena, o.out_bf16), (float*)at(arena, o.out_f32), nullptr, 4,
+                                                  (float*)at(arena, o.scratch), stream);
+                    break;
+                }
                 rc = mmvid_conv2d_nhwc(o.mode, at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
                                        (o.flags & 1) ? nullptr : at(arena, o.in1),
                                        (o.flags & 1) ? (const float*)at(arena, o.in1) : nullptr, (o.flags >> 1) & 1,

@@ -308,9 +308,10 @@ def cast_bf16(x, out=None):
 
 
 # ---------------------------------------------------------------------------------------------- VQGAN
-def conv2d_nhwc(x, w, bias, mode, residual=None, clamp01=False, out_dtype=bf16, gn_stats=None):
+def conv2d_nhwc(x, w, bias, mode, residual=None, clamp01=False, out_dtype=bf16, gn_stats=None, splitk=1):
     """x [N,H,W,Cin] bf16; w [Cout,taps,Cin] bf16 (taps 9 or 1); mode 0 3x3 | 1 down | 2 up | 3 1x1.
-    gn_stats: a gn_stats_buffer for the OUTPUT shape; its partial-sum area is filled by the epilogue."""
+    gn_stats: a gn_stats_buffer for the OUTPUT shape; its partial-sum area is filled by the epilogue.
+    splitk > 1: the reduction is cut into that many ranges, added in a fixed order (deep layers on small maps)."""
     _chk(x, bf16, 'x'), _chk(w, bf16, 'w')
     N, H, W, Cin = x.shape
     Cout = w.shape[0]
@@ -321,8 +322,9 @@ def conv2d_nhwc(x, w, bias, mode, residual=None, clamp01=False, out_dtype=bf16, 
     gp = None
     if gn_stats is not None:
         gp = ctypes.c_void_p(gn_stats.data_ptr() + N * Cout * 2 * 4)
-    call('mmvid_conv2d_nhwc', mode, _p(x), N, H, W, Cin, _p(w), _p(bias), Cout, _p(rb), _p(rf), int(clamp01),
-         _p(out) if out_dtype == bf16 else None, _p(out) if out_dtype == f32 else None, gp, _stream())
+    ws = torch.empty(splitk * N * Ho * Wo * Cout, device=x.device, dtype=f32) if splitk > 1 else None
+    call('mmvid_conv2d_nhwc_splitk', mode, _p(x), N, H, W, Cin, _p(w), _p(bias), Cout, _p(rb), _p(rf), int(clamp01),
+         _p(out) if out_dtype == bf16 else None, _p(out) if out_dtype == f32 else None, gp, int(splitk), _p(ws), _stream())
     return out
 
 

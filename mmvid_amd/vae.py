@@ -136,6 +136,7 @@ class VQModel(_H):  # vqgan.py:16-53
 _FUSE_GN = os.environ.get('MMVID_FUSE_GN', '1') != '0'
 _DUAL_OUT = os.environ.get('MMVID_DUAL_OUT', '1') != '0'
 _STRIP = os.environ.get('MMVID_CONV_STRIP', '1') != '0'
+_SPLITK = os.environ.get('MMVID_CONV_SPLITK', '1') != '0'
 
 
 def _pow2_at_least8(c):
@@ -240,6 +241,13 @@ class _Planner:
             out.gn_stats.blocks64 = strip
             flags |= 4
             scratch = out.gn_stats.off
+        ws = None
+        if _SPLITK and not strip and scratch < 0 and mode == 0 and ho * wo <= 64 and 9 * cin >= 2304 and cout % 4 == 0:
+            # deep 3x3 layer on an 8x8 map: its 128x128 output tiles alone cover a fraction of the chip -> split-K by 4 through
+            # an fp32 workspace, fixed-order reduce (the rule is geometry only, like every kernel choice of the encoder)
+            ws = self.alloc((4 * n * ho * wo * cout, ), f32)
+            flags |= 32
+            scratch = ws.off
         o16 = out.off if not out32 else -1
         if out32 and also_bf16 and _DUAL_OUT:
             out.bf16 = self.alloc((n, ho, wo, cout), bf16)
@@ -247,6 +255,7 @@ class _Planner:
         self._op(op=self.OP_CONV, mode=mode, N=n, H=h, W=wd, C=cin, Cout=cout, flags=flags, in0=x.off,
                  in1=residual.off if residual is not None else -1, out_bf16=o16,
                  out_f32=out.off if out32 else -1, scratch=scratch, w=w.data_ptr(), b=b.data_ptr())
+        del ws  # the workspace returns to the free list: later tensors of the plan may reuse it (one in-order stream)
         return out
 
     def _gn_stats(self, n, hw, c):

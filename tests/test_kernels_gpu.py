@@ -459,6 +459,30 @@ def test_conv_modes(ops, mode, N, H, Cin, Cout):
     close(out, (ref.clamp(-1, 1) + 1) * 0.5, 2e-4, 'conv clamp01')
 
 
+@pytest.mark.parametrize('mode,N,H,Cin,Cout', [(0, 54, 8, 512, 512), (0, 3, 8, 256, 512), (0, 5, 8, 64, 264), (1, 2, 16, 128, 128),
+                                               (3, 7, 8, 512, 256), (0, 1, 8, 8, 8)])
+def test_conv_split_k(ops, mode, N, H, Cin, Cout):
+    """Split-K convolution (deep layers on 8x8 maps): same values as the one-pass kernel up to fp32 summation order, every
+    epilogue (bias, bf16 / fp32 residual, clamp, both output precisions), ragged row counts, splits that get no K tile
+    (K = 72: two 64-deep tiles for four splits), and bit-reproducible between launches."""
+    taps = 1 if mode == 3 else 9
+    x = rnd(N, H, H, Cin, seed=1, dtype=torch.bfloat16)
+    w = rnd(Cout, taps, Cin, seed=2, scale=1 / math.sqrt(taps * Cin), dtype=torch.bfloat16)
+    b = rnd(Cout, seed=3) * 0.1
+    one = ops.conv2d_nhwc(x, w, b, mode, out_dtype=torch.float32)
+    res16, res32 = rnd(*one.shape, seed=4, dtype=torch.bfloat16), rnd(*one.shape, seed=5)
+    for sk in (2, 4):
+        out = ops.conv2d_nhwc(x, w, b, mode, out_dtype=torch.float32, splitk=sk)
+        close(out, one, 2e-5, f'split-K {sk} vs one pass')
+        assert torch.equal(out, ops.conv2d_nhwc(x, w, b, mode, out_dtype=torch.float32, splitk=sk))
+        close(ops.conv2d_nhwc(x, w, b, mode, residual=res16, splitk=sk), ops.conv2d_nhwc(x, w, b, mode, residual=res16), 1e-2,
+              'split-K + bf16 residual, bf16 out')
+        close(ops.conv2d_nhwc(x, w, b, mode, residual=res32, out_dtype=torch.float32, splitk=sk), one + res32, 2e-5,
+              'split-K + fp32 residual')
+        close(ops.conv2d_nhwc(x, w, b, mode, clamp01=True, out_dtype=torch.float32, splitk=sk), (one.clamp(-1, 1) + 1) * 0.5, 2e-5,
+              'split-K clamp01')
+
+
 @pytest.mark.parametrize('mode,N,H,Cin,Cout,out32', [(0, 3, 16, 128, 128, True), (0, 2, 32, 64, 256, False),
                                                      (1, 5, 32, 128, 128, True), (3, 2, 16, 256, 512, False),
                                                      (0, 1, 48, 128, 128, False)])
