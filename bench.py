@@ -111,26 +111,36 @@ def eager_step(trainer, fn, batch):
     return loss.detach()
 
 
-def pmc_traffic(prefix):
+PMC_KERNELS = {  # bench kernel family -> kernel-name prefixes in the rocprofv3 PMC summaries
+    'gemm_bf16_kernel<A.B^T> (forward)': ('gemm_bf16_kernel<false, false', ),
+    'gemm_bf16_kernel<dX>': ('gemm_bf16_kernel<false, true', ),
+    'gemm_bf16_kernel<dW>': ('gemm_bf16_kernel<true, true', ),
+    'conv_igemm_kernel (VQGAN)': ('conv_igemm_kernel', 'conv_strip_kernel'),
+    'attn_fwd_kernel': ('attn_fwd_kernel', ),
+    'attn_bwd (dq+dkv)': ('attn_bwd_', ),
+}
+
+
+def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_pmc_{fetch,write}_size.csv: `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate runs, kernel-trace only;
     the newest round present is used).  Units are KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
     reads, so it is doubled (MI355X_MICROARCH.md, HBM; cross-checked on adam_kernel: 2 x FETCH = 16.0 B, WRITE = 14.0 B per
-    parameter)."""
+    parameter).  Bytes and dispatches are summed over every kernel of the family (both convolution kernels; one template
+    instance per GEMM layout)."""
     import csv
+    prefixes = PMC_KERNELS.get(family, (family.split('<')[0].split(' ')[0], ))
     for rnd in ('r02', 'r01'):
-        tot, disp = 0.0, 0
+        tot, disp = 0.0, {}
         try:
             for name, mult in (('fetch', 2.0), ('write', 1.0)):
-                d = 0
                 with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{name}_size.csv')) as fh:
                     for r in csv.DictReader(fh):
-                        if r['kernel'].startswith(prefix):
+                        if r['kernel'].startswith(prefixes):
                             tot += mult * float(r['total']) * 1024.0
-                            d += int(r['dispatches'])
-                disp = d
-            if disp:
-                return tot / disp
+                            disp[name] = disp.get(name, 0) + int(r['dispatches'])
+            if disp.get('fetch'):
+                return tot / disp['fetch']
         except OSError:
             continue
     return None
@@ -409,7 +419,7 @@ def main():
         if dom:
             roofline = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS,
-                        'traffic': pmc_traffic(dom['kernel'].split('<')[0].split(' ')[0]),
+                        'traffic': pmc_traffic(dom['kernel']),
                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes committed under profiles/)',
                         'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches_per_step'],
                         'timed_steps': n_timed_steps}
