@@ -1,0 +1,222 @@
+"""Host-side data path either side of the model: text -> token ids, a frame-folder video dataset
+-> [T, 3, H, W] tensors in [0, 1], and decoded frames -> gif / png files.  Pure host code (no kernels): it exists so that a
+training or sampling script written against the reference finds the same entry points here.
+
+  SimpleTokenizer    mmvid_pytorch/tokenizer.py:61-171 (OpenAI CLIP byte-level BPE; 49,408 ids).  The merge table is the
+                     reference's data file `mmvid_pytorch/data/bpe_simple_vocab_16e6.txt`; it is NOT shipped here -- pass its
+                     path, or set MMVID_BPE_VOCAB.
+  TextVideoDataset   mmvid_pytorch/loader.py:206-562, the layout `<root>/video/<key>/<frames>` + `<root>/txt/<key>.txt` and
+                     the frame sampling (frame_num frames, frame_step apart; first caption line).  Built: mode='video', the
+                     deterministic transform (resize + centre crop) and the random start / random-resized-crop of the training
+                     transform with torch's generator; not built: pickle caches, negative sampling, 1frame mode.
+  save_image_tensor  utils/utils_html.py:157-186 ([T,3,H,W] or [3,H,W] in [0,1] -> .gif / .png; mp4 needs torchvision.io).
+"""
+import html
+import os
+import re as _re
+
+import torch
+
+_SOT, _EOT = '<|startoftext|>', '<|endoftext|>'
+IMG_EXT = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.tif', '.tiff', '.webp')
+
+
+def _byte_symbols():
+    """GPT-2's reversible byte -> printable-character table: the 188 printable latin-1 bytes stand for themselves, the other
+    68 bytes are mapped, in increasing order, to the code points from 256 upwards."""
+    keep = [b for b in range(256) if 33 <= b <= 126 or 161 <= b <= 172 or 174 <= b <= 255]
+    table, extra = {b: chr(b) for b in keep}, 0
+    for b in range(256):
+        if b not in table:
+            table[b] = chr(256 + extra)
+            extra += 1
+    return table, keep + [b for b in range(256) if not (33 <= b <= 126 or 161 <= b <= 172 or 174 <= b <= 255)]
+
+
+def _clean(text):
+    """tokenizer.py:50-58: ftfy.fix_text (when ftfy is installed), two rounds of html.unescape, whitespace collapsed."""
+    try:
+        import ftfy
+        text = ftfy.fix_text(text)
+    except ImportError:
+        pass
+    text = html.unescape(html.unescape(text)).strip()
+    return _re.sub(r'\s+', ' ', text).strip()
+
+
+class SimpleTokenizer:
+    vocab_size = 49408
+
+    def __init__(self, bpe_path=None):
+        import regex
+        bpe_path = bpe_path or os.environ.get('MMVID_BPE_VOCAB')
+        if not bpe_path or not os.path.exists(bpe_path):
+            raise FileNotFoundError('SimpleTokenizer needs the CLIP merge table (mmvid_pytorch/data/bpe_simple_vocab_16e6.txt of the '
+                                    'reference checkout): pass bpe_path= or set MMVID_BPE_VOCAB')
+        table, order = _byte_symbols()
+        self._byte_sym = table
+        self._sym_byte = {c: b for b, c in table.items()}
+        with open(bpe_path, encoding='utf8') as fh:
+            lines = fh.read().split('\n')
+        n_merges = self.vocab_size - 256 - 256 - 2  # ids: 256 byte symbols, 256 word-final ones, the merges, 2 specials
+        pairs = [tuple(ln.split()) for ln in lines[1:1 + n_merges]]
+        symbols = [table[b] for b in order]
+        vocab = symbols + [s + '</w>' for s in symbols] + [a + b for a, b in pairs] + [_SOT, _EOT]
+        self.encoder = {tok: i for i, tok in enumerate(vocab)}
+        self.decoder = {i: tok for tok, i in self.encoder.items()}
+        self._rank = {p: i for i, p in enumerate(pairs)}
+        self._memo = {_SOT: [_SOT], _EOT: [_EOT]}
+        self._split = regex.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+",
+                                    regex.IGNORECASE)
+
+    def _merge(self, token):
+        """Byte-pair merging of one pre-token (already in byte symbols): repeatedly fuse every occurrence of the adjacent pair
+        with the lowest merge rank until no adjacent pair is in the table."""
+        hit = self._memo.get(token)
+        if hit is not None:
+            return hit
+        parts = list(token[:-1]) + [token[-1] + '</w>']
+        while len(parts) > 1:
+            best, best_rank = None, None
+            for pair in zip(parts, parts[1:]):
+                r = self._rank.get(pair)
+                if r is not None and (best_rank is None or r < best_rank):
+                    best, best_rank = pair, r
+            if best is None:
+                break
+            fused, i = [], 0
+            while i < len(parts):
+                if i + 1 < len(parts) and parts[i] == best[0] and parts[i + 1] == best[1]:
+                    fused.append(parts[i] + parts[i + 1])
+                    i += 2
+                else:
+                    fused.append(parts[i])
+                    i += 1
+            parts = fused
+        self._memo[token] = parts
+        return parts
+
+    def encode(self, text):
+        ids = []
+        for piece in self._split.findall(_clean(text).lower()):
+            sym = ''.join(self._byte_sym[b] for b in piece.encode('utf-8'))
+            ids.extend(self.encoder[p] for p in self._merge(sym))
+        return ids
+
+    def decode(self, tokens, remove_start_end=True):
+        if torch.is_tensor(tokens):
+            tokens = tokens.tolist()
+        if remove_start_end:  # the reference drops ids 49406, 40407 (sic) and the padding id 0 (tokenizer.py:149-152)
+            tokens = [t for t in tokens if t not in (49406, 40407, 0)]
+        text = ''.join(self.decoder[t] for t in tokens)
+        return bytearray(self._sym_byte[c] for c in text).decode('utf-8', errors='replace').replace('</w>', ' ')
+
+    def tokenize(self, texts, context_length=256, truncate_text=False):
+        """-> int64 [len(texts), context_length], zero padded (tokenizer.py:157-171)."""
+        if isinstance(texts, str):
+            texts = [texts]
+        out = torch.zeros(len(texts), context_length, dtype=torch.long)
+        for i, text in enumerate(texts):
+            ids = self.encode(text)
+            if len(ids) > context_length:
+                if not truncate_text:
+                    raise RuntimeError(f'Input {text} is too long for context length {context_length}')
+                ids = ids[:context_length]
+            out[i, :len(ids)] = torch.tensor(ids, dtype=torch.long)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ dataset
+def _natural_key(name):
+    return [int(p) if p.isdigit() else p.lower() for p in _re.split(r'(\d+)', name)]
+
+
+def _load_frame(path, size):
+    """PIL image -> [3, size, size] float in [0, 1] (loader.py:414-417: Resize((size, size)) then to_tensor; bilinear)."""
+    import numpy as np
+    from PIL import Image
+    with Image.open(path) as im:
+        im = im.convert('RGB').resize((size, size), Image.BILINEAR)
+        arr = np.asarray(im, dtype=np.uint8)
+    return torch.from_numpy(arr.copy()).permute(2, 0, 1).float().div_(255.0)
+
+
+class TextVideoDataset(torch.utils.data.Dataset):
+    """`folder/video/<key>/*.jpg` + `folder/txt/<key>.txt` -> (token ids [text_len], frames [frame_num, 3, S, S]).
+    Videos shorter than max(8, (frame_num - 1) * frame_step + 1) frames are dropped (loader.py:252-262, 343-349)."""
+
+    def __init__(self, folder, text_len=256, image_size=128, truncate_captions=False, resize_ratio=0.75, tokenizer=None,
+                 frame_step=2, frame_num=8, deterministic=False, video_only=False, keys=None, generator=None):
+        super().__init__()
+        self.root, self.text_len, self.image_size = str(folder), text_len, image_size
+        self.truncate_captions, self.resize_ratio, self.tokenizer = truncate_captions, resize_ratio, tokenizer
+        self.frame_step, self.frame_num, self.deterministic, self.video_only = frame_step, frame_num, deterministic, video_only
+        self.generator = generator
+        self.min_len = max(8, (frame_num - 1) * frame_step + 1)
+        vroot, troot = os.path.join(self.root, 'video'), os.path.join(self.root, 'txt')
+        captions = set(os.listdir(troot)) if os.path.isdir(troot) else set()
+        self.videos, self.texts = {}, {}
+        for key in os.listdir(vroot):
+            d = os.path.join(vroot, key)
+            if not os.path.isdir(d) or (key + '.txt') not in captions:
+                continue
+            frames = sorted((f for f in os.listdir(d) if f.lower().endswith(IMG_EXT)), key=_natural_key)
+            if len(frames) >= self.min_len:
+                self.videos[key] = [os.path.join(d, f) for f in frames]
+                self.texts[key] = os.path.join(troot, key + '.txt')
+        if keys is not None:
+            self.videos = {k: v for k, v in self.videos.items() if k in set(keys)}
+        self.keys = sorted(self.videos)
+        assert len(self.keys) > 0, f'no usable videos under {vroot}'
+
+    def __len__(self):
+        return len(self.keys)
+
+    def _rand(self, n):
+        return int(torch.randint(0, n, (1, ), generator=self.generator))
+
+    def _frames(self, key):
+        paths = self.videos[key]
+        span = (self.frame_num - 1) * self.frame_step
+        start = 0 if self.deterministic else self._rand(len(paths) - span)  # loader.py:396-398 (inclusive upper bound)
+        x = torch.stack([_load_frame(paths[start + i * self.frame_step], self.image_size) for i in range(self.frame_num)])
+        if not self.deterministic:  # RandomResizedCrop(scale=(resize_ratio, 1), ratio=(1, 1)): one square crop for all frames
+            S = self.image_size
+            area = float(torch.empty(1).uniform_(self.resize_ratio, 1.0, generator=self.generator)) * S * S
+            side = max(1, min(S, int(round(area**0.5))))
+            top, left = self._rand(S - side + 1), self._rand(S - side + 1)
+            x = torch.nn.functional.interpolate(x[:, :, top:top + side, left:left + side], size=(S, S), mode='bilinear',
+                                                align_corners=False, antialias=True)
+        return x
+
+    def __getitem__(self, index):
+        key = self.keys[index]
+        frames = self._frames(key)
+        if self.video_only:
+            return frames, 0
+        with open(self.texts[key]) as fh:
+            caption = fh.read().split('\n')[0]  # loader.py: the first line is the description
+        tokens = self.tokenizer.tokenize(caption, self.text_len, truncate_text=self.truncate_captions).squeeze(0)
+        return tokens, frames
+
+
+# ------------------------------------------------------------------------------------------------ output side
+@torch.no_grad()
+def save_image_tensor(tensor, path, video_format='gif', fps=4):
+    """utils/utils_html.py:157-186.  [3,H,W] / [1,3,H,W] -> `<path>.png`; [T,3,H,W] / [1,T,3,H,W] -> `<path>.gif`.  Values are
+    clamped to [0, 1] and quantised by truncation (`* 255` then uint8), as the reference does.  Returns the file name."""
+    from PIL import Image
+    t = tensor.squeeze(0) if tensor.dim() in (4, 5) and tensor.shape[0] == 1 else tensor
+    u8 = (t.detach().float().cpu().clamp(0, 1) * 255).to(torch.uint8)
+    if u8.dim() == 3:
+        out = str(path) + '.png'
+        Image.fromarray(u8.permute(1, 2, 0).numpy()).save(out)
+    elif u8.dim() == 4:
+        if video_format != 'gif':
+            raise NotImplementedError("video_format='mp4' needs torchvision.io.write_video (utils_html.py:178-184)")
+        out = str(path) + '.gif'
+        frames = [Image.fromarray(f.permute(1, 2, 0).numpy()) for f in u8]
+        frames[0].save(out, save_all=True, append_images=frames[1:], duration=int(1000 / fps), loop=0)
+    else:
+        raise RuntimeError(f'save_image_tensor: unsupported shape {tuple(tensor.shape)}')
+    return os.path.basename(out)

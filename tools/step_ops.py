@@ -36,6 +36,25 @@ for ev in prof.events():
         key = (ev.name, str(ev.input_shapes)[:70], site)
         rows[key][0] += 1
         rows[key][1] += ev.self_device_time_total
+# device-to-device copies issued through the runtime (hipMemcpyAsync: blit kernels, not aten kernels)
+mem = defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.device_type != torch.autograd.DeviceType.CPU and ('emcpy' in ev.name or 'emset' in ev.name or 'copyBuffer' in ev.name):
+        mem[ev.name][0] += 1
+        mem[ev.name][1] += ev.device_time_total if hasattr(ev, 'device_time_total') else ev.cuda_time_total
+for name, (n, us) in sorted(mem.items(), key=lambda kv: -kv[1][1]):
+    print(f'{us:9.1f} us {n:4d}x  {name}')
+calls = defaultdict(int)
+for ev in prof.events():
+    if ev.device_type == torch.autograd.DeviceType.CPU and ('hipMemcpy' in ev.name or 'hipMemset' in ev.name):
+        site = ''
+        for fr in (ev.stack or []):
+            if '/mmvid_amd/' in fr or 'bench.py' in fr:
+                site = fr.split('/')[-1][:70]
+                break
+        calls[(ev.name, site)] += 1
+for (name, site), n in sorted(calls.items(), key=lambda kv: -kv[1]):
+    print(f'   runtime call {n:4d}x  {name:24s} {site}')
 tot = 0.0
 for (name, shp, site), (n, us) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     tot += us
