@@ -290,6 +290,54 @@ def run_artv_sampling(args, device, rank, world):
     print(json.dumps(out))
 
 
+MP_CONFIG = {'T1_n': 10, 'T2_n': 10, 'T3_n': 30, 'N1_n': 0.9, 'N2_n': 0.1, 'N3_n': 0.125, 'N4_n': 0.0625, 'T1_t': 10, 'T2_t': 5,
+             'T3_t': 35, 'N1_t': 0., 'N2_t': 0., 'N3_t': 0., 'N4_t': 0., 'T': 20, 'B': 1}  # utils_args.py:221-281 defaults
+
+
+def run_bert_sampling(args, device, rank, world):
+    """--config 2|4 --sample: a 'step' = one BERT.generate_images call: control embedding, mask-predict with the reference's
+    default schedule (mp_T = 20 tower passes per video, one candidate; scripts/*/test.sh), VQGAN decode of the 8 frames."""
+    model = build_model(args.config, device, args.layers).eval()
+    b = args.batch or 16  # scripts/mmvoxceleb/*/test.sh: --batch_size 16
+    gen = torch.Generator().manual_seed(42 + rank)
+    batch = synth_batch(b, 8, device, gen, visuals=1 if args.config == 4 else 0)
+    kw = dict(visual=batch['visual']) if args.config == 4 else {}
+    cfg = dict(MP_CONFIG, B=args.candidates)
+    call = lambda: model.generate_images(batch['text'], mask_predict_steps=0, mp_config=cfg, dynamic=False, **kw)
+    for _ in range(max(1, args.warmup)):
+        call()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        images = call()[0]
+    fence()
+    dt = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        return
+    per_call = dt / args.steps
+    L = model.total_seq_len
+    passes = 1 + (cfg['T'] - 1) * cfg['B']  # sequences through the tower per video: step 0, then B candidates per step
+    flops = world * b * passes * (12 * L * (24 * 768**2 + 4 * L * 768)) * args.layers / 12  # SURVEY 8d: F(L) per pass and sample
+    out = {'metric': 'video-tokens/sec training step, 8-frame 128px text-to-video', 'value': world * b * 512 / per_call,
+           'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': per_call * 1e3,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+           'config': {'workload': 'BERT.generate_images (mask-predict, mp_T=%d, %d candidate(s)) + VQGAN decode, 8 frames 128x128, '
+                                  'config %d model' % (cfg['T'], cfg['B'], args.config), 'config_id': args.config,
+                      'per_gpu_batch': b, 'seq_len': L, 'parallelism': f'replicas{world}', 'layers': args.layers,
+                      'note': 'value counts GENERATED video tokens (inference), not training tokens'},
+           'roofline': {'bound': 'mfma', 'kernel': 'tower forward passes of the sampler', 'achieved': flops / per_call / 1e12,
+                        'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / per_call / 1e12 / PEAK_BF16_TFLOPS, 'traffic': None,
+                        'tower_passes_per_video': passes, 'ms_per_tower_pass_of_the_batch': per_call * 1e3 / cfg['T']},
+           'image_checksum': float(images.float().mean())}
+    print(f"[bench] BERT sampling: {per_call * 1e3:.1f} ms per generate_images call of {b} videos = {out['value']:.0f} generated "
+          f"video-tokens/s", file=sys.stderr, flush=True)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -297,13 +345,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', type=int, default=2, choices=sorted(WORKLOADS), help='BASELINE.json config (1-based): 2 headline, 4, 5')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (even; config 2: the recipe is 48 / 8 GPUs)')
+    ap.add_argument('--sample', action='store_true', help='config 2 / 4: time BERT.generate_images (mask-predict) instead of training')
+    ap.add_argument('--candidates', type=int, default=1, help='--sample: beam candidates per step (mp_B)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='launch every step from Python instead of replaying the captured step graph')
     ap.add_argument('--force-exchange', action='store_true', help='run the gradient all-reduce path even with one rank (tests)')
     ap.add_argument('--layers', type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the model
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 2 if args.config == 5 else 10
+        args.steps = 2 if args.config == 5 else (3 if args.sample else 10)
 
     # a GPU box exposes all 256 hardware threads but a cgroup quota of a few cores: keep torch's CPU pool small so that
     # incidental host ops never fan out over hundreds of spinning OpenMP threads (cpu_baseline() sets its own count)
@@ -330,6 +380,11 @@ def main():
     # seed_everything(seed + rank) as train.py:87; identical initial weights come from the rank-0 broadcast
     seed = 42 + rank
     random.seed(seed), np.random.seed(seed), torch.manual_seed(seed)
+    if args.sample and args.config != 5:
+        run_bert_sampling(args, device, rank, world)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     if args.config == 5:
         run_artv_sampling(args, device, rank, world)
         if dist.is_initialized():

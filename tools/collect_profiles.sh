@@ -12,6 +12,8 @@ cp $g/gemm_microbench.log $p/${r}_gemm_microbench.log; cp $g/strip_microbench.lo
 cp $g/pmc_FETCH_SIZE.csv $p/${r}_pmc_fetch_size.csv; cp $g/pmc_WRITE_SIZE.csv $p/${r}_pmc_write_size.csv
 cp $g/prof/bench_kernel_stats.csv $p/${r}_rocprofv3_kernel_stats.csv
 cp $g/host.txt $p/${r}_host.txt; cp $g/rocm_smi.txt $p/${r}_rocm_smi.txt
+[ -f $g/bench_bert_sampling.log ] && cp $g/bench_bert_sampling.log $p/${r}_bench_bert_sampling.json
+[ -f $g/bench_bert_sampling_b3.log ] && cp $g/bench_bert_sampling_b3.log $p/${r}_bench_bert_sampling_3candidates.json
 [ -f $g/step_ops.log ] && cp $g/step_ops.log $p/${r}_framework_launches_per_step.log
 [ -f $g/stress_nan.log ] && cp $g/stress_nan.log $p/${r}_graph_replay_stress.log
 ls -la $p | grep ${r}_ | wc -l

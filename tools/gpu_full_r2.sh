@@ -15,6 +15,7 @@ echo "== smoke"; timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.
 echo "== gpu tests"; timeout 1500 python -m pytest tests -m gpu -v -s --timeout 400 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 gpurun_out/pytest_gpu.log; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_gpu.log | cut -c1-200
 echo "== config 4"; timeout 600 python bench.py --config 4 --steps 20 --warmup 3 > gpurun_out/bench_c4.log 2> gpurun_out/bench_c4.err; grep "bench\]" gpurun_out/bench_c4.err | cut -c1-200
 echo "== config 5"; timeout 900 python bench.py --config 5 --steps 2 --warmup 1 > gpurun_out/bench_c5.log 2> gpurun_out/bench_c5.err; echo "rc=$?"
+echo "== BERT sampling (mask-predict)"; timeout 900 python bench.py --sample --steps 3 --warmup 1 > gpurun_out/bench_bert_sampling.log 2> gpurun_out/bench_bert_sampling.err; grep "bench\]" gpurun_out/bench_bert_sampling.err | cut -c1-200; timeout 900 python bench.py --sample --candidates 3 --batch 4 --steps 3 --warmup 1 > gpurun_out/bench_bert_sampling_b3.log 2>> gpurun_out/bench_bert_sampling.err; tail -1 gpurun_out/bench_bert_sampling.err | cut -c1-200
 echo "== launcher, forced exchange"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --force-exchange > gpurun_out/bench_ddp1.log 2> gpurun_out/bench_ddp1.err; grep "bench\]" gpurun_out/bench_ddp1.err | cut -c1-200
 echo "== vqgan per-op profile"; timeout 300 python tools/conv_layer_profile.py 54 > gpurun_out/conv_profile_54.log 2>&1; grep -E "^total" gpurun_out/conv_profile_54.log
 echo "== decode step"; timeout 600 python tools/bench_decode_step.py 1 > gpurun_out/decode_step_b1.log 2>&1; timeout 600 python tools/bench_decode_step.py 4 > gpurun_out/decode_step_b4.log 2>&1; grep -E "generate_images|graph replay" gpurun_out/decode_step_b1.log | tail -3 | cut -c1-200
