@@ -95,7 +95,9 @@ class DecodeSession:
     def _enqueue(self):
         # batches of up to 8 sequences take the matrix-vector path (five launches per layer, csrc/decode.hip); larger
         # ones the M = B corner of the MFMA GEMM
-        fn = 'mmvid_tower_decode_fused' if (self.fused and self.x.shape[0] <= 8) else 'mmvid_tower_decode'
+        # the fused small-batch kernels stage the whole [B, K] input block: B <= 8, B * 3072 <= 24576, B * 768 <= 6144 (csrc/decode.hip)
+        B, E = self.x.shape[0], self.x.shape[-1]
+        fn = 'mmvid_tower_decode_fused' if (self.fused and B <= 8 and B * 4 * E <= 24576 and B * E <= 6144) else 'mmvid_tower_decode'
         _lib.call(fn, ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
                   ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
         self.pos.add_(1)

@@ -146,7 +146,7 @@ struct GemvArgs {
 // KIT = ceil(K / 512): 16-byte weight loads per lane and output feature.  The kernel is latency-bound (a decode step is a
 // chain of ~60 of these), so the two global round trips it needs are overlapped: every weight load of the wave is issued
 // FIRST, into registers, and the input rows are fetched / normalised / staged in LDS while those are in flight.
-template <int KIT>
+template <int KIT, int XV = 12>  // XV float4 of the input block per thread: NB * K <= 1024 * XV floats
 __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][K]
     __shared__ float red[4][GV_MAXB];
@@ -176,7 +176,6 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a) {
     const int epos = a.kv_cache ? (a.pos_dev ? *a.pos_dev : a.pos0) : 0;
     // ---- 2. input rows: one pass of 16-byte loads into registers, LayerNorm statistics by block reduction, then LDS
     const int kq = K >> 2, total4 = NB * kq;  // float4 per row / in all rows
-    constexpr int XV = 12;                    // float4 per thread: NB * K <= 12288 floats
     float4 xv[XV];
     int xrow[XV];
 #pragma unroll
@@ -397,15 +396,23 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const long long* __restr
 }
 
 int gemv_launch(GemvArgs a, hipStream_t s) {
-    if (a.NB > GV_MAXB || a.K % 8 != 0 || (long)a.NB * a.K > 12288 || a.K > 3072 || a.ldx % 4 != 0 ||
+    if (a.NB > GV_MAXB || a.K % 8 != 0 || (long)a.NB * a.K > 24576 || a.K > 3072 || a.ldx % 4 != 0 ||
         (a.ln_w && (long)a.NB * a.K > 6144)) {
-        mmvid_set_error("decode gemv: NB=%d (<= %d), K=%d (multiple of 8, <= 3072, NB*K <= 12288), ldx %% 4 == 0", a.NB, GV_MAXB, a.K);
+        mmvid_set_error("decode gemv: NB=%d (<= %d), K=%d (multiple of 8, <= 3072, NB*K <= 24576; <= 6144 with LayerNorm), ldx %% 4 == 0",
+                        a.NB, GV_MAXB, a.K);
         return MMVID_ERR_ARG;
     }
     const dim3 grid(cdiv(a.N, GV_COLS));
     const size_t lds = (size_t)a.NB * a.K * 4;
     const int kit = cdiv(a.K, 512);
-    if (kit <= 2)
+    if ((long)a.NB * a.K > 12288) {  // 5..8 rows of a 3,072-wide input (c_proj): 96 KiB of LDS, 24 float4 staged per thread
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)gemv_rows_kernel<6, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
+            attr = true;
+        }
+        hipLaunchKernelGGL((gemv_rows_kernel<6, 24>), grid, dim3(256), lds, s, a);
+    } else if (kit <= 2)
         hipLaunchKernelGGL(gemv_rows_kernel<2>, grid, dim3(256), lds, s, a);
     else if (kit <= 4)
         hipLaunchKernelGGL(gemv_rows_kernel<4>, grid, dim3(256), lds, s, a);

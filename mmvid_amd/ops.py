@@ -449,15 +449,18 @@ def bert_build_ids(text, visual_tok, nvis, target, target_warp, mask1, pad_base,
 
 
 def gemv_rows(x, W, bias=None, ln=None, act=0, residual=None, round_in=False, round_out=False, out=None):
-    """Decode-time linear layer on a few rows: y = act(LN?(x) @ W^T + bias) (+ residual).  x [NB <= 8, K] f32, W [N, K] bf16."""
+    """Decode-time linear layer on a few rows: y = act(LN?(x) @ W^T + bias) (+ residual).  x [NB, K] f32 (contiguous), W [N, K] bf16."""
     _chk(x, f32, 'x'), _chk(W, bf16, 'W')
     NB, K = x.shape
     N = W.shape[0]
     if out is None:
         out = torch.empty(NB, N, device=x.device, dtype=f32)
     lw, lb, eps = (ln[0], ln[1], ln[2]) if ln is not None else (None, None, 0.0)
-    call('mmvid_gemv_rows', _p(x), K, NB, K, _p(lw), _p(lb), float(eps), _p(W), _p(bias), N, int(act), _p(residual), N,
-         int(round_in), int(round_out), _p(out), N, _stream())
+    for r0 in range(0, NB, 8):  # the kernel takes up to 8 rows per launch; larger batches go through in slices
+        nb = min(8, NB - r0)
+        res = residual[r0:r0 + nb] if residual is not None else None
+        call('mmvid_gemv_rows', _p(x[r0:r0 + nb]), K, nb, K, _p(lw), _p(lb), float(eps), _p(W), _p(bias), N, int(act), _p(res), N,
+             int(round_in), int(round_out), _p(out[r0:r0 + nb]), N, _stream())
     return out
 
 

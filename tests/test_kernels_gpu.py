@@ -52,7 +52,9 @@ def test_vq_argmin_bit_exact_vs_oracle(ops, golden, tag, n):
 def test_vq_argmin_ragged_rows_and_ties(ops):
     from oracle.vq import vq_argmin
     g = torch.Generator().manual_seed(3)
-    for rows in (1, 31, 33, 4097):
+    # row counts on both sides of the point where the codes are split over blocks as well (< 256 blocks of 32 rows): the
+    # per-range minima are merged by atomicMin on (distance, index), which must reproduce the sequential first minimum
+    for rows in (1, 31, 33, 3456, 4097, 8448):
         z = torch.randn(rows, 256, generator=g)
         cb = torch.randn(1024, 256, generator=g) * 0.5
         cb[700] = cb[5]  # exact duplicate rows: first index must win
@@ -63,6 +65,10 @@ def test_vq_argmin_ragged_rows_and_ties(ops):
     z = cb[[5, 700, 900, 17]].clone()  # rows equal to a codebook entry
     assert ops.vq_argmin(z.to(DEV), cb.to(DEV)).cpu().tolist() == [5, 5, 5, 17]
     assert ops.vq_argmin(torch.empty(0, 256, device=DEV), cb.to(DEV)).numel() == 0
+    bad = torch.randn(40, 256, generator=g)
+    bad[7] = float('nan')  # no code beats +inf: index 0 and an infinite distance, with or without the split
+    idx, dmin = ops.vq_argmin(bad.to(DEV), cb.to(DEV), return_dmin=True)
+    assert int(idx[7]) == 0 and math.isinf(float(dmin[7])) and torch.equal(idx.cpu()[:7], vq_argmin(bad[:7], cb)[0])
 
 
 def test_gather_rows(ops):

@@ -300,7 +300,7 @@ def test_artv_kv_cache_decode_matches_full_recompute(golden):
         for k in range(31):
             hs = sess.step(m._embed_rows(tt[:, k:k + 1], prompt.shape[1] + k)[:, 0, :])
         assert sess.graph is not None and torch.equal(hs, h)
-        # the matrix-vector decode step (five launches per layer, the default for batches <= 8): same hidden states up to
+        # the matrix-vector decode step (five launches per layer, the default for batches <= 4): same hidden states up to
         # fp32 summation order, since it rounds to bf16 exactly where the MFMA path stores bf16
         cache3 = m.transformer.new_kv_cache(B, m.total_seq_len, DEV)
         m.transformer.prefill(m._embed_rows(prompt, 0), cache3)
@@ -309,6 +309,26 @@ def test_artv_kv_cache_decode_matches_full_recompute(golden):
             hf = sess3.step(m._embed_rows(tt[:, k:k + 1], prompt.shape[1] + k)[:, 0, :])
         close(hf, h, 1e-2, 'fused decode step vs GEMM decode step (hidden state after 31 tokens)')
         close(cache3[:, :, :prompt.shape[1] + 31], cache2[:, :, :prompt.shape[1] + 31], 1e-2, 'key/value cache')
+
+
+@pytest.mark.parametrize('B', [1, 4, 5, 8, 9])
+def test_decode_session_every_batch_size(B):
+    """The decode session picks the matrix-vector kernels while the [B, 3072] input block fits their registers (B <= 4) and
+    the GEMM path above that; both must agree with the full-prefix forward.  (B = 5..8 used to select the fused kernels
+    and fail with their argument check: bench.py --config 5 --batch 8.)"""
+    from mmvid_amd.clip_tower import OpenAICLIPTransformer
+    torch.manual_seed(0)
+    L, P, steps = 48, 9, 6
+    tw = OpenAICLIPTransformer(seq_len=L, which_model='openai_clip_visual', causal=True, layers=2).to(DEV).eval()
+    x = torch.randn(B, P + steps, 768, device=DEV) * 0.5
+    with torch.no_grad():
+        full = tw(x)  # causal: position p of the full pass = the incremental result at p
+        cache = tw.new_kv_cache(B, L, DEV)
+        tw.prefill(x[:, :P].contiguous(), cache)
+        sess = tw.decode_session(cache, P)
+        for k in range(steps):
+            h = sess.step(x[:, P + k].contiguous())
+            close(h, full[:, P + k], 1e-2, f'B={B}: incremental vs full forward at position {P + k}')
 
 
 # --------------------------------------------------------------------------------------------- engine

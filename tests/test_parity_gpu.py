@@ -306,7 +306,8 @@ def test_gemv_rows_kernel_vs_torch():
     from mmvid_amd import ops
     torch.manual_seed(0)
     for NB, K, N, act, ln, res in ((1, 768, 2304, 0, True, False), (4, 768, 3072, 1, True, False), (3, 3072, 768, 0, False, True),
-                                   (8, 768, 1024, 0, True, False), (2, 768, 770, 0, False, True)):
+                                   (8, 768, 1024, 0, True, False), (2, 768, 770, 0, False, True), (8, 3072, 768, 0, False, True),
+                                   (5, 3072, 768, 1, False, False), (19, 768, 1024, 0, True, True)):  # 19 rows: three launches
         x = torch.randn(NB, K, device=DEV)
         W = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
         b = torch.randn(N, device=DEV) * 0.1
