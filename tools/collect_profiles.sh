@@ -14,6 +14,7 @@ cp $g/prof/bench_kernel_stats.csv $p/${r}_rocprofv3_kernel_stats.csv
 cp $g/host.txt $p/${r}_host.txt; cp $g/rocm_smi.txt $p/${r}_rocm_smi.txt
 [ -f $g/bench_bert_sampling.log ] && cp $g/bench_bert_sampling.log $p/${r}_bench_bert_sampling.json
 [ -f $g/bench_bert_sampling_b3.log ] && cp $g/bench_bert_sampling_b3.log $p/${r}_bench_bert_sampling_3candidates.json
+[ -f $g/shape_sweep.log ] && grep -v -E 'amdgpu.ids|Warning|warn' $g/shape_sweep.log > $p/${r}_shape_sweep.log
 [ -f $g/step_ops.log ] && cp $g/step_ops.log $p/${r}_framework_launches_per_step.log
 [ -f $g/stress_nan.log ] && cp $g/stress_nan.log $p/${r}_graph_replay_stress.log
 ls -la $p | grep ${r}_ | wc -l

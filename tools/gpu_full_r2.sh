@@ -22,6 +22,7 @@ echo "== decode step"; timeout 600 python tools/bench_decode_step.py 1 > gpurun_
 echo "== microbench"; timeout 600 python tools/bench_gemm.py > gpurun_out/gemm_microbench.log 2>&1; timeout 300 python tools/bench_gemm.py strip > gpurun_out/strip_microbench.log 2>&1
 echo "== framework launches per step"; timeout 300 python tools/step_ops.py > gpurun_out/step_ops.log 2>&1; tail -1 gpurun_out/step_ops.log
 echo "== graph replay stress (the LDS-DMA race showed as NaN within 20 replays in 1 run of 3)"; (for s in 42 44 46 49; do timeout 300 python tools/stress_nan2.py 50 $s graph 2>&1 | grep -E "finite|step "; done) > gpurun_out/stress_nan.log 2>&1; cat gpurun_out/stress_nan.log | cut -c1-200
+echo "== shape sweep"; timeout 600 python tools/shape_sweep.py > gpurun_out/shape_sweep.log 2>&1; tail -1 gpurun_out/shape_sweep.log | cut -c1-200
 echo "== rocprofv3 kernel stats"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -o bench -- python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --eager > $ROOT/gpurun_out/prof.log 2>&1; echo "rocprof rc=$?")
 find gpurun_out/prof -type f ! -name "*kernel_stats*" -delete
