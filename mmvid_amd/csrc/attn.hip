@@ -170,7 +170,8 @@ __device__ __forceinline__ void block_coords(int nrt, int H, int& rt, int& hd, i
 }
 
 // ------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int L, int H, int E,
+template <int MINB>
+__global__ __launch_bounds__(256, MINB) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int L, int H, int E,
                                                           int nrt, float scale_log2, MaskSpec mask,
                                                           bf16_t* __restrict__ out, long ldo, float* __restrict__ lse2) {
     __shared__ __attribute__((aligned(16))) char smem[2][2 * TILE];  // K tile, V tile
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld,
+template <int MINB>
+__global__ __launch_bounds__(256, MINB) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                              const bf16_t* __restrict__ O, long ldo,
                                                              const bf16_t* __restrict__ dO, long lddo,
                                                              const float* __restrict__ lse2,
@@ -362,7 +364,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // ------------------------------------------------------------------------------------------ dK, dV
 constexpr int DKV_BUF = 2 * TILE + 512;  // Q tile, dO tile, lse2[64], delta[64]
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld,
+template <int MINB>
+__global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld,
                                                               const bf16_t* __restrict__ dO, long lddo,
                                                               const float* __restrict__ lse2,
                                                               const float* __restrict__ delta, int L, int H, int E,
@@ -511,7 +514,12 @@ extern "C" int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, in
     MMVID_REQUIRE((int64_t)L * ld * 2 < (1ll << 31), "attention_fwd: one batch entry of qkv must be smaller than 2 GiB");
     MmvidProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * 64, (hipStream_t)stream);
     const int nrt = cdiv(L, ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
+    if (mmvid_option(MMVID_OPT_ATTN_OCC) & 1)
+        hipLaunchKernelGGL((attn_fwd_kernel<5>), dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
+                       L, H, E, nrt, scale * 1.4426950408889634f, make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out,
+                       (long)ldo, lse2);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<2>), dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
                        L, H, E, nrt, scale * 1.4426950408889634f, make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out,
                        (long)ldo, lse2);
     MMVID_LAUNCH_CHECK("attention_fwd");
@@ -532,9 +540,17 @@ extern "C" int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, i
     const float sl2 = scale * 1.4426950408889634f;
     MmvidProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)L * L * 64, s);  // 5 GEMM-equivalents (recompute counted once)
     const int nrt = cdiv(L, ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+    if (mmvid_option(MMVID_OPT_ATTN_OCC) & 2)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<4>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
                        (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+    else
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<2>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
+    if (mmvid_option(MMVID_OPT_ATTN_OCC) & 4)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<3>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
+    else
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
                        (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
     MMVID_LAUNCH_CHECK("attention_bwd");
     return MMVID_OK;

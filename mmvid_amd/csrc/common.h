@@ -81,12 +81,15 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   ln_bwd_blocks  MMVID_LN_BWD_BLOCKS  grid cap of the LayerNorm backward (default 512: its dw/db atomics scale with the
 //                                       grid -- measured on the whole step 2048: +0.6 ms, 1024: +0.11 ms, 256: +0.25 ms)
 //   strip_sched    MMVID_STRIP_SCHED    strip convolution: 0 = LDS-DMA requests right after the tile barrier, 1 = spread over the
-//                                       first three k-steps of the tile (tools/bench_gemm.py strip)
+//                                       first three k-steps of the tile, 2 = two-group ping-pong (default; whole-step A/B with
+//                                       tools/ab_graph.py: 18.59 / 18.53 / 18.49 ms for 0 / 1 / 2)
 //   gemm_wshape    MMVID_GEMM_WSHAPE    forward / dX GEMMs on the 4-wave 256x128 shape with two blocks per CU (gemm.hip): 0 = off
 //                                       (default: measured 5-25 % slower, profiles/r02_gemm_anatomy.log), 1 = when the grid has
 //                                       >= 200 tiles, 2 = always
+//   attn_occ       MMVID_ATTN_OCC       attention kernels compiled for one more block per CU (registers capped, a few spilled):
+//                                       bit 0 forward (5 instead of 4), bit 1 dQ (4 instead of 3), bit 2 dK/dV (3 instead of 2)
 //   gemm_debug     MMVID_GEMM_DEBUG     measurement only (tools/bench_gemm.py anatomy): 1 = the GEMM epilogue skips its global
 //                                       stores, 2 = the K loop is skipped (results are wrong in both)
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_COUNT = 9 };
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_COUNT = 10 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

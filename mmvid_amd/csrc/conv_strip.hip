@@ -340,7 +340,7 @@ extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int 
     }
     MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * 9 * Cin, (hipStream_t)stream);
     const int blocks = cdiv(p.M, ST_M) * (Cout / ST_N);
-    if (mmvid_option(MMVID_OPT_STRIP_SCHED) == 2)
+    if (mmvid_option(MMVID_OPT_STRIP_SCHED) >= 2)
         hipLaunchKernelGGL(conv_strip_kernel<2>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
     else if (mmvid_option(MMVID_OPT_STRIP_SCHED) == 1)
         hipLaunchKernelGGL(conv_strip_kernel<1>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);

@@ -38,9 +38,10 @@ Opt g_opts[MMVID_OPT_COUNT] = {{"gemm_tile", "MMVID_GEMM_TILE", 0, 0, false},
                                {"ln_bwd_blocks", "MMVID_LN_BWD_BLOCKS", 512, 0, false},
                                {"gemm_sched", "MMVID_GEMM_SCHED", 2, 0, false},
                                {"fuse_colsum", "MMVID_FUSE_COLSUM", 1, 0, false},
-                               {"strip_sched", "MMVID_STRIP_SCHED", 1, 0, false},
+                               {"strip_sched", "MMVID_STRIP_SCHED", 2, 0, false},
                                {"gemm_debug", "MMVID_GEMM_DEBUG", 0, 0, false},
-                               {"gemm_wshape", "MMVID_GEMM_WSHAPE", 0, 0, false}};
+                               {"gemm_wshape", "MMVID_GEMM_WSHAPE", 0, 0, false},
+                               {"attn_occ", "MMVID_ATTN_OCC", 0, 0, false}};
 }  // namespace
 
 int mmvid_option(int which) {
@@ -60,7 +61,7 @@ extern "C" int mmvid_set_option(const char* name, int value) {
             g_opts[i].value = value, g_opts[i].set = true;
             return MMVID_OK;
         }
-    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs, ln_bwd_blocks, gemm_sched, fuse_colsum, strip_sched, gemm_debug, gemm_wshape)", name);
+    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs, ln_bwd_blocks, gemm_sched, fuse_colsum, strip_sched, gemm_debug, gemm_wshape, attn_occ)", name);
     return MMVID_ERR_ARG;
 }
 

@@ -23,24 +23,24 @@ def main():
     opt, values = sys.argv[1], [int(v) for v in sys.argv[2:]]
     dev = torch.device('cuda', 0)
     torch.manual_seed(0), np.random.seed(0)
-    model = bench.build_model(dev).train()
-    tr = FlatTrainer(model, order=backward_order)
-    text, frames = bench.synth_batch(6, dev, torch.Generator().manual_seed(0))
+    model = bench.build_model(2, dev, 12).train()
+    tr = FlatTrainer(model, lr=1e-4, max_grad_norm=1.0, order=backward_order)
+    inputs = bench.synth_batch(6, 8, dev, torch.Generator().manual_seed(0))
+    fn = bench.loss_fn(model, 2)
     for _ in range(2):
-        bench.train_step(model, tr, text, frames)
-    inputs = bench.host_random_inputs(model, text, frames)
+        bench.eager_step(tr, fn, inputs)
     steps = {}
     for v in values:
         _lib.call('mmvid_set_option', opt.encode(), v)
-        steps[v] = GraphedStep(tr, bench.loss_fn(model), inputs, warmup=1)
+        steps[v] = GraphedStep(tr, fn, inputs, warmup=1)
     res = {v: [] for v in values}
     for rep in range(8):
         for v in values:
-            steps[v](**inputs)
+            steps[v]()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(5):
-                steps[v](**inputs)
+                steps[v]()
             torch.cuda.synchronize()
             res[v].append((time.perf_counter() - t0) / 5 * 1e3)
     for v in values:  # host cost of ONE replay issued into an idle queue (no back-pressure from earlier work)
@@ -48,7 +48,7 @@ def main():
         for _ in range(5):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            steps[v](**inputs)
+            steps[v]()
             hs.append((time.perf_counter() - t0) * 1e3)
             torch.cuda.synchronize()
         print(f'{opt}={v}: host time of one replay call (copies + hipGraphLaunch) {[round(x, 2) for x in hs]} ms')
