@@ -89,17 +89,18 @@ def synth_batch(B, frames, device, gen, visuals=0):
 
 def loss_fn(model, cfg):
     """The step's forward as a capture-safe function of the data tensors: every random choice is drawn on the device."""
+    from mmvid_amd.functional import weighted_loss
     if cfg == 4:
         def fn(text, frames, visual):
             lm, lr, lv = model(text, visual=visual, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
                                vc_mode='mask_8x8', msm_strategy_prob=MSM_PROB, msm_bernoulli_prob=MSM_BERN, vid_strategy_prob=VID_PROB)
-            return 7.0 * lm + 0.5 * lr + 0.5 * lv
+            return weighted_loss((lm, lr, lv), (7.0, 0.5, 0.5))
         return fn
 
     def fn(text, frames):
         lm, lr, lv = model(text, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
                            msm_strategy_prob=MSM_PROB, msm_bernoulli_prob=MSM_BERN, vid_strategy_prob=VID_PROB)
-        return 7.0 * lm + 0.5 * lr + 0.5 * lv
+        return weighted_loss((lm, lr, lv), (7.0, 0.5, 0.5))  # train.py:320, one launch each way
     return fn
 
 

@@ -99,6 +99,23 @@ int mmvid_cross_entropy_bwd(const float* logits, int64_t ldl, const int64_t* tar
                             const float* lse, const float* gscale, int64_t rows, int V, void* dlogits_bf16,
                             int64_t ldd, void* stream);
 int mmvid_colsum_bf16(const void* dy, int64_t ld, int64_t M, int N, float* db, void* stream);
+/* Dense positional table of a sequence (dalle_bert.py:903-973; axial_positional_embedding, summed mode) in one launch, and
+ * its backward in one launch.  A segment fills table rows [dst0, dst0 + rows): naxes == 0 -> rows src0.. of w[0] ([*, E]);
+ * naxes 2 / 3 -> row i gets w[0][i0] + w[1][i1] (+ w[2][i2]) with (i0, i1, i2) the row-major index of i in d[0] x d[1] (x d[2]).
+ * Rows no segment covers are zero.  Backward: gw[a] += d(table) summed over the rows that read it (fixed order); null gw skips. */
+typedef struct {
+    const float* w[3];
+    float* gw[3];
+    int32_t dst0, rows, naxes, src0;
+    int32_t d[3];
+    int32_t pad;
+} mmvid_pos_segment_t;
+int mmvid_pos_table_fwd(const mmvid_pos_segment_t* segs, int nseg, int L, int E, float* out, void* stream);
+int mmvid_pos_table_bwd(const mmvid_pos_segment_t* segs, int nseg, int E, const float* g, void* stream);
+/* out[0] = wa a[0] + wb b[0] + wc c[0] on device scalars (train.py:320: the weighted sum of the three losses; null = term
+ * absent), and its backward ga / gb / gc = w * g[0]. */
+int mmvid_lincomb3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float* out, void* stream);
+int mmvid_scale3(const float* g, float wa, float wb, float wc, float* ga, float* gb, float* gc, void* stream);
 /* Kernels never fault on a bad index: an embedding id outside its table reads row 0, a cross-entropy target outside [0, V)
  * counts as class 0 -- and both are COUNTED on the device (the reference's nn.Embedding / F.cross_entropy raise a device-side
  * assert instead).  counts[0] = bad embedding ids, counts[1] = bad CE targets, [2..3] reserved; reset != 0 clears them.

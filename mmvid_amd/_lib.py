@@ -101,10 +101,20 @@ SIGNATURES = {
     'mmvid_graph_stats': [P],
     'mmvid_set_option': [c_char_p, I],
     'mmvid_device_faults': [P, I],
+    'mmvid_pos_table_fwd': [P, I, I, I, P, P],
+    'mmvid_pos_table_bwd': [P, I, I, P, P],
+    'mmvid_lincomb3': [P, P, P, F, F, F, P, P],
+    'mmvid_scale3': [P, F, F, F, P, P, P, P],
     'mmvid_prof_end': [P, P, P, P, I],
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I),
          'mmvid_warp_params_bytes': ([], I)}
+
+class PosSegment(ctypes.Structure):
+    """mmvid_pos_segment_t (include/mmvid_hip.h)."""
+    _fields_ = [('w', ctypes.c_void_p * 3), ('gw', ctypes.c_void_p * 3), ('dst0', ctypes.c_int32), ('rows', ctypes.c_int32),
+                ('naxes', ctypes.c_int32), ('src0', ctypes.c_int32), ('d', ctypes.c_int32 * 3), ('pad', ctypes.c_int32)]
+
 
 _lib = None
 

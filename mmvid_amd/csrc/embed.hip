@@ -3,6 +3,7 @@
 //   assemble_sequence_bwd  scatter-add of dx rows into the table gradients (fp32 atomics) + dpos = sum_b dx
 //   cross_entropy fwd/bwd  dalle_bert.py:1040 F.cross_entropy(logits[~mask1], target[~mask1]) (mean over selected rows)
 //   colsum                 bias gradients: db[n] += sum_m dY[m][n]
+#include "../../include/mmvid_hip.h"
 #include "common.h"
 
 namespace {
@@ -297,6 +298,178 @@ extern "C" int mmvid_colsum_bf16(const void* dy, int64_t ld, int64_t M, int N, f
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(N, 256), cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dy, (long)ld, (long)M, N, db);
     MMVID_LAUNCH_CHECK("colsum_bf16");
+    return MMVID_OK;
+}
+
+// ---- dense positional table of a BERT sequence (dalle_bert.py:903-973: special / text / visual-axial / target-axial
+// positional embeddings laid out along the sequence; axial_positional_embedding in summed mode) in ONE launch, and its
+// backward in one launch.  A segment maps `rows` consecutive table rows [dst0, dst0 + rows) to either consecutive rows
+// of one parameter (naxes = 0: w[0][src0 + i]) or the sum of up to three axial weights (row i -> indices (i / (d1 d2),
+// (i / d2) % d1, i % d2) with the trailing dims; w[a] is [d_a][E]).  Rows no segment covers are zero ([SEP] slots).
+namespace {
+struct PosSeg {
+    const float* w[3];
+    float* gw[3];
+    int dst0, rows, naxes, src0, d[3];
+};
+constexpr int POS_MAXSEG = 12;
+struct PosSegs {
+    PosSeg s[POS_MAXSEG];
+    int n;
+};
+__device__ __forceinline__ void axial_index(const PosSeg& sg, int i, int (&ix)[3]) {
+    if (sg.naxes == 3)
+        ix[0] = i / (sg.d[1] * sg.d[2]), ix[1] = (i / sg.d[2]) % sg.d[1], ix[2] = i % sg.d[2];
+    else if (sg.naxes == 2)
+        ix[0] = i / sg.d[1], ix[1] = i % sg.d[1], ix[2] = 0;
+    else
+        ix[0] = i, ix[1] = 0, ix[2] = 0;
+}
+// one wave per table row
+__global__ __launch_bounds__(256) void pos_table_fwd_kernel(PosSegs ps, int L, int E, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= L) return;
+    int which = -1;
+    for (int k = 0; k < ps.n; ++k)
+        if (row >= ps.s[k].dst0 && row < ps.s[k].dst0 + ps.s[k].rows) which = k;
+    float4* dst = reinterpret_cast<float4*>(out + (long)row * E);
+    if (which < 0) {
+        for (int c = lane; c < (E >> 2); c += 64) dst[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const PosSeg& sg = ps.s[which];
+    const int i = row - sg.dst0;
+    if (sg.naxes == 0) {
+        const float4* src = reinterpret_cast<const float4*>(sg.w[0] + (long)(sg.src0 + i) * E);
+        for (int c = lane; c < (E >> 2); c += 64) dst[c] = src[c];
+        return;
+    }
+    int ix[3];
+    axial_index(sg, i, ix);
+    for (int c = lane; c < (E >> 2); c += 64) {
+        float4 a = reinterpret_cast<const float4*>(sg.w[0] + (long)ix[0] * E)[c];  // ((w0 + w1) + w2): the order of AxialPositionalEmbedding.table()
+        if (sg.naxes >= 2) {
+            const float4 b = reinterpret_cast<const float4*>(sg.w[1] + (long)ix[1] * E)[c];
+            a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        }
+        if (sg.naxes >= 3) {
+            const float4 b = reinterpret_cast<const float4*>(sg.w[2] + (long)ix[2] * E)[c];
+            a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        }
+        dst[c] = a;
+    }
+}
+// blockIdx.x enumerates (segment, axis, index) parameter rows in the order of `first`; fixed-order sums (deterministic)
+__global__ __launch_bounds__(256) void pos_table_bwd_kernel(PosSegs ps, int E, const float* __restrict__ g) {
+    int job = blockIdx.x, k = 0, a = 0;
+    for (k = 0; k < ps.n; ++k) {
+        const PosSeg& sg = ps.s[k];
+        const int na = sg.naxes == 0 ? 1 : sg.naxes;
+        bool found = false;
+        for (a = 0; a < na; ++a) {
+            const int cnt = sg.naxes == 0 ? sg.rows : sg.d[a];
+            if (job < cnt) {
+                found = true;
+                break;
+            }
+            job -= cnt;
+        }
+        if (found) break;
+    }
+    if (k >= ps.n) return;
+    const PosSeg& sg = ps.s[k];
+    float* dstp = sg.gw[a];
+    if (!dstp) return;  // a frozen parameter
+    for (int c = threadIdx.x; c < (E >> 2); c += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sg.naxes == 0) {
+            acc = reinterpret_cast<const float4*>(g + (long)(sg.dst0 + job) * E)[c];
+            float4* d = reinterpret_cast<float4*>(dstp + (long)(sg.src0 + job) * E) + c;
+            const float4 o = *d;
+            *d = make_float4(o.x + acc.x, o.y + acc.y, o.z + acc.z, o.w + acc.w);
+            continue;
+        }
+        for (int i = 0; i < sg.rows; ++i) {
+            int ix[3];
+            axial_index(sg, i, ix);
+            if (ix[a] != job) continue;
+            const float4 v = reinterpret_cast<const float4*>(g + (long)(sg.dst0 + i) * E)[c];
+            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        }
+        float4* d = reinterpret_cast<float4*>(dstp + (long)job * E) + c;
+        const float4 o = *d;
+        *d = make_float4(o.x + acc.x, o.y + acc.y, o.z + acc.z, o.w + acc.w);
+    }
+}
+// out = wa * a + wb * b + wc * c (device scalars; null = absent)   |   ga, gb, gc = w * g
+__global__ void lincomb3_kernel(const float* a, const float* b, const float* c, float wa, float wb, float wc, float* out) {
+    if (threadIdx.x == 0) out[0] = (a ? wa * a[0] : 0.f) + (b ? wb * b[0] : 0.f) + (c ? wc * c[0] : 0.f);
+}
+__global__ void scale3_kernel(const float* g, float wa, float wb, float wc, float* ga, float* gb, float* gc) {
+    if (threadIdx.x == 0) {
+        const float v = g[0];
+        if (ga) ga[0] = wa * v;
+        if (gb) gb[0] = wb * v;
+        if (gc) gc[0] = wc * v;
+    }
+}
+int fill_segs(PosSegs& ps, const mmvid_pos_segment_t* segs, int nseg) {
+    MMVID_REQUIRE(segs && nseg >= 1 && nseg <= POS_MAXSEG, "pos_table: 1..%d segments", POS_MAXSEG);
+    ps.n = nseg;
+    for (int k = 0; k < nseg; ++k) {
+        const mmvid_pos_segment_t& in = segs[k];
+        MMVID_REQUIRE(in.naxes >= 0 && in.naxes <= 3 && in.rows > 0 && in.w[0], "pos_table: bad segment %d", k);
+        PosSeg& o = ps.s[k];
+        for (int a = 0; a < 3; ++a) o.w[a] = in.w[a], o.gw[a] = in.gw[a], o.d[a] = in.d[a] > 0 ? in.d[a] : 1;
+        o.dst0 = in.dst0, o.rows = in.rows, o.naxes = in.naxes, o.src0 = in.src0;
+        if (in.naxes > 0) {
+            long prod = 1;
+            for (int a = 0; a < in.naxes; ++a) prod *= o.d[a];
+            MMVID_REQUIRE(in.rows <= prod, "pos_table: segment %d has %d rows but its axes hold %ld", k, in.rows, prod);
+        }
+    }
+    return MMVID_OK;
+}
+}  // namespace
+
+extern "C" int mmvid_pos_table_fwd(const mmvid_pos_segment_t* segs, int nseg, int L, int E, float* out, void* stream) {
+    MMVID_REQUIRE(out && L > 0 && E % 4 == 0, "pos_table_fwd: bad arguments");
+    PosSegs ps;
+    int rc = fill_segs(ps, segs, nseg);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pos_table_fwd_kernel, dim3(cdiv(L, 4)), dim3(256), 0, (hipStream_t)stream, ps, L, E, out);
+    MMVID_LAUNCH_CHECK("pos_table_fwd");
+    return MMVID_OK;
+}
+
+// gw[a] += the gradient of w[a] given g = dL/d(table) [L][E]; segments whose gw is null are skipped
+extern "C" int mmvid_pos_table_bwd(const mmvid_pos_segment_t* segs, int nseg, int E, const float* g, void* stream) {
+    MMVID_REQUIRE(g && E % 4 == 0, "pos_table_bwd: bad arguments");
+    PosSegs ps;
+    int rc = fill_segs(ps, segs, nseg);
+    if (rc) return rc;
+    int jobs = 0;
+    for (int k = 0; k < nseg; ++k) {
+        if (ps.s[k].naxes == 0)
+            jobs += ps.s[k].rows;
+        else
+            for (int a = 0; a < ps.s[k].naxes; ++a) jobs += ps.s[k].d[a];
+    }
+    hipLaunchKernelGGL(pos_table_bwd_kernel, dim3(jobs), dim3(256), 0, (hipStream_t)stream, ps, E, g);
+    MMVID_LAUNCH_CHECK("pos_table_bwd");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_lincomb3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float* out, void* stream) {
+    MMVID_REQUIRE(out && (a || b || c), "lincomb3: null pointer");
+    hipLaunchKernelGGL(lincomb3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, wa, wb, wc, out);
+    MMVID_LAUNCH_CHECK("lincomb3");
+    return MMVID_OK;
+}
+extern "C" int mmvid_scale3(const float* g, float wa, float wb, float wc, float* ga, float* gb, float* gc, void* stream) {
+    MMVID_REQUIRE(g, "scale3: null pointer");
+    hipLaunchKernelGGL(scale3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g, wa, wb, wc, ga, gb, gc);
+    MMVID_LAUNCH_CHECK("scale3");
     return MMVID_OK;
 }
 

@@ -24,7 +24,7 @@ from torch import nn
 from . import ops, sampling
 from .clip_tower import OpenAICLIPTransformer
 from .frontend import Frontend, face_choices
-from .functional import AssembleSequence, BertHeads, LNLinear
+from .functional import PosTable, AssembleSequence, BertHeads, LNLinear
 from .modules import AxialPositionalEmbedding, AxialPositionalEmbeddingList
 
 
@@ -176,9 +176,28 @@ class BERT(nn.Module):
         vis = self.visual_emb.weight if (self.num_visuals > 0 and self.visual_emb is not None) else self.image_emb.weight
         return (self.special_emb.weight, self.text_emb.weight, vis, self.image_emb.weight)
 
+    def _pos_layout(self):
+        """Segments of the positional table for functional.PosTable: (dst0, rows, src0, params, axial dims)."""
+        sp, f = self.special_pos_emb.weight, self.image_fmap_size
+        lay = [(0, 1, 0, (sp, ), ()), (1, self.text_seq_len, 0, (self.text_pos_emb.weight, ), ())]
+        at = 1 + self.text_seq_len
+        if self.num_visuals > 0:
+            for m in self.visual_pos_emb.module_list:  # one (h, w) axial table per visual frame, + a zero [SEP] row each
+                lay.append((at, f * f, 0, (m.weights_0, m.weights_1), (f, f)))  # [1,f,1,E] / [1,1,f,E]: rows of E in memory
+                at += f * f + (1 if self.insert_sep else 0)
+        lay.append((at, 2, 1, (sp, ), ()))
+        at += 2
+        tp, T = self.target_pos_emb, self.num_targets
+        lay.append((at, T * f * f, 0, (tp.weights_0, tp.weights_1, tp.weights_2), (T, f, f)))
+        return lay, at + T * f * f
+
     def _pos_table(self):
         """[total_seq_len, dim]: special_pos / text_pos / axial tables laid out along the sequence."""
         sp = self.special_pos_emb.weight
+        if sp.is_cuda:  # one launch forward, one backward (functional.PosTable); the torch construction below is the host form
+            lay, L = self._pos_layout()
+            params = [w for seg in lay for w in seg[3]]
+            return PosTable.apply(lay, L, *params)
         parts = [sp[0:1], self.text_pos_emb.weight[:self.text_seq_len]]
         if self.num_visuals > 0:
             parts.append(self.visual_pos_emb.table(insert_sep=bool(self.insert_sep)))

@@ -34,6 +34,71 @@ class AssembleSequence(torch.autograd.Function):
         return (dpos, None, None) + (None, ) * len(ctx.tables)
 
 
+class PosTable(torch.autograd.Function):
+    """The dense positional table [L, E] of a sequence from its (tiny) parameters in ONE launch, gradients accumulated into
+    `p.grad` in ONE launch (the torch construction -- slices, expands, sums, cat -- and its backward were 22 of the step's
+    41 framework launches).  `layout`: list of (dst0, rows, src0, (params...), dims) -- see mmvid_pos_table_fwd."""
+
+    @staticmethod
+    def forward(ctx, layout, L, *params):
+        from . import _lib
+        E = params[0].shape[-1]
+        ctx.layout, ctx.L, ctx.E = layout, L, E
+        out = torch.empty(L, E, device=params[0].device, dtype=f32)
+        segs = PosTable._segments(layout, grads=False)
+        _lib.call('mmvid_pos_table_fwd', segs, len(layout), L, E, ops._p(out), ops._stream())
+        return out
+
+    @staticmethod
+    def _segments(layout, grads):
+        from . import _lib
+        arr = (_lib.PosSegment * len(layout))()
+        for k, (dst0, rows, src0, ws, dims) in enumerate(layout):
+            sg = arr[k]
+            sg.dst0, sg.rows, sg.src0, sg.naxes = dst0, rows, src0, len(dims)
+            for a in range(3):
+                w = ws[a] if a < len(ws) else None
+                sg.w[a] = w.data_ptr() if w is not None else None
+                sg.gw[a] = _grad_buf(w).data_ptr() if (grads and w is not None and w.requires_grad) else None
+                sg.d[a] = dims[a] if a < len(dims) else 1
+        return arr
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        g = ops._chk(g.contiguous(), f32, 'dpos')
+        segs = PosTable._segments(ctx.layout, grads=True)
+        _lib.call('mmvid_pos_table_bwd', segs, len(ctx.layout), ctx.E, ops._p(g), ops._stream())
+        return (None, None) + (None, ) * (len(ctx.needs_input_grad) - 2)
+
+
+class WeightedLoss(torch.autograd.Function):
+    """wa * a + wb * b + wc * c on device scalars (train.py:320) as one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, wa, wb, wc, a, b, c):
+        from . import _lib
+        ctx.w = (float(wa), float(wb), float(wc))
+        out = torch.empty((), device=a.device, dtype=f32)
+        sc = [ops._chk(t.detach().reshape(1).contiguous(), f32, 'loss') for t in (a, b, c)]
+        _lib.call('mmvid_lincomb3', ops._p(sc[0]), ops._p(sc[1]), ops._p(sc[2]), *ctx.w, ops._p(out), ops._stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        gs = torch.empty(3, device=g.device, dtype=f32)
+        g = g.to(f32).reshape(1).contiguous()
+        _lib.call('mmvid_scale3', ops._p(g), *ctx.w, ops._p(gs[0:1]), ops._p(gs[1:2]), ops._p(gs[2:3]), ops._stream())
+        return None, None, None, gs[0].reshape(()), gs[1].reshape(()), gs[2].reshape(())
+
+
+def weighted_loss(losses, weights):
+    """sum_i weights[i] * losses[i] for the three BERT losses (train.py:320), fused."""
+    lm, lr, lv = losses
+    return WeightedLoss.apply(weights[0], weights[1], weights[2], lm, lr, lv)
+
+
 class LNLinear(torch.autograd.Function):
     """nn.Sequential(nn.LayerNorm(E), nn.Linear(E, N)) of dalle_bert.py:414-417 / dalle_artv.py:210-213 on rows
     x [R, E] fp32 -> logits [R, N] fp32 (bf16 MFMA GEMM, fp32 accumulate)."""

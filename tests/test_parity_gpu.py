@@ -2,6 +2,7 @@
 sampler trajectories (SURVEY 8c vi), the device front-end's distributions, the fused heads, and the boundary closures
 (decode_train, optimiser state, shadows)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -321,6 +322,42 @@ def test_gemv_rows_kernel_vs_torch():
         if res:
             ref = ref + r
         close(y, ref, 2e-5, f'gemv NB={NB} K={K} N={N}')
+
+
+def test_positional_table_and_weighted_loss_kernels(golden):
+    """functional.PosTable (one launch each way) against the torch construction it replaces -- cat of special / text /
+    per-visual axial (+ zero [SEP] rows) / target axial tables -- values bit-equal (same summation order), parameter
+    gradients equal up to fp32 summation order; functional.weighted_loss against the arithmetic of train.py:320."""
+    from mmvid_amd.functional import weighted_loss
+    for nv, sep in ((0, False), (1, False), (2, True)):
+        torch.manual_seed(nv)
+        m = tiny_bert(nv, nv > 0, insert_sep=sep).to(DEV) if sep else tiny_bert(nv, nv > 0).to(DEV)
+        names = [n for n, _ in m.named_parameters() if 'pos_emb' in n]
+        assert names
+        table = m._pos_table()
+        sp = m.special_pos_emb.weight
+        parts = [sp[0:1], m.text_pos_emb.weight[:m.text_seq_len]]
+        if m.num_visuals > 0:
+            parts.append(m.visual_pos_emb.table(insert_sep=bool(m.insert_sep)))
+        parts += [sp[1:3], m.target_pos_emb.table()]
+        ref = torch.cat(parts, 0)
+        assert table.shape == ref.shape == (m.total_seq_len, 768) and torch.equal(table, ref)
+        g = torch.randn_like(ref)
+        want = torch.autograd.grad(ref, [p for n, p in m.named_parameters() if n in names], g, allow_unused=True)
+        for p in m.parameters():
+            p.grad = None
+        table.backward(g)
+        for n, w in zip(names, want):
+            got = dict(m.named_parameters())[n].grad
+            if w is None:
+                assert got is None or float(got.abs().max()) == 0.0, n
+            else:
+                close(got, w, 1e-6, f'pos-table gradient of {n} (visuals {nv}, sep {sep})')
+    a, b, c = [torch.tensor(v, device=DEV, requires_grad=True) for v in (1.25, -0.5, 3.0)]
+    tot = weighted_loss((a, b, c), (7.0, 0.5, 0.25))
+    assert float(tot) == 7.0 * 1.25 + 0.5 * -0.5 + 0.25 * 3.0
+    (tot * 2.0).backward()
+    assert (float(a.grad), float(b.grad), float(c.grad)) == (14.0, 1.0, 0.5)
 
 
 # ------------------------------------------------------------------------------------------- heads, ids
