@@ -736,6 +736,53 @@ def test_graphed_step_with_captured_gradient_exchange(golden):
         dist.destroy_process_group()
 
 
+def test_graphed_step_falls_back_to_eager_when_capture_fails(golden):
+    """If the step cannot be captured (here: a host read inside it; on a multi-GPU node it could be a collective the runtime
+    refuses to capture) GraphedStep reports why and keeps training with eager launches: same losses as a plain eager loop."""
+    import copy
+
+    from mmvid_amd.engine import FlatTrainer, GraphedStep, backward_order
+    g = golden('bert_tiny')
+    base = load_synth(tiny_bert(), g, 17).train()
+    text, frames = g['text'].to(DEV), g['frames'].to(DEV)
+    mask1, warped = g['mask1'].to(DEV), g['warped_frames'].to(DEV)
+    nfm = torch.ones(text.shape[0], device=DEV)
+
+    def run(host_read, graphed):
+        m = copy.deepcopy(base)
+        tr = FlatTrainer(m, lr=1e-3, order=backward_order)
+
+        def fn(text, frames):
+            lm, lr, lv = m(text, target=frames, return_loss=True, rel=True, vid=True, _mask1=mask1, _target_warp=warped,
+                           _not_fully_masked=nfm)
+            if host_read:
+                float(lm)  # a device->host synchronisation: illegal during stream capture
+            return 7.0 * lm + 0.5 * lr + 0.5 * lv
+
+        if not graphed:
+            out = []
+            for _ in range(4):
+                tr.zero_grad()
+                loss = fn(text, frames)
+                loss.backward()
+                tr.step()
+                out.append(loss.item())
+            return None, out
+        step = GraphedStep(tr, fn, dict(text=text, frames=frames), warmup=1)
+        return step, [step().item() for _ in range(3)]
+
+    step, got = run(True, True)
+    assert step.graph is None and step.capture_error, 'a step with a host read must not have been captured'
+    print('capture refused as expected:', step.capture_error)
+    _, want = run(False, False)
+    for a, b in zip(got, want[1:]):  # the graphed run spent its first step on warm-up
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (got, want)
+    step2, again = run(False, True)  # and capturing still works afterwards in the same process
+    assert step2.graph is not None
+    for a, b in zip(again, want[1:]):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (again, want)
+
+
 def test_artv_flat_trainer_keeps_head_shadow_current(golden):
     """Advisor finding: DALLE's 51,584-way head must train against a bf16 weight that follows the fused optimiser."""
     from mmvid_amd.dalle_artv import DALLE
