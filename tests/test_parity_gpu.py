@@ -55,6 +55,36 @@ def test_strict_tokens_of_bert_goldens(golden, name, nv, cvae):
         assert torch.equal(m.get_image_tokens(g['visual'].to(DEV), which_vae='cvae').cpu(), g['visual_tok'])
 
 
+def test_token_helpers_recon_codebook_emb_masks(golden):
+    """BERT.recon_images / get_codebook_emb / decode_images / decode_masks (dalle_bert.py:503-512, 754-778) on the HIP path,
+    against the CPU oracle's VQGAN (strict mode: the same tokens, pixels within the fp32 tolerance) and plain indexing."""
+    from oracle import vqgan
+    g = golden('bert_tiny_visual')
+    m = load_synth(tiny_bert(1, True), g, 17).eval()
+    sd = synth_model_sd(g, 17)
+    frames = g['frames'].to(DEV)  # [B, T, 3, 64, 64]
+    B, T = frames.shape[:2]
+    for which, prefix in (('vae', 'vae.model.'), ('cvae', 'cvae.model.')):
+        vae = m.vae if which == 'vae' else m.cvae
+        vae.strict = True
+        idx_o = vqgan.get_codebook_indices(sd, g['frames'].reshape(-1, 3, 64, 64), 64, prefix)
+        rec_o = vqgan.decode(sd, idx_o, 64, prefix)
+        rec = m.recon_images(frames, which_vae=which)
+        assert rec.shape == (B * T, 3, 64, 64)
+        close(rec, rec_o, 2e-5, f'recon_images ({which}) vs oracle encode -> decode')
+        code, emb = m.get_codebook_emb(frames, which_vae=which)
+        assert code.shape == (B, T, 16) and torch.equal(code.cpu().view(B * T, -1), idx_o)
+        assert torch.equal(emb, m.image_emb.weight.detach()[code])
+        vae.strict = False
+    tok = m.get_image_tokens(frames)
+    close(m.decode_images(tok), m.vae.decode(tok.view(B * T, -1)), 0.0, 'decode_images == vae.decode of the reshaped tokens')
+    mask = (torch.rand(B, T * 16, device=DEV) < 0.4).float()
+    red = m.decode_masks(mask)
+    assert red.shape == (B * T, 3, 64, 64) and float(red[:, 1:].abs().max()) == 0.0
+    up = mask.view(B * T, 1, 4, 4).repeat_interleave(16, 2).repeat_interleave(16, 3)
+    assert torch.equal(red[:, :1], up)
+
+
 def test_strict_tokens_of_artv_golden(golden):
     g = golden('artv_tiny')
     vae = tiny_vae()
