@@ -160,6 +160,12 @@ class DALLE(nn.Module):
                 image = image.view(b, -1)
         return image
 
+    @torch.no_grad()
+    def recon_images(self, images, which_vae='vae'):
+        """dalle_artv.py:344-354: frames -> tokens -> frames through the (control) VQGAN."""
+        vae = self.cvae if (which_vae == 'cvae' and self.cvae is not None) else self.vae
+        return vae.decode(self.get_image_tokens(images, reshape=False, which_vae=which_vae))
+
     def random_erase_codebook(self, image, eraser, erase_half=False):
         f = self.image_fmap_size
         image = image.contiguous()

@@ -255,6 +255,19 @@ class BERT(nn.Module):
         img_code = img_seq.view(b, t, -1)
         return img_code, ops.gather_rows(self.image_emb.weight.detach(), img_code.contiguous())
 
+    def swap_one_frame_along_batch(self, tokens, t=1):
+        """dalle_bert.py:854-866 (a helper no forward path calls): in every sample one randomly chosen frame of the [b, n, c]
+        token embeddings is replaced by the frame picked in the sample half a batch away.  The frame index is drawn on
+        the device (the reference uses numpy's global generator)."""
+        b, n, c = tokens.shape
+        out = tokens.detach().clone().reshape(b, t, n // t, c)
+        rows = torch.arange(b, device=tokens.device)
+        idx = torch.randint(0, t, (b, ), device=tokens.device)
+        picked = out[rows, idx]
+        h = (b + 1) // 2  # torch.chunk(x, 2)[::-1]: the second (shorter) half first
+        out[rows, idx] = torch.cat((picked[h:], picked[:h]), 0)
+        return out.reshape(b, n, c)
+
     def decode_images(self, img_seq):
         return self.vae.decode(img_seq.reshape(-1, self.image_seq_len))
 

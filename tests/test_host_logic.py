@@ -222,6 +222,35 @@ def test_divide_max_stable_option():
     assert tiny_bert(0, False).stable is False and not hasattr(tiny_bert(0, False), 'norm_by_max')
 
 
+def test_api_surface_matches_reference_classes():
+    """Every public method of the reference's BERT / DALLE / VQGanVAE1024 exists here (names captured from the reference in
+    the build container), and the one helper no forward path uses behaves as dalle_bert.py:854-866."""
+    from mmvid_amd.dalle_artv import DALLE
+    from mmvid_amd.dalle_bert import BERT
+    from mmvid_amd.vae import VQGanVAE1024
+    ref = {BERT: ['decode_images', 'decode_masks', 'erase_codebook_face', 'forward', 'generate_images', 'get_codebook_emb',
+                  'get_image_tokens', 'get_special_token', 'mask_predict', 'random_erase_codebook', 'recon_images',
+                  'swap_one_frame_along_batch', 'transformer_forward'],
+           DALLE: ['erase_codebook_face', 'forward', 'generate_images', 'get_image_tokens', 'random_erase_codebook', 'recon_images'],
+           VQGanVAE1024: ['decode', 'decode_train', 'forward', 'get_codebook_indices']}
+    for cls, names in ref.items():
+        missing = [n for n in names if not callable(getattr(cls, n, None))]
+        assert not missing, (cls.__name__, missing)
+    m = tiny_bert(0, False)
+    for b in (4, 5):
+        x = torch.arange(b * 6 * 2.).view(b, 6, 2)
+        torch.manual_seed(b)
+        y = m.swap_one_frame_along_batch(x, t=3).view(b, 3, 2, 2)
+        torch.manual_seed(b)
+        idx = torch.randint(0, 3, (b, ))  # the helper's only draw
+        xv = x.view(b, 3, 2, 2)
+        partner = torch.cat(torch.chunk(torch.arange(b), 2, dim=0)[::-1], dim=0)  # the reference's half swap of the batch
+        for i in range(b):
+            for t in range(3):  # slot idx[i] receives the partner's picked frame, every other slot is untouched
+                want = xv[partner[i], idx[partner[i]]] if t == idx[i] else xv[i, t]
+                assert torch.equal(y[i, t], want), (b, i, t)
+
+
 def test_half_keeps_fp32_master_weights():
     """train.py:194-195 calls `.half()` under --fp16.  Compute here is always bf16 MFMA over fp32 master weights; `.half()`
     must not strand the kernels with fp16 parameters: it warns and leaves the module as it is."""
