@@ -96,3 +96,11 @@ def test_save_image_tensor_gif_and_png(tmp_path):
     assert torch.equal(px, (img * 255).to(torch.uint8))  # truncation, as `(x * 255).type(torch.uint8)` in the reference
     with pytest.raises(NotImplementedError):
         save_image_tensor(video, tmp_path / 'x', video_format='mp4')
+
+
+def test_reference_import_paths():
+    """utils_train.py:25,187 import these names from `mmvid_pytorch.loader` / `.tokenizer`: the same module paths exist here."""
+    from mmvid_amd import data
+    from mmvid_amd.loader import TextVideoDataset
+    from mmvid_amd.tokenizer import SimpleTokenizer
+    assert TextVideoDataset is data.TextVideoDataset and SimpleTokenizer is data.SimpleTokenizer
