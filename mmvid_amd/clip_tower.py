@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from . import _lib, ops
+from .functional import _note_params, _with_param_zeros
 
 TOWER_SHAPES = {  # which_model -> (width, layers, heads), clip_model.py:538-541 with ViT-B/32
     'openai_clip_visual': (768, 12, 12),
@@ -63,6 +64,7 @@ class _TowerParams(_Holder):
 class _TowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, tower, keep, *params):
+        _note_params(ctx, (x, tower, keep) + params)  # under DistributedDataParallel: see functional._with_param_zeros
         ctx.tower = tower
         y, saved = tower._run_forward(x, keep=keep)  # NB: grad mode is always off inside Function.forward
         ctx.saved_arena = saved
@@ -74,7 +76,7 @@ class _TowerFn(torch.autograd.Function):
         g = gy.contiguous().clone()  # updated in place into dL/dx
         ctx.tower._run_backward(g, ctx.saved_arena, ctx.shape)
         ctx.saved_arena = None
-        return (g.view(ctx.shape), None, None) + (None, ) * (len(ctx.needs_input_grad) - 3)
+        return _with_param_zeros(ctx, (g.view(ctx.shape), None, None) + (None, ) * (len(ctx.needs_input_grad) - 3))
 
 
 class DecodeSession:

@@ -13,6 +13,42 @@ def _grad_buf(p):
     return p.grad
 
 
+# ---- torch.nn.parallel.DistributedDataParallel compatibility (train.py:28-35 wraps the model in DDP) -----------------------
+# The kernels add parameter gradients straight into `p.grad`, so autograd sees no gradient for a parameter and DDP's reducer --
+# which hooks every parameter's gradient accumulation -- would wait for hooks that never fire.  When a Function's forward runs
+# inside a DDP-wrapped module's forward, its backward therefore returns a (stride-0, scalar-backed) ZERO gradient for every
+# trainable parameter input: autograd's accumulation `p.grad += 0` then runs after the kernels have written the real gradient,
+# the hook fires, and DDP all-reduces `p.grad` as usual.  Cost: one extra elementwise pass per parameter per step; the flat
+# engine (engine.FlatTrainer) avoids both DDP and this.
+_ZERO = {}
+
+
+def _inside_ddp():
+    ddp = getattr(torch.nn.parallel, 'DistributedDataParallel', None)
+    return ddp is not None and getattr(ddp, '_active_ddp_module', None) is not None
+
+
+def _note_params(ctx, args):
+    """Call in forward: remembers which inputs are trainable parameters when the model runs under DDP."""
+    ctx._ddp_params = [a if (isinstance(a, torch.nn.Parameter) and a.requires_grad) else None for a in args] if _inside_ddp() else None
+
+
+def _with_param_zeros(ctx, grads):
+    """Call on backward's return tuple: under DDP, None -> zeros for the parameter inputs noted in forward."""
+    ps = getattr(ctx, '_ddp_params', None)
+    if ps is None:
+        return grads
+    out = list(grads)
+    for i, p in enumerate(ps):
+        if p is not None and i < len(out) and out[i] is None:
+            _grad_buf(p)  # exists (zeros) even if no kernel of this backward wrote it: the accumulation below stays in place
+            key = (p.device, p.dtype)
+            if key not in _ZERO:
+                _ZERO[key] = torch.zeros((), device=p.device, dtype=p.dtype)
+            out[i] = _ZERO[key].expand(p.shape)
+    return tuple(out)
+
+
 class AssembleSequence(torch.autograd.Function):
     """x[b,l,:] = tables[seg[l]][ids[b,l]] + pos[l]   (dalle_bert.py:899-973, 1030-1035; dalle_artv.py:441-491).
     `pos` is a dense [L, E] tensor built from the (tiny) positional parameters with ordinary torch ops, so its
@@ -20,6 +56,7 @@ class AssembleSequence(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, ids, seg, *tables):
+        _note_params(ctx, (pos, ids, seg) + tables)
         ctx.tables = tables
         ctx.save_for_backward(ids, seg)
         return ops.assemble_sequence([t.detach() for t in tables], ids, seg, pos.detach().contiguous())
@@ -31,7 +68,7 @@ class AssembleSequence(torch.autograd.Function):
         gts = [_grad_buf(t) if t.requires_grad else None for t in ctx.tables]
         dpos = torch.empty(dx.shape[1:], device=dx.device, dtype=f32) if ctx.needs_input_grad[0] else None
         ops.assemble_sequence_bwd(gts, [t.shape[0] for t in ctx.tables], ids, seg, dx, dpos)
-        return (dpos, None, None) + (None, ) * len(ctx.tables)
+        return _with_param_zeros(ctx, (dpos, None, None) + (None, ) * len(ctx.tables))
 
 
 class PosTable(torch.autograd.Function):
@@ -42,6 +79,7 @@ class PosTable(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layout, L, *params):
         from . import _lib
+        _note_params(ctx, (layout, L) + params)
         E = params[0].shape[-1]
         ctx.layout, ctx.L, ctx.E = layout, L, E
         out = torch.empty(L, E, device=params[0].device, dtype=f32)
@@ -69,7 +107,7 @@ class PosTable(torch.autograd.Function):
         g = ops._chk(g.contiguous(), f32, 'dpos')
         segs = PosTable._segments(ctx.layout, grads=True)
         _lib.call('mmvid_pos_table_bwd', segs, len(ctx.layout), ctx.E, ops._p(g), ops._stream())
-        return (None, None) + (None, ) * (len(ctx.needs_input_grad) - 2)
+        return _with_param_zeros(ctx, (None, None) + (None, ) * (len(ctx.needs_input_grad) - 2))
 
 
 class WeightedLoss(torch.autograd.Function):
@@ -105,6 +143,7 @@ class LNLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, w, b, w_bf16):
+        _note_params(ctx, (x, ln_w, ln_b, w, b, w_bf16))
         x = x.contiguous()
         h, mean, rstd = ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), 1e-5)
         y = ops.gemm(h, w_bf16, bias=b.detach(), out_dtype=f32)
@@ -117,7 +156,7 @@ class LNLinear(torch.autograd.Function):
         x, mean, rstd, h = ctx.saved_tensors
         ln_w, ln_b, w, b, w_bf16 = ctx.params
         d16 = dy if dy.dtype == bf16 else ops.cast_bf16(dy.contiguous())
-        return LNLinear._backward_bf16(d16, x, mean, rstd, h, ln_w, ln_b, w, b, w_bf16)
+        return _with_param_zeros(ctx, LNLinear._backward_bf16(d16, x, mean, rstd, h, ln_w, ln_b, w, b, w_bf16))
 
     @staticmethod
     def _backward_bf16(d16, x, mean, rstd, h, ln_w, ln_b, w, b, w_bf16, cols=None):
@@ -143,6 +182,7 @@ class LNLinearCrossEntropy(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, target, select, ln_w, ln_b, w, b, w_bf16, cols=None):
+        _note_params(ctx, (x, target, select, ln_w, ln_b, w, b, w_bf16, cols))
         x = x.contiguous()
         h, mean, rstd = ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), 1e-5)
         ctx.cols = cols
@@ -163,7 +203,7 @@ class LNLinearCrossEntropy(torch.autograd.Function):
         gs = (gloss.to(f32) / cnt).reshape(1).contiguous()
         d16 = ops.cross_entropy_bwd(logits, target, sel8, lse, gs)
         dx = LNLinear._backward_bf16(d16, x, mean, rstd, h, *ctx.params, cols=ctx.cols)[0]
-        return (dx, ) + (None, ) * 8
+        return _with_param_zeros(ctx, (dx, ) + (None, ) * 8)
 
 
 class BertHeads(torch.autograd.Function):
@@ -179,6 +219,8 @@ class BertHeads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, target_full, select_full, count, nfm, labels, rel_rows, vid_rows, weight_by_nfm, B, w_bf16, ln_w,
                 ln_b, w, b, rel_ln_w, rel_ln_b, rel_w, rel_b, vid_ln_w, vid_ln_b, vid_w, vid_b):
+        _note_params(ctx, (y, target_full, select_full, count, nfm, labels, rel_rows, vid_rows, weight_by_nfm, B, w_bf16, ln_w,
+                           ln_b, w, b, rel_ln_w, rel_ln_b, rel_w, rel_b, vid_ln_w, vid_ln_b, vid_w, vid_b))
         nB, L, E = y.shape
         y2d = y.contiguous().view(nB * L, E)
         rows = B * L
@@ -240,4 +282,4 @@ class BertHeads(torch.autograd.Function):
                               float(ctx.B), g.to(f32).reshape(1).contiguous(), gy,
                               _grad_buf(hw).view(-1) if hw.requires_grad else None, _grad_buf(hb) if hb.requires_grad else None,
                               _grad_buf(lw) if lw.requires_grad else None, _grad_buf(lb) if lb.requires_grad else None)
-        return (gy.view(nB, L, E), ) + (None, ) * 22
+        return _with_param_zeros(ctx, (gy.view(nB, L, E), ) + (None, ) * 22)

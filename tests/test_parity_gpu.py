@@ -813,6 +813,53 @@ def test_graphed_step_falls_back_to_eager_when_capture_fails(golden):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (again, want)
 
 
+def test_unchanged_train_loop_under_torch_ddp(golden):
+    """train.py:28-35 wraps the model in DistributedDataParallel(find_unused_parameters=True) and steps a torch optimiser.
+    The kernels write parameter gradients straight into p.grad, so under DDP every Function also hands autograd a zero
+    gradient per parameter: the reducer's hooks fire and the step completes.  Same parameters as the unwrapped model."""
+    import copy
+    import socket
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    g = golden('bert_tiny')
+    base = load_synth(tiny_bert(), g, 17).train()
+    text, frames = g['text'].to(DEV), g['frames'].to(DEV)
+    mask1, warped = g['mask1'].to(DEV), g['warped_frames'].to(DEV)
+    nfm = torch.ones(text.shape[0], device=DEV)
+
+    def run(wrap):
+        m = copy.deepcopy(base)
+        model = DDP(m, device_ids=[0], find_unused_parameters=True) if wrap else m
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        losses = []
+        for _ in range(3):
+            lm, lr, lv = model(text, target=frames, return_loss=True, rel=True, vid=True, _mask1=mask1, _target_warp=warped,
+                               _not_fully_masked=nfm)
+            loss = 7.0 * lm + 0.5 * lr + 0.5 * lv
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+            opt.step()
+            losses.append(loss.item())
+        return losses, torch.cat([p.detach().flatten()[::97] for p in m.parameters() if p.requires_grad])
+
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        lw, pw = run(True)
+    finally:
+        dist.destroy_process_group()
+    lp, pp = run(False)
+    print('DDP-wrapped losses', lw, 'plain', lp)
+    for a, b in zip(lw, lp):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b))
+    close(pw, pp, 5e-3, 'sampled parameters after 3 Adam steps: DDP-wrapped vs plain')
+
+
 def test_artv_flat_trainer_keeps_head_shadow_current(golden):
     """Advisor finding: DALLE's 51,584-way head must train against a bf16 weight that follows the fused optimiser."""
     from mmvid_amd.dalle_artv import DALLE
