@@ -225,9 +225,13 @@ def comm_report(trainer, step_ms, world):
             torch.cuda.current_stream().wait_stream(trainer._comm_stream)
         fence()
         ar_ms = (time.perf_counter() - t0) / reps * 1e3
-        wire = 2.0 * max(world - 1, 1) / world * 4.0 * trainer.numel  # bytes per GPU on the links, ring-equivalent (world 1: loop-back)
+        dense = trainer.numel - sum(b - a for a, b in trainer._sparse_ranges())  # elements that go through the all-reduce
+        wire = 2.0 * max(world - 1, 1) / world * 4.0 * dense  # bytes per GPU on the links, ring-equivalent (world 1: loop-back)
         return {'allreduce_alone_ms': ar_ms, 'bytes_per_gpu_on_wire': wire, 'bus_bandwidth_GBps': wire / (ar_ms * 1e-3) / 1e9,
-                'gradient_bytes': 4.0 * trainer.numel, 'note': 'overlap = 1 - (step - step_without_exchange) / allreduce_alone'}
+                'gradient_bytes': 4.0 * trainer.numel, 'dense_allreduce_bytes': 4.0 * dense,
+                'row_wise_tables': [n for n in getattr(trainer.model, 'sparse_grad_rows', dict)()],
+                'note': 'overlap = 1 - (step - step_without_exchange) / allreduce_alone; the tables listed under row_wise_tables '
+                        'are exchanged as (row id, row) pairs of the rows the batch touched, not all-reduced'}
     except Exception as e:  # never lose the headline line to a diagnostics failure
         return {'error': repr(e)}
 

@@ -132,6 +132,7 @@ class BERT(nn.Module):
         self._w16_cache = {}
         self._row_cache = {}
         self._debug_keep = None
+        self._text_id_log = []
         # segment table: which embedding table each position reads (0 special, 1 text, 2 visual, 3 image)
         seg = [0] + [1] * self.text_seq_len + [2] * self.visual_seq_len + [0, 0] + [3] * self.target_seq_len
         self.register_buffer('_seg', torch.tensor(seg, dtype=torch.int32), persistent=False)
@@ -175,6 +176,16 @@ class BERT(nn.Module):
     def _tables(self):
         vis = self.visual_emb.weight if (self.num_visuals > 0 and self.visual_emb is not None) else self.image_emb.weight
         return (self.special_emb.weight, self.text_emb.weight, vis, self.image_emb.weight)
+
+    def sparse_grad_rows(self):
+        """Tables whose gradient has few non-zero rows per step, with the row ids of the last forward (engine.FlatTrainer
+        exchanges them row-wise instead of all-reducing 152 MB of mostly zeros)."""
+        log = self._text_id_log
+        return {'text_emb.weight': (log[0] if len(log) == 1 else torch.cat(log)) if log else None}
+
+    def reset_sparse_grad_rows(self):
+        """Called by FlatTrainer.zero_grad(): the gradients start from zero, so does the list of touched rows."""
+        self._text_id_log = []
 
     def _pos_layout(self):
         """Segments of the positional table for functional.PosTable: (dst0, rows, src0, params, axial dims)."""
@@ -395,6 +406,10 @@ class BERT(nn.Module):
             text_neg_ids = ops._chk(text_neg.contiguous(), torch.int64, 'text_neg')
         ids, sel, tfull, cnt = ops.bert_build_ids(text, vis_tok, self.visual_seq_len, target, target_warp, mask1, pad_base, MASK,
                                                   bool(rel), bool(do_vid), text_neg=text_neg_ids)
+        # every text-segment id of the step's sequences: the only rows of text_emb a backward can touch (sparse_grad_rows);
+        # logged per forward since the last zero_grad, so gradient accumulation over several forwards stays covered
+        if torch.is_grad_enabled():
+            self._text_id_log = (self._text_id_log + [ids[:, 1:1 + self.text_seq_len].reshape(-1)])[-16:]
         x_seq = self._assemble(ids, self.total_seq_len)
         y = self.transformer_forward(x_seq)  # [nseq*B, L, dim]
         if self._debug_keep is not None:  # tools/stress_nan2.py: the stage tensors of the last (replayed) forward

@@ -11,6 +11,8 @@
 
 One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -47,8 +49,10 @@ class WarmupLR:
 
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 process_group=None, bucket_mb=64, order=None, lr_schedule=None, force_exchange=False):
+                 process_group=None, bucket_mb=64, order=None, lr_schedule=None, force_exchange=False, sparse_tables=True):
         self.model = model
+        # row-wise exchange of the tables model.sparse_grad_rows() names (MMVID_SPARSE_TABLES=0 forces the dense all-reduce)
+        self.sparse_tables = bool(sparse_tables) and os.environ.get('MMVID_SPARSE_TABLES', '1') != '0'
         self.lr_schedule = lr_schedule
         # force_exchange: run the all-reduce path even in a group of one (exercises RCCL + graph capture on a 1-GPU box)
         self.force_exchange = bool(force_exchange) and dist.is_available() and dist.is_initialized()
@@ -176,20 +180,80 @@ class FlatTrainer:
     # ---------------------------------------------------------------------------------------------
     def zero_grad(self):
         self.G.zero_()
+        reset = getattr(self.model, 'reset_sparse_grad_rows', None)
+        if reset is not None:
+            reset()
+
+    def _sparse_ranges(self):
+        """Flat ranges of the tables whose gradient is exchanged row-wise (see _exchange_sparse): excluded from the all-reduce."""
+        fn = getattr(self.model, 'sparse_grad_rows', None)
+        if not self.sparse_tables or fn is None:
+            return []
+        out = []
+        for name in fn():
+            if name in self.names:
+                i = self.names.index(name)
+                out.append((self.offsets[i], self.offsets[i] + _round_up(self.params[i].numel(), ALIGN)))
+        return sorted(out)
 
     def _send(self, lo, hi):
         """All-reduce G[lo:hi] (SUM) on the side stream, in messages of at most bucket_elems."""
         if (self.world == 1 and not self.force_exchange) or hi <= lo or not self.exchange_enabled:
             return
+        pieces, at = [], lo
+        for a, b in self._sparse_ranges():  # cut the row-wise exchanged tables out of [lo, hi)
+            if b <= at or a >= hi:
+                continue
+            if a > at:
+                pieces.append((at, a))
+            at = max(at, b)
+        if at < hi:
+            pieces.append((at, hi))
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
-        for s in range(lo, hi, self.bucket_elems):
-            e = min(s + self.bucket_elems, hi)
-            if self._comm_stream is not None:
-                with torch.cuda.stream(self._comm_stream):
+        for plo, phi in pieces:
+            for s in range(plo, phi, self.bucket_elems):
+                e = min(s + self.bucket_elems, phi)
+                if self._comm_stream is not None:
+                    with torch.cuda.stream(self._comm_stream):
+                        self._works.append(dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                else:
                     self._works.append(dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-            else:
-                self._works.append(dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _gather(self, t):
+        """[n, ...] on every rank -> [world * n, ...] (rank-major)."""
+        out = torch.empty((self.world * t.shape[0], ) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        if dist.get_backend(self.pg) == 'nccl':
+            dist.all_gather_into_tensor(out, t, group=self.pg)
+        else:
+            dist.all_gather(list(out.chunk(self.world, 0)), t, group=self.pg)
+        return out
+
+    def _exchange_sparse(self):
+        """Row-wise gradient exchange of the tables `model.sparse_grad_rows()` names (BERT: the 49,472 x 768 text embedding,
+        152 MB dense, of which a step touches at most B * 64 rows).  The table is the LAST gradient of the backward, so its
+        dense all-reduce cannot overlap anything: instead every rank gathers (row id, gradient row) of the rows ITS batch
+        touched -- ids sorted, repeats blanked, fixed shapes, so the step stays capturable -- and adds the other ranks' rows
+        to its own table gradient: the same sum, ~1 MB per rank on the wire instead of 152 MB."""
+        fn = getattr(self.model, 'sparse_grad_rows', None)
+        if not self.sparse_tables or fn is None or not self.exchange_enabled:
+            return
+        rank = dist.get_rank(self.pg)
+        for name, ids in fn().items():
+            if name not in self.names or ids is None:
+                continue
+            W = self.params[self.names.index(name)].grad  # [V, E] view into G
+            srt, _ = torch.sort(ids.reshape(-1))
+            first = torch.ones_like(srt, dtype=torch.bool)
+            first[1:] = srt[1:] != srt[:-1]
+            uid = torch.where(first, srt, torch.full_like(srt, -1))
+            rows = W.index_select(0, srt) * first.unsqueeze(1).to(W.dtype)
+            n = srt.shape[0]
+            all_ids, all_rows = self._gather(uid), self._gather(rows)
+            own = torch.zeros(self.world * n, dtype=torch.bool, device=ids.device)
+            own[rank * n:(rank + 1) * n] = True
+            valid = (all_ids >= 0) & ~own
+            W.index_add_(0, all_ids.clamp_min(0), all_rows * valid.unsqueeze(1).to(W.dtype))
 
     def layers_done(self, first_layer):
         """Tower backward callback: gradients of layers >= first_layer (and everything after them in the flat
@@ -204,6 +268,11 @@ class FlatTrainer:
         """Send whatever is still local (embedding tables, or everything when no callback fired) and wait."""
         if self.world > 1 or self.force_exchange:
             self._send(0, self._sent_from)
+            if self._comm_stream is not None:
+                with torch.cuda.stream(self._comm_stream):  # after the dense messages, on the same stream
+                    self._exchange_sparse()
+            else:
+                self._exchange_sparse()
             for w in self._works:
                 w.wait()
             self._works = []

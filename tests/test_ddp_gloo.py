@@ -113,7 +113,7 @@ def _worker_real(rank, world, port, q):
         m = tiny_bert(1, True)
         m.transformer.backward_chunk_layers = 1
         broadcast_parameters(m)
-        tr = FlatTrainer(m, order=backward_order, bucket_mb=1)
+        tr = FlatTrainer(m, order=backward_order, bucket_mb=1, sparse_tables=False)  # the dense path; row-wise exchange: below
         assert m.transformer.on_layers_done == tr.layers_done
         n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
         assert sum(p.numel() for p in tr.params) == n_train and not any(n.startswith(('vae.', 'cvae.')) for n in tr.names)
@@ -150,6 +150,71 @@ def _worker_real(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
     finally:
         dist.destroy_process_group()
+
+
+class _ToySparse(_Toy):
+    """_Toy whose text embedding reports the rows a step touched (as BERT.sparse_grad_rows does)."""
+
+    def sparse_grad_rows(self):
+        return {'text_emb.weight': self.ids}
+
+    def reset_sparse_grad_rows(self):
+        pass
+
+
+def _worker_sparse(rank, world, port, q):
+    """Row-wise exchange of a table gradient: equals the dense all-reduce sum, with ids repeated inside a rank, shared between
+    ranks and disjoint; every other parameter still goes through the dense path around the excluded range."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from mmvid_amd.engine import FlatTrainer, backward_order, broadcast_parameters
+        torch.manual_seed(5 + rank)
+        m = _ToySparse()
+        m.ids = None  # nothing touched yet (BERT before its first forward)
+        for p in m.parameters():
+            p.data.normal_()
+        broadcast_parameters(m)
+        tr = FlatTrainer(m, order=backward_order, bucket_mb=0.001)
+        assert tr.sparse_tables and tr._sparse_ranges() == [(0, 512)]  # text_emb [50, 8] = 400 elements, padded to 4 x 128
+        for step in range(2):
+            tr.zero_grad()
+            m.ids = torch.tensor([[3, 7, 7, 49], [3, 0, 11 + rank, 20 + 5 * step]])  # 3 shared, 7 repeated, 11 + rank disjoint
+            for i, p in enumerate(tr.params):
+                p.grad.fill_(float((rank + 1) * (i + 1)))
+            g = m.text_emb.weight.grad
+            g.zero_()
+            for r in m.ids.unique().tolist():  # what a scatter-add of this rank's batch leaves: only its rows are non-zero
+                g[r] = torch.arange(8.) + 10 * r + 100 * rank + step
+            mine = g.clone()
+            tr.layers_done(0)
+            tr.allreduce_grads()
+            dense = mine.clone()
+            dist.all_reduce(dense)  # the reference result: a dense all-reduce of the same table gradient
+            assert torch.equal(m.text_emb.weight.grad, dense), (rank, step)
+            for i, (n, p) in enumerate(zip(tr.names, tr.params)):
+                if n != 'text_emb.weight':
+                    assert torch.all(p.grad == sum((r + 1) * (i + 1) for r in range(world))), n
+        q.put((rank, 'ok'))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_trainer_sparse_table_exchange_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sparse, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == 'ok' for r in res), res
 
 
 @pytest.mark.timeout(300)
