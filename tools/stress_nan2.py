@@ -13,14 +13,16 @@ from mmvid_amd.engine import FlatTrainer, WarmupLR, backward_order  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 42
 mode = sys.argv[3] if len(sys.argv) > 3 else 'graph'
+cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 2  # BASELINE config: 2 (text) or 4 (text + visual control)
 dev = torch.device('cuda', 0)
 torch.manual_seed(seed)
-model = bench.build_model(2, dev, 12)
+model = bench.build_model(cfg, dev, 12)
 model.frontend.seed = seed
 model.train()
 tr = FlatTrainer(model, lr=1e-4, max_grad_norm=1.0, order=backward_order, lr_schedule=WarmupLR(1e-6, 1e-4, 5000, every=1))
 gen = torch.Generator().manual_seed(seed)
-batch = bench.synth_batch(6, 8, dev, gen)
+batch = bench.synth_batch(6 if cfg == 2 else 2, 8, dev, gen, visuals=1 if cfg == 4 else 0)
+vkw = dict(visual=batch['visual']) if cfg == 4 else {}
 parts = torch.zeros(3, device=dev)
 model._debug_keep = {}
 model.transformer.debug_keep_saved = True
@@ -29,7 +31,7 @@ model.transformer.debug_keep_saved = True
 def fb():
     tr.zero_grad()
     lm, lr, lv = model(batch['text'], target=batch['frames'], return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
-                       msm_strategy_prob=bench.MSM_PROB, msm_bernoulli_prob=bench.MSM_BERN, vid_strategy_prob=bench.VID_PROB)
+                       msm_strategy_prob=bench.MSM_PROB, msm_bernoulli_prob=bench.MSM_BERN, vid_strategy_prob=bench.VID_PROB, **vkw)
     parts.copy_(torch.stack([lm.detach(), lr.detach(), lv.detach()]))
     loss = 7.0 * lm + 0.5 * lr + 0.5 * lv
     loss.backward()
@@ -75,7 +77,7 @@ for i in range(steps):
         if sv is not None:
             nl = model.transformer.layers
             per = sv.numel() // nl
-            M, E = 18 * 579, 768
+            M, E = model._debug_keep['y'].shape[0] * model._debug_keep['y'].shape[1], 768
             a256 = lambda x: (x + 255) // 256 * 256
             for li in range(nl):
                 base = li * per
