@@ -343,6 +343,48 @@ def test_attention_reproducible_in_graph_replay_under_memory_pressure(ops):
             assert torch.equal(out, ref_out) and torch.equal(lse2, ref_lse) and torch.equal(dqkv, ref_dqkv), (rep, i)
 
 
+def test_mfma_kernels_reproducible_in_graph_replay_under_memory_pressure(ops):
+    """The same hazard check as the attention test, for every other kernel that stages tiles by LDS-DMA: the three GEMM
+    layouts (dW with the deterministic split-K), the implicit-GEMM convolution (one-pass and split-K) and the strip
+    convolution, replayed back to back as a hipGraph with copy traffic in between.  None of them uses atomics on these
+    paths, so every replay must equal the first result bit for bit."""
+    M = 10422
+    X = rnd(M, 768, seed=1, dtype=torch.bfloat16)
+    W = rnd(2304, 768, seed=2, scale=0.03, dtype=torch.bfloat16)
+    dY = rnd(M, 2304, seed=3, dtype=torch.bfloat16)
+    bias = rnd(2304, seed=4)
+    x8 = rnd(54, 8, 8, 512, seed=5, dtype=torch.bfloat16)
+    w8 = rnd(512, 9, 512, seed=6, scale=0.02, dtype=torch.bfloat16)
+    x32 = rnd(8, 32, 32, 256, seed=7, dtype=torch.bfloat16)
+    w32 = rnd(256, 9, 256, seed=8, scale=0.02, dtype=torch.bfloat16)
+    b512, b256 = rnd(512, seed=9), rnd(256, seed=10)
+    big_a, big_b = torch.empty(64 << 20, device=DEV), torch.empty(64 << 20, device=DEV)
+
+    def work():
+        dW = torch.zeros(2304, 768, device=DEV)
+        return (ops.gemm(X, W, bias=bias), ops.gemm(dY, W, b_kmajor=True, out_dtype=torch.float32), ops.gemm_dw(dY, X, dW),
+                ops.conv2d_nhwc(x8, w8, b512, 0, out_dtype=torch.float32), ops.conv2d_nhwc(x8, w8, b512, 0, splitk=4),
+                ops.conv2d_nhwc(x32, w32, b256, 0), ops.conv3x3_strip(x32, w32, b256))
+
+    ref = [t.clone() for t in work()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            res = []
+            for _ in range(6):
+                big_b.copy_(big_a)
+                res.append(work())
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(25):
+        g.replay()
+        torch.cuda.synchronize()
+        for i, outs in enumerate(res):
+            for k, (a, b) in enumerate(zip(outs, ref)):
+                assert torch.equal(a, b), (rep, i, k)
+
+
 # ------------------------------------------------------------------------------------- embed / losses
 def test_out_of_range_ids_are_counted_not_silent(ops):
     """An embedding id outside its table reads row 0 and a CE target outside [0, V) counts as class 0 (a kernel must never
