@@ -15,7 +15,7 @@ Other BASELINE configs, for driver-visible numbers next to the headline:
   python bench.py --gpus N --steps K --warmup W        (N > 1 via `python -m torch.distributed.run ...`)
 
 Prints ONE JSON line on rank 0: value = whole-job video tokens / second, a `roofline` object for the dominant kernel
-(HIP-event timed inside the timed region) and, at N = 1 / config 2, a `cpu_baseline` object (the fp32 CPU oracle timed on
+(HIP events around every launch of one eagerly launched step right after the timed region) and, at N = 1 / config 2, a `cpu_baseline` object (the fp32 CPU oracle timed on
 the host cores on a bounded sample of the same workload).  The step is ONE hipGraph replay at every N: with
 torch.distributed the bucketed RCCL all-reduces are captured inside it, overlapped with the backward.
 """
@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 
 TEXT_LEN, SIZE = 64, 128
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PROF_EVERY = 10  # every 10th timed step (at least the last one) runs eagerly with per-launch HIP events; the others are graph replays
+PROF_STEPS = 1  # eagerly launched steps with per-launch HIP events, run right AFTER the timed region (kernel-family table / roofline)
 CLASS_NAMES = ['gemm_bf16_kernel<A.B^T> (forward)', 'gemm_bf16_kernel<dX>', 'gemm_bf16_kernel<dW>',
                'conv_igemm_kernel (VQGAN)', 'attn_fwd_kernel', 'attn_bwd (dq+dkv)']
 MSM_PROB, MSM_BERN, VID_PROB = [0.7, 0.1, 0.1, 0.1], [0.2, 0.2], [0.25, 0.25, 0.25, 0.25]
@@ -424,18 +424,24 @@ def main():
     lib.mmvid_prof_enable(0)
     t0 = time.perf_counter()
     host_s = 0.0  # time the host spends issuing the steps (it runs ahead of the GPU; ~= dt would mean host-bound)
-    for i in range(args.steps):
+    for i in range(args.steps):  # the timed region: exactly `steps` steps as the product runs them (one graph replay each)
         th = time.perf_counter()
-        timed = i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY and i == args.steps - 1
-        if timed or graphed is None or graphed.graph is None:  # per-launch HIP events need direct launches
-            lib.mmvid_prof_enable(1 if timed else 0)
+        if graphed is None or graphed.graph is None:
             loss = eager_step(trainer, fn, batch)
-            lib.mmvid_prof_enable(0)
         else:
             loss = graphed()
         host_s += time.perf_counter() - th
     fence()
     dt = time.perf_counter() - t0
+    # Per-kernel-family timing: HIP events around every launch need direct launches (they cannot be recorded inside a graph
+    # replay), so PROF_STEPS extra steps of the SAME step run eagerly right after the timed region.  (They used to replace
+    # every 10th timed step: an eagerly launched step is ~600 launches and 25-150 ms on a loaded host, which moved the
+    # headline by 0.6-3 ms per step depending on the box.)
+    for _ in range(PROF_STEPS):
+        lib.mmvid_prof_enable(1)
+        eager_step(trainer, fn, batch)
+        lib.mmvid_prof_enable(0)
+    fence()
     nc = len(CLASS_NAMES)
     ms, cnt, fl, tot = (ctypes.c_double * nc)(), (ctypes.c_int64 * nc)(), (ctypes.c_double * nc)(), (ctypes.c_int64 * nc)()
     lib.mmvid_prof_end(ms, cnt, fl, tot, nc)
@@ -468,7 +474,7 @@ def main():
               f'{host_s / args.steps * 1e3:.2f} ms/step, load average {os.getloadavg()[0]:.1f} on {host_cores()} usable cores',
               file=sys.stderr, flush=True)
         kernels = []
-        n_timed_steps = max(1, sum(1 for i in range(args.steps) if i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY and i == args.steps - 1))
+        n_timed_steps = PROF_STEPS
         for i in range(nc):
             if cnt[i]:
                 kernels.append({'kernel': CLASS_NAMES[i], 'timed_launches': int(cnt[i]), 'avg_ms': ms[i] / cnt[i],
@@ -482,7 +488,9 @@ def main():
                         'traffic': pmc_traffic(dom['kernel']),
                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes committed under profiles/)',
                         'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches_per_step'],
-                        'timed_steps': n_timed_steps}
+                        'timed_steps': n_timed_steps,
+                        'measured_in': 'HIP events around every launch of %d eagerly launched step(s) of the same workload, run right '
+                                       'after the timed region (events cannot be recorded inside a hipGraph replay)' % n_timed_steps}
         L = model.total_seq_len
         _lib.check_device_faults()  # an out-of-range token id / CE target anywhere in the run is an error, not a silent row 0
         loss_value = float(loss.detach())

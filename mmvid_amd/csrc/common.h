@@ -88,8 +88,10 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //                                       >= 200 tiles, 2 = always
 //   attn_occ       MMVID_ATTN_OCC       attention kernels compiled for one more block per CU (registers capped, a few spilled):
 //                                       bit 0 forward (5 instead of 4), bit 1 dQ (4 instead of 3), bit 2 dK/dV (3 instead of 2)
+//   gemm_persist   MMVID_GEMM_PERSIST   1 (default) = GEMMs with more tiles than CUs run 256 persistent blocks that walk the tiles
+//                                       (whole-step A/B: 17.82 -> 17.77 ms; the block turnover is paid once per launch)
 //   gemm_debug     MMVID_GEMM_DEBUG     measurement only (tools/bench_gemm.py anatomy): 1 = the GEMM epilogue skips its global
 //                                       stores, 2 = the K loop is skipped (results are wrong in both)
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_COUNT = 10 };
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_COUNT = 11 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

@@ -41,7 +41,8 @@ Opt g_opts[MMVID_OPT_COUNT] = {{"gemm_tile", "MMVID_GEMM_TILE", 0, 0, false},
                                {"strip_sched", "MMVID_STRIP_SCHED", 2, 0, false},
                                {"gemm_debug", "MMVID_GEMM_DEBUG", 0, 0, false},
                                {"gemm_wshape", "MMVID_GEMM_WSHAPE", 0, 0, false},
-                               {"attn_occ", "MMVID_ATTN_OCC", 0, 0, false}};
+                               {"attn_occ", "MMVID_ATTN_OCC", 0, 0, false},
+                               {"gemm_persist", "MMVID_GEMM_PERSIST", 1, 0, false}};
 }  // namespace
 
 int mmvid_option(int which) {
@@ -61,7 +62,7 @@ extern "C" int mmvid_set_option(const char* name, int value) {
             g_opts[i].value = value, g_opts[i].set = true;
             return MMVID_OK;
         }
-    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs, ln_bwd_blocks, gemm_sched, fuse_colsum, strip_sched, gemm_debug, gemm_wshape, attn_occ)", name);
+    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs, ln_bwd_blocks, gemm_sched, fuse_colsum, strip_sched, gemm_debug, gemm_wshape, attn_occ, gemm_persist)", name);
     return MMVID_ERR_ARG;
 }
 

@@ -49,6 +49,7 @@ struct GemmParams {
     float* partial;  // split-K workspace [splitk][M][N] (plain stores, reduced by splitk_reduce_kernel) or null
     float* colsum;   // [N] += column sums of the stored result (the bias gradient when the result is a dY), or null
     int debug;       // option gemm_debug (measurement only): 1 = no global stores, 2 = no K loop
+    int tiles_n, tiles_m;  // > 0: persistent blocks walk this tile grid (option gemm_persist); 0: one block per tile
 };
 
 __device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
@@ -170,9 +171,15 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS bases stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
-    const int wg = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-    const int bn0 = (wg % gridDim.x) * BN, bm0 = (wg / gridDim.x) * S::ROWS;
+    // p.tiles_n > 0: PERSISTENT blocks (option gemm_persist) -- gridDim.x blocks walk the p.tiles_n x p.tiles_m output tiles in
+    // XCD-aware order, so a CU pays the block turnover once per launch instead of once per tile
+    const int ntiles = p.tiles_n > 0 ? p.tiles_n * p.tiles_m : 1;
+    const int tile_step = p.tiles_n > 0 ? (int)gridDim.x : 1;
     const int batch = blockIdx.z / p.splitk, ks = blockIdx.z % p.splitk;
+  for (int tile = p.tiles_n > 0 ? (int)blockIdx.x : 0; tile < ntiles; tile += tile_step) {
+    const int gx = p.tiles_n > 0 ? p.tiles_n : (int)gridDim.x;
+    const int wg = p.tiles_n > 0 ? xcd_remap(tile, ntiles) : xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int bn0 = (wg % gx) * BN, bm0 = (wg / gx) * S::ROWS;
     const bf16_t* A = p.A + (long)batch * p.strideA;
     const bf16_t* B = p.B + (long)batch * p.strideB;
 
@@ -240,6 +247,8 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     }
 
     gemm_epilogue<S::THREADS, 64, 2>(p, smem, acc, bm0, bn0, batch, ks, tid, wm, wn, lane);
+    if (tile + tile_step < ntiles) __syncthreads();  // the slab has been read: the next tile's DMA may overwrite the stages
+  }
 }
 
 // ================================================================================================================
@@ -436,7 +445,13 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
         attr = true;
     }
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, S::ROWS), batch * p.splitk);
-    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP>), grid, dim3(S::THREADS), S::LDS_BYTES, stream, p);
+    GemmParams q = p;
+    q.tiles_n = q.tiles_m = 0;
+    if (WM == 4 && mmvid_option(MMVID_OPT_GEMM_PERSIST) && (long)grid.x * grid.y > 256) {  // more than one tile per CU
+        q.tiles_n = (int)grid.x, q.tiles_m = (int)grid.y;
+        grid = dim3(256, 1, grid.z);
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP>), grid, dim3(S::THREADS), S::LDS_BYTES, stream, q);
 }
 
 template <bool BKM>
@@ -513,6 +528,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.out_f32 = out_f32, p.out_bf16 = (bf16_t*)out_bf16, p.ldc = ldc;
     p.partial = nullptr, p.colsum = out_colsum;
     p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
+    p.tiles_n = p.tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor)
         launch<false, false>(p, batch, s);
@@ -554,6 +570,7 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     p.partial = splitk > 1 ? workspace : nullptr;
     p.colsum = nullptr;
     p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
+    p.tiles_n = p.tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
     launch<true, true>(p, 1, s);
     if (splitk > 1) {
