@@ -226,8 +226,9 @@ def comm_report(trainer, step_ms, world):
         fence()
         ar_ms = (time.perf_counter() - t0) / reps * 1e3
         dense = trainer.numel - sum(b - a for a, b in trainer._sparse_ranges())  # elements that go through the all-reduce
-        wire = 2.0 * max(world - 1, 1) / world * 4.0 * dense  # bytes per GPU on the links, ring-equivalent (world 1: loop-back)
-        return {'allreduce_alone_ms': ar_ms, 'bytes_per_gpu_on_wire': wire, 'bus_bandwidth_GBps': wire / (ar_ms * 1e-3) / 1e9,
+        wire = 2.0 * (world - 1) / world * 4.0 * dense  # bytes per GPU on the links, ring-equivalent
+        return {'allreduce_alone_ms': ar_ms, 'bytes_per_gpu_on_wire': wire if world > 1 else 0.0,
+                'bus_bandwidth_GBps': wire / (ar_ms * 1e-3) / 1e9 if world > 1 else None,  # a group of one is a loop-back: no links
                 'gradient_bytes': 4.0 * trainer.numel, 'dense_allreduce_bytes': 4.0 * dense,
                 'row_wise_tables': [n for n in getattr(trainer.model, 'sparse_grad_rows', dict)()],
                 'note': 'overlap = 1 - (step - step_without_exchange) / allreduce_alone; the tables listed under row_wise_tables '
@@ -343,6 +344,39 @@ def run_bert_sampling(args, device, rank, world):
     print(json.dumps(out))
 
 
+def self_launch(n):
+    """Re-run this command under `torch.distributed.run` with n ranks on this node (one process per GPU, rendezvous on
+    127.0.0.1 at a free port).  stdout / stderr pass through, so rank 0's JSON line is this process's output."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'[bench] --gpus {n} without a launcher: starting {n} ranks ({" ".join(cmd[1:8])} ...)', file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def dry_run(args, world, rank):
+    """Arg / rank plumbing without a GPU: join a gloo group, check every rank agrees on the arguments, print the skeleton."""
+    if world > 1 or 'RANK' in os.environ:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1), float(args.steps), float(args.gpus)])
+        dist.all_reduce(t)
+        assert t[0].item() == world * (world + 1) / 2 and t[1].item() == world * args.steps and t[2].item() == world * args.gpus
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        B = args.batch or (6 if args.config == 2 else 2)
+        print(json.dumps({'metric': 'video-tokens/sec training step, 8-frame 128px text-to-video', 'value': None, 'unit': 'video-tokens/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'scaling': 'weak',
+                          'config': {'workload': WORKLOADS[args.config], 'per_gpu_batch': B, 'global_batch': world * B,
+                                     'parallelism': f'dp{world}'}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -356,7 +390,14 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch every step from Python instead of replaying the captured step graph')
     ap.add_argument('--force-exchange', action='store_true', help='run the gradient all-reduce path even with one rank (tests)')
     ap.add_argument('--layers', type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the model
+    ap.add_argument('--dry-run', action='store_true', help='rank plumbing only (gloo, no GPU work): start the ranks, all-reduce '
+                    'one scalar, print the JSON skeleton')
+    ap.add_argument('--strict', action='store_true', help='run the VQGAN encoder in its exact-index mode (vae.strict)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher (train.py:47-66 spawns its ranks from main() the
+        # same way); the ranks run this file again with RANK / LOCAL_RANK / WORLD_SIZE set and rank 0 prints the JSON line
+        raise SystemExit(self_launch(args.gpus))
     if args.steps is None:
         args.steps = 2 if args.config == 5 else (3 if args.sample else 10)
 
@@ -366,7 +407,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
+    if world != args.gpus:
+        raise SystemExit(f'[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks')
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    ndev = torch.cuda.device_count()
+    if ndev < world or local >= ndev:
+        raise SystemExit(f'[bench] --gpus {args.gpus}: only {ndev} device(s) visible on this node (rank {rank}, local rank {local}); '
+                         'one process per GPU needs as many devices as ranks')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     under_launcher = 'RANK' in os.environ  # torch.distributed.run: join the group even when it has one member
@@ -396,6 +444,10 @@ def main():
             dist.destroy_process_group()
         return
     model = build_model(args.config, device, args.layers)
+    if args.strict:  # exact-index tokenisation (vae.strict; 'split' = 3-term bf16 split on the MFMA pipe, True = f32 MFMA)
+        model.vae.strict = True
+        if model.cvae is not None:
+            model.cvae.strict = True
     model.frontend.seed = seed  # every rank draws its own masks / warps
     broadcast_parameters(model)
     model.train()
@@ -500,8 +552,9 @@ def main():
             'metric': 'video-tokens/sec training step, 8-frame 128px text-to-video', 'value': value,
             'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': WORKLOADS[args.config], 'config_id': args.config, 'per_gpu_batch': B, 'global_batch': world * B,
+            'dtype': 'bf16 (transformer) + fp32 (VQGAN encoder, exact token indices)' if args.strict else 'bf16', 'data': 'synthetic',
+            'config': {'workload': WORKLOADS[args.config] + (' [vae.strict: fp32 encoder]' if args.strict else ''),
+                       'config_id': args.config, 'per_gpu_batch': B, 'global_batch': world * B,
                        'seq_len': L, 'parallelism': f'dp{world}', 'step_launch': step_launch, 'layers': args.layers},
             'loss': loss_value, 'roofline': roofline, 'kernels': kernels,
             'host_issue_ms_per_step': host_s / args.steps * 1e3, 'host_load_average': os.getloadavg()[0],

@@ -143,13 +143,21 @@ int mmvid_counter_add(float* counter, float value, void* stream);
 int mmvid_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
 /* ---- stochastic front-end of a BERT training step on the device (csrc/frontend.hip).  Every decision is a
- * function of (seed, *step_dev, sample, purpose) through Philox4x32-10; step_dev may be NULL (step 0).
+ * function of (key, step, sample, purpose) through Philox4x32-10.  step_dev is the front-end STATE: four 32-bit device words
+ * {forward-call counter (fp32), seed low word, seed high word, reserved}; key = seed argument XOR the state's seed words, so
+ * a captured step follows a seed kept on the device (train.py:87 seeds every rank with seed + rank).  step_dev may be NULL
+ * (step 0, key = seed argument).
  * MSM masks, dalle_bert.py:992-1029: strategy_prob[4] = Bernoulli(p ~ U(bern_lo, bern_hi)) | fully masked | RandomErasing
  * box hidden | only the box visible; pc_prob: frame preservation (1022-1026).  mask1 [B, T*f*f] (1 = token visible),
  * not_fully_masked [B]; strategy_out (optional) [B] the strategy drawn (tests). */
 int mmvid_msm_masks(uint64_t seed, const float* step_dev, int B, int T, int f, const float* strategy_prob, float bern_lo,
                     float bern_hi, float pc_prob, uint8_t* mask1, float* not_fully_masked, int32_t* strategy_out,
                     void* stream);
+/* The same kernel with the decisions supplied instead of drawn (parity tests against a reference run, tests/golden/
+ * frontend.npz): decisions [B, 72] int32 = {strategy 1..4, has_box, box i, j, h, w, 2 reserved, keep_frame[64]}; bernoulli
+ * [B, T*f*f] uint8 = the Bernoulli field of strategy 1 (may be NULL when no sample uses it). */
+int mmvid_msm_masks_inject(const int32_t* decisions, const uint8_t* bernoulli, int B, int T, int f, uint8_t* mask1,
+                           float* not_fully_masked, void* stream);
 /* VID negative, dalle_bert.py:204-238 (+93-202): x, out [B,T,C,H,W] fp32 in [0,1]; strategy_prob[4] = frame of another
  * sample | frame shuffle | colour shift | affine warp (affine_grid + bilinear grid_sample, reflection padding).
  * params_scratch: B * mmvid_warp_params_bytes() bytes; draw_params = 0 applies the parameters already in it (tests). */
@@ -177,6 +185,12 @@ int mmvid_erase_tokens_choice(uint64_t seed, const float* step_dev, int nchoice,
 int mmvid_random_erase_tokens(uint64_t seed, const float* step_dev, int B, int Tv, int f, float p, float scale_lo,
                               float scale_hi, float ratio_lo, float ratio_hi, int erase_half, int64_t value, int64_t* tok,
                               void* stream);
+
+/* visual_aug_mode 'motion_color' (dalle_bert.py:140-158, 940-943; dalle_artv.py:460-463): with probability p (one draw per
+ * call) every sample's frames first_frame.. of x [B,Tv,C,H,W] fp32 get a per-sample colour shift U(-0.5,0.5) on all channels
+ * or one of them, clamped to [0,1]; in place.  params_out (optional) [B,3] = {gate, shift, channel choice 0..3}. */
+int mmvid_visual_color_jitter(uint64_t seed, const float* step_dev, float* x, int B, int Tv, int C, int H, int W, float p,
+                              int first_frame, float* params_out, void* stream);
 
 /* ---- whole CLIP tower (12 x ResidualAttentionBlock), layer loop in native code:
  * clip_model.py:580-584 -> 230-247 -> 224-227.  x is [B*L, E] fp32, batch-first. */

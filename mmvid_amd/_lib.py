@@ -85,11 +85,13 @@ SIGNATURES = {
     'mmvid_lr_schedule': [P, I, F, F, I, I, P, P],
     'mmvid_counter_add': [P, F, P],
     'mmvid_msm_masks': [U64, P, I, I, I, P, F, F, F, P, P, P, P],
+    'mmvid_msm_masks_inject': [P, P, I, I, I, P, P, P],
     'mmvid_vid_warp': [U64, P, P, I, I, I, I, I, P, P, I, P, P],
     'mmvid_vid_warp_new_frames': [U64, P, P, I, I, I, I, I, P, P, I, P, P],
     'mmvid_vid_warp_tokens': [P, P, P, I, I, I, P, P],
     'mmvid_erase_tokens_choice': [U64, P, I, P, P, P, I, I, I, I, I64, P, P],
     'mmvid_random_erase_tokens': [U64, P, I, I, I, F, F, F, F, F, I, I64, P, P],
+    'mmvid_visual_color_jitter': [U64, P, P, I, I, I, I, I, F, I, P, P],
     'mmvid_gemm_f32': [I, I, I, I, P, I64, P, I64, I, I64, I64, I64, F, P, P, P, I64, P],
     'mmvid_conv2d_nhwc_f32': [I, P, I, I, I, I, P, P, I, P, I, P, P],
     'mmvid_image_to_nhwc4_f32': [P, I, I, I, P, P],

@@ -43,11 +43,15 @@ struct Rng {  // one stream = (seed, step, sample, purpose); draw i of the strea
 __device__ __forceinline__ Rng make_rng(uint64_t seed, const float* step_dev, int sample, int purpose) {
     Rng g;
     g.k0 = (uint32_t)seed, g.k1 = (uint32_t)(seed >> 32);
-    g.step = step_dev ? (uint32_t)(*step_dev) : 0u;
+    g.step = 0u;
+    if (step_dev) {  // front-end state: {forward-call counter (fp32), seed low word, seed high word, reserved}
+        g.step = (uint32_t)step_dev[0];
+        g.k0 ^= __float_as_uint(step_dev[1]), g.k1 ^= __float_as_uint(step_dev[2]);
+    }
     g.sample = (uint32_t)sample, g.purpose = (uint32_t)purpose;
     return g;
 }
-enum { P_STRATEGY = 1, P_BERNOULLI = 2, P_BOX = 3, P_PC = 4, P_WARP = 5, P_PERM = 6, P_ERASE = 7, P_FACE = 8 };
+enum { P_STRATEGY = 1, P_BERNOULLI = 2, P_BOX = 3, P_PC = 4, P_WARP = 5, P_PERM = 6, P_ERASE = 7, P_FACE = 8, P_VCOLOR = 9 };
 
 // torchvision.transforms.RandomErasing.get_params (third-party, absent from /root/reference; restated from the
 // published semantics): up to 10 attempts of { area*U(scale), exp(U(log ratio)) -> h, w = round(sqrt(..)) ; accept if
@@ -74,12 +78,21 @@ __device__ bool erasing_box(const Rng& g, uint32_t base, int H, int W, float s0,
 __global__ __launch_bounds__(256) void msm_mask_kernel(uint64_t seed, const float* __restrict__ step_dev, int T, int f,
                                                        float p1, float p2, float p3, float bern_lo, float bern_hi,
                                                        float pc_prob, unsigned char* __restrict__ mask1,
-                                                       float* __restrict__ nfm, int* __restrict__ strategy_out) {
+                                                       float* __restrict__ nfm, int* __restrict__ strategy_out,
+                                                       const int* __restrict__ inject,
+                                                       const unsigned char* __restrict__ bern_inject) {
     __shared__ int s_strat, s_box[4], s_hasbox;
     __shared__ float s_p;
     __shared__ unsigned char s_keep_frame[64];
     const int b = blockIdx.x, TS = T * f * f;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && inject) {  // tests: the decisions of a reference run instead of draws (MSM_INJECT_WORDS per sample:
+        const int* d = inject + (long)b * 72;  // strategy, has_box, box i, j, h, w, 2 reserved, keep_frame[64])
+        s_strat = d[0], s_hasbox = d[1], s_p = 0.f;
+        s_box[0] = d[2], s_box[1] = d[3], s_box[2] = d[4], s_box[3] = d[5];
+        for (int t = 0; t < 64; ++t) s_keep_frame[t] = (t < T && d[8 + t]) ? 1 : 0;
+        nfm[b] = d[0] == 2 ? 0.f : 1.f;
+        if (strategy_out) strategy_out[b] = d[0];
+    } else if (threadIdx.x == 0) {
         const Rng g = make_rng(seed, step_dev, b, P_STRATEGY);
         const float u = g.uniform(0);
         const int strat = u < p1 ? 1 : (u < p1 + p2 ? 2 : (u < p1 + p2 + p3 ? 3 : 4));  // np.random.choice([1,2,3,4], p)
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(256) void msm_mask_kernel(uint64_t seed, const floa
         const int t = p / (f * f), rem = p - t * f * f, y = rem / f, x = rem - y * f;
         unsigned char m;
         if (strat == 1) {
-            m = gbern.uniform(p) < s_p ? 1 : 0;  // torch.bernoulli(ones * p)
+            m = bern_inject ? bern_inject[(long)b * TS + p] : (gbern.uniform(p) < s_p ? 1 : 0);  // torch.bernoulli(ones * p)
         } else if (strat == 2) {
             m = 0;
         } else {
@@ -348,6 +361,32 @@ __global__ __launch_bounds__(256) void random_erase_tokens_kernel(uint64_t seed,
     }
 }
 
+// visual_aug_mode == 'motion_color' (dalle_bert.py:140-158, 940-943; dalle_artv.py:460-463): with probability p -- ONE draw
+// per forward call, `random.random() < 0.9` -- every sample's visual frames first_frame.. get the same per-sample colour
+// shift c ~ U(-0.5, 0.5) on all channels or on one of them (random.randint(0, 3)), clamped to [0, 1]; earlier frames and a
+// failed gate leave the pixels untouched.  x [B, Tv, C, H, W] fp32, in place.  params_out (optional, tests): per sample
+// {gate, shift, chan}.
+__global__ __launch_bounds__(256) void visual_color_kernel(uint64_t seed, const float* __restrict__ step_dev, int B, int Tv, int C,
+                                                           long hw, float p, int first_frame, float* __restrict__ x,
+                                                           float* __restrict__ params_out) {
+    const long per_b = (long)Tv * C * hw;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * per_b) return;
+    const int b = (int)(idx / per_b);
+    const long r = idx - (long)b * per_b;
+    const int t = (int)(r / (C * hw)), c = (int)((r - (long)t * C * hw) / hw);
+    const Rng gate = make_rng(seed, step_dev, 0, P_VCOLOR);
+    const bool on = gate.uniform(0) < p;
+    const Rng g = make_rng(seed, step_dev, b + 1, P_VCOLOR);
+    const float shift = g.uniform(0) - 0.5f;
+    int chan = (int)(g.uniform(1) * 4.0f);
+    if (chan > 3) chan = 3;
+    if (params_out && r == 0) params_out[3 * b] = on ? 1.f : 0.f, params_out[3 * b + 1] = shift, params_out[3 * b + 2] = (float)chan;
+    if (!on || t < first_frame) return;
+    const float m = (chan == 0 || chan - 1 == c) ? shift : 0.f;
+    x[idx] = fminf(fmaxf(x[idx] + m, 0.f), 1.f);
+}
+
 __global__ void counter_add_kernel(float* c, float v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += v;
 }
@@ -381,8 +420,18 @@ extern "C" int mmvid_msm_masks(uint64_t seed, const float* step_dev, int B, int 
                                int32_t* strategy_out, void* stream) {
     MMVID_REQUIRE(strategy_prob && mask1 && not_fully_masked && B > 0 && T > 0 && T <= 64 && f > 0, "msm_masks: bad arguments");
     hipLaunchKernelGGL(msm_mask_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, seed, step_dev, T, f, strategy_prob[0],
-                       strategy_prob[1], strategy_prob[2], bern_lo, bern_hi, pc_prob, mask1, not_fully_masked, strategy_out);
+                       strategy_prob[1], strategy_prob[2], bern_lo, bern_hi, pc_prob, mask1, not_fully_masked, strategy_out,
+                       (const int*)nullptr, (const unsigned char*)nullptr);
     MMVID_LAUNCH_CHECK("msm_masks");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_msm_masks_inject(const int32_t* decisions, const uint8_t* bernoulli, int B, int T, int f, uint8_t* mask1,
+                                      float* not_fully_masked, void* stream) {
+    MMVID_REQUIRE(decisions && mask1 && not_fully_masked && B > 0 && T > 0 && T <= 64 && f > 0, "msm_masks_inject: bad arguments");
+    hipLaunchKernelGGL(msm_mask_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (uint64_t)0, (const float*)nullptr, T, f, 0.f, 0.f,
+                       0.f, 0.f, 0.f, 0.f, mask1, not_fully_masked, (int*)nullptr, decisions, bernoulli);
+    MMVID_LAUNCH_CHECK("msm_masks_inject");
     return MMVID_OK;
 }
 
@@ -454,6 +503,16 @@ extern "C" int mmvid_random_erase_tokens(uint64_t seed, const float* step_dev, i
     hipLaunchKernelGGL(random_erase_tokens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, seed, step_dev, Tv, f, p, scale_lo,
                        scale_hi, ratio_lo, ratio_hi, erase_half, (long long)value, (long long*)tok);
     MMVID_LAUNCH_CHECK("random_erase_tokens");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_visual_color_jitter(uint64_t seed, const float* step_dev, float* x, int B, int Tv, int C, int H, int W, float p,
+                                         int first_frame, float* params_out, void* stream) {
+    MMVID_REQUIRE(x && B > 0 && Tv > 0 && C > 0 && H > 0 && W > 0, "visual_color_jitter: bad arguments");
+    const long total = (long)B * Tv * C * H * W;
+    hipLaunchKernelGGL(visual_color_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, seed, step_dev, B, Tv, C,
+                       (long)H * W, p, first_frame, x, params_out);
+    MMVID_LAUNCH_CHECK("visual_color_jitter");
     return MMVID_OK;
 }
 

@@ -83,7 +83,7 @@ class DALLE(nn.Module):
         self.to_logits = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, self.total_tokens))
         self.loss_vis_weight, self.loss_img_weight = 1., loss_img_weight
         self.eraser = dict(p=1.0, scale=(0.4, 0.8), ratio=(0.5, 2.0))  # RandomErasing(value=-1), dalle_artv.py:229-232
-        self.frontend = Frontend(seed=kwargs.get('frontend_seed', 0))
+        self.frontend = Frontend(seed=kwargs.get('frontend_seed'))
         self._w16_cache = None
         seg = [0] * (text_seq_len + 1) + [1] * self.visual_seq_len + [2] * self.target_seq_len
         self.register_buffer('_seg', torch.tensor(seg, dtype=torch.int32), persistent=False)
@@ -187,8 +187,10 @@ class DALLE(nn.Module):
     def _visual_tokens(self, visual, erase_visual, erase_visual_half, vc_mode, face_mode, visual_aug_mode):
         if not (exists(visual) and not is_empty(visual)):
             return None
-        if visual_aug_mode == 'motion_color':
-            raise NotImplementedError("visual_aug_mode='motion_color' is not used by any recipe in scripts/ and is not built")
+        if visual_aug_mode == 'motion_color' and torch.is_tensor(visual) and visual.dim() == 5:
+            # scripts/mmvoxceleb/image_and_video/train.sh:10; dalle_bert.py:940-943 / dalle_artv.py:460-463: colour jitter of the
+            # video part (frames 1..) of the visual control, gated at 0.9 per call -- drawn on the device
+            visual = self.frontend.visual_color_jitter(visual, 0.9, 1)
         tok = self.get_image_tokens(visual, which_vae='cvae')
         if erase_visual:
             tok = self.random_erase_codebook(tok, self.eraser, erase_visual_half)

@@ -59,6 +59,8 @@ class DivideMax(nn.Module):  # utils/utils.py:18-25 (only when stable=True; no d
 
 
 class BERT(nn.Module):
+    TEXT_ID_LOG_MAX = 16  # forwards between two zero_grad() calls whose text ids are kept for the row-wise gradient exchange
+
     def __init__(self, *, dim, vae, cvae=None, num_text_tokens=10000, text_seq_len=256, stable=False,
                  text_feature_dim=0, fixed_language_model=None, which_transformer='none', num_visuals=1,
                  num_targets=1, use_separate_visual_emb=False, insert_sep=False, text_emb_bottleneck=False,
@@ -128,11 +130,11 @@ class BERT(nn.Module):
         self.to_logits_rel = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, 1))
         self.to_logits_vid = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, 1))
         self.current_step = 0
-        self.frontend = Frontend(seed=kwargs.get('frontend_seed', 0))  # reseed per rank: frontend.seed = seed + rank
+        self.frontend = Frontend(seed=kwargs.get('frontend_seed'))  # None: torch.initial_seed() + rank at first use (train.py:87)
         self._w16_cache = {}
         self._row_cache = {}
         self._debug_keep = None
-        self._text_id_log = []
+        self._text_id_log, self._text_id_overflow = [], False
         # segment table: which embedding table each position reads (0 special, 1 text, 2 visual, 3 image)
         seg = [0] + [1] * self.text_seq_len + [2] * self.visual_seq_len + [0, 0] + [3] * self.target_seq_len
         self.register_buffer('_seg', torch.tensor(seg, dtype=torch.int32), persistent=False)
@@ -181,11 +183,24 @@ class BERT(nn.Module):
         """Tables whose gradient has few non-zero rows per step, with the row ids of the last forward (engine.FlatTrainer
         exchanges them row-wise instead of all-reducing 152 MB of mostly zeros)."""
         log = self._text_id_log
-        return {'text_emb.weight': (log[0] if len(log) == 1 else torch.cat(log)) if log else None}
+        if not log or self._text_id_overflow:  # nothing logged / more forwards since zero_grad than the log holds: the
+            return {'text_emb.weight': None}   # trainer falls back to the dense all-reduce for this table
+        return {'text_emb.weight': log[0] if len(log) == 1 else torch.cat(log)}
 
     def reset_sparse_grad_rows(self):
         """Called by FlatTrainer.zero_grad(): the gradients start from zero, so does the list of touched rows."""
-        self._text_id_log = []
+        self._text_id_log, self._text_id_overflow = [], False
+
+    def _log_text_ids(self, ids):
+        """Every text-segment id of a grad-enabled forward: the only rows of text_emb its backward can touch.  Logged per
+        forward since the last zero_grad so gradient accumulation stays covered; past TEXT_ID_LOG_MAX forwards the log is
+        declared incomplete (sparse_grad_rows -> None -> dense all-reduce) rather than silently dropping the oldest."""
+        if not torch.is_grad_enabled():
+            return
+        if len(self._text_id_log) >= self.TEXT_ID_LOG_MAX:
+            self._text_id_overflow = True
+            return
+        self._text_id_log.append(ids[:, 1:1 + self.text_seq_len].reshape(-1))
 
     def _pos_layout(self):
         """Segments of the positional table for functional.PosTable: (dst0, rows, src0, params, axial dims)."""
@@ -310,9 +325,10 @@ class BERT(nn.Module):
         """Token ids of the visual control segment (dalle_bert.py:933-957), or None = all [MASK]."""
         if self.num_visuals == 0 or not (exists(visual) and len(visual)):
             return None
-        if visual_aug_mode == 'motion_color':
-            raise NotImplementedError("visual_aug_mode='motion_color' (per-frame colour jitter of the visual control, "
-                                      'dalle_bert.py:936-943) is not used by any recipe in scripts/ and is not built')
+        if visual_aug_mode == 'motion_color' and torch.is_tensor(visual) and visual.dim() == 5:
+            # scripts/mmvoxceleb/image_and_video/train.sh:10; dalle_bert.py:940-943 / dalle_artv.py:460-463: colour jitter of the
+            # video part (frames 1..) of the visual control, gated at 0.9 per call -- drawn on the device
+            visual = self.frontend.visual_color_jitter(visual, 0.9, 1)
         tok = self.get_image_tokens(visual, insert_sep=self.insert_sep, which_vae='cvae')
         if erase_visual:
             tok = self.random_erase_codebook(tok, self.visual_eraser, erase_visual_half)
@@ -357,6 +373,7 @@ class BERT(nn.Module):
             ids = ops.bert_build_ids(text, vis_tok, self.visual_seq_len, empty, None, torch.empty(B, 0, dtype=torch.uint8, device=device),
                                      pad_base, MASK, False, False)[0]
             self.frontend.advance(device)
+            self._log_text_ids(ids)
             return self._assemble(ids, self.control_seq_len)
 
         T, f = self.num_targets, self.image_fmap_size
@@ -406,10 +423,7 @@ class BERT(nn.Module):
             text_neg_ids = ops._chk(text_neg.contiguous(), torch.int64, 'text_neg')
         ids, sel, tfull, cnt = ops.bert_build_ids(text, vis_tok, self.visual_seq_len, target, target_warp, mask1, pad_base, MASK,
                                                   bool(rel), bool(do_vid), text_neg=text_neg_ids)
-        # every text-segment id of the step's sequences: the only rows of text_emb a backward can touch (sparse_grad_rows);
-        # logged per forward since the last zero_grad, so gradient accumulation over several forwards stays covered
-        if torch.is_grad_enabled():
-            self._text_id_log = (self._text_id_log + [ids[:, 1:1 + self.text_seq_len].reshape(-1)])[-16:]
+        self._log_text_ids(ids)  # rows of text_emb this forward's backward can touch (sparse_grad_rows)
         x_seq = self._assemble(ids, self.total_seq_len)
         y = self.transformer_forward(x_seq)  # [nseq*B, L, dim]
         if self._debug_keep is not None:  # tools/stress_nan2.py: the stage tensors of the last (replayed) forward

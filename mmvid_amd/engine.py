@@ -141,7 +141,8 @@ class FlatTrainer:
     # --------------------------------------------------------------------------------------------- checkpoint
     def state_dict(self):
         """Optimiser state in torch.optim.Adam's layout (train.py:202-203, 352, 387 save / restore `optimizer`): per
-        parameter exp_avg / exp_avg_sq / step, keyed by position in `self.names` order."""
+        parameter exp_avg / exp_avg_sq / step, keyed by position in `self.names` order (recorded under 'names'), plus the
+        front-end's (seed, forward count) so a resumed run continues its mask / warp stream instead of replaying it."""
         state = {}
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
@@ -149,27 +150,52 @@ class FlatTrainer:
                         'exp_avg_sq': self.V[o:o + n].view(p.shape).clone()}
         group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.wd, 'amsgrad': False,
                  'params': list(range(len(self.params)))}
-        return {'state': state, 'param_groups': [group], 'names': list(self.names)}
+        out = {'state': state, 'param_groups': [group], 'names': list(self.names)}
+        fe = getattr(self.model, 'frontend', None)
+        if fe is not None and hasattr(fe, 'state_dict'):
+            out['frontend'] = fe.state_dict()
+        return out
 
     def load_state_dict(self, sd):
-        names = sd.get('names', self.names)
-        assert list(names) == list(self.names), 'optimizer state was saved for a different parameter order'
-        steps = set()
-        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-            st = sd['state'].get(i, sd['state'].get(str(i)))
+        """Accepts this class's own state_dict and a plain torch.optim.Adam one (the reference's checkpoints,
+        train.py:352): without a 'names' entry the indices are torch's -- position in the requires_grad-filtered
+        `model.parameters()` order the reference hands to Adam (utils_train.py:167-172) -- and are mapped through the
+        parameter names to the flat layout; every entry's shape is checked, so moments can never land on another layer."""
+        if 'names' in sd:
+            names = list(sd['names'])
+        else:
+            names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+        if sorted(names) != sorted(self.names):
+            raise ValueError('optimizer state was saved for a different set of parameters: '
+                             f'{sorted(set(names) ^ set(self.names))[:6]} ...')
+        at = {n: i for i, n in enumerate(self.names)}
+        steps, loaded = set(), []
+        for j, name in enumerate(names):
+            st = sd['state'].get(j, sd['state'].get(str(j)))
             if st is None:
                 continue
-            n = p.numel()
+            i = at[name]
+            p, o, n = self.params[i], self.offsets[i], self.params[i].numel()
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if tuple(st[k].shape) != tuple(p.shape):
+                    raise ValueError(f'optimizer state entry {j} ({name}): {k} has shape {tuple(st[k].shape)}, the parameter '
+                                     f'{tuple(p.shape)}')
+            loaded.append((o, n, st))
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('per-parameter step counts differ')
+        for o, n, st in loaded:
             self.M[o:o + n].copy_(st['exp_avg'].reshape(-1))
             self.V[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
-            steps.add(int(float(st['step'])))
         if steps:
-            assert len(steps) == 1, 'per-parameter step counts differ'
             self.step_count = steps.pop()
             if self._step_dev is not None:
                 self._step_dev.fill_(float(self.step_count))
         g = sd['param_groups'][0]
         self.lr, self.betas, self.eps, self.wd = g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']
+        fe = getattr(self.model, 'frontend', None)
+        if fe is not None and 'frontend' in sd and hasattr(fe, 'load_state_dict'):
+            fe.load_state_dict(sd['frontend'])
 
     def refresh_shadows(self):
         """Call after writing parameters behind the trainer's back (model.load_state_dict): re-cast the bf16 shadow."""
@@ -190,8 +216,10 @@ class FlatTrainer:
         if not self.sparse_tables or fn is None:
             return []
         out = []
-        for name in fn():
-            if name in self.names:
+        for name, ids in fn().items():
+            # ids None = the model has no (complete) list of the rows this step touched -- no forward logged yet, or its
+            # log overflowed under gradient accumulation: that table goes through the dense all-reduce like any other
+            if name in self.names and ids is not None:
                 i = self.names.index(name)
                 out.append((self.offsets[i], self.offsets[i] + _round_up(self.params[i].numel(), ALIGN)))
         return sorted(out)
@@ -238,22 +266,34 @@ class FlatTrainer:
         fn = getattr(self.model, 'sparse_grad_rows', None)
         if not self.sparse_tables or fn is None or not self.exchange_enabled:
             return
-        rank = dist.get_rank(self.pg)
+        rank = self._rank()
         for name, ids in fn().items():
             if name not in self.names or ids is None:
-                continue
+                continue  # None: the table was not cut out of the dense all-reduce (_sparse_ranges)
             W = self.params[self.names.index(name)].grad  # [V, E] view into G
-            srt, _ = torch.sort(ids.reshape(-1))
-            first = torch.ones_like(srt, dtype=torch.bool)
-            first[1:] = srt[1:] != srt[:-1]
-            uid = torch.where(first, srt, torch.full_like(srt, -1))
-            rows = W.index_select(0, srt) * first.unsqueeze(1).to(W.dtype)
-            n = srt.shape[0]
-            all_ids, all_rows = self._gather(uid), self._gather(rows)
-            own = torch.zeros(self.world * n, dtype=torch.bool, device=ids.device)
-            own[rank * n:(rank + 1) * n] = True
-            valid = (all_ids >= 0) & ~own
-            W.index_add_(0, all_ids.clamp_min(0), all_rows * valid.unsqueeze(1).to(W.dtype))
+            uid, rows = self.pack_rows(W, ids)
+            self.merge_rows(W, self._gather(uid), self._gather(rows), rank, uid.shape[0])
+
+    def _rank(self):
+        return dist.get_rank(self.pg)
+
+    @staticmethod
+    def pack_rows(W, ids):
+        """This rank's message: (ids sorted, repeats blanked to -1) and the matching gradient rows (zero where blanked)."""
+        srt, _ = torch.sort(ids.reshape(-1))
+        first = torch.ones_like(srt, dtype=torch.bool)
+        first[1:] = srt[1:] != srt[:-1]
+        uid = torch.where(first, srt, torch.full_like(srt, -1))
+        rows = W.index_select(0, srt) * first.unsqueeze(1).to(W.dtype)
+        return uid, rows
+
+    @staticmethod
+    def merge_rows(W, all_ids, all_rows, rank, n):
+        """Add every OTHER rank's rows (rank-major gathered messages of n rows each) to this rank's table gradient."""
+        own = torch.zeros(all_ids.shape[0], dtype=torch.bool, device=all_ids.device)
+        own[rank * n:(rank + 1) * n] = True
+        valid = (all_ids >= 0) & ~own
+        W.index_add_(0, all_ids.clamp_min(0), all_rows * valid.unsqueeze(1).to(W.dtype))
 
     def layers_done(self, first_layer):
         """Tower backward callback: gradients of layers >= first_layer (and everything after them in the flat

@@ -19,18 +19,82 @@ def _farr(vals):
 
 
 class Frontend:
-    def __init__(self, seed=0):
-        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-        self.step = None  # device fp32 [1], created on first use (counts forward calls)
+    """`state` is a device buffer of four 32-bit words: [0] the forward-call counter (fp32, advanced by a device op), [1..2]
+    the 64-bit seed, [3] reserved.  The kernels read the seed from there (their by-value seed argument is XORed on top and
+    is 0 here), so a step captured in a hipGraph follows `frontend.seed = ...` and `load_state_dict` without re-capture.
+    seed=None (the default): derived at first use from torch.initial_seed() + rank, as train.py:87 seeds every rank with
+    seed + rank -- ranks draw different masks / warps, and `torch.manual_seed` controls the stream."""
+
+    def __init__(self, seed=None):
+        self._seed = None if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.state = None  # created on first use, on the device of that use
+        self._pending_step = None
         self._warp_scratch = None
 
-    def _step(self, device):
+    # ---- seed / step live on the device once `state` exists
+    @staticmethod
+    def _default_seed():
+        import torch.distributed as dist
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        return (int(torch.initial_seed()) + rank) & 0xFFFFFFFFFFFFFFFF
+
+    @property
+    def seed(self):
+        if self._seed is None:
+            self._seed = self._default_seed()
+        return self._seed
+
+    @seed.setter
+    def seed(self, value):
+        self._seed = int(value) & 0xFFFFFFFFFFFFFFFF
+        if self.state is not None:
+            self._write_seed()
+
+    def _write_seed(self):
+        lo, hi = self.seed & 0xFFFFFFFF, self.seed >> 32
+        words = torch.tensor([lo - (1 << 32) if lo >= (1 << 31) else lo, hi - (1 << 32) if hi >= (1 << 31) else hi], dtype=torch.int32)
+        self.state.view(torch.int32)[1:3].copy_(words)
+
+    @property
+    def step(self):
+        """Device fp32 [1] view of the forward-call counter (None before the first use)."""
+        return None if self.state is None else self.state[0:1]
+
+    @step.setter
+    def step(self, value):
+        if value is None:
+            self.state = None  # next use starts a fresh counter
+        else:
+            self._state(value.device)[0:1].copy_(value)
+
+    def _state(self, device):
         dev = torch.device(device)
         if dev.type == 'cuda' and dev.index is None:
             dev = torch.device('cuda', torch.cuda.current_device())
-        if self.step is None or self.step.device != dev:
-            self.step = torch.zeros(1, device=dev, dtype=f32)
-        return self.step
+        if self.state is None or self.state.device != dev:
+            old = self.state
+            self.state = torch.zeros(4, device=dev, dtype=f32)
+            if old is not None:
+                self.state[0:1].copy_(old[0:1])
+            if self._pending_step is not None:  # load_state_dict before the first use
+                self.state[0:1].fill_(self._pending_step)
+                self._pending_step = None
+            self._write_seed()
+        return self.state
+
+    def _step(self, device):
+        return self._state(device)
+
+    def state_dict(self):
+        return {'seed': self.seed, 'step': 0.0 if self.state is None else float(self.state[0])}
+
+    def load_state_dict(self, sd):
+        self._seed = int(sd['seed']) & 0xFFFFFFFFFFFFFFFF
+        self._pending_step = float(sd.get('step', 0.0))
+        if self.state is not None:
+            self.state[0:1].fill_(self._pending_step)
+            self._write_seed()
+            self._pending_step = None
 
     def advance(self, device):
         """One more forward call happened: later draws use a new counter block (a device op: graph-capturable)."""
@@ -42,9 +106,19 @@ class Frontend:
         nfm = torch.empty(B, device=device, dtype=f32)
         strat = torch.empty(B, device=device, dtype=torch.int32) if want_strategy else None
         p = list(strategy_prob)
-        _lib.call('mmvid_msm_masks', self.seed, _p(self._step(device)), B, T, fmap, _farr(p), float(bernoulli_prob[0]),
+        _lib.call('mmvid_msm_masks', 0, _p(self._step(device)), B, T, fmap, _farr(p), float(bernoulli_prob[0]),
                   float(bernoulli_prob[1]), float(pc_prob), _p(mask1), _p(nfm), _p(strat), _stream())
         return (mask1, nfm, strat) if want_strategy else (mask1, nfm)
+
+    @staticmethod
+    def msm_masks_from_decisions(decisions, bernoulli, T, fmap):
+        """The mask kernel on supplied decisions (tests): decisions int32 [B, 72], bernoulli uint8 [B, T*fmap*fmap] or None."""
+        B = decisions.shape[0]
+        mask1 = torch.empty(B, T * fmap * fmap, device=decisions.device, dtype=u8)
+        nfm = torch.empty(B, device=decisions.device, dtype=f32)
+        _lib.call('mmvid_msm_masks_inject', _p(ops._chk(decisions, torch.int32, 'decisions')), _p(bernoulli), B, T, fmap, _p(mask1),
+                  _p(nfm), _stream())
+        return mask1, nfm
 
     def vid_warp(self, x, strategy_prob, out=None, params=None):
         """x [B,T,C,H,W] f32 in [0,1] -> the VID negative.  `params` (a uint8 tensor of B * warp_params_bytes): apply
@@ -60,7 +134,7 @@ class Frontend:
             scratch, draw = params, 0
         if out is None:
             out = torch.empty_like(x)
-        _lib.call('mmvid_vid_warp', self.seed, _p(self._step(x.device)), _p(x), B, T, C, H, W, _farr(list(strategy_prob)),
+        _lib.call('mmvid_vid_warp', 0, _p(self._step(x.device)), _p(x), B, T, C, H, W, _farr(list(strategy_prob)),
                   _p(scratch), draw, _p(out), _stream())
         return out
 
@@ -76,7 +150,7 @@ class Frontend:
         ops._chk(x, f32, 'x')
         B, T, C, H, W = x.shape
         assert out.shape == (B, C, H, W) and out.is_contiguous() and out.dtype == f32
-        _lib.call('mmvid_vid_warp_new_frames', self.seed, _p(self._step(x.device)), _p(x), B, T, C, H, W,
+        _lib.call('mmvid_vid_warp_new_frames', 0, _p(self._step(x.device)), _p(x), B, T, C, H, W,
                   _farr(list(strategy_prob)), _p(self._scratch(B, x.device)), 1, _p(out), _stream())
         return out
 
@@ -87,6 +161,16 @@ class Frontend:
         _lib.call('mmvid_vid_warp_tokens', _p(target_tok), _p(new_tok.contiguous()), _p(self._warp_scratch), B, T, n, _p(out),
                   _stream())
         return out
+
+    def visual_color_jitter(self, visual, p=0.9, first_frame=1, want_params=False):
+        """visual_aug_mode='motion_color': visual [B,Tv,C,H,W] -> a copy whose frames first_frame.. carry a per-sample colour
+        shift with probability p (one gate per call)."""
+        x = ops._chk(visual.detach().float().clone().contiguous(), f32, 'visual')
+        B, Tv, C, H, W = x.shape
+        params = torch.empty(B, 3, device=x.device, dtype=f32) if want_params else None
+        _lib.call('mmvid_visual_color_jitter', 0, _p(self._step(x.device)), _p(x), B, Tv, C, H, W, float(p), int(first_frame),
+                  _p(params), _stream())
+        return (x, params) if want_params else x
 
     def erase_choice(self, tok, Tv, fmap, value, choices, frame0_full=False):
         """tok [B, Tv*fmap*fmap] int64 (modified in place).  choices: list of (prob, mode, (r0, r1, c0, c1)); one is
@@ -101,13 +185,13 @@ class Frontend:
         modes = (ctypes.c_int32 * n)(*[m for _, m, _ in choices])
         boxes = (ctypes.c_int32 * (4 * n))(*[v for _, _, bx in choices for v in bx])
         B = tok.shape[0]
-        _lib.call('mmvid_erase_tokens_choice', self.seed, _p(self._step(tok.device)), n, _farr(cum), modes, boxes,
+        _lib.call('mmvid_erase_tokens_choice', 0, _p(self._step(tok.device)), n, _farr(cum), modes, boxes,
                   int(frame0_full), B, Tv, fmap, int(value), _p(tok), _stream())
         return tok
 
     def random_erase(self, tok, Tv, fmap, value, p, scale, ratio, erase_half=False):
         ops._chk(tok, i64, 'tok')
-        _lib.call('mmvid_random_erase_tokens', self.seed, _p(self._step(tok.device)), tok.shape[0], Tv, fmap, float(p),
+        _lib.call('mmvid_random_erase_tokens', 0, _p(self._step(tok.device)), tok.shape[0], Tv, fmap, float(p),
                   float(scale[0]), float(scale[1]), float(ratio[0]), float(ratio[1]), int(erase_half), int(value), _p(tok),
                   _stream())
         return tok

@@ -74,12 +74,15 @@ def head(sd, p, x):
     return F.linear(h, sd[p + '.1.weight'], sd[p + '.1.bias'])
 
 
-def tower_fwd(sd, cfg, tokens):
-    return T.tower(sd, tokens, cfg.mask, 'transformer.transformer.')
+def tower_fwd(sd, cfg, tokens, stable=False):
+    out = T.tower(sd, tokens, cfg.mask, 'transformer.transformer.')
+    if stable:  # dalle_bert.py:489-493 -> utils/utils.py:18-25 (DivideMax over the feature axis)
+        out = out / out.amax(dim=-1, keepdim=True)
+    return out
 
 
 def forward_losses(sd, cfg, text, target_tok, mask1, warp_tok=None, visual_tok=None, rel=True, vid=True,
-                   rel_no_fully_masked=True, not_fully_masked=None):
+                   rel_no_fully_masked=True, not_fully_masked=None, stable=False):
     """dalle_bert.py:1030-1127 given the injected mask / warped tokens.  Returns dict."""
     B = text.shape[0]
     ctrl = control_embedding(sd, cfg, text, visual_tok)
@@ -90,7 +93,7 @@ def forward_losses(sd, cfg, text, target_tok, mask1, warp_tok=None, visual_tok=N
     tm = torch.where(mask1, target_tok, cfg.MASK)
     temb = sd['image_emb.weight'][tm] + tpos
     tokens_msm = torch.cat([ctrl, temb], 1)
-    out = tower_fwd(sd, cfg, tokens_msm)
+    out = tower_fwd(sd, cfg, tokens_msm, stable)
     logits_msm = head(sd, 'to_logits', out[:, csl:])
     loss_msm = F.cross_entropy(logits_msm[~mask1], target_tok[~mask1])
     res = dict(control_emb=ctrl, tokens_msm=tokens_msm, out_msm=out, logits_msm=logits_msm, loss_msm=loss_msm)
@@ -98,7 +101,7 @@ def forward_losses(sd, cfg, text, target_tok, mask1, warp_tok=None, visual_tok=N
     if rel:
         half = B // 2
         ctrl_swap = torch.cat([ctrl[half:], ctrl[:half]], 0)  # swap(): chunk(2)[::-1], 110-114
-        out_neg = tower_fwd(sd, cfg, torch.cat([ctrl_swap, temb], 1))
+        out_neg = tower_fwd(sd, cfg, torch.cat([ctrl_swap, temb], 1), stable)
         lp = head(sd, 'to_logits_rel', out[:, 0]).squeeze()
         ln = head(sd, 'to_logits_rel', out_neg[:, 0]).squeeze()
         if rel_no_fully_masked:
@@ -113,7 +116,7 @@ def forward_losses(sd, cfg, text, target_tok, mask1, warp_tok=None, visual_tok=N
         res['loss_rel'] = torch.tensor(0.0)
     if vid and cfg.num_targets > 1:
         wm = torch.where(mask1, warp_tok, cfg.MASK)
-        out_neg = tower_fwd(sd, cfg, torch.cat([ctrl, sd['image_emb.weight'][wm] + tpos], 1))
+        out_neg = tower_fwd(sd, cfg, torch.cat([ctrl, sd['image_emb.weight'][wm] + tpos], 1), stable)
         lp = head(sd, 'to_logits_vid', out[:, cfg.vid])
         ln = head(sd, 'to_logits_vid', out_neg[:, cfg.vid])
         if rel_no_fully_masked:  # NB reference does not multiply by not_fully_masked here (1107-1116)

@@ -6,6 +6,11 @@ The reference draws these on the host inside forward(), from numpy / `random` / 
                    dalle_artv.py:229-232 -- THIRD PARTY (torchvision is absent from /root/reference and unpinned in its
                    requirements.txt): restated from the published semantics, "parity unpinned" for the box distribution
   warp             dalle_bert.py:93-238 (frame from another sample / frame shuffle / colour shift / affine warp)
+PINNED (tests/test_oracle_golden.py::test_frontend_*): given the decisions the reference's generators drew (recovered by
+tools/make_golden.py::case_frontend by replaying the draws), `apply_warp`, `affine_warp`, `color_shift`,
+`video_color_shift`, `swap_halves` and `build_msm_mask` reproduce the outputs of the reference's own warp / warp_with_affine /
+warp_with_color / warp_video_with_color / swap / MSM loop (tests/golden/frontend.npz).  What stays unpinned is only the
+distribution of torchvision's RandomErasing box (third party).
 The product draws the same DISTRIBUTIONS on the device (mmvid_amd/csrc/frontend.hip) from a counter-based generator;
 bit-level agreement of two different generators is impossible, so tests compare statistics (strategy frequencies, box
 area / aspect / position moments, keep rates) and compare the deterministic parts (the affine resampling for given
@@ -30,6 +35,56 @@ def erasing_box(rng, H, W, scale, ratio):
             continue
         return int(rng.randint(0, H - h + 1)), int(rng.randint(0, W - w + 1)), h, w
     return None
+
+
+def build_msm_mask(strategy, T, f, bern=None, box=None, keep_frames=()):
+    """One sample's mask1 (True = visible) from the decisions of dalle_bert.py:996-1026: strategy 1 keeps where the Bernoulli
+    draw `bern` is 1, 2 hides everything, 3 hides the RandomErasing box (i, j, h, w), 4 shows only the box; afterwards the
+    frames in keep_frames are made fully visible (1022-1026).  -> (mask bool [T*f*f], not_fully_masked)."""
+    n = f * f
+    if strategy == 1:
+        m = np.asarray(bern).reshape(-1) == 1
+    elif strategy == 2:
+        m = np.zeros(T * n, bool)
+    else:
+        one = np.ones((T, f, f), bool)
+        if box is not None:
+            i0, j0, h, w = box
+            one[:, i0:i0 + h, j0:j0 + w] = False
+        m = one.reshape(-1) if strategy == 3 else ~one.reshape(-1)
+    m = m.copy()
+    for tt in keep_frames:
+        m[n * tt:n * (tt + 1)] = True
+    return m, 0.0 if strategy == 2 else 1.0
+
+
+def color_shift(frame, shift, num):
+    """warp_with_color (dalle_bert.py:124-135) for a drawn (c_shift, num): frame [C,H,W]; num 0 = every channel."""
+    m = torch.zeros_like(frame)
+    if num == 0:
+        m += shift
+    else:
+        m[num - 1] += shift
+    return torch.clamp(frame + m, 0, 1)
+
+
+def video_color_shift(video, params):
+    """warp_video_with_color (dalle_bert.py:140-158): video [n,t,C,H,W], one (c_shift, num) per sample for all its frames."""
+    out = []
+    for x, (shift, num) in zip(video, params):
+        m = torch.zeros_like(x)
+        if int(num) == 0:
+            m += float(shift)
+        else:
+            m[:, int(num) - 1] += float(shift)
+        out.append(torch.clamp(x + m, 0, 1))
+    return torch.stack(out)
+
+
+def swap_halves(x):
+    """swap(tensor, 0) for an even batch (dalle_bert.py:110-113): the two halves exchanged."""
+    h = x.shape[0] // 2
+    return torch.cat((x[h:], x[:h]), 0)
 
 
 def msm_masks(rng, B, T, f, strategy_prob, bernoulli_prob, pc_prob=0.0):
@@ -61,9 +116,12 @@ def msm_masks(rng, B, T, f, strategy_prob, bernoulli_prob, pc_prob=0.0):
 
 
 def affine_theta(angle, t1, t2, scale):
-    """dalle_bert.py:168-202: [[s cos a, s sin(-a), t1], [s sin a, s cos a, t2]]."""
-    return torch.tensor([[scale * math.cos(angle), scale * math.sin(-angle), t1],
-                         [scale * math.sin(angle), scale * math.cos(angle), t2]], dtype=torch.float32)
+    """dalle_bert.py:168-202: [[s cos a, s sin(-a), t1], [s sin a, s cos a, t2]], in fp32 tensor arithmetic as the reference."""
+    a, s = torch.tensor(angle, dtype=torch.float32), torch.tensor(scale, dtype=torch.float32)
+    th = torch.empty(2, 3)
+    th[0, 0], th[0, 1], th[0, 2] = s * torch.cos(a), s * torch.sin(-a), t1
+    th[1, 0], th[1, 1], th[1, 2] = s * torch.sin(a), s * torch.cos(a), t2
+    return th
 
 
 def affine_warp(frame, theta):

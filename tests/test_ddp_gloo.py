@@ -176,7 +176,10 @@ def _worker_sparse(rank, world, port, q):
             p.data.normal_()
         broadcast_parameters(m)
         tr = FlatTrainer(m, order=backward_order, bucket_mb=0.001)
-        assert tr.sparse_tables and tr._sparse_ranges() == [(0, 512)]  # text_emb [50, 8] = 400 elements, padded to 4 x 128
+        # nothing logged yet: the table is NOT cut out of the dense all-reduce (it would otherwise never be summed)
+        assert tr.sparse_tables and tr._sparse_ranges() == []
+        m.ids = torch.tensor([[1]])
+        assert tr._sparse_ranges() == [(0, 512)]  # text_emb [50, 8] = 400 elements, padded to 4 x 128
         for step in range(2):
             tr.zero_grad()
             m.ids = torch.tensor([[3, 7, 7, 49], [3, 0, 11 + rank, 20 + 5 * step]])  # 3 shared, 7 repeated, 11 + rank disjoint
@@ -201,6 +204,69 @@ def _worker_sparse(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_dense_fallback(rank, world, port, q):
+    """A table whose row log is missing (ids None: no forward logged, or the log overflowed) goes through the dense
+    all-reduce: every rank still ends with the full sum."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from mmvid_amd.engine import FlatTrainer, backward_order
+        torch.manual_seed(5)
+        m = _ToySparse()
+        m.ids = None
+        tr = FlatTrainer(m, order=backward_order, bucket_mb=0.001)
+        tr.zero_grad()
+        for i, p in enumerate(tr.params):
+            p.grad.fill_(float((rank + 1) * (i + 1)))
+        tr.layers_done(0)
+        tr.allreduce_grads()
+        for i, (n, p) in enumerate(zip(tr.names, tr.params)):
+            assert torch.all(p.grad == sum((r + 1) * (i + 1) for r in range(world))), n
+        q.put((rank, 'ok'))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_trainer_dense_fallback_without_row_log_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dense_fallback, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == 'ok' for r in res), res
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without a launcher (how the driver runs every N) must start its own ranks
+    (train.py:47-66 spawns them from main()); --dry-run = rank / argument plumbing over gloo, no GPU work.  Without
+    --dry-run on a box with fewer devices than ranks it must fail AFTER spawning, with a clear message."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run'],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['dry_run'] and out['config']['global_batch'] == 12
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                           capture_output=True, text=True, timeout=240, env=env)
+        assert r.returncode != 0 and 'device(s) visible' in r.stderr, r.stderr[-2000:]
 
 
 @pytest.mark.timeout(300)
@@ -243,3 +309,44 @@ def test_flat_trainer_exchange_world2():
     for p in procs:
         p.join(60)
     assert all(r[1] == 'ok' for r in res), res
+
+
+def test_flat_trainer_loads_torch_adam_state_by_name():
+    """a plain torch.optim.Adam state_dict (the reference's checkpoints, train.py:352) is indexed in
+    model.parameters() order, the flat buffer in backward order: moments must land on the parameter of the same NAME
+    (the tower layers have identical shapes, so an index mix-up would go unnoticed), shapes are verified, and the
+    trainer's own state_dict round-trips together with the front-end's (seed, step)."""
+    from mmvid_amd.engine import FlatTrainer, backward_order
+    torch.manual_seed(0)
+    m = _Toy()
+    for p in m.parameters():
+        p.data.normal_()
+    named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+    opt = torch.optim.Adam([p for _, p in named], lr=3e-4)
+    for i, (_, p) in enumerate(named):
+        p.grad = torch.full_like(p, float(i + 1))
+    opt.step()
+    sd = opt.state_dict()
+    assert 'names' not in sd
+    order = lambda ps: list(reversed(backward_order(ps)))  # any flat order that is not torch's
+    tr = FlatTrainer(m, order=order)
+    assert tr.names != [n for n, _ in named]  # the two orders really differ
+    tr.load_state_dict(sd)
+    assert tr.step_count == 1 and tr.lr == 3e-4
+    for j, (n, p) in enumerate(named):
+        i = tr.names.index(n)
+        o, k = tr.offsets[i], p.numel()
+        assert torch.equal(tr.M[o:o + k].view(p.shape), sd['state'][j]['exp_avg']), n
+        assert torch.equal(tr.V[o:o + k].view(p.shape), sd['state'][j]['exp_avg_sq']), n
+    # own format round trip
+    own = tr.state_dict()
+    tr2 = FlatTrainer(m, order=order)
+    tr2.load_state_dict(own)
+    assert torch.equal(tr2.M, tr.M) and torch.equal(tr2.V, tr.V)
+    # a state saved for other parameters / shapes is refused
+    bad = {'state': {0: {'step': torch.tensor(1.), 'exp_avg': torch.zeros(3, 3), 'exp_avg_sq': torch.zeros(3, 3)}},
+           'param_groups': sd['param_groups']}
+    with pytest.raises(ValueError):
+        tr2.load_state_dict(bad)
+    with pytest.raises(ValueError):
+        tr2.load_state_dict(dict(own, names=own['names'][:-1] + ['nope']))

@@ -169,3 +169,106 @@ def test_race_sampler_matches_multinomial_distributions():
     pres = np.array([1, 0, 0, 0, 0, 0], bool)
     k = S.keep_race(w, rng.exponential(size=6).astype(np.float32), pres, 2)
     assert k[0] and k.sum() == 3
+
+
+def _warp_params(dec):
+    """tests/golden/frontend.npz `warp_decisions` rows -> oracle.frontend.apply_warp parameter dicts."""
+    from oracle.frontend import affine_theta
+    out = []
+    for r in dec.tolist():
+        out.append(dict(mode=int(r[0]), j1=int(r[1]), src_b=int(r[2]), src_t=int(r[3]), chan=int(r[4]), shift=float(np.float32(r[5])),
+                        theta=affine_theta(*[float(np.float32(v)) for v in r[6:10]]), perm=[int(v) for v in r[10:16]]))
+    return out
+
+
+def test_frontend_oracle_pinned_to_reference_warps(golden):
+    """H6 / N2 pin: oracle/frontend.py against the reference's OWN warp_with_affine / warp_with_color /
+    warp_video_with_color / swap / warp (dalle_bert.py:93-238), given the decisions its generators drew."""
+    from oracle import frontend as F
+    g = golden('frontend')
+    frame = g['frame']
+    for p, ref in zip(g['affine_params'], g['affine_out']):
+        got = F.affine_warp(frame, F.affine_theta(*[float(v) for v in p]))
+        assert relerr(got, ref) <= 1e-6
+    for (shift, num), ref in zip(g['color_params'].tolist(), g['color_out']):
+        assert torch.equal(F.color_shift(frame, float(np.float32(shift)), int(num)), ref)
+    vp = [(float(np.float32(a)), int(b)) for a, b in g['video_color_params'].tolist()]
+    assert torch.equal(F.video_color_shift(g['video'], vp), g['video_color_out'])
+    assert torch.equal(F.swap_halves(g['swap_in']), g['swap_out'])
+    x = g['clip']
+    seen = set()
+    for dec, ref in zip(g['warp_decisions'], g['warp_out']):
+        params = _warp_params(dec)
+        seen |= {p['mode'] for p in params}
+        got = F.apply_warp(x, params)
+        for b, p in enumerate(params):
+            if p['mode'] == 3:
+                assert relerr(got[b], ref[b]) <= 1e-6
+            else:
+                assert torch.equal(got[b], ref[b]), (b, p['mode'])
+    assert seen == {0, 1, 2, 3}
+
+
+def test_frontend_oracle_pinned_to_reference_msm_loop(golden):
+    """The MSM masking loop of BERT.forward (dalle_bert.py:992-1029) run by the reference: build_msm_mask applied to the
+    recorded decisions (strategy, Bernoulli field, RandomErasing box, preserved frames) gives the reference's mask1."""
+    from oracle.frontend import build_msm_mask
+    g = golden('frontend')
+    T, f = g.meta['T'], g.meta['fmap']
+    strat, box, keep, bern, ref = g['msm_strategy'], g['msm_box'], g['msm_keep_frames'], g['msm_bernoulli'], g['msm_mask1']
+    assert sorted(set(strat.tolist())) == [1, 2, 3, 4] and keep.sum() > 0
+    for i in range(len(strat)):
+        kf = [t for t in range(T) if keep[i, t] > 0]
+        m, nfm = build_msm_mask(int(strat[i]), T, f, bern[i].numpy(), tuple(box[i].tolist()), kf)
+        assert np.array_equal(m, ref[i].numpy()), (i, int(strat[i]))
+        assert nfm == (0.0 if int(strat[i]) == 2 else 1.0)
+
+
+def test_race_sampler_pinned_to_reference_mask_predict(golden):
+    """oracle/sampling.py against the reference's mask_predict (dalle_bert.py:514-714) run with torch.multinomial replaced by
+    the exponential race on recorded variates (tests/golden/mask_predict_race.npz): every token draw, keep set, candidate
+    update / choice and the dynamic stop, decision for decision."""
+    from oracle import sampling as S
+    g = golden('mask_predict_race')
+    for tag, c in g.meta['cases'].items():
+        nv, steps, dyn, Bm = c['videos'], c['steps'], c['dynamic'], c['B']
+        logits, Et, tok, Yt = g[tag + '_logits'], g[tag + '_E_tok'], g[tag + '_tok'], g[tag + '_Y_tok']
+        Ek, Yk, kk, keep = g[tag + '_E_keep'], g[tag + '_Y_keep'], g[tag + '_k_keep'], g[tag + '_keep']
+        itok, zr, zv, final = g[tag + '_itok'], g[tag + '_z_rel'], g[tag + '_z_vid'], g[tag + '_final']
+        TS = final.shape[1]
+        # every token draw: first argmin of E / P and its probability
+        for r in range(logits.shape[0]):
+            t_, Y_, _ = S.token_race(logits[r], Et[r])
+            assert np.array_equal(t_, tok[r].numpy()), (tag, r)
+            assert np.allclose(Y_, Yt[r].numpy(), rtol=2e-6, atol=0)
+        ti = ki = ii = 0
+        for v in range(nv):
+            ii += 1  # tok_in of this video
+            Y, I_tok = Yt[ti].numpy(), tok[ti].numpy()
+            ti += 1
+            Smax, tmax, Imax, stopped = 0.0, 0, None, False
+            for t in range(1, steps):
+                masks = []
+                for j in range(Bm):
+                    assert np.allclose(Yk[ki].numpy(), Y, rtol=0, atol=0), 'the confidences the reference drew the keep set from'
+                    assert np.array_equal(itok[ii].numpy(), I_tok)
+                    k = S.keep_race(Y, Ek[ki], None, int(kk[ki]))
+                    assert np.array_equal(k, keep[ki].numpy()), (tag, v, t, j)
+                    masks.append(k)
+                    ki += 1
+                    ii += 1
+                Ynew = np.stack([Yt[ti + j].numpy() for j in range(Bm)])
+                Inew = np.stack([tok[ti + j].numpy() for j in range(Bm)])
+                Y, I_tok, Sc, jmax = S.update(Y, I_tok, np.stack(masks), Ynew, Inew, zr[ti - v - 1:ti - v - 1 + Bm], zv[ti - v - 1:ti - v - 1 + Bm])
+                ti += Bm
+                if dyn:
+                    Smax, tmax, took, stop = S.dynamic_stop(float(Sc[jmax]), t, Smax, tmax)
+                    if took:
+                        Imax = I_tok
+                    if stop:
+                        stopped = True
+                        break
+                else:
+                    Imax = I_tok
+            assert np.array_equal(Imax, final[v].numpy()), (tag, v)
+        assert ti == logits.shape[0] and ki == Ek.shape[0], (tag, ti, ki)

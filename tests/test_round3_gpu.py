@@ -1,0 +1,336 @@
+"""Round-3 parity pins on a real MI355X: the device front-end and the samplers against outputs of the REFERENCE's own
+functions (tests/golden/frontend.npz, mask_predict_race.npz: tools/make_golden.py::case_frontend / case_mask_predict_race),
+the remaining BERT options (stable, motion_color, width-512 tower), and the data-parallel row-wise exchange with a
+simulated second rank."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr
+from test_host_logic import tiny_bert
+from test_models_gpu import DEV, close, load_synth
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------------------------- H6 / N2: front-end vs the reference
+def _pack_warp_params(dec, T):
+    """golden `warp_decisions` rows -> the kernel's WarpParams records (176 B: 5 int, shift, theta[6], perm[32])."""
+    from oracle.frontend import affine_theta
+    B = dec.shape[0]
+    raw = np.zeros((B, 44), np.int32)
+    f = raw.view(np.float32)
+    for b, r in enumerate(dec.tolist()):
+        mode = int(r[0])
+        raw[b, 0], raw[b, 1], raw[b, 2], raw[b, 3], raw[b, 4] = mode, int(r[1]), int(r[2]) if mode == 0 else b, int(r[3]), int(r[4])
+        f[b, 5] = np.float32(r[5])
+        if mode == 3:
+            f[b, 6:12] = affine_theta(*[float(np.float32(v)) for v in r[6:10]]).reshape(-1).numpy()
+        raw[b, 12:44] = np.arange(32)
+        if mode == 1:
+            raw[b, 12:12 + T] = [int(v) for v in r[10:10 + T]]
+    return torch.from_numpy(raw.view(np.uint8).reshape(-1).copy())
+
+
+def test_device_vid_warp_equals_reference_warp(golden):
+    """mmvid_vid_warp applied to the decisions the reference's `warp` drew (dalle_bert.py:204-238) gives the reference's
+    warped clip: frame swap / shuffle / colour shift exactly, the affine resampling within fp32 round-off."""
+    from mmvid_amd.frontend import Frontend
+    g = golden('frontend')
+    x = g['clip'].to(DEV)
+    fe = Frontend(seed=0)
+    seen = set()
+    for dec, ref in zip(g['warp_decisions'], g['warp_out']):
+        params = _pack_warp_params(dec, x.shape[1]).to(DEV)
+        out = fe.vid_warp(x, [0.25] * 4, params=params).cpu()
+        for b in range(x.shape[0]):
+            mode = int(dec[b, 0])
+            seen.add(mode)
+            if mode == 3:
+                assert relerr(out[b], ref[b]) <= 2e-5, (b, relerr(out[b], ref[b]))
+            else:
+                assert torch.equal(out[b], ref[b]), (b, mode)
+        # the one-new-frame form used by BERT.forward: the new frame equals the reference's frame j1
+        nf = torch.empty(x.shape[0], *x.shape[2:], device=DEV)
+        import mmvid_amd._lib as L
+        from mmvid_amd.ops import _p, _stream
+        L.call('mmvid_vid_warp_new_frames', 0, None, _p(x), x.shape[0], x.shape[1], 3, x.shape[3], x.shape[4],
+               (L.F * 4)(0.25, 0.25, 0.25, 0.25), _p(params), 0, _p(nf), _stream())
+        for b in range(x.shape[0]):
+            if int(dec[b, 0]) in (2, 3):
+                assert relerr(nf[b].cpu(), ref[b, int(dec[b, 1])]) <= 2e-5
+    assert seen == {0, 1, 2, 3}
+
+
+def test_device_msm_kernel_on_reference_decisions(golden):
+    """The MSM mask kernel fed the decisions of a reference BERT.forward run (strategy, Bernoulli field, RandomErasing box,
+    preserved frames; dalle_bert.py:992-1029) reproduces the reference's mask1 and not_fully_masked."""
+    from mmvid_amd.frontend import Frontend
+    g = golden('frontend')
+    T, f = g.meta['T'], g.meta['fmap']
+    strat, box, keep = g['msm_strategy'], g['msm_box'], g['msm_keep_frames']
+    B = strat.shape[0]
+    dec = torch.zeros(B, 72, dtype=torch.int32)
+    dec[:, 0] = strat.int()
+    dec[:, 1] = (strat >= 3).int()
+    dec[:, 2:6] = box.int()
+    dec[:, 8:8 + T] = (keep > 0).int()
+    mask1, nfm = Frontend.msm_masks_from_decisions(dec.to(DEV), g['msm_bernoulli'].to(torch.uint8).to(DEV), T, f)
+    assert torch.equal(mask1.cpu().bool(), g['msm_mask1'])
+    assert torch.equal(nfm.cpu(), (strat != 2).float())
+
+
+def test_motion_color_on_device(golden):
+    """visual_aug_mode='motion_color' (dalle_bert.py:140-158, 940-943): the device kernel's output equals
+    oracle.frontend.video_color_shift -- pinned to the reference's warp_video_with_color -- for the parameters it drew;
+    frame 0 is never touched; the gate fires with probability 0.9; the BERT / ART-V forward accept the mode."""
+    from mmvid_amd.frontend import Frontend
+    from oracle.frontend import video_color_shift
+    g = golden('frontend')
+    video = g['video']  # [4, 3, 3, 16, 16]
+    fe = Frontend(seed=11)
+    gates, chans = [], []
+    for rep in range(60):
+        out, prm = fe.visual_color_jitter(video.to(DEV), 0.9, 1, want_params=True)
+        prm = prm.cpu()
+        gates.append(float(prm[0, 0]))
+        assert (prm[:, 0] == prm[0, 0]).all()  # ONE gate per call
+        assert torch.equal(out[:, 0].cpu(), video[:, 0])
+        if prm[0, 0] > 0:
+            ref = video_color_shift(video[:, 1:], [(float(s), int(c)) for _, s, c in prm.tolist()])
+            assert torch.equal(out[:, 1:].cpu(), ref)
+            chans += [int(c) for c in prm[:, 2].tolist()]
+            assert (prm[:, 1] >= -0.5).all() and (prm[:, 1] < 0.5).all()
+        else:
+            assert torch.equal(out.cpu(), video)
+        fe.advance(DEV)
+    assert 0.75 <= np.mean(gates) <= 1.0 and set(chans) == {0, 1, 2, 3}
+    # the golden's own parameters through the oracle are pinned on CPU (test_oracle_golden); here: model plumbing
+    m = load_synth(tiny_bert(1, True), golden('bert_tiny_visual'), 17).train()
+    gb = golden('bert_tiny_visual')
+    vis = torch.rand(2, 1, 3, 64, 64, device=DEV)
+    out = m(gb['text'].to(DEV), visual=vis, target=gb['frames'].to(DEV), return_loss=True, rel=True, vid=True,
+            visual_aug_mode='motion_color')
+    assert all(torch.isfinite(o) for o in out)
+
+
+# -------------------------------------------------------------------------------- H7: samplers vs the reference's race run
+def test_sampler_kernels_on_reference_race_trajectory(golden):
+    """The reference's mask_predict with torch.multinomial as an exponential race on recorded variates
+    (tests/golden/mask_predict_race.npz): the HIP kernels, fed the reference's logits / confidences and the same variates,
+    take the reference's decisions -- every sampled token and its probability, every keep set, the sequential candidate
+    update, the best-candidate choice and the dynamic stop."""
+    from mmvid_amd import ops
+    g = golden('mask_predict_race')
+    for tag, c in g.meta['cases'].items():
+        nv, steps, dyn, Bm = c['videos'], c['steps'], c['dynamic'], c['B']
+        logits, Et, tok, Yt = g[tag + '_logits'], g[tag + '_E_tok'], g[tag + '_tok'], g[tag + '_Y_tok']
+        Ek, kk, keep = g[tag + '_E_keep'], g[tag + '_k_keep'], g[tag + '_keep']
+        zr, zv, final = g[tag + '_z_rel'], g[tag + '_z_vid'], g[tag + '_final']
+        P, TS, V = logits.shape
+        t_dev, y_dev = ops.sample_race(logits.view(P * TS, V).contiguous().to(DEV), Et.view(P * TS, V).contiguous().to(DEV))
+        assert torch.equal(t_dev.cpu().view(P, TS), tok), f'{tag}: {(t_dev.cpu().view(P, TS) != tok).sum().item()} token draws differ'
+        assert relerr(y_dev.cpu().view(P, TS), Yt) <= 2e-6
+        ti = ki = 0
+        for v in range(nv):
+            Y = Yt[ti:ti + 1].clone().to(DEV).contiguous()
+            I_tok = tok[ti:ti + 1].clone().to(DEV).contiguous()
+            ti += 1
+            Imax = I_tok.clone()
+            Smax, tmax = torch.zeros(1, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+            active = torch.ones(1, dtype=torch.uint8, device=DEV)
+            for t in range(1, steps):
+                if not bool(active[0]):
+                    break
+                mask1 = ops.mp_select_keep(Y, Ek[ki:ki + Bm].view(1, Bm, TS).contiguous().to(DEV), None, int(kk[ki]))
+                assert torch.equal(mask1.cpu().view(Bm, TS).bool(), keep[ki:ki + Bm]), (tag, v, t)
+                ki += Bm
+                pz = ti - v - 1
+                ops.mp_update(mask1, Yt[ti:ti + Bm].contiguous().to(DEV), tok[ti:ti + Bm].contiguous().to(DEV),
+                              zr[pz:pz + Bm].contiguous().to(DEV), zv[pz:pz + Bm].contiguous().to(DEV), t, dyn, Y, I_tok, Imax,
+                              Smax, tmax, active)
+                ti += Bm
+            assert torch.equal(Imax.cpu()[0], final[v]), (tag, v)
+        assert ti == P and ki == Ek.shape[0], (tag, ti, ki)
+
+
+def test_mask_predict_free_running_against_reference_race_run(golden):
+    """The whole HIP sampler (bf16 tower) on the reference's variates, free running: step 0 must reproduce the
+    reference's tokens up to bf16 near-ties; the final agreement is reported (one flipped near-tie changes the inputs of
+    every later step, so it is informational -- the decision-level pin is the test above)."""
+    g, gb = golden('mask_predict_race'), golden('bert_tiny')
+    from oracle.synth import synth_tokens
+    m = load_synth(tiny_bert(), gb, 17).eval()
+    text = synth_tokens('text', (2, 16), 49408, 17, low=1)
+    text[0, 11:] = 0
+    text[1, 5:] = 0
+    c = g.meta['cases']['a']
+    Et, Ek, tok = g['a_E_tok'], g['a_E_keep'], g['a_tok']
+    Bm, steps, TS = c['B'], c['steps'], 32
+    per_video = 1 + (steps - 1) * Bm  # tower passes per video in the reference's order: video-major
+    trace = []
+
+    def race(name, shape):
+        if name == 'tok0':
+            return torch.cat([Et[v * per_video] for v in range(2)]).to(DEV)
+        t = int(name[3:] if name.startswith('tok') else name[4:])
+        if name.startswith('keep'):
+            rows = [Ek[v * (steps - 1) * Bm + (t - 1) * Bm + j] for v in range(2) for j in range(Bm)]
+            return torch.stack(rows).view(2, Bm, TS).to(DEV)
+        rows = [Et[v * per_video + 1 + (t - 1) * Bm + j] for v in range(2) for j in range(Bm)]
+        return torch.cat(rows).to(DEV)
+
+    mp = dict(g.meta['mp_config'], B=Bm)
+    _, _, seq = m.generate_images(text.to(DEV), mask_predict_steps=steps, mp_config=mp, dynamic=False, _race=race, _trace=trace)
+    step0 = trace[0]['I_tok'].cpu()
+    ref0 = torch.stack([tok[v * per_video] for v in range(2)])
+    agree0 = (step0 == ref0).float().mean().item()
+    agree = (seq.cpu().view(2, TS) == g['a_final']).float().mean().item()
+    print(f'free-running HIP sampler vs the reference race run: step-0 tokens {agree0:.3f}, final tokens {agree:.3f} equal')
+    assert agree0 >= 0.9
+
+
+# --------------------------------------------------------------------------------------------- X1: stable=True on the device
+def test_stable_divide_max_on_device(golden):
+    """BERT(stable=True): transformer_forward divides the tower output by its row maximum (utils/utils.py:18-25,
+    dalle_bert.py:489-493); forward + backward run on the HIP path and agree with the unnormalised model / amax."""
+    g = golden('bert_tiny')
+    m = load_synth(tiny_bert(), g, 17).train()
+    ms = load_synth(tiny_bert(stable=True), g, 17).train()
+    assert ms.stable and ms.norm_by_max is not None
+    x = torch.randn(2, ms.total_seq_len, 768, device=DEV)
+    y, ys = m.transformer_forward(x), ms.transformer_forward(x)
+    assert torch.allclose(ys, y / y.amax(dim=-1, keepdim=True), rtol=1e-6, atol=1e-7)
+    text, frames = g['text'].to(DEV), g['frames'].to(DEV)
+    lm, lr, lv = ms(text, target=frames, return_loss=True, rel=True, vid=True, _mask1=g['mask1'], _target_warp=g['warped_frames'].to(DEV))
+    (7 * lm + 0.5 * lr + 0.5 * lv).backward()
+    gr = ms.transformer.transformer.resblocks[0].mlp.c_fc.weight.grad
+    assert all(torch.isfinite(v) for v in (lm, lr, lv)) and torch.isfinite(gr).all() and gr.abs().sum() > 0
+    # oracle: the same losses with the same normalisation (fp32 CPU)
+    from oracle import bert as ob
+    from conftest import synth_model_sd
+    sd = synth_model_sd(g, 17)
+    cfg = ob.Cfg(sd, 16, 0, 2, 64)
+    r = ob.forward_losses(sd, cfg, g['text'], g['target_tok'], g['mask1'], g['warp_tok'], rel_no_fully_masked=False, stable=True)
+    tt = ms.get_image_tokens(frames).cpu()
+    if torch.equal(tt, g['target_tok']):  # bf16 encoder reproduced the tokens: the losses are comparable
+        for got, ref, nm in ((lm, r['loss_msm'], 'msm'), (lr, r['loss_rel'], 'rel'), (lv, r['loss_vid'], 'vid')):
+            assert abs(got.item() - ref.item()) <= 3e-2 * max(1.0, abs(ref.item())), (nm, got.item(), ref.item())
+
+
+# -------------------------------------------------------------------------------- width-512 text tower on the HIP path
+def test_openai_clip_text_tower_width512():
+    """which_transformer='openai_clip_text' (clip_model.py:538-547: width 512, 8 heads of 64): forward + backward against the
+    fp32 oracle tower on the same weights."""
+    from mmvid_amd.clip_tower import OpenAICLIPTransformer
+    from oracle import tower as ot
+    torch.manual_seed(3)
+    L = 77
+    tw = OpenAICLIPTransformer(L, 'openai_clip_text', causal=True, mask_type='causal', layers=2).to(DEV)
+    assert (tw.width, tw.heads) == (512, 8)
+    with torch.no_grad():
+        for p in tw.parameters():
+            if p.dim() > 1:
+                p.normal_(0, 0.03)
+    x = torch.randn(2, L, 512, device=DEV, requires_grad=True)
+    gy = torch.randn(2, L, 512, device=DEV)
+    y = tw(x)
+    y.backward(gy)
+    sd = {k: v.detach().float().cpu().requires_grad_(True) for k, v in tw.state_dict().items()}
+    xc = x.detach().cpu().requires_grad_(True)
+    mask = torch.full((L, L), float('-inf')).triu_(1)
+    yr = ot.tower(sd, xc, mask, 'transformer.', heads=8)
+    yr.backward(gy.cpu())
+    close(y, yr, 2e-2, 'width-512 tower y')
+    close(x.grad, xc.grad, 3e-2, 'width-512 tower dx')
+    close(tw.transformer.resblocks[0].attn.in_proj_weight.grad, sd['transformer.resblocks.0.attn.in_proj_weight'].grad, 3e-2, 'd in_proj')
+    close(tw.transformer.resblocks[1].mlp.c_proj.weight.grad, sd['transformer.resblocks.1.mlp.c_proj.weight'].grad, 3e-2, 'd c_proj')
+
+
+# ------------------------------------------------------------------- (e): row-wise exchange with a simulated second rank
+def test_sparse_exchange_with_simulated_peer_on_device(golden):
+    """FlatTrainer._exchange_sparse on the GPU with world = 2 simulated on one device: `_gather` is fed a fake peer's
+    (row ids, gradient rows), so the branch that adds OTHER ranks' rows (never taken with one real rank) runs as device
+    code; the result must equal the dense sum of both ranks' table gradients.  The dense `_send` path is checked the same
+    way through a fake all-reduce."""
+    from mmvid_amd.engine import FlatTrainer, backward_order
+    g = golden('bert_tiny')
+    m = load_synth(tiny_bert(), g, 17).train()
+    tr = FlatTrainer(m, order=backward_order)
+    text, frames = g['text'].to(DEV), g['frames'].to(DEV)
+    tr.zero_grad()
+    lm, lr, lv = m(text, target=frames, return_loss=True, rel=True, vid=True)
+    (7 * lm + 0.5 * lr + 0.5 * lv).backward()
+    W = m.text_emb.weight.grad
+    mine = W.clone()
+    ids = m.sparse_grad_rows()['text_emb.weight']
+    assert ids is not None and tr._sparse_ranges(), 'the text embedding is exchanged row-wise after a logged forward'
+    # the fake peer: overlapping, repeated and disjoint row ids, random rows; its dense table gradient
+    torch.manual_seed(1)
+    n = ids.numel()
+    peer_ids = torch.cat((ids[:n // 2], torch.randint(0, 49408, (n - n // 2, ), device=DEV)))
+    peer_dense = torch.zeros_like(W)
+    peer_dense[peer_ids.unique()] = torch.randn(peer_ids.unique().numel(), W.shape[1], device=DEV)
+    for my_rank in (0, 1):
+        W.copy_(mine)
+        puid, prows = FlatTrainer.pack_rows(peer_dense, peer_ids)
+        calls = []
+
+        def fake_gather(t, my_rank=my_rank, puid=puid, prows=prows):
+            peer = puid if t.dim() == 1 else prows
+            assert peer.shape == t.shape and peer.dtype == t.dtype
+            calls.append(t.shape)
+            return torch.cat((t, peer) if my_rank == 0 else (peer, t), 0)
+
+        tr.world, tr._gather, tr._rank = 2, fake_gather, (lambda my_rank=my_rank: my_rank)
+        tr._exchange_sparse()
+        assert len(calls) == 2
+        torch.testing.assert_close(W, mine + peer_dense, rtol=1e-6, atol=1e-6)
+        touched = torch.zeros(W.shape[0], dtype=torch.bool, device=DEV)
+        touched[ids] = True
+        touched[peer_ids] = True
+        assert W[~touched].abs().sum() == 0
+    # no forward logged (or the log overflowed) -> the table is NOT cut out of the dense all-reduce
+    tr.zero_grad()
+    assert m.sparse_grad_rows()['text_emb.weight'] is None and tr._sparse_ranges() == []
+    with torch.no_grad():
+        for _ in range(m.TEXT_ID_LOG_MAX + 1):
+            m._log_text_ids(torch.zeros(2, 1 + 16, dtype=torch.long, device=DEV))
+    assert m.sparse_grad_rows()['text_emb.weight'] is None  # torch.no_grad(): nothing is logged
+    for _ in range(m.TEXT_ID_LOG_MAX + 1):
+        m._log_text_ids(torch.zeros(2, 1 + 16, dtype=torch.long, device=DEV))
+    assert m._text_id_overflow and m.sparse_grad_rows()['text_emb.weight'] is None and tr._sparse_ranges() == []
+
+
+def test_frontend_seed_lives_on_the_device_and_follows_torch_seed(golden):
+    """the front-end seed defaults to torch.initial_seed() (+ rank), is read by the kernels from device memory (a
+    captured step follows `frontend.seed = ...`), and (seed, step) travel with the trainer's state_dict."""
+    from mmvid_amd.frontend import Frontend
+    torch.manual_seed(1234)
+    fe = Frontend()
+    a = fe.msm_masks(8, 2, 4, DEV, [0.25] * 4, [0.2, 0.5])[0].clone()
+    assert fe.seed == 1234
+    fe2 = Frontend(seed=1234)
+    assert torch.equal(a, fe2.msm_masks(8, 2, 4, DEV, [0.25] * 4, [0.2, 0.5])[0])
+    graph = torch.cuda.CUDAGraph()
+    out = torch.empty(64, 32, device=DEV, dtype=torch.uint8)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fe2.msm_masks(64, 2, 4, DEV, [0.25] * 4, [0.2, 0.5])
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        out.copy_(fe2.msm_masks(64, 2, 4, DEV, [0.25] * 4, [0.2, 0.5])[0])
+    graph.replay()
+    first = out.clone()
+    fe2.seed = 99  # written into the device state: the captured kernel reads it on the next replay
+    graph.replay()
+    assert not torch.equal(first, out)
+    fe3 = Frontend(seed=99)
+    assert torch.equal(out, fe3.msm_masks(64, 2, 4, DEV, [0.25] * 4, [0.2, 0.5])[0])
+    fe3.advance(DEV), fe3.advance(DEV)
+    sd = fe3.state_dict()
+    assert sd == {'seed': 99, 'step': 2.0}
+    fe4 = Frontend()
+    fe4.load_state_dict(sd)
+    assert torch.equal(fe4.msm_masks(64, 2, 4, DEV, [0.25] * 4, [0.2, 0.5])[0], fe3.msm_masks(64, 2, 4, DEV, [0.25] * 4, [0.2, 0.5])[0])

@@ -8,7 +8,7 @@ layout), and the reference's outputs.  Run:
 
     PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [case ...]
 
-Cases: vq vqgan_tiny vqgan_full tower bert_tiny bert_tiny_visual artv_tiny mask_predict
+Cases: vq vqgan_tiny vqgan_full tower bert_tiny bert_tiny_visual artv_tiny mask_predict frontend mask_predict_race
 """
 import json
 import os
@@ -337,9 +337,229 @@ def case_mask_predict():
     save('mask_predict', meta=dict(seed=17, vae_seed=11, torch_seed=31, mp_config=MP_CONFIG), **res)
 
 
+def case_frontend():
+    """The stochastic front-end's building blocks, run from the REFERENCE's own functions (dalle_bert.py:93-238, 992-1029):
+    outputs together with the decisions its generators drew, recovered by replaying the same draws from the same generator
+    states (the replay below follows the reference's draw order line by line; it decides nothing about the arithmetic)."""
+    import mmvid_pytorch.dalle_bert as db
+    res, meta = {}, {}
+    S = 32
+    # -- warp_with_affine (168-202): theta from the 4 uniform_ draws, replayed
+    frame = synth_input('frame', (3, S, S), 41, 'uniform')
+    res['frame'] = frame
+    aff_p, aff_o = [], []
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        out = db.warp_with_affine(frame, 30, 0.1, 0.1)
+        torch.manual_seed(seed)
+        pa = torch.FloatTensor(4)
+        ang = np.pi * 30 / 180.
+        pa[0].uniform_(-ang, ang), pa[1].uniform_(-0.1, 0.1), pa[2].uniform_(-0.1, 0.1), pa[3].uniform_(0.9, 1.1)
+        aff_p.append(pa.clone()), aff_o.append(out[0])
+    res['affine_params'], res['affine_out'] = torch.stack(aff_p), torch.stack(aff_o)  # (angle, t1, t2, scale)
+    # -- warp_with_color (124-135): c_shift = torch.rand(1) - 0.5, num = random.randint(0, 3)
+    col_p, col_o = [], []
+    for seed in (1, 2, 3, 4, 5, 6):
+        seed_all(seed)
+        out = db.warp_with_color(frame)
+        seed_all(seed)
+        shift = float(torch.rand(1) - 0.5)
+        num = random.randint(0, 3)
+        col_p.append([shift, num]), col_o.append(out[0])
+    res['color_params'], res['color_out'] = torch.tensor(col_p, dtype=torch.float64), torch.stack(col_o)
+    # -- warp_video_with_color (140-158; visual_aug_mode == 'motion_color'): per sample one shift for every frame
+    video = synth_input('video', (4, 3, 3, 16, 16), 42, 'uniform')
+    seed_all(9)
+    vout = db.warp_video_with_color(video)
+    seed_all(9)
+    vp = []
+    for _ in range(video.shape[0]):
+        shift = float(torch.rand(1) - 0.5)
+        vp.append([shift, random.randint(0, 3)])
+    res['video'], res['video_color_params'], res['video_color_out'] = video, torch.tensor(vp, dtype=torch.float64), vout
+    # -- swap (110-122), even batch: halves exchanged
+    ctl = synth_input('ctl', (4, 5, 8), 43, 'normal')
+    res['swap_in'], res['swap_out'] = ctl, db.swap(ctl, 0)
+    # -- warp (204-238): B = 4 samples x 8 seeds so every strategy occurs; decisions replayed in the reference's draw order
+    x = synth_input('clip', (4, 6, 3, 16, 16), 44, 'uniform')  # t = 6: randperm takes the torch.randperm branch (n >= 6)
+    res['clip'] = x
+    prob = [0.25, 0.25, 0.25, 0.25]
+    rows, outs = [], []
+    for seed in range(8):
+        seed_all(100 + seed)
+        y = db.warp(x, prob)
+        seed_all(100 + seed)
+        b, t = x.shape[:2]
+        for i in range(b):  # (mode, j1, src_b, src_t, chan, shift, angle, t1, t2, scale, perm[6])
+            rec = [0.] * 16
+            strategy = int(np.random.choice(range(4), p=prob))
+            rec[0] = strategy
+            if strategy == 0:
+                i_ = int(np.random.choice(list(set(range(b)) - {i})))
+                j1, j2 = random.randint(0, t - 1), random.randint(0, t - 1)
+                rec[1], rec[2], rec[3] = j1, i_, j2
+            elif strategy == 1:
+                perm_ord = torch.tensor(range(t))
+                while True:
+                    perm = torch.randperm(t)
+                    if (perm != perm_ord).any():
+                        break
+                rec[10:16] = [float(v) for v in perm]
+            elif strategy == 2:
+                rec[1] = random.randint(0, t - 1)
+                rec[5] = float(torch.rand(1) - 0.5)
+                rec[4] = random.randint(0, 3)
+            else:
+                rec[1] = random.randint(0, t - 1)
+                pa = torch.FloatTensor(4)
+                ang = np.pi * 30 / 180.
+                pa[0].uniform_(-ang, ang), pa[1].uniform_(-0.1, 0.1), pa[2].uniform_(-0.1, 0.1), pa[3].uniform_(0.9, 1.1)
+                rec[6:10] = [float(v) for v in pa]
+            rows.append(rec)
+        outs.append(y)
+    res['warp_decisions'] = torch.tensor(rows, dtype=torch.float64).view(8, 4, 16)
+    res['warp_out'] = torch.stack(outs)
+    # -- MSM masking loop (992-1029) inside BERT.forward: strategies / Bernoulli p from the numpy stream (replayed), boxes
+    #    recorded from the RandomErasing stand-in, the Bernoulli field and the final mask1 from the forward itself
+    m, man = _build_bert(0, False, 17, num_targets=4)
+    B, T, TL = 8, 4, 16
+    text = synth_tokens('text', (B, TL), 49408, 17, low=1)
+    tok = synth_tokens('tok', (B, T * 16), 256, 17)
+    boxes, bern = [], []
+    get_params = ref_stubs.RandomErasing.get_params
+
+    def rec_params(img, scale, ratio, value=None):
+        r = get_params(img, scale, ratio, value)
+        boxes.append([int(r[0]), int(r[1]), int(r[2]), int(r[3])])
+        return r
+
+    bern_orig = torch.bernoulli
+
+    def rec_bern(p, *a, **k):
+        r = bern_orig(p, *a, **k)
+        bern.append(r.clone())
+        return r
+
+    cap = []
+    h = m.image_emb.register_forward_hook(lambda mod, i, o: cap.append(i[0].clone()))
+    m.train()
+    msm_rows = []
+    strat_prob = [0.3, 0.1, 0.3, 0.3]
+    for case, (seed, pc_prob) in enumerate(((7, 0.0), (8, 0.0), (9, 0.6))):
+        boxes.clear(), bern.clear(), cap.clear()
+        ref_stubs.RandomErasing.get_params = staticmethod(rec_params)
+        torch.bernoulli = rec_bern
+        seed_all(seed)
+        np_state, py_state = np.random.get_state(), random.getstate()
+        with torch.no_grad():
+            m(text, target=tok, return_loss=True, rel=False, vid=False, msm_strategy_prob=np.array(strat_prob),
+              msm_bernoulli_prob=[0.2, 0.5], pc_prob=pc_prob)
+        ref_stubs.RandomErasing.get_params = staticmethod(get_params)
+        torch.bernoulli = bern_orig
+        mask1 = cap[0] != m.image_token_lut['[MASK]']
+        # replay the numpy / python streams in the loop's order
+        np.random.set_state(np_state), random.setstate(py_state)
+        bi, ki = 0, 0
+        for i in range(B):
+            which = int(np.random.choice([1, 2, 3, 4], p=strat_prob))
+            p, box, field, keep = 0.0, [0, 0, 0, 0], torch.zeros(T * 16), [0.] * T
+            if which == 1:
+                p = float(np.random.uniform(0.2, 0.5))
+                field = bern[ki]
+                ki += 1
+            elif which >= 3:
+                box = boxes[bi]
+                bi += 1
+            if pc_prob > 0 and random.random() < pc_prob:
+                t_overlap = random.randint(1, T // 2)
+                for tt in random.sample(range(T), t_overlap):
+                    keep[tt] = 1.
+            msm_rows.append(dict(case=case, strategy=which, p=p, box=box, keep_frames=keep, bern=field, mask1=mask1[i]))
+        assert bi == len(boxes) and ki == len(bern)
+    h.remove()
+    res['msm_strategy'] = torch.tensor([r['strategy'] for r in msm_rows])
+    res['msm_p'] = torch.tensor([r['p'] for r in msm_rows], dtype=torch.float64)
+    res['msm_box'] = torch.tensor([r['box'] for r in msm_rows])  # (i, j, h, w) of the erased rectangle on the f x f map
+    res['msm_keep_frames'] = torch.tensor([r['keep_frames'] for r in msm_rows])
+    res['msm_bernoulli'] = torch.stack([r['bern'] for r in msm_rows])  # the reference's torch.bernoulli draw (strategy 1)
+    res['msm_mask1'] = torch.stack([r['mask1'] for r in msm_rows])
+    meta.update(T=T, fmap=4, strategies_seen=sorted(set(int(v) for v in res['msm_strategy'])),
+                warp_modes_seen=sorted(set(int(v) for v in res['warp_decisions'][..., 0].flatten())))
+    assert meta['strategies_seen'] == [1, 2, 3, 4] and meta['warp_modes_seen'] == [0, 1, 2, 3], meta
+    save('frontend', meta=meta, **res)
+
+
+def case_mask_predict_race():
+    """The reference's mask_predict (dalle_bert.py:514-714) with torch.multinomial replaced by the exponential race it
+    implements (q ~ Exp(1) per category; with replacement: argmax p / q; without: the k largest), the variates recorded:
+    every draw's inputs and decisions, the state after every step, the final tokens.  oracle/sampling.py and the HIP
+    sampler must take the same decisions from the same variates."""
+    m, man = _build_bert(0, False, 17)
+    text = synth_tokens('text', (2, 16), 49408, 17, low=1)
+    text[0, 11:] = 0
+    text[1, 5:] = 0
+    m.eval()
+    real_multinomial = torch.multinomial
+    res = {}
+    for tag, nvid, steps, dyn, Bm in (('a', 2, 4, False, 2), ('b', 1, 9, True, 1)):
+        gen = torch.Generator().manual_seed(77)
+        calls, logit_cap, itok_cap, zr, zv = [], [], [], [], []
+
+        def race_multinomial(p, k, replacement=False):
+            E = torch.empty(p.shape).exponential_(generator=gen)
+            key = torch.where(p > 0, E / p, torch.full_like(p, float('inf')))
+            if p.dim() == 2:
+                assert k == 1
+                idx = key.argmin(1, keepdim=True)
+            else:
+                if k <= 0 or k > int((p > 0).sum()):
+                    raise RuntimeError('invalid multinomial draw (as torch.multinomial raises)')
+                idx = torch.sort(key, stable=True)[1][:k]
+            calls.append(dict(E=E, p=p.clone(), k=k, idx=idx.clone()))
+            return idx
+
+        hooks = [m.to_logits.register_forward_hook(lambda mod, i, o: logit_cap.append(o[0].clone())),
+                 m.image_emb.register_forward_hook(lambda mod, i, o: itok_cap.append(i[0].clone())),
+                 m.to_logits_rel.register_forward_hook(lambda mod, i, o: zr.append(o.reshape(-1).clone())),
+                 m.to_logits_vid.register_forward_hook(lambda mod, i, o: zv.append(o.reshape(-1).clone()))]
+        cfg = dict(MP_CONFIG, B=Bm)
+        torch.multinomial = race_multinomial
+        try:
+            seed_all(31)
+            with torch.no_grad():
+                ctrl = m(text[:nvid], return_loss=False)
+                seq, _ = m.mask_predict(ctrl, dynamic=dyn, steps=steps, mp_config=cfg)
+        finally:
+            torch.multinomial = real_multinomial
+            for h in hooks:
+                h.remove()
+        tok_calls = [c for c in calls if c['p'].dim() == 2]
+        keep_calls = [c for c in calls if c['p'].dim() == 1]
+        assert len(tok_calls) == len(logit_cap)
+        res[tag + '_final'] = seq
+        res[tag + '_logits'] = torch.stack(logit_cap)  # one [TS, V] per tower pass, in call order
+        res[tag + '_E_tok'] = torch.stack([c['E'] for c in tok_calls])
+        res[tag + '_tok'] = torch.stack([c['idx'].view(-1) for c in tok_calls])
+        res[tag + '_Y_tok'] = torch.stack([torch.gather(c['p'], 1, c['idx']).view(-1) for c in tok_calls])
+        res[tag + '_E_keep'] = torch.stack([c['E'] for c in keep_calls])
+        res[tag + '_Y_keep'] = torch.stack([c['p'] for c in keep_calls])  # the confidences the keep draw saw
+        res[tag + '_k_keep'] = torch.tensor([c['k'] for c in keep_calls])
+        keep = torch.zeros(len(keep_calls), seq.shape[1], dtype=torch.bool)
+        for r, c in enumerate(keep_calls):
+            keep[r, c['idx']] = True
+        res[tag + '_keep'] = keep
+        # image_emb inputs: [MASK] row (target_pos_emb setup), then per video tok_in and, per (step, candidate), I_tok BEFORE it
+        res[tag + '_itok'] = torch.stack([t.view(-1) for t in itok_cap[1:]])
+        res[tag + '_z_rel'], res[tag + '_z_vid'] = torch.cat(zr), torch.cat(zv)
+        res[tag + '_tower_passes'] = torch.tensor([len(logit_cap)])
+    save('mask_predict_race', meta=dict(seed=17, vae_seed=11, race_seed=77, mp_config=MP_CONFIG,
+                                        cases=dict(a=dict(videos=2, steps=4, dynamic=False, B=2),
+                                                   b=dict(videos=1, steps=9, dynamic=True, B=1))), **res)
+
+
 CASES = dict(vq=case_vq, vqgan_tiny=case_vqgan_tiny, vqgan_full=case_vqgan_full, tower=case_tower,
              bert_tiny=case_bert_tiny, bert_tiny_visual=case_bert_tiny_visual, artv_tiny=case_artv_tiny,
-             mask_predict=case_mask_predict)
+             mask_predict=case_mask_predict, frontend=case_frontend, mask_predict_race=case_mask_predict_race)
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
