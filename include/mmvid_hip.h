@@ -46,6 +46,9 @@ int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void*
                     int64_t ldc, float* out_colsum,
                     void* stream);
 
+/* Measurement only (tools/gemm_timeline.py): per-block time stamps of the next 256x128 GEMM launches; NULL switches it off. */
+int mmvid_gemm_trace(void* dev_buf);
+
 /* Weight gradient dW[N][K] (+)= dY^T X over M tokens (autograd of nn.Linear); split-K through `workspace`
  * ([splitk][N][K] fp32) with a fixed-order reduction: deterministic. */
 int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64_t ldy, const void* X, int64_t ldx, int splitk,

@@ -98,6 +98,7 @@ SIGNATURES = {
     'mmvid_groupnorm_swish_nhwc_f32': [P, I, I64, I, P, P, F, I, P, P, P],
     'mmvid_spatial_attention_f32': [P, P, P, I, I, I, F, P, P, P],
     'mmvid_probe': [I, P, P, P],
+    'mmvid_gemm_trace': [P],
     'mmvid_prof_begin': [I],
     'mmvid_prof_enable': [I],
     'mmvid_graph_stats': [P],

@@ -92,6 +92,11 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //                                       (whole-step A/B: 17.82 -> 17.77 ms; the block turnover is paid once per launch)
 //   gemm_debug     MMVID_GEMM_DEBUG     measurement only (tools/bench_gemm.py anatomy): 1 = the GEMM epilogue skips its global
 //                                       stores, 2 = the K loop is skipped (results are wrong in both)
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_COUNT = 11 };
+//   gemm_epi       MMVID_GEMM_EPI       epilogue of the 256x128 GEMM blocks: 0 = accumulators staged through an LDS slab (row-contiguous
+//                                       512-B stores), 1 = stored straight from the MFMA registers through buffer descriptors
+//                                       (16 B per lane, 8 stores per 128-B line) with the NEXT tile's first two K tiles requested
+//                                       before the stores, so a persistent block never waits for its own writes; 2 = as 1, and
+//                                       persistent bf16-output GEMMs defer a tile's stores into the next tile's K loop
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_COUNT = 12 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

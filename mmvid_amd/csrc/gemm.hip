@@ -50,11 +50,20 @@ struct GemmParams {
     float* colsum;   // [N] += column sums of the stored result (the bias gradient when the result is a dY), or null
     int debug;       // option gemm_debug (measurement only): 1 = no global stores, 2 = no K loop
     int tiles_n, tiles_m;  // > 0: persistent blocks walk this tile grid (option gemm_persist); 0: one block per tile
+    int defer;       // EPI >= 2: issue a tile's stores from inside the next tile's K loop (persistent blocks)
+    unsigned long long* trace;  // measurement only (mmvid_gemm_trace): per block, wave group and tile 8 time stamps (100 MHz)
 };
+unsigned long long* g_gemm_trace = nullptr;
+constexpr int TRACE_TILES = 8;
 
-__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
+// sigmoid(1.702 x) on the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 right after): an IEEE division here is
+// ~10 VALU instructions per element, and the epilogue of the c_fc GEMM evaluates 32,768 of them per tile with no MFMA to hide under
+__device__ __forceinline__ float sigmoid1702(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
+__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoid1702(x); }
 __device__ __forceinline__ float quick_gelu_grad(float x) {
-    float s = sigmoidf_(1.702f * x);
+    float s = sigmoid1702(x);
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
@@ -164,7 +173,227 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, char* smem, f
     }
 }
 
-template <bool AKM, bool BKM, int WM, int PP>
+
+// ---- register-direct epilogue (option gemm_epi = 1; 256x128 blocks).  A lane of the swapped-operand 32x32x16 MFMA holds, for
+// fragment (i, j) and q = 0..3, four consecutive columns n = bn0 + wn*64 + j*32 + 8q + 4*(lane>>5) of row m = bm0 + wm*64 + i*32 +
+// (lane&31): one 16-B (fp32) / 8-B (bf16) piece, so a store instruction writes 32 B / 16 B into each of 32 rows and the eight
+// (j, q) stores of a fragment row fill one 128-B line.  Poorly coalesced per instruction -- but it needs no LDS slab and no
+// barrier, so (a) the next tile's first two K tiles are requested BEFORE the stores and (b) the waves fall straight into the next
+// K loop while the writes drain: the LDS-staged epilogue costs ~10 us per block round at M = 10,422 (three dependent phases per
+// 32-row slab behind two barriers, then the first-tile latency of the next tile behind the in-order vmcnt of the stores:
+// profiles/r02_gemm_anatomy.log).  Every global access goes through a buffer descriptor with out-of-range lanes pointed at the
+// OOB marker: the instruction count per wave is then a compile-time constant (no exec-masked branches skipping stores), which
+// is what lets k_loop_pingpong's first waits be counted exactly (stores_after_prologue).
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+struct DirectEpi {
+    rsrc_t r_add, r_pre_in, r_pre_out, r_f32, r_bf16;
+    bool has_add, has_dact, has_save, has_f32, has_bf16;
+    int nst;  // vector-memory STORES per wave and tile (16 per output tensor)
+    __device__ __forceinline__ void init(const GemmParams& p, int batch) {
+        const long cb = (long)batch * p.strideC;
+        const float* addbase = p.residual ? p.residual + cb : ((p.accumulate && p.out_f32) ? p.out_f32 + cb : nullptr);
+        const long ldadd = p.residual ? p.ldr : p.ldc;
+        has_add = addbase != nullptr, has_dact = p.dact_pre != nullptr, has_save = p.save_pre != nullptr;
+        has_f32 = p.out_f32 != nullptr, has_bf16 = p.out_bf16 != nullptr;
+        const void* any = p.out_f32 ? (const void*)p.out_f32 : (const void*)p.out_bf16;
+        r_add = make_rsrc(has_add ? (const void*)addbase : any, has_add ? (uint32_t)(((long)(p.M - 1) * ldadd + p.N) * 4) : 0u);
+        r_pre_in = make_rsrc(has_dact ? (const void*)(p.dact_pre + cb) : any, has_dact ? (uint32_t)(((long)(p.M - 1) * p.ldp + p.N) * 2) : 0u);
+        r_pre_out = make_rsrc(has_save ? (const void*)(p.save_pre + cb) : any, has_save ? (uint32_t)(((long)(p.M - 1) * p.ldp + p.N) * 2) : 0u);
+        r_f32 = make_rsrc(has_f32 ? (const void*)(p.out_f32 + cb) : any, has_f32 ? (uint32_t)(((long)(p.M - 1) * p.ldc + p.N) * 4) : 0u);
+        r_bf16 = make_rsrc(has_bf16 ? (const void*)(p.out_bf16 + cb) : any, has_bf16 ? (uint32_t)(((long)(p.M - 1) * p.ldc + p.N) * 2) : 0u);
+        nst = 16 * ((has_save ? 1 : 0) + (has_f32 ? 1 : 0) + (has_bf16 ? 1 : 0));
+    }
+};
+// ---- deferred form (persistent blocks, bf16 outputs, N % 128 == 0): the finished tile is turned into its PACKED bf16 results
+// (bias / activation applied; 32 dwords per output tensor and lane) and the stores are issued a few at a time from inside the
+// NEXT tile's K loop (k_loop_pingpong's `drain`).  Measured why (tools/gemm_timeline.py, profiles/r03_gemm_timeline_*): all 256
+// blocks reach their epilogue together and the chip takes a 16-32 MB write burst at ~2.5-4 TB/s -- 3.8-11 us per round during
+// which the matrix pipe idles, against 10.7 us of K loop; spread over the next K loop the same bytes are ~1.6 TB/s of
+// background traffic.
+template <int NOUT>
+struct Pending {
+    u32x4_t v[NOUT][2][2][2];   // [tensor][i][j][k]: 16 B = 8 consecutive bf16 columns of one row (after the half-wave exchange)
+    uint32_t row[NOUT][2];      // byte offset of (row m_i, this lane's first column of j = k = 0), or OOB
+    int left;                   // store slots not yet issued (counts down from 8; a slot = one store per tensor)
+};
+template <int NOUT>
+__device__ __forceinline__ void pending_store(const DirectEpi& d, const Pending<NOUT>& pd, int o, int s) {
+    // s = 0..7 -> (i, j, k); a uniform switch: the register operands must be static
+    const rsrc_t r = (NOUT == 2 && o == 0) ? d.r_pre_out : d.r_bf16;
+#define MMVID_PS(I, J, K) __builtin_amdgcn_raw_buffer_store_b128(pd.v[o][I][J][K], r, pd.row[o][I] + (J * 64 + K * 32), 0, 0)
+    switch (s) {
+        case 0: MMVID_PS(0, 0, 0); break;
+        case 1: MMVID_PS(0, 0, 1); break;
+        case 2: MMVID_PS(0, 1, 0); break;
+        case 3: MMVID_PS(0, 1, 1); break;
+        case 4: MMVID_PS(1, 0, 0); break;
+        case 5: MMVID_PS(1, 0, 1); break;
+        case 6: MMVID_PS(1, 1, 0); break;
+        default: MMVID_PS(1, 1, 1); break;
+    }
+#undef MMVID_PS
+}
+// one drain slot = one store per output tensor, in (i, j, k) order; returns how many instructions were issued
+template <int NOUT>
+struct DrainSlot {
+    const DirectEpi* d;
+    Pending<NOUT>* pd;
+    __device__ __forceinline__ int operator()(int) const {
+        if (pd->left <= 0) return 0;
+        const int s = 8 - pd->left;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) pending_store<NOUT>(*d, *pd, o, s);
+        pd->left -= 1;
+        return NOUT;
+    }
+};
+template <int NOUT>
+__device__ __forceinline__ int pending_flush(const DirectEpi& d, Pending<NOUT>& pd) {
+    const int n = pd.left > 0 ? pd.left * NOUT : 0;
+    while (pd.left > 0) {
+        const int s = 8 - pd.left;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) pending_store<NOUT>(d, pd, o, s);
+        pd.left -= 1;
+    }
+    return n;
+}
+// the half-wave exchange of MI355X_MICROARCH / cdna_hip_programming.md T21: a lane holds columns 8q + 4 fh .. +3 of its row for q =
+// 0..3; v_permlane32_swap on (q = 2k, q = 2k+1) leaves lanes 0-31 with columns 16k .. 16k+7 and lanes 32-63 with 16k+8 .. 16k+15:
+// one 16-B store instead of two 8-B ones (a store costs its issue slot, not its bytes)
+__device__ __forceinline__ u32x4_t widen_pair(u32x2_t lo, u32x2_t hi) {
+    const auto a = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+    return u32x4_t{a[0], b[0], a[1], b[1]};
+}
+// this lane's 32 bias values of a tile ([j][q] float4), read from the LDS copy BEFORE the next tile's LDS-DMA is requested (an LDS
+// read behind in-flight LDS-DMA makes hipcc drain vmcnt)
+struct BiasRegs {
+    float4 b[2][4];
+};
+__device__ __forceinline__ void bias_load(const float* bias_lds, int bn0, int wn, int lane, BiasRegs& br) {
+    const int fh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            br.b[j][q] = bias_lds ? *reinterpret_cast<const float4*>(bias_lds + bn0 + wn * 64 + j * 32 + 8 * q + 4 * fh) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// accumulators -> packed results (bias, activation; out tensor 0 = save_pre when NOUT == 2, last = out_bf16)
+template <int NOUT>
+__device__ __forceinline__ void pending_fill(const GemmParams& p, const BiasRegs& br, f32x16 (&acc)[2][2], Pending<NOUT>& pd,
+                                             int bm0, int bn0, int wm, int wn, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) mfma_settle(acc[i][0]), mfma_settle(acc[i][1]);
+    const int frow = lane & 31, fh = lane >> 5;
+    const int n0 = bn0 + wn * 64 + 8 * fh;  // after the exchange: lanes 32-63 own the second 8 columns of every 16
+    const bool scaled = p.alpha != 1.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = bm0 + wm * 64 + i * 32 + frow;
+        const bool ok = m < p.M && p.debug != 1;
+        if constexpr (NOUT == 2) pd.row[0][i] = ok ? (uint32_t)(((long)m * p.ldp + n0) * 2) : OOB;
+        pd.row[NOUT - 1][i] = ok ? (uint32_t)(((long)m * p.ldc + n0) * 2) : OOB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x2_t pre[4], out[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = scaled ? acc[i][j][4 * q + e] * p.alpha : acc[i][j][4 * q + e];
+                v[0] += br.b[j][q].x, v[1] += br.b[j][q].y, v[2] += br.b[j][q].z, v[3] += br.b[j][q].w;
+                pre[q] = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+                }
+                out[q] = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if constexpr (NOUT == 2) pd.v[0][i][j][k] = widen_pair(pre[2 * k], pre[2 * k + 1]);
+                pd.v[NOUT - 1][i][j][k] = widen_pair(out[2 * k], out[2 * k + 1]);
+            }
+        }
+    }
+    pd.left = 8;
+}
+
+// bias_lds: the whole bias vector [N] staged in LDS once per block (or null: no bias).  Returns nothing; d.nst stores were issued.
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const DirectEpi& d, const float* bias_lds,
+                                                     f32x16 (&acc)[2][2], int bm0, int bn0, int wm, int wn, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) mfma_settle(acc[i][0]), mfma_settle(acc[i][1]);
+    const int frow = lane & 31, fh = lane >> 5;
+    const bool no_store = p.debug == 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = bm0 + wm * 64 + i * 32 + frow;
+        const bool m_ok = m < p.M && !no_store;
+        f32x4 add4[2][4];
+        u32x2_t pre2[2][4];
+        uint32_t eoff[2][4];  // element offsets m * ld + n for ld = ldc; OOB when out of range
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = bn0 + wn * 64 + j * 32 + 8 * q + 4 * fh;
+                const bool ok = m_ok && n < p.N;
+                eoff[j][q] = ok ? (uint32_t)n : OOB;
+                if (d.has_add) {
+                    const long ldadd = p.residual ? p.ldr : p.ldc;
+                    const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(d.r_add, ok ? (uint32_t)(((long)m * ldadd + n) * 4) : OOB, 0, 0);
+                    add4[j][q] = __builtin_bit_cast(f32x4, t);
+                }
+                if (d.has_dact) pre2[j][q] = __builtin_amdgcn_raw_buffer_load_b64(d.r_pre_in, ok ? (uint32_t)(((long)m * p.ldp + n) * 2) : OOB, 0, 0);
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = bn0 + wn * 64 + j * 32 + 8 * q + 4 * fh;
+                const bool ok = eoff[j][q] != OOB;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                if (bias_lds) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + (n < p.N ? n : 0));
+                    v[0] += b4.x, v[1] += b4.y, v[2] += b4.z, v[3] += b4.w;
+                }
+                if (d.has_save) {
+                    const u32x2_t w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(w, d.r_pre_out, ok ? (uint32_t)(((long)m * p.ldp + n) * 2) : OOB, 0, 0);
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+                }
+                if (d.has_dact) {
+                    v[0] *= quick_gelu_grad(bf_lo(pre2[j][q].x));
+                    v[1] *= quick_gelu_grad(bf_hi(pre2[j][q].x));
+                    v[2] *= quick_gelu_grad(bf_lo(pre2[j][q].y));
+                    v[3] *= quick_gelu_grad(bf_hi(pre2[j][q].y));
+                }
+                if (d.has_add) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += add4[j][q][e];
+                }
+                if (d.has_f32) {
+                    const f32x4 o = {v[0], v[1], v[2], v[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), d.r_f32,
+                                                           ok ? (uint32_t)(((long)m * p.ldc + n) * 4) : OOB, 0, 0);
+                }
+                if (d.has_bf16) {
+                    const u32x2_t w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(w, d.r_bf16, ok ? (uint32_t)(((long)m * p.ldc + n) * 2) : OOB, 0, 0);
+                }
+            }
+    }
+}
+
+template <bool AKM, bool BKM, int WM, int PP, int EPI = 0>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(GemmParams p) {
     using S = BlockShape<WM>;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSTAGE][A sub-tiles | B tile]
@@ -176,7 +405,28 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     const int ntiles = p.tiles_n > 0 ? p.tiles_n * p.tiles_m : 1;
     const int tile_step = p.tiles_n > 0 ? (int)gridDim.x : 1;
     const int batch = blockIdx.z / p.splitk, ks = blockIdx.z % p.splitk;
-  for (int tile = p.tiles_n > 0 ? (int)blockIdx.x : 0; tile < ntiles; tile += tile_step) {
+    // EPI = 1 (ping-pong 256x128 blocks only): register-direct epilogue.  The bias vector lives in the 16 KiB of LDS above the
+    // three stages (read with ds_read: no vmcnt traffic between the prologue loads and the stores)
+    [[maybe_unused]] DirectEpi de;
+    [[maybe_unused]] float* bias_lds = nullptr;
+    [[maybe_unused]] int stores_after_prologue = -1;
+    constexpr int NOUT = EPI == 3 ? 2 : 1;
+    [[maybe_unused]] Pending<NOUT> pend;
+    if constexpr (EPI >= 2) pend.left = 0;
+    if constexpr (EPI >= 1) {
+        de.init(p, batch);
+        if (p.bias) {
+            bias_lds = reinterpret_cast<float*>(smem + S::LDS_BYTES);
+            for (int e = tid; e < p.N; e += S::THREADS) bias_lds[e] = p.bias[e];
+            __syncthreads();
+        }
+    }
+  int tile_no = 0;
+  for (int tile = p.tiles_n > 0 ? (int)blockIdx.x : 0; tile < ntiles; tile += tile_step, ++tile_no) {
+    unsigned long long* stamp = nullptr;
+    if (p.trace && lane == 0 && (wave & 3) == 0 && tile_no < TRACE_TILES)
+        stamp = p.trace + ((((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 2 + (wave >> 2)) * TRACE_TILES + tile_no) * 8;
+    if (stamp) stamp[0] = wall_clock64();
     const int gx = p.tiles_n > 0 ? p.tiles_n : (int)gridDim.x;
     const int wg = p.tiles_n > 0 ? xcd_remap(tile, ntiles) : xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
     const int bn0 = (wg % gx) * BN, bm0 = (wg / gx) * S::ROWS;
@@ -203,6 +453,59 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     OperandStage<BKM, 1, S::PPW> sb;
     sa.init(A, p.lda, p.M, p.K, bm0, wave, lane);
     sb.init(B, p.ldb, p.N, p.K, bn0, wave, lane);
+    if constexpr (EPI >= 2) {
+        // packed bf16 result(s): stored with 16-B-per-lane buffer stores AFTER the next tile's first two K tiles have been
+        // requested; with p.defer the stores are issued from inside the next tile's K loop instead (one slot per K tile)
+        auto issueA = [&](int t, char* buf) { sa.issue((kt0 + t) * BK, p.K, buf, wave, lane); };
+        auto issueB = [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); };
+        k_loop_pingpong<AKM, BKM, PP == 2>(smem, nt, wave, lane, wm, wn, acc, issueA, issueB, stores_after_prologue, stamp,
+                                           DrainSlot<NOUT>{&de, &pend});
+        if (stamp) stamp[2] = wall_clock64();
+        int pre_stores = pending_flush<NOUT>(de, pend);  // what the K loop had no slot for (short K), before the registers are reused
+        // bias registers (LDS reads) -> the next tile's prologue -> the math -> this tile's stores
+        BiasRegs br;
+        bias_load(bias_lds, bn0, wn, lane, br);
+        const int next = tile + tile_step;
+        if (next < ntiles) {
+            const int wg2 = xcd_remap(next, ntiles);
+            const int bn2 = (wg2 % gx) * BN, bm2 = (wg2 / gx) * S::ROWS;
+            sa.init(A, p.lda, p.M, p.K, bm2, wave, lane);
+            sb.init(B, p.ldb, p.N, p.K, bn2, wave, lane);
+            if (pre_stores) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (rare) keep the counted waits exact
+            pp_prologue(smem, nt, issueA, issueB);
+            stores_after_prologue = 0;
+        }
+        if (stamp) stamp[3] = wall_clock64();
+        pending_fill<NOUT>(p, br, acc, pend, bm0, bn0, wm, wn, lane);
+        if (next >= ntiles || !p.defer) {
+            const int n = pending_flush<NOUT>(de, pend);
+            if (next < ntiles) stores_after_prologue = n;  // 8 or 16, younger than the prologue
+        }
+        if (stamp) stamp[4] = wall_clock64();
+        continue;
+    }
+    if constexpr (EPI == 1) {
+        auto issueA = [&](int t, char* buf) { sa.issue((kt0 + t) * BK, p.K, buf, wave, lane); };
+        auto issueB = [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); };
+        // (the first tile's prologue is issued inside the loop call; later tiles' were issued before the previous epilogue)
+        k_loop_pingpong<AKM, BKM, PP == 2>(smem, nt, wave, lane, wm, wn, acc, issueA, issueB, stores_after_prologue, stamp);
+        if (stamp) stamp[2] = wall_clock64();
+        // every wave is past its last MFMA cluster (the loop's closing barrier), i.e. past its last LDS read: all three stages
+        // are free.  Request the NEXT tile's first two K tiles, then store this tile from the registers.
+        const int next = tile + tile_step;
+        if (next < ntiles) {
+            const int wg2 = xcd_remap(next, ntiles);
+            const int bn2 = (wg2 % gx) * BN, bm2 = (wg2 / gx) * S::ROWS;
+            sa.init(A, p.lda, p.M, p.K, bm2, wave, lane);
+            sb.init(B, p.ldb, p.N, p.K, bn2, wave, lane);
+            pp_prologue(smem, nt, issueA, issueB);
+            stores_after_prologue = de.nst;
+        }
+        if (stamp) stamp[3] = wall_clock64();
+        gemm_epilogue_direct(p, de, bias_lds, acc, bm0, bn0, wm, wn, lane);
+        if (stamp) stamp[4] = wall_clock64();
+        continue;
+    }
     auto stage_tile = [&](int t, char* buf) {
         const int k0 = (kt0 + t) * BK;
         sa.issue(k0, p.K, buf, wave, lane);
@@ -225,7 +528,8 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     } else if constexpr (PP != 0) {
         k_loop_pingpong<AKM, BKM, PP == 2>(
             smem, nt, wave, lane, wm, wn, acc, [&](int t, char* buf) { sa.issue((kt0 + t) * BK, p.K, buf, wave, lane); },
-            [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); });
+            [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); }, -1, stamp);
+        if (stamp) stamp[2] = wall_clock64();
     } else {
         // 3-stage ring: tile t+2 is requested right after the barrier that ends tile t-1 (its buffer is free then);
         // each wave only waits for ITS OWN pieces of tile t (counted vmcnt: tile t+1's stay in flight).
@@ -247,6 +551,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     }
 
     gemm_epilogue<S::THREADS, 64, 2>(p, smem, acc, bm0, bn0, batch, ks, tid, wm, wn, lane);
+    if (stamp) stamp[4] = wall_clock64();
     if (tile + tile_step < ntiles) __syncthreads();  // the slab has been read: the next tile's DMA may overwrite the stages
   }
 }
@@ -435,21 +740,71 @@ bool use_big_tile(long M, long N, long zdim) {
     return M >= 256 && blocks >= 200;
 }
 
+constexpr int BIAS_LDS_BYTES = 16384;  // EPI = 1: the bias vector above the stages (N <= 4096)
+// register-direct epilogue: everything elementwise; not split-K, no column sums (those reduce across rows), N fits the bias slab,
+// outputs addressable through 32-bit buffer offsets
+bool direct_epilogue_ok(const GemmParams& p, int batch, bool any_mode = false) {
+    if ((mmvid_option(MMVID_OPT_GEMM_EPI) < 1 && !any_mode) || p.splitk != 1 || p.partial || p.colsum || p.N > BIAS_LDS_BYTES / 4) return false;
+    const long rows = p.M - 1;
+    const long ld = p.ldc > p.ldp ? p.ldc : p.ldp;
+    const long ldr = p.residual ? p.ldr : 0;
+    return (rows * (ld > ldr ? ld : ldr) + p.N) * 4 < (1ll << 31);
+}
+
 template <bool AKM, bool BKM, int WM, int PP>
 void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     using S = BlockShape<WM>;
+    dim3 grid(cdiv(p.N, BN), cdiv(p.M, S::ROWS), batch * p.splitk);
+    GemmParams q = p;
+    q.tiles_n = q.tiles_m = 0;
+    q.defer = 0;
+    if (WM == 4 && mmvid_option(MMVID_OPT_GEMM_PERSIST) && (long)grid.x * grid.y > 256) {  // more than one tile per CU
+        q.tiles_n = (int)grid.x, q.tiles_m = (int)grid.y;
+        grid = dim3(256, 1, grid.z);
+    }
+    if constexpr (WM == 4 && PP == 2) {
+        // packed-bf16 epilogue: bf16 result(s) only, nothing read in the epilogue, whole 128-column tiles
+        const int epi = mmvid_option(MMVID_OPT_GEMM_EPI);
+        const bool packed = epi >= 1 && direct_epilogue_ok(p, batch, true) && p.out_bf16 && !p.out_f32 && !p.residual && !p.dact_pre &&
+                            !p.accumulate && p.N % 128 == 0 && batch == 1;
+        if (packed) {
+            q.defer = (epi >= 2 && q.tiles_n > 0) ? 1 : 0;
+            static bool attr2 = false, attr3 = false;
+            if (p.save_pre) {
+                if (!attr3) {
+                    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM, PP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              S::LDS_BYTES + BIAS_LDS_BYTES);
+                    attr3 = true;
+                }
+                hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP, 3>), grid, dim3(S::THREADS), S::LDS_BYTES + BIAS_LDS_BYTES, stream, q);
+            } else {
+                if (!attr2) {
+                    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM, PP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              S::LDS_BYTES + BIAS_LDS_BYTES);
+                    attr2 = true;
+                }
+                hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP, 2>), grid, dim3(S::THREADS), S::LDS_BYTES + BIAS_LDS_BYTES, stream, q);
+            }
+            return;
+        }
+    }
+    if constexpr (WM == 4 && PP != 0) {
+        if (direct_epilogue_ok(p, batch)) {
+            static bool attr1 = false;
+            if (!attr1) {
+                (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM, PP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          S::LDS_BYTES + BIAS_LDS_BYTES);
+                attr1 = true;
+            }
+            hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP, 1>), grid, dim3(S::THREADS), S::LDS_BYTES + BIAS_LDS_BYTES, stream, q);
+            return;
+        }
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   S::LDS_BYTES);
         attr = true;
-    }
-    dim3 grid(cdiv(p.N, BN), cdiv(p.M, S::ROWS), batch * p.splitk);
-    GemmParams q = p;
-    q.tiles_n = q.tiles_m = 0;
-    if (WM == 4 && mmvid_option(MMVID_OPT_GEMM_PERSIST) && (long)grid.x * grid.y > 256) {  // more than one tile per CU
-        q.tiles_n = (int)grid.x, q.tiles_m = (int)grid.y;
-        grid = dim3(256, 1, grid.z);
     }
     hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP>), grid, dim3(S::THREADS), S::LDS_BYTES, stream, q);
 }
@@ -492,6 +847,13 @@ int launch(const GemmParams& p, int batch, hipStream_t stream) {
 
 }  // namespace
 
+// Measurement only: device buffer of [blocks][2 wave groups][8 tiles][8] uint64 time stamps (100-MHz wall clock) written by the
+// next 256x128 GEMM launches: 0 tile start, 1 first K tile visible, 2 K loop done, 3 next prologue issued, 4 epilogue issued.
+extern "C" int mmvid_gemm_trace(void* dev_buf) {
+    g_gemm_trace = (unsigned long long*)dev_buf;
+    return MMVID_OK;
+}
+
 // See include/mmvid_hip.h for the contract.
 extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int64_t lda,
                                const void* B, int64_t ldb, int batch, int64_t strideA, int64_t strideB,
@@ -529,6 +891,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.partial = nullptr, p.colsum = out_colsum;
     p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
     p.tiles_n = p.tiles_m = 0;
+    p.trace = g_gemm_trace;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor)
         launch<false, false>(p, batch, s);
@@ -571,6 +934,7 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     p.colsum = nullptr;
     p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
     p.tiles_n = p.tiles_m = 0;
+    p.trace = nullptr;
     hipStream_t s = (hipStream_t)stream;
     launch<true, true>(p, 1, s);
     if (splitk > 1) {

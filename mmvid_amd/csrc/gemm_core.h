@@ -292,23 +292,82 @@ __device__ __forceinline__ void pp_compute_half(bf16x8_t (&a)[2][2], bf16x8_t (&
 // B); true: from inside the MFMA clusters (after the first four MFMAs of each), which shortens the load part to the
 // eight fragment reads.  Either way the refilled buffer is tile t-1's, which the other group finished reading before
 // its previous cluster, and the wait before barrier 3 lets exactly the already-issued pieces of tile t+2 stay in flight.
-template <bool AKM, bool BKM, bool DMA_IN_CLUSTER, class IssueA, class IssueB>
+// s_waitcnt vmcnt(BASE + extra), extra in {0, 16, 32, 48}: `extra` vector-memory operations YOUNGER than the awaited loads
+// (the previous tile's epilogue stores, see below; a multiple of 8 up to 48) may stay in flight on top of the BASE younger loads
+template <int BASE>
+__device__ __forceinline__ void wait_vm_plus(int extra) {
+    static_assert(BASE + 48 <= 63, "vmcnt is a 6-bit counter");
+    switch (extra) {
+        case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 8) : "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 16) : "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 24) : "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 32) : "memory"); break;
+        case 40: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 40) : "memory"); break;
+        case 48: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 48) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // unknown count: wait for everything (never under-waits)
+    }
+}
+// s_waitcnt vmcnt(BASE + extra) for a small wave-uniform extra in 0..4 (the deferred epilogue stores issued since the awaited loads)
+template <int BASE>
+__device__ __forceinline__ void wait_vm_small(int extra) {
+    if (extra == 0)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
+    else if (extra == 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 1) : "memory");
+    else if (extra == 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 2) : "memory");
+    else if (extra == 3)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 3) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 4) : "memory");
+}
+struct NoDrain {
+    __device__ __forceinline__ int operator()(int) const { return 0; }
+};
+// the first two K tiles of an output tile (stages 0 and 1)
+template <class IssueA, class IssueB>
+__device__ __forceinline__ void pp_prologue(char* smem, int nt, IssueA issueA, IssueB issueB) {
+    using S = BlockShape<4>;
+    if (nt <= 0) return;
+    issueA(0, smem), issueB(0, smem);
+    if (nt > 1) issueA(1, smem + S::STAGE_BYTES), issueB(1, smem + S::STAGE_BYTES);
+}
+// `stores_after_prologue` (wave-uniform; 0 / 16 / 32 / 48, or -1 = the prologue has not been issued: do it here): how many
+// vector-memory operations this wave issued AFTER pp_prologue() -- the register-direct epilogue of the previous output tile
+// stores while the first K tiles of this one are already in flight.  vmcnt retires in order, so the waits for K tiles 0 and 1
+// (older than those stores) let exactly that many more operations stay in flight; every later wait is for loads younger than
+// the stores and is unchanged (by then the stores have had more than a K tile of time).
+// `drain(t)`: called once per K tile from INSIDE the second MFMA cluster, right after the B pieces of tile t+2 have been
+// requested -- the DEFERRED epilogue of the previous output tile issues a few of its (unconditional, buffer-addressed) stores
+// there and returns how many (wave-uniform, at most 4).  A vector-memory instruction costs its wave ~60-100 issue cycles on
+// this chip whatever it moves (MI355X_MICROARCH.md, "store-ISSUE-bound"); inside the cluster that stall is covered by the four
+// MFMAs already queued, in a load part it would hold up the barrier both wave groups meet at (measured: K loop 10.7 -> 23 us).
+// In the in-order vmcnt queue the stores sit behind B(t+2): the wait in K tile t+1 lets them stay in flight together with the
+// A pieces of tile t+3 (exact count); the wait in K tile t+2 is the first that needs them acknowledged (~1.7 K tiles later).
+template <bool AKM, bool BKM, bool DMA_IN_CLUSTER, class IssueA, class IssueB, class Drain = NoDrain>
 __device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, int lane, int wm, int wn, f32x16 (&acc)[2][2],
-                                                IssueA issueA, IssueB issueB) {
+                                                IssueA issueA, IssueB issueB, int stores_after_prologue = -1,
+                                                unsigned long long* stamp = nullptr, Drain drain = Drain()) {
     using S = BlockShape<4>;
     constexpr int PIECES_A = S::NSUB * S::PPW;  // this wave's A pieces of a tile; the B pieces are PPW
     char* b0 = smem;
     char* b1 = smem + S::STAGE_BYTES;
     char* b2 = smem + 2 * S::STAGE_BYTES;
     if (nt <= 0) return;
-    issueA(0, b0), issueB(0, b0);
+    int extra = stores_after_prologue;
+    int drained = 0;
+    if (extra < 0) {
+        pp_prologue(smem, nt, issueA, issueB);
+        extra = 0;
+    }
     if (nt > 1) {
-        issueA(1, b1), issueB(1, b1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::DMA_PER_TILE) : "memory");
+        wait_vm_plus<S::DMA_PER_TILE>(extra);
     } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vm_plus<0>(extra);
     }
     __builtin_amdgcn_s_barrier();                 // tile 0 is visible to everyone
+    if (stamp) stamp[1] = wall_clock64();
     if (wave >= 4) __builtin_amdgcn_s_barrier();  // the trailing group starts one barrier late
     for (int t = 0; t < nt; ++t) {
         const char* At = b0 + (wm >> 1) * TILE_BYTES;
@@ -322,6 +381,7 @@ __device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, in
         }
         const bool more = t + 2 < nt;
         bf16x8_t a[2][2], b[2][2];
+        const int drained_prev = drained;  // stores issued in the previous K tile's second cluster (younger than B(t+1))
         // ---- phase A: k-steps 0, 1
         pp_load_half<AKM, BKM, 0>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
         if (!DMA_IN_CLUSTER && more) issueA(t + 2, b2);
@@ -335,14 +395,22 @@ __device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, in
         // ---- phase B: k-steps 2, 3
         pp_load_half<AKM, BKM, 1>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
         if (!DMA_IN_CLUSTER && more) issueB(t + 2, b2);
-        if (more)  // own pieces of tile t+1 landed; what has been issued of tile t+2 may stay in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_IN_CLUSTER ? PIECES_A : S::DMA_PER_TILE) : "memory");
-        else if (t + 1 < nt)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) {  // own pieces of tile t+1 landed; what has been issued of tile t+2 may stay in flight
+            if (t == 0 && extra != 0)
+                wait_vm_plus<DMA_IN_CLUSTER ? PIECES_A : S::DMA_PER_TILE>(extra);  // tile 1 is older than the epilogue stores
+            else  // (the stores drained in the previous K tile are younger than tile t+1's pieces: they may stay in flight too)
+                wait_vm_small<DMA_IN_CLUSTER ? PIECES_A : S::DMA_PER_TILE>(drained_prev);
+        } else if (t + 1 < nt) {
+            if (t == 0)
+                wait_vm_plus<0>(extra);
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 3
         pp_compute_half<AKM, BKM>(a, b, acc, [&]() {
             if (DMA_IN_CLUSTER && more) issueB(t + 2, b2);
+            drained = drain(t);
         });
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 4
