@@ -71,6 +71,12 @@ int mmvid_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* x, int64_
                            const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
                            int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum, float* workspace,
                            int64_t workspace_floats, void* stream);
+/* The same with the incoming gradient in bf16 (dy_is_bf16 != 0): the tower's dX GEMMs write d(LN output) as packed bf16 (half
+ * the store instructions and bytes of an fp32 result) and this kernel reads half. */
+int mmvid_layernorm_bwd_ex(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                           const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx, int add_into_dx,
+                           void* dx_bf16, float* dw, float* db, float* dx_colsum, float* workspace, int64_t workspace_floats,
+                           void* stream);
 /* GroupNorm(32, eps) [+ swish] on NHWC: taming/modules/diffusionmodules/model.py:38-42, 33-35.
  * stats_scratch: fp32 [N * (2*C + 64 * ceil(hw / 128))] = the per-channel affine [N][C][2], then partial sums
  * [N][blocks][32][2].  partial_blocks = 0: the statistics pass runs here; = hw/128: the producing convolution
@@ -140,6 +146,17 @@ int mmvid_adam_step_lr(float* p, const float* g, float* m, float* v, void* shado
                        const float* step_dev, float max_norm, const float* sqnorm, float grad_scale, void* stream);
 /* utils_train.py:373-385 (deepspeed WarmupLR, restated) evaluated on the device from the optimiser-step counter:
  * kind 0 constant lr_max | 1 warm-up log schedule stepped every `every` iterations (train.py:373-374). */
+/* Adam / gradient norm with one LAZY table inside the flat buffers: elements [table_lo, table_lo + table_rows * rowlen) are rows
+ * of an embedding table, row_flags[r] != 0 marks the rows that have EVER received a gradient.  Unflagged rows have g = m = v = 0:
+ * Adam without weight decay leaves them unchanged and they add nothing to the norm, so both kernels skip them -- exact, and 30 B
+ * per skipped parameter less traffic (BERT's text embedding is 30 % of its parameters; a step touches <= 3*B*64 of 49,472 rows).
+ * row_flags NULL = the plain kernels. */
+int mmvid_grad_sqnorm_rows(const float* g, int64_t n, float* partials, float* out_accum, const uint8_t* row_flags,
+                           int64_t table_lo, int64_t table_rows, int rowlen, void* stream);
+int mmvid_adam_step_rows(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                         const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int step,
+                         const float* step_dev, float max_norm, const float* sqnorm, float grad_scale,
+                         const uint8_t* row_flags, int64_t table_lo, int64_t table_rows, int rowlen, void* stream);
 int mmvid_lr_schedule(const float* step_dev, int kind, float lr_min, float lr_max, int warmup_steps, int every,
                       float* lr_out, void* stream);
 int mmvid_counter_add(float* counter, float value, void* stream);

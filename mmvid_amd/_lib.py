@@ -44,6 +44,7 @@ SIGNATURES = {
     'mmvid_layernorm_fwd': [P, I64, I64, I, P, P, F, P, P, I64, P, P, P],
     'mmvid_layernorm_bwd': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P],
     'mmvid_layernorm_bwd_ws': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P, I64, P],
+    'mmvid_layernorm_bwd_ex': [P, I, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P, I64, P],
     'mmvid_groupnorm_swish_nhwc': [P, I, I, I64, I, P, P, F, I, P, I, P, P, P],
     'mmvid_attention_fwd': [P, I64, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
     'mmvid_attention_bwd': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P],
@@ -83,6 +84,8 @@ SIGNATURES = {
     'mmvid_grad_sqnorm_det': [P, I64, P, P, P],
     'mmvid_adam_step_lr': [P, P, P, P, P, I64, F, P, F, F, F, F, I, P, F, P, F, P],
     'mmvid_lr_schedule': [P, I, F, F, I, I, P, P],
+    'mmvid_grad_sqnorm_rows': [P, I64, P, P, P, I64, I64, I, P],
+    'mmvid_adam_step_rows': [P, P, P, P, P, I64, F, P, F, F, F, F, I, P, F, P, F, P, I64, I64, I, P],
     'mmvid_counter_add': [P, F, P],
     'mmvid_msm_masks': [U64, P, I, I, I, P, F, F, F, P, P, P, P],
     'mmvid_msm_masks_inject': [P, P, I, I, I, P, P, P],

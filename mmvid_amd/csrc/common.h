@@ -97,6 +97,8 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //                                       (16 B per lane, 8 stores per 128-B line) with the NEXT tile's first two K tiles requested
 //                                       before the stores, so a persistent block never waits for its own writes; 2 = as 1, and
 //                                       persistent bf16-output GEMMs defer a tile's stores into the next tile's K loop
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_COUNT = 12 };
+//   dh_bf16        MMVID_DH_BF16        1 (default) = the tower backward keeps d(LayerNorm output) in bf16 between the dX GEMM and the
+//                                       LayerNorm backward (as every other GEMM operand gradient already is); 0 = fp32
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_COUNT = 13 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

@@ -86,17 +86,24 @@ __global__ __launch_bounds__(256) void assemble_bwd_scatter_kernel(GradTables tb
         lead[tid] = l;
     }
     __syncthreads();
-    for (int r = 0; r < SC_ROWS; ++r) {
-        if (lead[r] != r) continue;  // block-uniform
-        const long k = key[r];
-        float* dst = tb.t[(int)(k >> 40)] + (k & ((1l << 40) - 1)) * E;
-        for (int c = tid; c < (E >> 2); c += 256) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r2 = r; r2 < SC_ROWS; ++r2) {
+    // every row of the chunk is loaded first (32 independent 16-B loads per thread in flight), then merged by leader in registers:
+    // the round-2 form loaded inside the leader loop, i.e. 32 dependent memory latencies per block (92 us for 32 MB)
+    for (int c = tid; c < (E >> 2); c += 256) {
+        float4 v[SC_ROWS];
+#pragma unroll
+        for (int r = 0; r < SC_ROWS; ++r)
+            v[r] = lead[r] >= 0 ? *reinterpret_cast<const float4*>(dx + (base + r) * E + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < SC_ROWS; ++r) {
+            if (lead[r] != r) continue;  // block-uniform
+            float4 a = v[r];
+#pragma unroll
+            for (int r2 = r + 1; r2 < SC_ROWS; ++r2) {
                 if (lead[r2] != r) continue;
-                const float4 v = *reinterpret_cast<const float4*>(dx + (base + r2) * E + 4 * c);
-                a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+                a.x += v[r2].x, a.y += v[r2].y, a.z += v[r2].z, a.w += v[r2].w;
             }
+            const long k = key[r];
+            float* dst = tb.t[(int)(k >> 40)] + (k & ((1l << 40) - 1)) * E;
             unsafeAtomicAdd(dst + 4 * c, a.x), unsafeAtomicAdd(dst + 4 * c + 1, a.y);
             unsafeAtomicAdd(dst + 4 * c + 2, a.z), unsafeAtomicAdd(dst + 4 * c + 3, a.w);
         }
@@ -389,12 +396,23 @@ __global__ __launch_bounds__(256) void pos_table_bwd_kernel(PosSegs ps, int E, c
             *d = make_float4(o.x + acc.x, o.y + acc.y, o.z + acc.z, o.w + acc.w);
             continue;
         }
-        for (int i = 0; i < sg.rows; ++i) {
-            int ix[3];
-            axial_index(sg, i, ix);
-            if (ix[a] != job) continue;
-            const float4 v = reinterpret_cast<const float4*>(g + (long)(sg.dst0 + i) * E)[c];
-            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        // the rows whose axis-a index is `job`, enumerated directly (rows / d[a] of them, fixed order: deterministic): the
+        // round-2 form scanned all rows of the segment with a division per row (154 us for a 1.7-MB table)
+        const int d1 = sg.naxes > 1 ? sg.d[1] : 1, d2 = sg.naxes > 2 ? sg.d[2] : 1;
+        const int inner = a == 0 ? d1 * d2 : (a == 1 ? d2 : 1);  // rows sharing the index are `inner` apart in blocks of ...
+        const int cnt = (sg.d[0] * d1 * d2) / sg.d[a];  // (rows beyond sg.rows -- a truncated table -- are skipped below)
+        for (int j0 = 0; j0 < cnt; j0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                // j -> (outer, within): row = outer * (d[a] * inner) + job * inner + within
+                const int outer = j / inner, within = j - outer * inner;
+                const int i = outer * (sg.d[a] * inner) + job * inner + within;
+                v[u] = (j < cnt && i < sg.rows) ? reinterpret_cast<const float4*>(g + (long)(sg.dst0 + i) * E)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc.x += v[u].x, acc.y += v[u].y, acc.z += v[u].z, acc.w += v[u].w;
         }
         float4* d = reinterpret_cast<float4*>(dstp + (long)job * E) + c;
         const float4 o = *d;

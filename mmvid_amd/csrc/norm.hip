@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // dx_colsum (optional) += column sums of the UPDATED dx: that is the bias gradient of the Linear whose output
 // gradient this tensor is (out_proj / c_proj of the tower), so no separate column-sum pass over it is needed.
 // Each block walks rows blockIdx.x, +gridDim.x, ... with 4 waves; per-lane partial dw/db stay in registers.
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, long lddy,
+// DY = float, or bf16_t: the dX GEMM that produces dy then writes half the bytes (packed 16-B stores) and this kernel reads half
+template <typename DY>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DY* __restrict__ dy, long lddy,
                                                             const float* __restrict__ x, long ldx,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
@@ -96,7 +98,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
-                const float4 d4 = reinterpret_cast<const float4*>(dy + r * lddy)[c];
+                float4 d4;
+                if constexpr (sizeof(DY) == 4) {
+                    d4 = reinterpret_cast<const float4*>(dy + r * lddy)[c];
+                } else {
+                    const uint2 u = reinterpret_cast<const uint2*>(dy + r * lddy)[c];
+                    d4 = make_float4(bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y));
+                }
                 const float4 x4 = reinterpret_cast<const float4*>(x + r * ldx)[c];
                 xh[i] = make_float4((x4.x - mu) * rs, (x4.y - mu) * rs, (x4.z - mu) * rs, (x4.w - mu) * rs);
                 g[i] = make_float4(d4.x * w4[i].x, d4.y * w4[i].y, d4.z * w4[i].z, d4.w * w4[i].w);
@@ -351,6 +359,10 @@ extern "C" int mmvid_layernorm_bwd_ws(const float* dy, int64_t lddy, const float
                                       const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
                                       int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
                                       float* workspace, int64_t workspace_floats, void* stream);
+extern "C" int mmvid_layernorm_bwd_ex(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                      const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
+                                      int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
+                                      float* workspace, int64_t workspace_floats, void* stream);
 
 extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                                    const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
@@ -364,6 +376,14 @@ extern "C" int mmvid_layernorm_bwd(const float* dy, int64_t lddy, const float* x
 // gradients are reduced in two stages (per-block rows, then a fixed-order column reduction): no atomics, deterministic,
 // and the grid no longer has to be kept small to bound the atomic traffic (more waves in flight -> closer to HBM speed).
 extern "C" int mmvid_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                      const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
+                                      int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
+                                      float* workspace, int64_t workspace_floats, void* stream) {
+    return mmvid_layernorm_bwd_ex(dy, 0, lddy, x, ldx, mean, rstd, w, rows, E, dx, lddx, add_into_dx, dx_bf16, dw, db, dx_colsum,
+                                  workspace, workspace_floats, stream);
+}
+
+extern "C" int mmvid_layernorm_bwd_ex(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                                       const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
                                       int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
                                       float* workspace, int64_t workspace_floats, void* stream) {
@@ -387,10 +407,16 @@ extern "C" int mmvid_layernorm_bwd_ws(const float* dy, int64_t lddy, const float
         if (blocks > cap) blocks = cap;
     }
     // in two-stage mode the kernel needs non-null dw/db to take the reduction branch at all
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, (long)lddy, x,
-                       (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16,
-                       partial ? (dw ? dw : workspace) : dw, partial ? (db ? db : workspace) : db,
-                       partial ? (dx_colsum ? dx_colsum : nullptr) : dx_colsum, partial);
+    if (dy_is_bf16)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)lddy, x,
+                           (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16,
+                           partial ? (dw ? dw : workspace) : dw, partial ? (db ? db : workspace) : db,
+                           partial ? (dx_colsum ? dx_colsum : nullptr) : dx_colsum, partial);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (long)lddy, x,
+                           (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16,
+                           partial ? (dw ? dw : workspace) : dw, partial ? (db ? db : workspace) : db,
+                           partial ? (dx_colsum ? dx_colsum : nullptr) : dx_colsum, partial);
     if (partial)
         hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(E, 32), 3), dim3(1024), 0, (hipStream_t)stream, partial, blocks, E,
                            dw, db, dx_colsum);

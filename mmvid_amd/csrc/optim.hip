@@ -6,6 +6,7 @@
 //                 m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
 //                 p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 //                 also refreshes the bf16 shadow copy the MFMA kernels read.
+#include "../../include/mmvid_hip.h"
 #include "common.h"
 
 namespace {
@@ -32,13 +33,25 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
 struct AdamArgs {
     float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, max_norm, grad_scale;
 };
+// "Lazy rows": one table inside the flat buffers (elements [lo, lo + rows * rowlen)) whose rows carry a flag "has ever received
+// a gradient".  A row that never did has g = m = v = 0, so Adam (without weight decay) leaves p, m, v unchanged and its g^2 is 0:
+// skipping it is EXACT, and saves all 30 B per parameter.  The text embedding is 49,472 x 768 = 30 % of BERT's parameters and
+// a step touches at most 3 * B * 64 of its rows (the engine sets the flags from the ids the model logged).
+struct LazyRows {
+    const unsigned char* flags;  // null: no lazy table
+    long lo, hi;                 // element range of the table in the flat buffer
+    int rowlen;
+};
+__device__ __forceinline__ bool lazy_skip(const LazyRows& z, long i) {
+    return z.flags && i >= z.lo && i < z.hi && z.flags[(i - z.lo) / z.rowlen] == 0;
+}
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ shadow, long n, AdamArgs a,
                                                    const float* __restrict__ sqnorm,
                                                    const float* __restrict__ step_dev,
-                                                   const float* __restrict__ lr_dev) {
+                                                   const float* __restrict__ lr_dev, LazyRows z) {
     if (lr_dev) a.lr = *lr_dev;  // learning rate kept on the device (mmvid_lr_schedule): a captured step follows the schedule
     if (step_dev) {  // step count kept on the device (whole-step graph replay): bias corrections computed here
         const float t = *step_dev;
@@ -53,6 +66,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float step = a.lr / a.bc1;
     const long stride = (long)gridDim.x * 256 * 4;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (lazy_skip(z, i)) continue;  // (rowlen % 4 == 0 and lo % 4 == 0: the four elements share a row)
         if (i + 3 < n) {
             float4 pp = *reinterpret_cast<float4*>(p + i);
             const float4 gg = *reinterpret_cast<const float4*>(g + i);
@@ -115,10 +129,12 @@ extern "C" int mmvid_grad_sqnorm(const float* g, int64_t n, float* out_accum, vo
 
 // fixed-order version of grad_sqnorm: per-block partial sums, then one block adds them in index order (deterministic:
 // the clip coefficient of a step no longer depends on atomic arrival order)
-__global__ __launch_bounds__(256) void grad_sqnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void grad_sqnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part,
+                                                                  LazyRows z) {
     float a = 0.f;
     const long stride = (long)gridDim.x * 256 * 4;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (lazy_skip(z, i)) continue;
         if (i + 3 < n) {
             const float4 v = *reinterpret_cast<const float4*>(g + i);
             a += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -145,12 +161,29 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     if (threadIdx.x == 0) out[0] += sh[0];
 }
 
+static int make_lazy(LazyRows& z, const uint8_t* flags, int64_t lo, int64_t rows, int rowlen, int64_t n) {
+    z.flags = nullptr, z.lo = z.hi = 0, z.rowlen = 1;
+    if (!flags) return MMVID_OK;
+    MMVID_REQUIRE(lo >= 0 && rows >= 0 && rowlen > 0 && rowlen % 4 == 0 && lo % 4 == 0 && lo + rows * rowlen <= n,
+                  "lazy rows: the table [%lld, +%lld x %d) must lie inside the buffer and be 4-element aligned", (long long)lo,
+                  (long long)rows, rowlen);
+    z.flags = flags, z.lo = lo, z.hi = lo + rows * rowlen, z.rowlen = rowlen;
+    return MMVID_OK;
+}
+
 extern "C" int mmvid_grad_sqnorm_det(const float* g, int64_t n, float* partials, float* out_accum, void* stream) {
+    return mmvid_grad_sqnorm_rows(g, n, partials, out_accum, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int mmvid_grad_sqnorm_rows(const float* g, int64_t n, float* partials, float* out_accum, const uint8_t* row_flags,
+                                      int64_t table_lo, int64_t table_rows, int rowlen, void* stream) {
     MMVID_REQUIRE(g && partials && out_accum && n >= 0, "grad_sqnorm_det: bad arguments");
     MMVID_REQUIRE(((uintptr_t)g & 15) == 0, "grad_sqnorm_det: buffer must be 16-byte aligned");
     if (n == 0) return MMVID_OK;
+    LazyRows z;
+    if (int rc = make_lazy(z, row_flags, table_lo, table_rows, rowlen, n)) return rc;
     const int nb = grid_for(n);  // <= 2048: `partials` holds 2048 floats
-    hipLaunchKernelGGL(grad_sqnorm_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (long)n, partials);
+    hipLaunchKernelGGL(grad_sqnorm_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (long)n, partials, z);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, out_accum);
     MMVID_LAUNCH_CHECK("grad_sqnorm_det");
     return MMVID_OK;
@@ -171,7 +204,18 @@ extern "C" int mmvid_adam_step(float* p, const float* g, float* m, float* v, voi
 extern "C" int mmvid_adam_step_lr(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                                   const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int step,
                                   const float* step_dev, float max_norm, const float* sqnorm, float grad_scale, void* stream) {
+    return mmvid_adam_step_rows(p, g, m, v, shadow_bf16, n, lr, lr_dev, beta1, beta2, eps, weight_decay, step, step_dev, max_norm,
+                                sqnorm, grad_scale, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int mmvid_adam_step_rows(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
+                                    const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int step,
+                                    const float* step_dev, float max_norm, const float* sqnorm, float grad_scale,
+                                    const uint8_t* row_flags, int64_t table_lo, int64_t table_rows, int rowlen, void* stream) {
     MMVID_REQUIRE(p && g && m && v && n >= 0 && (step >= 1 || step_dev), "adam_step: bad arguments");
+    MMVID_REQUIRE(!row_flags || weight_decay == 0.f, "adam_step: lazy rows are exact only without weight decay");
+    LazyRows z;
+    if (int rc = make_lazy(z, row_flags, table_lo, table_rows, rowlen, n)) return rc;
     MMVID_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)shadow_bf16 & 7) == 0,
                   "adam_step: buffers must be 16-byte aligned");
     if (n == 0) return MMVID_OK;
@@ -181,7 +225,7 @@ extern "C" int mmvid_adam_step_lr(float* p, const float* g, float* m, float* v, 
     a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)(step >= 1 ? step : 1)));
     a.max_norm = max_norm, a.grad_scale = grad_scale;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16,
-                       (long)n, a, sqnorm, step_dev, lr_dev);
+                       (long)n, a, sqnorm, step_dev, lr_dev, z);
     MMVID_LAUNCH_CHECK("adam_step");
     return MMVID_OK;
 }

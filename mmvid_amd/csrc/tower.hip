@@ -65,7 +65,7 @@ Scratch scratch_layout(const Dims& d) {
     };
     s.delta = take((int64_t)d.B * d.H * d.L * 4);
     s.dqkv = take(d.M * 3 * d.E * 2);
-    s.d_h = take(d.M * d.E * 4);
+    s.d_h = take(d.M * d.E * 4);  // (bf16 by default: half of it is used)
     s.d_o = take(d.M * d.E * 2);
     s.d_pre = take(d.M * d.F * 2);
     s.g_bf16 = take(d.M * d.E * 2);
@@ -246,7 +246,10 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
     char* scr = (char*)scratch;
     const float scale = 0.125f;
     void* gb = scr + sc.g_bf16;
-    float* d_h = (float*)(scr + sc.d_h);
+    // d(LN output), produced by the dX GEMMs of c_fc / in_proj and consumed by the LayerNorm backward: bf16 (option dh_bf16, the
+    // default) halves the GEMM's store burst and the LayerNorm backward's read; fp32 as round 2 had it otherwise
+    const bool dh16 = mmvid_option(MMVID_OPT_DH_BF16) != 0;
+    void* d_h = scr + sc.d_h;
     float* ws = (float*)(scr + sc.splitk_ws);
     float* ln_ws = (float*)(scr + sc.ln_ws);
     const int64_t ln_ws_floats = (int64_t)kLnBwdBlocks * 3 * d.E;
@@ -290,9 +293,9 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         fork();
         TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, fuse_fc_bias ? nullptr : ly.g_fc_b, ws, wst));
         ev_fc = mark();
-        TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, d_h, nullptr, stream));
+        TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
         wait(ev_pj);  // the LayerNorm backward overwrites gb
-        TRY(mmvid_layernorm_bwd_ws(d_h, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
+        TRY(mmvid_layernorm_bwd_ex(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
                                    (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, gb, ly.g_ln2_w, ly.g_ln2_b,
                                    ly.g_out_b, ln_ws, ln_ws_floats, stream));
         // ---- attention branch: x_mid = x_in + out_proj(MHA(LN1 x_in))
@@ -307,9 +310,9 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         fork();
         TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, ly.g_in_b, ws, wst));
         ev_in = mark();
-        TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, d_h, nullptr, stream));
+        TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
         wait(ev_out);  // the LayerNorm backward overwrites gb
-        TRY(mmvid_layernorm_bwd_ws(d_h, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
+        TRY(mmvid_layernorm_bwd_ex(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
                                    (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, i > 0 ? gb : nullptr, ly.g_ln1_w,
                                    ly.g_ln1_b, i > 0 ? layers[i - 1].g_pj_b : nullptr, ln_ws, ln_ws_floats, stream));
     }

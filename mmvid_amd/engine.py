@@ -49,7 +49,8 @@ class WarmupLR:
 
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 process_group=None, bucket_mb=64, order=None, lr_schedule=None, force_exchange=False, sparse_tables=True):
+                 process_group=None, bucket_mb=64, order=None, lr_schedule=None, force_exchange=False, sparse_tables=True,
+                 lazy_rows=True):
         self.model = model
         # row-wise exchange of the tables model.sparse_grad_rows() names (MMVID_SPARSE_TABLES=0 forces the dense all-reduce)
         self.sparse_tables = bool(sparse_tables) and os.environ.get('MMVID_SPARSE_TABLES', '1') != '0'
@@ -104,6 +105,57 @@ class FlatTrainer:
         tw = getattr(model, 'transformer', None)
         if tw is not None and hasattr(tw, 'on_layers_done') and self._layer_start:
             tw.on_layers_done = self.layers_done
+        self._init_lazy_rows(lazy_rows and os.environ.get('MMVID_LAZY_ROWS', '1') != '0')
+
+    # ------------------------------------------------------------------------------------------ lazy table rows
+    def _init_lazy_rows(self, enabled):
+        """The table `model.sparse_grad_rows()` names (BERT: text_emb, 49,472 x 768 = 30 % of the parameters) gets a flag per row
+        "has ever received a gradient".  Rows that never did have g = m = v = 0: Adam (no weight decay) and the gradient norm skip
+        them exactly (csrc/optim.hip), and zero_grad() only clears the rows the last step touched.  The flags follow the ids the
+        model logs per forward (and, under data parallelism, the ids every rank sent); anything the trainer cannot account for
+        -- an overflowed log, a gradient accumulated outside the flat buffer, a loaded optimiser state -- raises the flags."""
+        self._lazy = None
+        fn = getattr(self.model, 'sparse_grad_rows', None)
+        if not enabled or fn is None or self.S is None or self.wd != 0.0:
+            return
+        names = [n for n in fn() if n in self.names]
+        if len(names) != 1:
+            return
+        i = self.names.index(names[0])
+        p = self.params[i]
+        if p.dim() != 2 or p.shape[1] % 4 != 0:
+            return
+        dev = p.device
+        self._lazy = {'name': names[0], 'lo': self.offsets[i], 'rows': p.shape[0], 'rowlen': p.shape[1],
+                      'flags': torch.zeros(p.shape[0], device=dev, dtype=torch.uint8),
+                      'dirty': None, 'dirty_n': 0, 'all_dirty': True}  # rows whose gradient is non-zero right now
+
+    def _lazy_arg(self):
+        z = self._lazy
+        return None if z is None else (z['flags'], z['lo'], z['rows'], z['rowlen'])
+
+    def _lazy_mark(self, ids):
+        """Rows `ids` (int64, any shape; -1 = blank) carry a gradient this step.  ids None: unknown -> every row from now on."""
+        z = self._lazy
+        if z is None:
+            return
+        if ids is None:
+            z['flags'].fill_(1)
+            z['all_dirty'] = True
+            return
+        ids = ids.reshape(-1).clamp_min(0)
+        z['flags'].index_fill_(0, ids, 1)
+        if z['all_dirty']:
+            return
+        n = ids.numel()
+        if z['dirty'] is None or z['dirty_n'] + n > z['dirty'].numel():
+            if z['dirty'] is not None and z['dirty_n'] > 0 or torch.cuda.is_current_stream_capturing():
+                z['all_dirty'] = True  # no room (and no allocation inside a capture): the next zero_grad clears the whole table
+                return
+            z['dirty'] = torch.zeros(max(4 * n, 1024), device=ids.device, dtype=torch.int64)
+            z['dirty_n'] = 0
+        z['dirty'][z['dirty_n']:z['dirty_n'] + n].copy_(ids)
+        z['dirty_n'] += n
 
     def _shadow_view(self, p):
         i = next(k for k, q in enumerate(self.params) if q is p)
@@ -137,6 +189,8 @@ class FlatTrainer:
                 p.grad = self.G[o:o + p.numel()].view(p.shape)
                 if stray is not None:  # gradients were accumulated into a detached tensor this step: fold them in
                     p.grad.add_(stray)
+                    if self._lazy is not None and o == self._lazy['lo']:
+                        self._lazy_mark(None)  # rows the id log does not know about
 
     # --------------------------------------------------------------------------------------------- checkpoint
     def state_dict(self):
@@ -196,6 +250,11 @@ class FlatTrainer:
         fe = getattr(self.model, 'frontend', None)
         if fe is not None and 'frontend' in sd and hasattr(fe, 'load_state_dict'):
             fe.load_state_dict(sd['frontend'])
+        z = getattr(self, '_lazy', None)
+        if z is not None:  # rows with loaded moments must keep decaying
+            lo, hi = z['lo'], z['lo'] + z['rows'] * z['rowlen']
+            live = (self.M[lo:hi].view(z['rows'], -1).abs().amax(1) > 0) | (self.V[lo:hi].view(z['rows'], -1).amax(1) > 0)
+            z['flags'].copy_(live.to(torch.uint8) | z['flags'])
 
     def refresh_shadows(self):
         """Call after writing parameters behind the trainer's back (model.load_state_dict): re-cast the bf16 shadow."""
@@ -205,7 +264,17 @@ class FlatTrainer:
 
     # ---------------------------------------------------------------------------------------------
     def zero_grad(self):
-        self.G.zero_()
+        z = self._lazy
+        if z is None or z['all_dirty']:
+            self.G.zero_()
+        else:  # everything but the lazy table, and of the table only the rows the last step left a gradient in
+            lo, hi = z['lo'], z['lo'] + z['rows'] * z['rowlen']
+            self.G[:lo].zero_()
+            self.G[hi:].zero_()
+            if z['dirty_n']:
+                self.G[lo:hi].view(z['rows'], z['rowlen']).index_fill_(0, z['dirty'][:z['dirty_n']], 0.0)
+        if z is not None:
+            z['all_dirty'], z['dirty_n'] = False, 0
         reset = getattr(self.model, 'reset_sparse_grad_rows', None)
         if reset is not None:
             reset()
@@ -272,7 +341,10 @@ class FlatTrainer:
                 continue  # None: the table was not cut out of the dense all-reduce (_sparse_ranges)
             W = self.params[self.names.index(name)].grad  # [V, E] view into G
             uid, rows = self.pack_rows(W, ids)
-            self.merge_rows(W, self._gather(uid), self._gather(rows), rank, uid.shape[0])
+            all_ids = self._gather(uid)
+            self.merge_rows(W, all_ids, self._gather(rows), rank, uid.shape[0])
+            if self._lazy is not None and self._lazy['name'] == name:
+                self._lazy_mark(all_ids)  # the other ranks' rows now carry a gradient here too
 
     def _rank(self):
         return dist.get_rank(self.pg)
@@ -324,6 +396,8 @@ class FlatTrainer:
         """clip_grad_norm_(max_norm) + Adam (train.py:324-325) on the averaged gradients."""
         self._check_bindings()
         self.allreduce_grads()
+        if self._lazy is not None:
+            self._lazy_mark(self.model.sparse_grad_rows().get(self._lazy['name']))
         self.step_count += 1
         gscale = 1.0 / self.world
         # the update itself is the HIP kernel; on a host tensor ops.adam_step raises (there is no CPU path)
@@ -335,9 +409,9 @@ class FlatTrainer:
                 ops.lr_schedule(self._step_dev, 1, sc.min_lr, sc.max_lr, sc.warmup, sc.every, self._lr_dev)
                 lr_dev = self._lr_dev
             ops.counter_add(self._step_dev, 1.0)
-        ops.grad_sqnorm(self.G, self._sq, partials=self._sq_partials)
+        ops.grad_sqnorm(self.G, self._sq, partials=self._sq_partials, lazy=self._lazy_arg())
         ops.adam_step(self.P, self.G, self.M, self.V, self.S, self.step_count, self.lr, self.betas, self.eps, self.wd,
-                      self.max_norm, self._sq, gscale, step_dev=self._step_dev, lr_dev=lr_dev)
+                      self.max_norm, self._sq, gscale, step_dev=self._step_dev, lr_dev=lr_dev, lazy=self._lazy_arg())
         tw = getattr(self.model, 'transformer', None)
         if tw is not None and hasattr(tw, 'mark_shadow_fresh') and getattr(self, '_tower_shadow_attached', False):
             tw.mark_shadow_fresh()  # the Adam kernel wrote the attached bf16 views; an un-attached tower recasts itself

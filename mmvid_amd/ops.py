@@ -272,22 +272,29 @@ def colsum_bf16(dy, db):
 
 
 # ------------------------------------------------------------------------------------------ optimiser
-def grad_sqnorm(g, out, partials=None):
-    """out[0] += sum g^2.  With `partials` (fp32 [2048] scratch) the reduction order is fixed (deterministic)."""
+def grad_sqnorm(g, out, partials=None, lazy=None):
+    """out[0] += sum g^2.  With `partials` (fp32 [2048] scratch) the reduction order is fixed (deterministic).
+    lazy = (row_flags uint8 [rows], table_lo, rows, rowlen): skip the rows of that table whose flag is 0 (they are all-zero)."""
     _chk(g, f32, 'g'), _chk(out, f32, 'out')
-    if partials is not None:
+    if lazy is not None:
+        assert partials is not None
+        fl, lo, rows, rowlen = lazy
+        call('mmvid_grad_sqnorm_rows', _p(g), g.numel(), _p(partials), _p(out), _p(_chk(fl, torch.uint8, 'row_flags')), int(lo), int(rows),
+             int(rowlen), _stream())
+    elif partials is not None:
         call('mmvid_grad_sqnorm_det', _p(g), g.numel(), _p(partials), _p(out), _stream())
     else:
         call('mmvid_grad_sqnorm', _p(g), g.numel(), _p(out), _stream())
 
 
 def adam_step(p, g, m, v, shadow, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0,
-              sqnorm=None, grad_scale=1.0, step_dev=None, lr_dev=None):
+              sqnorm=None, grad_scale=1.0, step_dev=None, lr_dev=None, lazy=None):
     for t, n in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
         _chk(t, f32, n)
-    call('mmvid_adam_step_lr', _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), _p(lr_dev), float(betas[0]),
+    fl, lo, rows, rowlen = lazy if lazy is not None else (None, 0, 0, 0)
+    call('mmvid_adam_step_rows', _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), _p(lr_dev), float(betas[0]),
          float(betas[1]), float(eps), float(weight_decay), int(step), _p(step_dev), float(max_norm), _p(sqnorm),
-         float(grad_scale), _stream())
+         float(grad_scale), _p(fl), int(lo), int(rows), int(rowlen), _stream())
 
 
 def lr_schedule(step_dev, kind, lr_min, lr_max, warmup, every, lr_out):

@@ -334,3 +334,41 @@ def test_frontend_seed_lives_on_the_device_and_follows_torch_seed(golden):
     fe4 = Frontend()
     fe4.load_state_dict(sd)
     assert torch.equal(fe4.msm_masks(64, 2, 4, DEV, [0.25] * 4, [0.2, 0.5])[0], fe3.msm_masks(64, 2, 4, DEV, [0.25] * 4, [0.2, 0.5])[0])
+
+
+def test_lazy_table_rows_are_exact(golden):
+    """FlatTrainer(lazy_rows=True): rows of text_emb that never received a gradient are skipped by Adam, the gradient norm
+    and zero_grad.  Must be EXACT: parameters, moments and the bf16 shadow equal the dense trainer's bit for bit over
+    several steps with changing text (new rows get touched, old ones keep decaying), and across a state_dict round trip."""
+    from mmvid_amd.engine import FlatTrainer, backward_order
+    g = golden('bert_tiny')
+    frames = g['frames'].to(DEV)
+    ms = [load_synth(tiny_bert(), g, 17).train() for _ in range(2)]
+    trs = [FlatTrainer(ms[0], lr=1e-3, order=backward_order, lazy_rows=True), FlatTrainer(ms[1], lr=1e-3, order=backward_order, lazy_rows=False)]
+    assert trs[0]._lazy is not None and trs[1]._lazy is None
+    gen = torch.Generator().manual_seed(3)
+    touched = set()
+    for step in range(5):
+        text = torch.randint(1, 49408, (2, 16), generator=gen)
+        text[0, 9:] = 0
+        touched |= set(torch.where(text == 0, torch.arange(16) + 49408, text).view(-1).tolist())
+        mask1 = torch.rand(2, 32, generator=gen) < 0.4
+        # one backward (the scatter-add / bias column sums use fp32 atomics: two backward passes differ in the last bits), the
+        # SAME gradient buffer through both optimisers
+        trs[0].zero_grad(), trs[1].zero_grad()
+        lm, lr, lv = ms[0](text.to(DEV), target=frames, return_loss=True, rel=True, vid=True, _mask1=mask1, _target_warp=frames)
+        (7 * lm + 0.5 * lr + 0.5 * lv).backward()
+        trs[1].G.copy_(trs[0].G)
+        trs[0].step(), trs[1].step()
+        assert torch.equal(trs[0].P, trs[1].P), f'step {step}: parameters differ'
+        assert torch.equal(trs[0].M, trs[1].M) and torch.equal(trs[0].V, trs[1].V) and torch.equal(trs[0].S, trs[1].S)
+        assert float(trs[0]._sq) == float(trs[1]._sq)
+    flags = trs[0]._lazy['flags'].cpu()
+    assert set(flags.nonzero().view(-1).tolist()) >= touched and int(flags.sum()) <= len(touched) + 1
+    # the table gradient outside the touched rows was never written and stays zero; zero_grad clears what the step left
+    trs[0].zero_grad()
+    assert float(trs[0].G.abs().sum()) == 0.0
+    # a loaded optimiser state raises the flags of every row with live moments
+    tr2 = FlatTrainer(load_synth(tiny_bert(), g, 17).train(), lr=1e-3, order=backward_order)
+    tr2.load_state_dict(trs[1].state_dict())
+    assert int(tr2._lazy['flags'].sum()) >= len(touched)
