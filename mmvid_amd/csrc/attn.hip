@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, MINB) void attn_fwd_kernel(const bf16_t* __res
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const int key0 = t * 64 + 32 * ss;
+            if (key0 >= L) continue;  // a sub-tile of padding only (L = 579: keys 608..639): nothing to add (block-uniform)
             f32x16 s = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) s = mfma32(row_frag(Kt, 32 * ss + l32, ks, h), qf[ks], s);
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dq_kernel(const bf16_t* __
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const int key0 = t * 64 + 32 * ss;
+            if (key0 >= L) continue;  // padding-only sub-tile
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* _
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 const int q0 = t * 64 + 32 * ss;
+                if (q0 >= L) continue;  // padding-only query sub-tile: P = 0 there
                 f32x16 s = zero16(), dp = zero16();
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {

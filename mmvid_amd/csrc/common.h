@@ -99,6 +99,11 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //                                       persistent bf16-output GEMMs defer a tile's stores into the next tile's K loop
 //   dh_bf16        MMVID_DH_BF16        1 (default) = the tower backward keeps d(LayerNorm output) in bf16 between the dX GEMM and the
 //                                       LayerNorm backward (as every other GEMM operand gradient already is); 0 = fp32
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_COUNT = 13 };
+//   gemm_loader    MMVID_GEMM_LOADER    1 (default) = 256x128 GEMM blocks with a register-direct epilogue run 8 MFMA waves + 1 LOADER wave
+//                                       that issues every LDS-DMA request (the MFMA waves issue no vector-memory instruction in
+//                                       the K loop); 0 = every wave requests its own share between its MFMAs (round 2)
+//   gemm_groupn    MMVID_GEMM_GROUPN    1 = persistent GEMM blocks walk the output tiles in column groups sized to the XCD L2 (default 0: measured
+//                                       no gain, profiles/r03_gemm_variants.log -- the K loop is not bound by L2 misses)
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_COUNT = 15 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

@@ -50,6 +50,7 @@ struct GemmParams {
     float* colsum;   // [N] += column sums of the stored result (the bias gradient when the result is a dY), or null
     int debug;       // option gemm_debug (measurement only): 1 = no global stores, 2 = no K loop
     int tiles_n, tiles_m;  // > 0: persistent blocks walk this tile grid (option gemm_persist); 0: one block per tile
+    int group_n;     // persistent blocks: tiles are walked column-GROUP-major (groups of group_n column tiles), see launch_shape
     int defer;       // EPI >= 2: issue a tile's stores from inside the next tile's K loop (persistent blocks)
     unsigned long long* trace;  // measurement only (mmvid_gemm_trace): per block, wave group and tile 8 time stamps (100 MHz)
 };
@@ -557,6 +558,104 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
 }
 
 // ================================================================================================================
+// Loader-wave form of the 256x128 block (option gemm_loader, default): 8 MFMA waves + NLOAD loader waves (gemm_core.h,
+// k_loop_loader / k_loop_consumer), register-direct epilogues only (EPI 1: general, 2 / 3: packed bf16 with one / two outputs).
+// The loader requests the next output tile's first two K tiles while the MFMA waves are in their epilogue, so a persistent block
+// streams operands continuously; the MFMA waves never wait on vmcnt (their epilogue stores drain on their own).
+template <bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_kernel(GemmParams p) {
+    using S = BlockShape<4>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // three stages, then the bias vector
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave & 7) >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_n > 0 ? p.tiles_n * p.tiles_m : 1;
+    const int tile_step = p.tiles_n > 0 ? (int)gridDim.x : 1;
+    const int batch = blockIdx.z;
+    const int gx = p.tiles_n > 0 ? p.tiles_n : (int)gridDim.x;
+    const bf16_t* A = p.A + (long)batch * p.strideA;
+    const bf16_t* B = p.B + (long)batch * p.strideB;
+    const int nt = p.debug == 2 ? 0 : (p.K + BK - 1) / BK;
+    float* bias_lds = nullptr;
+    if (p.bias) {
+        bias_lds = reinterpret_cast<float*>(smem + S::LDS_BYTES);
+        for (int e = tid; e < p.N; e += 512 + 64 * NLOAD) bias_lds[e] = p.bias[e];
+        __syncthreads();
+    }
+    auto tile_origin = [&](int tile, int& bm0, int& bn0) {
+        const int wg = p.tiles_n > 0 ? xcd_remap(tile, ntiles) : xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+        int tn = wg % gx, tm = wg / gx;
+        if (p.tiles_n > 0 && p.group_n > 0) {  // column-group-major: group g = column tiles [g * group_n, ...), rows inside it, columns fastest
+            const int per_group = p.tiles_m * p.group_n;
+            const int g = wg / per_group, rem = wg - g * per_group;
+            const int c0 = g * p.group_n;
+            const int width = p.tiles_n - c0 < p.group_n ? p.tiles_n - c0 : p.group_n;
+            tm = rem / width, tn = c0 + rem - tm * width;
+        }
+        bn0 = tn * BN, bm0 = tm * S::ROWS;
+    };
+    const int first = p.tiles_n > 0 ? (int)blockIdx.x : 0;
+    if (wave >= 8) {  // ---------------------------------------------------------------- the loader waves
+        const int w = wave - 8;
+        LoaderStage<AKM> sa;
+        LoaderStage<BKM> sb;
+        bool have = false;
+        for (int tile = first; tile < ntiles; tile += tile_step) {
+            int bm0, bn0;
+            if (!have) {
+                tile_origin(tile, bm0, bn0);
+                sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0);
+                loader_prologue<AKM, BKM>(sa, sb, smem, 0, nt, p.K, w, lane);
+            }
+            k_loop_loader<AKM, BKM>(sa, sb, smem, 0, nt, p.K, w, lane, p.debug == 4);
+            have = false;
+            if (tile + tile_step < ntiles) {  // every stage is free: stream the next output tile's first K tiles during the epilogue
+                tile_origin(tile + tile_step, bm0, bn0);
+                sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0);
+                loader_prologue<AKM, BKM>(sa, sb, smem, 0, nt, p.K, w, lane);
+                have = true;
+            }
+        }
+        return;
+    }
+    // ------------------------------------------------------------------------------------- the eight MFMA waves
+    DirectEpi de;
+    de.init(p, batch);
+    constexpr int NOUT = EPI == 3 ? 2 : 1;
+    [[maybe_unused]] Pending<NOUT> pend;
+    int tile_no = 0;
+    for (int tile = first; tile < ntiles; tile += tile_step, ++tile_no) {
+        unsigned long long* stamp = nullptr;
+        if (p.trace && lane == 0 && (wave & 3) == 0 && tile_no < TRACE_TILES)
+            stamp = p.trace + ((((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 2 + (wave >> 2)) * TRACE_TILES + tile_no) * 8;
+        if (stamp) stamp[0] = wall_clock64();
+        int bm0, bn0;
+        tile_origin(tile, bm0, bn0);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        if (stamp) stamp[5] = __builtin_readcyclecounter();  // shader clock (s_memtime), against the 100-MHz stamps: the actual frequency
+        k_loop_consumer<AKM, BKM>(smem, nt, wave, lane, wm, wn, acc, stamp, p.debug == 4);
+        if (stamp) stamp[2] = wall_clock64(), stamp[6] = __builtin_readcyclecounter(), stamp[7] = wall_clock64();
+        if constexpr (EPI >= 2) {
+            BiasRegs br;
+            bias_load(bias_lds, bn0, wn, lane, br);
+            if (stamp) stamp[3] = wall_clock64();
+            pending_fill<NOUT>(p, br, acc, pend, bm0, bn0, wm, wn, lane);
+            pending_flush<NOUT>(de, pend);
+        } else {
+            if (stamp) stamp[3] = wall_clock64();
+            gemm_epilogue_direct(p, de, bias_lds, acc, bm0, bn0, wm, wn, lane);
+        }
+        if (stamp) stamp[4] = wall_clock64();
+    }
+}
+
+// ================================================================================================================
 // Block shape "W": 256x128 output tile computed by FOUR waves (2x2), each 128x64 = 4x2 MFMA tiles; K tile 32; three
 // 24-KiB LDS stages (72 KiB) and __launch_bounds__(256, 2): TWO blocks per CU.
 //
@@ -757,12 +856,48 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, S::ROWS), batch * p.splitk);
     GemmParams q = p;
     q.tiles_n = q.tiles_m = 0;
-    q.defer = 0;
+    q.defer = 0, q.group_n = 0;
     if (WM == 4 && mmvid_option(MMVID_OPT_GEMM_PERSIST) && (long)grid.x * grid.y > 256) {  // more than one tile per CU
         q.tiles_n = (int)grid.x, q.tiles_m = (int)grid.y;
         grid = dim3(256, 1, grid.z);
+        // Several rounds per CU: an XCD's 32 blocks then meet the same B (weight) column tiles again in every round, and with all
+        // column tiles in play (qkv: 3.5 MB, c_fc: 4.7 MB of W next to the A panels) they do not survive in its 4-MB L2 -- PMC r02:
+        // 34 % L2 misses, 2.4x the algorithmic reads.  Walking the tiles in column GROUPS keeps one group's B tiles resident:
+        // the widest group whose B tiles plus the A panels of one round (32 tiles) fit ~3 MB.
+        if (mmvid_option(MMVID_OPT_GEMM_GROUPN)) {
+            const double b_tile = 128.0 * p.K * 2, a_panel = 256.0 * p.K * 2;
+            int best = 0;
+            for (int c = 1; c <= q.tiles_n; ++c) {
+                const double rows_per_round = 32.0 / c < 1.0 ? 1.0 : 32.0 / c;
+                if (c * b_tile + (rows_per_round + 1.0) * a_panel <= 3.0e6) best = c;
+            }
+            if (best > 0 && best < q.tiles_n) {
+                const int ngroups = cdiv(q.tiles_n, best);
+                q.group_n = cdiv(q.tiles_n, ngroups);  // equal-width groups
+            }
+        }
     }
     if constexpr (WM == 4 && PP == 2) {
+        if (mmvid_option(MMVID_OPT_GEMM_LOADER) && mmvid_option(MMVID_OPT_GEMM_EPI) >= 1 && direct_epilogue_ok(p, batch, true)) {
+            const bool packed = p.out_bf16 && !p.out_f32 && !p.residual && !p.dact_pre && !p.accumulate && p.N % 128 == 0 && batch == 1;
+            const int epi = packed ? (p.save_pre ? 3 : 2) : 1;
+            const size_t lds = S::LDS_BYTES + BIAS_LDS_BYTES;
+            static bool attr[4] = {false, false, false, false};
+            auto go = [&](auto kern) {
+                if (!attr[epi]) {
+                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    attr[epi] = true;
+                }
+                hipLaunchKernelGGL(kern, grid, dim3(512 + 64 * NLOAD), lds, stream, q);
+            };
+            if (epi == 3)
+                go(gemm_bf16_lw_kernel<AKM, BKM, 3>);
+            else if (epi == 2)
+                go(gemm_bf16_lw_kernel<AKM, BKM, 2>);
+            else
+                go(gemm_bf16_lw_kernel<AKM, BKM, 1>);
+            return;
+        }
         // packed-bf16 epilogue: bf16 result(s) only, nothing read in the epilogue, whole 128-column tiles
         const int epi = mmvid_option(MMVID_OPT_GEMM_EPI);
         const bool packed = epi >= 1 && direct_epilogue_ok(p, batch, true) && p.out_bf16 && !p.out_f32 && !p.residual && !p.dact_pre &&

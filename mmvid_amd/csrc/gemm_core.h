@@ -420,6 +420,145 @@ __device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, in
     if (wave < 4) __builtin_amdgcn_s_barrier();  // the leading group waits for the trailing one
 }
 
+// ---- loader-wave K loop (block = 8 MFMA waves + 1 loader wave) -------------------------------------------------------------
+// Measured on the ping-pong loop above (tools/gemm_timeline.py): a K tile takes 0.9 us where its 128 MFMAs need 0.55 us, because
+// every wave interleaves its MFMAs with its share of the LDS-DMA requests and a vector-memory instruction costs its wave 60-185
+// issue cycles on this chip (MI355X_MICROARCH.md: "LDS-DMA piece issue cost").  Here the eight MFMA waves issue NO vector-memory
+// instruction inside the K loop; loader waves request the 48 one-KiB pieces of a K tile (a third after each of the first three
+// barriers of the tile, so that a refilled stage is never touched before both wave groups have passed their last read of it),
+// wait for their own requests with counted vmcnt and publish them through the barriers all waves of the block share.
+template <bool KM>
+struct LoaderStage {
+    rsrc_t rsrc;
+    long ld;
+    int rows, r0;
+    __device__ __forceinline__ void init(const bf16_t* base, long ld_, int rows_, int K, int r0_) {
+        ld = ld_, rows = rows_, r0 = r0_;
+        rsrc = KM ? make_rsrc(base, (uint32_t)(((long)(K - 1) * ld + rows) * 2)) : make_rsrc(base, (uint32_t)(((long)(rows - 1) * ld + K) * 2));
+    }
+    // piece j (0..15) of 128-row sub-tile `sub` of K tile [k0, k0 + 64) -> tile + j KiB
+    __device__ __forceinline__ void piece(int k0, int K, char* tile, int sub, int j, int lane) const {
+        uint32_t v, soff;
+        if constexpr (KM) {
+            const int kr = j * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ ((kr & 3) << 2);
+            const int r = r0 + sub * 128 + c * 8;
+            v = r < rows ? (uint32_t)(((long)kr * ld + r) * 2) : OOB;  // k >= K: beyond the descriptor (zero-filled)
+            soff = (uint32_t)((long)k0 * ld * 2);
+        } else {
+            const int row = j * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int gr = r0 + sub * 128 + row;
+            v = (gr < rows && k0 + c * 8 < K) ? (uint32_t)(((long)gr * ld + c * 8) * 2) : OOB;
+            soff = (uint32_t)k0 * 2;
+        }
+        blds16(rsrc, v, soff, tile + j * 1024);
+    }
+};
+// One vector-memory instruction costs its WAVE ~60 issue cycles, so one loader wave tops out near 40 GB/s (measured: K tile 1.14 us
+// with a single loader against 0.9 us with every wave loading).  NLOAD = 4 loader waves, one per SIMD: loader w requests pieces
+// 4 w .. 4 w + 3 of each 16-piece group (A sub-tile 0, A sub-tile 1, B), i.e. 12 of the 48 pieces of a K tile, and waits for them.
+constexpr int NLOAD = 4;
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void loader_issue_group(const LoaderStage<AKM>& sa, const LoaderStage<BKM>& sb, int k0, int K, char* stage, int g,
+                                                   int w, int lane) {
+    if (g < 2) {
+#pragma unroll
+        for (int jj = 0; jj < 16 / NLOAD; ++jj) sa.piece(k0, K, stage + g * TILE_BYTES, g, w * (16 / NLOAD) + jj, lane);
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < 16 / NLOAD; ++jj) sb.piece(k0, K, stage + 2 * TILE_BYTES, 0, w * (16 / NLOAD) + jj, lane);
+    }
+}
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void loader_prologue(const LoaderStage<AKM>& sa, const LoaderStage<BKM>& sb, char* smem, int kt0, int nt, int K,
+                                                int w, int lane) {
+    using S = BlockShape<4>;
+    if (nt <= 0) return;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) loader_issue_group<AKM, BKM>(sa, sb, kt0 * BK, K, smem, g, w, lane);
+    if (nt > 1) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) loader_issue_group<AKM, BKM>(sa, sb, (kt0 + 1) * BK, K, smem + S::STAGE_BYTES, g, w, lane);
+    }
+}
+// a loader wave's K loop: the prologue (its pieces of K tiles 0 and 1) has been requested
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM>& sa, const LoaderStage<BKM>& sb, char* smem, int kt0, int nt, int K,
+                                              int w, int lane, bool half_barriers = false) {
+    using S = BlockShape<4>;
+    constexpr int PER_TILE = 48 / NLOAD;  // this wave's pieces of a K tile
+    char* b0 = smem;
+    char* b1 = smem + S::STAGE_BYTES;
+    char* b2 = smem + 2 * S::STAGE_BYTES;
+    if (nt <= 0) return;
+    if (nt > 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");  // own pieces of K tile 0 have landed (tile 1's may fly)
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile 0 is visible to everyone
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 2 < nt;
+        const int k0 = (kt0 + t + 2) * BK;
+        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 1: the trailing group has finished its last read of tile t-1 (whose stage b2 is refilled)
+        if (more) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 0, w, lane);
+        __builtin_amdgcn_s_barrier();  // 2
+        if (more) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 1, w, lane);
+        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 3
+        if (more) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 2, w, lane);
+        if (t + 1 < nt) {  // tile t+1 has landed before the barrier after which the leading group reads it
+            if (more)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // 4
+        char* tmp = b0;
+        b0 = b1, b1 = b2, b2 = tmp;
+    }
+    __builtin_amdgcn_s_barrier();  // the closing barrier of the leading group
+}
+// the MFMA waves' K loop: the schedule of k_loop_pingpong without any vector-memory instruction or vmcnt wait
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, int lane, int wm, int wn, f32x16 (&acc)[2][2],
+                                                unsigned long long* stamp = nullptr, bool half_barriers = false) {
+    using S = BlockShape<4>;
+    char* b0 = smem;
+    char* b1 = smem + S::STAGE_BYTES;
+    char* b2 = smem + 2 * S::STAGE_BYTES;
+    if (nt <= 0) return;
+    __builtin_amdgcn_s_barrier();                 // tile 0 is visible to everyone
+    if (stamp) stamp[1] = wall_clock64();
+    if (wave >= 4) __builtin_amdgcn_s_barrier();  // the trailing group starts one barrier late
+    for (int t = 0; t < nt; ++t) {
+        const char* At = b0 + (wm >> 1) * TILE_BYTES;
+        const char* Bt = b0 + S::NSUB * TILE_BYTES;
+        uint32_t ka[2] = {0, 0}, kb[2] = {0, 0};
+        if constexpr (AKM) {
+            ka[0] = lds_addr(At) + km_lane_off((wm & 1) * 64, lane), ka[1] = lds_addr(At) + km_lane_off((wm & 1) * 64 + 32, lane);
+        }
+        if constexpr (BKM) {
+            kb[0] = lds_addr(Bt) + km_lane_off(wn * 64, lane), kb[1] = lds_addr(Bt) + km_lane_off(wn * 64 + 32, lane);
+        }
+        bf16x8_t a[2][2], b[2][2];
+        pp_load_half<AKM, BKM, 0>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 1   (half_barriers: gemm_debug 4, a timing experiment -- results are wrong)
+        pp_compute_half<AKM, BKM>(a, b, acc, []() {});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // 2
+        pp_load_half<AKM, BKM, 1>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 3
+        pp_compute_half<AKM, BKM>(a, b, acc, []() {});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // 4
+        char* tmp = b0;
+        b0 = b1, b1 = b2, b2 = tmp;
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();  // the leading group waits for the trailing one
+}
+
 // ---- epilogue staging: one 32-row slab of every wave's accumulators -> LDS [64][SLAB_PITCH] fp32, so that the
 // global reads/writes of the epilogue are row-contiguous (512 B per row) instead of 16-B pieces at a row stride.
 constexpr int SLAB_PITCH = 132;  // floats; +4 keeps the 8-lane ds_write_b128 groups on distinct banks

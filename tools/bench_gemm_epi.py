@@ -38,8 +38,10 @@ for name, A, N, K, kw in cases():
     pre_in = torch.randn(M, N, device=dev).to(bf) if kw.get('dact') else None
     outs = {}
     row = f'{name:34s} {M}x{N}x{K}:'
-    for epi in (0, 1, 2):
-        _lib.call('mmvid_set_option', b'gemm_epi', epi)
+    for epi in (0, 1, 4, 3):
+        _lib.call('mmvid_set_option', b'gemm_epi', min(epi, 1))
+        _lib.call('mmvid_set_option', b'gemm_loader', 1 if epi >= 3 else 0)
+        _lib.call('mmvid_set_option', b'gemm_groupn', 0 if epi == 4 else 1)
         save = torch.zeros(M, N, device=dev, dtype=bf) if kw.get('save') else None
         base = torch.randn(M, N, device=dev, generator=torch.Generator(dev).manual_seed(3)) if kw.get('accumulate') else None
 
@@ -52,8 +54,8 @@ for name, A, N, K, kw in cases():
         scratch = base.clone() if base is not None else None
         t = timeit(lambda: run(scratch))
         fl = 2.0 * M * N * K
-        row += f'  epi {epi}: {t * 1e3:6.1f} us {fl / t / 1e9:6.1f} TF'
-    same = all(torch.equal(outs[0][0], outs[e][0]) and (outs[0][1] is None or torch.equal(outs[0][1], outs[e][1])) for e in (1, 2))
+        row += f'  {["lds", "direct", "defer", "LOADER+groups", "LOADER"][epi]}: {t * 1e3:6.1f} us {fl / t / 1e9:6.1f} TF'
+    same = all(torch.equal(outs[0][0], outs[e][0]) and (outs[0][1] is None or torch.equal(outs[0][1], outs[e][1])) for e in (1, 4, 3))
     fin = bool(torch.isfinite(outs[1][0].float()).all())
     row += f'  | bit-identical {same} finite {fin}'
     print(row, flush=True)
@@ -65,18 +67,21 @@ for (m, n, k) in ((1000, 136, 64), (777, 2304, 128), (2561, 776, 200), (300, 307
     Wt = (torch.randn(n, k, device=dev) * 0.05).to(bf)
     b = torch.randn(n, device=dev)
     ys = []
-    for epi in (0, 1, 2):
-        _lib.call('mmvid_set_option', b'gemm_epi', epi)
+    for epi in (0, 1, 3):
+        _lib.call('mmvid_set_option', b'gemm_epi', min(epi, 1))
+        _lib.call('mmvid_set_option', b'gemm_loader', 1 if epi == 3 else 0)
         _lib.call('mmvid_set_option', b'gemm_tile', 256)
         ys.append(ops.gemm(A, Wt, bias=b, out_dtype=torch.float32))
     ref = A.float() @ Wt.float().t() + b
     err = (ys[1] - ref).abs().max().item() / ref.abs().max().item()
     yb = []
-    for epi in (0, 2):  # bf16 output: the deferred path when there are more tiles than CUs
-        _lib.call('mmvid_set_option', b'gemm_epi', epi)
+    for epi in (0, 2, 3):  # bf16 output: the deferred path when there are more tiles than CUs; the loader-wave kernel
+        _lib.call('mmvid_set_option', b'gemm_epi', min(epi, 2) if epi != 3 else 1)
+        _lib.call('mmvid_set_option', b'gemm_loader', 1 if epi == 3 else 0)
         yb.append(ops.gemm(A, Wt, bias=b))
-    print(f'ragged {m}x{n}x{k}: bit-identical {torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])} (bf16 deferred {torch.equal(yb[0], yb[1])}), rel err vs fp32 torch {err:.2e}')
-    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]) and torch.equal(yb[0], yb[1]) and err < 1e-2
+    print(f'ragged {m}x{n}x{k}: bit-identical {torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])} (bf16 deferred {torch.equal(yb[0], yb[1])} loader {torch.equal(yb[0], yb[2])}), rel err vs fp32 torch {err:.2e}')
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]) and torch.equal(yb[0], yb[1]) and torch.equal(yb[0], yb[2]) and err < 1e-2
 _lib.call('mmvid_set_option', b'gemm_tile', 0)
 _lib.call('mmvid_set_option', b'gemm_epi', 1)
+_lib.call('mmvid_set_option', b'gemm_loader', 1)
 print('ok')

@@ -25,8 +25,10 @@ for name, N, K, kw in (('qkv fwd', 2304, 768, {}), ('fc fwd', 3072, 768, {'gelu'
             return ops.gemm(X, W, bias=bias, residual=res, out_dtype=torch.float32)
         return ops.gemm(X, W, bias=bias)
 
-    for epi in (0, 1, 2):
-        _lib.call('mmvid_set_option', b'gemm_epi', epi)
+    for epi in (1, 3, 4):
+        _lib.call('mmvid_set_option', b'gemm_epi', 1)
+        _lib.call('mmvid_set_option', b'gemm_loader', 1 if epi >= 3 else 0)
+        _lib.call('mmvid_set_option', b'gemm_debug', 4 if epi == 4 else 0)
         for _ in range(3):
             run()
         nblk = 256 if N > 768 else 246
@@ -47,4 +49,5 @@ for name, N, K, kw in (('qkv fwd', 2304, 768, {}), ('fc fwd', 3072, 768, {'gelu'
             s = st[ok] - t0
             print(f'   tile {tile}: {int(ok.sum()):3d} blocks  start {s[:,0].mean():6.2f}  first-K-visible +{(s[:,1]-s[:,0]).mean():5.2f}  '
                   f'K loop +{(s[:,2]-s[:,1]).mean():5.2f}  ' + (f'prologue-issue +{(s[:,3]-s[:,2]).mean():5.2f}  epilogue +{(s[:,4]-s[:,3]).mean():5.2f}' if epi else
-                                                                f'epilogue +{(s[:,4]-s[:,2]).mean():5.2f}') + f'  end {s[:,4].mean():6.2f} (max {s[:,4].max():6.2f})')
+                                                                f'epilogue +{(s[:,4]-s[:,2]).mean():5.2f}') + f'  end {s[:,4].mean():6.2f} (max {s[:,4].max():6.2f})'
+                  + (f'  shader clock in the K loop {(100.0 * (st[ok][:,6]-st[ok][:,5]) / (st[ok][:,7]-st[ok][:,0])).mean():7.1f} MHz' if epi >= 3 else ''))
