@@ -113,9 +113,9 @@ def eager_step(trainer, fn, batch):
 
 
 PMC_KERNELS = {  # bench kernel family -> kernel-name prefixes in the rocprofv3 PMC summaries
-    'gemm_bf16_kernel<A.B^T> (forward)': ('gemm_bf16_kernel<false, false', ),
-    'gemm_bf16_kernel<dX>': ('gemm_bf16_kernel<false, true', ),
-    'gemm_bf16_kernel<dW>': ('gemm_bf16_kernel<true, true', ),
+    'gemm_bf16_kernel<A.B^T> (forward)': ('gemm_bf16_kernel<false, false', 'gemm_bf16_lw_kernel<false, false'),
+    'gemm_bf16_kernel<dX>': ('gemm_bf16_kernel<false, true', 'gemm_bf16_lw_kernel<false, true'),
+    'gemm_bf16_kernel<dW>': ('gemm_bf16_kernel<true, true', 'gemm_bf16_lw_kernel<true, true'),
     'conv_igemm_kernel (VQGAN)': ('conv_igemm_kernel', 'conv_strip_kernel'),
     'attn_fwd_kernel': ('attn_fwd_kernel', ),
     'attn_bwd (dq+dkv)': ('attn_bwd_', ),
@@ -131,7 +131,7 @@ def pmc_traffic(family):
     instance per GEMM layout)."""
     import csv
     prefixes = PMC_KERNELS.get(family, (family.split('<')[0].split(' ')[0], ))
-    for rnd in ('r02', 'r01'):
+    for rnd in ('r03', 'r02', 'r01'):
         tot, disp = 0.0, {}
         try:
             for name, mult in (('fetch', 2.0), ('write', 1.0)):
@@ -399,7 +399,7 @@ def main():
         # same way); the ranks run this file again with RANK / LOCAL_RANK / WORLD_SIZE set and rank 0 prints the JSON line
         raise SystemExit(self_launch(args.gpus))
     if args.steps is None:
-        args.steps = 2 if args.config == 5 else (3 if args.sample else 10)
+        args.steps = 2 if args.config == 5 else (3 if args.sample else 50)  # 50 graph replays = ~0.85 s timed
 
     # a GPU box exposes all 256 hardware threads but a cgroup quota of a few cores: keep torch's CPU pool small so that
     # incidental host ops never fan out over hundreds of spinning OpenMP threads (cpu_baseline() sets its own count)

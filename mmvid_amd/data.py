@@ -189,15 +189,37 @@ class TextVideoDataset(torch.utils.data.Dataset):
                                                 align_corners=False, antialias=True)
         return x
 
+    def _visual(self, key):
+        """loader.py:418-422: one frame of the same video (frame 0 when deterministic, else uniformly random), through the same
+        image transform -- the `visual` control the training loop passes on when --visual is set."""
+        paths = self.videos[key]
+        idx = 0 if self.deterministic else self._rand(len(paths))
+        x = _load_frame(paths[idx], self.image_size).unsqueeze(0)
+        if not self.deterministic:
+            S = self.image_size
+            area = float(torch.empty(1).uniform_(self.resize_ratio, 1.0, generator=self.generator)) * S * S
+            side = max(1, min(S, int(round(area**0.5))))
+            top, left = self._rand(S - side + 1), self._rand(S - side + 1)
+            x = torch.nn.functional.interpolate(x[:, :, top:top + side, left:left + side], size=(S, S), mode='bilinear',
+                                                align_corners=False, antialias=True)
+        return x[0]
+
     def __getitem__(self, index):
+        """-> (tokenized_text, frames [T,3,S,S], visual [3,S,S]) as loader.py:500-562 (`text, frames, visuals = batch`).
+        video_only: the text is the reference's 'dummy text' placeholder."""
         key = self.keys[index]
         frames = self._frames(key)
+        visual = self._visual(key)
         if self.video_only:
-            return frames, 0
-        with open(self.texts[key]) as fh:
-            caption = fh.read().split('\n')[0]  # loader.py: the first line is the description
+            caption = 'dummy text'
+        else:
+            with open(self.texts[key]) as fh:
+                lines = [t for t in fh.read().split('\n') if len(t) > 0]  # loader.py:518-519: empty lines dropped
+            if not lines:
+                raise IndexError(f'{self.texts[key]} holds no caption')
+            caption = lines[0] if self.deterministic else lines[self._rand(len(lines))]  # loader.py:521-524
         tokens = self.tokenizer.tokenize(caption, self.text_len, truncate_text=self.truncate_captions).squeeze(0)
-        return tokens, frames
+        return tokens, frames, visual
 
 
 # ------------------------------------------------------------------------------------------------ output side

@@ -64,8 +64,9 @@ def test_text_video_dataset_layout_and_sampling(tmp_path):
     _make_folder(tmp_path, {'clip_b': 20, 'clip_a': 12, 'short': 5, 'uncaptioned': 30})
     ds = TextVideoDataset(tmp_path, text_len=16, image_size=32, tokenizer=_FakeTok(), frame_step=2, frame_num=4, deterministic=True)
     assert ds.keys == ['clip_a', 'clip_b'] and ds.min_len == 8  # 'short' < max(8, 3*2+1) frames, 'uncaptioned' has no txt
-    tokens, frames = ds[1]
+    tokens, frames, visual = ds[1]  # the reference's contract (loader.py:500-562): `text, frames, visuals = batch`
     assert tokens.shape == (16, ) and tokens[0] == ord('c') % 251 + 1
+    assert visual.shape == (3, 32, 32) and torch.equal(visual, frames[0])  # deterministic: frame 0 of the video
     assert frames.shape == (4, 3, 32, 32) and 0.0 <= float(frames.min()) and float(frames.max()) <= 1.0
     # natural order (frame10 after frame9) and a stride of two frames from frame 0: grey levels 0, 18, 36, 54
     assert [round(float(f[0, 0, 0]) * 255) for f in frames] == [0, 18, 36, 54]
@@ -76,7 +77,13 @@ def test_text_video_dataset_layout_and_sampling(tmp_path):
     assert torch.equal(a, b) and a.shape == (4, 3, 32, 32)
     starts = {round(float(mk(s)[1][1][0, 0, 0, 0]) * 255) // 9 for s in range(12)}
     assert len(starts) > 1 and max(starts) <= 20 - 6 - 1  # start in [0, len - span - 1], as random.randint's inclusive bound
-    assert TextVideoDataset(tmp_path, image_size=32, frame_num=4, video_only=True, deterministic=True)[0][1] == 0
+    # video_only keeps the (text, frames, visual) order with the reference's 'dummy text' placeholder
+    vo = TextVideoDataset(tmp_path, text_len=16, image_size=32, tokenizer=_FakeTok(), frame_num=4, video_only=True, deterministic=True)[0]
+    assert len(vo) == 3 and vo[0].shape == (16, ) and vo[0][0] == ord('d') % 251 + 1 and vo[1].shape == (4, 3, 32, 32)
+    # a random non-empty caption line when not deterministic
+    (tmp_path / 'txt' / 'clip_b.txt').write_text('caption one\n\nzebra two\n')
+    firsts = {int(mk(s)[1][0][0]) for s in range(16)}
+    assert firsts == {ord('c') % 251 + 1, ord('z') % 251 + 1}
 
 
 def test_save_image_tensor_gif_and_png(tmp_path):

@@ -974,11 +974,13 @@ def test_config2_full_size_graphed_step_matches_eager():
     close(pg, pe, 1e-3, 'sampled parameters after 3 steps: graphed vs eager')
 
 
-def test_config4_full_size_text_and_mask():
+@pytest.mark.parametrize('layers', [4, 12])
+def test_config4_full_size_text_and_mask(layers):
     """BASELINE config 4: text_and_mask, one visual control frame through the cvae, L = 643 with the restricted rows at
-    129 / 130; a full step with the device front-end (vc_mode mask_8x8 as scripts/mmvoxceleb/text_and_mask/train.sh)."""
+    129 / 130; a full step with the device front-end (vc_mode mask_8x8 as scripts/mmvoxceleb/text_and_mask/train.sh).
+    layers = 12 is the model of the config, 4 the fast variant."""
     from mmvid_amd.engine import FlatTrainer, backward_order
-    m = _full_bert(1, layers=4)
+    m = _full_bert(1, layers=layers)
     assert m.total_seq_len == 643 and (m.st1_tok_index, m.vid_tok_index) == (129, 130)
     assert m.transformer.mask_spec == ('rows', [(129, 129), (130, 130)])
     B = 4
@@ -1004,16 +1006,17 @@ def test_config4_full_size_text_and_mask():
     assert ce.shape == (B, 131, 768)
 
 
-def test_config5_full_size_artv_forward_and_cached_decode():
+@pytest.mark.parametrize('layers', [4, 12])
+def test_config5_full_size_artv_forward_and_cached_decode(layers):
     """BASELINE config 5: ART-V, 16 frames, L = 1152, 51,584 classes.  Training loss + backward at full length, then 64
-    cached decode steps against full recomputation of the same prefixes."""
+    cached decode steps against full recomputation of the same prefixes.  layers = 12 is the model of the config."""
     from mmvid_amd.dalle_artv import DALLE
     from mmvid_amd.vae import VQGanVAE1024
     torch.manual_seed(0)
     vae = VQGanVAE1024(None, 128)
     vae.image_size = 128
     m = DALLE(dim=768, vae=vae, cvae=None, num_text_tokens=49408, text_seq_len=64, which_transformer='openai_clip_visual',
-              num_visuals=1, num_targets=16, transformer_layers=4).to(DEV)
+              num_visuals=1, num_targets=16, transformer_layers=layers).to(DEV)
     assert m.total_seq_len == 1152 and m.total_tokens == 51584
     B = 2
     text = torch.randint(1, 49408, (B, 64), device=DEV)
