@@ -268,6 +268,49 @@ __device__ __forceinline__ u32x4_t widen_pair(u32x2_t lo, u32x2_t hi) {
     const auto b = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
     return u32x4_t{a[0], b[0], a[1], b[1]};
 }
+// the inverse exchange: a 16-B piece (8 consecutive columns) loaded per lane -> the lane's own 4 columns of q = 2k and q = 2k+1
+__device__ __forceinline__ void narrow_pair(u32x4_t t, u32x2_t& lo, u32x2_t& hi) {
+    const auto a = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
+    lo = u32x2_t{a[0], b[0]}, hi = u32x2_t{a[1], b[1]};
+}
+// dact operand of a tile (the saved pre-activation, bf16): 8 16-B loads per lane, requested at the START of the tile so that
+// they land under the K loop
+struct PreRegs {
+    u32x4_t t[2][2][2];  // [i][j][k]
+};
+__device__ __forceinline__ void pre_load(const GemmParams& p, const DirectEpi& d, int bm0, int bn0, int wm, int wn, int lane, PreRegs& pr) {
+    const int frow = lane & 31, fh = lane >> 5;
+    const int n0 = bn0 + wn * 64 + 8 * fh;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = bm0 + wm * 64 + i * 32 + frow;
+        const uint32_t row = m < p.M ? (uint32_t)(((long)m * p.ldp + n0) * 2) : OOB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) pr.t[i][j][k] = __builtin_amdgcn_raw_buffer_load_b128(d.r_pre_in, row + (j * 64 + k * 32), 0, 0);
+    }
+}
+// column sums of a wave's 64 x 64 result: cs[c] (c = 16 j + 4 q + e, already summed over the lane's two rows) is reduced over the
+// 32 lanes of each half by a halving exchange -- 31 cross-lane moves instead of 160 -- after which lane l holds column l of its
+// half; one atomic per lane
+__device__ __forceinline__ void colsum_wave(float (&cs)[32], float* colsum, int bn0, int wn, int lane, int N) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int m = 1 << s;
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int t = 0; t < (16 >> s); ++t) {
+            const float keep = up ? cs[2 * t + 1] : cs[2 * t];
+            const float send = up ? cs[2 * t] : cs[2 * t + 1];
+            cs[t] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+    const int c = lane & 31, fh = lane >> 5;
+    const int n = bn0 + wn * 64 + (c >> 4) * 32 + ((c >> 2) & 3) * 8 + 4 * fh + (c & 3);
+    if (n < N) unsafeAtomicAdd(colsum + n, cs[0]);
+}
 // this lane's 32 bias values of a tile ([j][q] float4), read from the LDS copy BEFORE the next tile's LDS-DMA is requested (an LDS
 // read behind in-flight LDS-DMA makes hipcc drain vmcnt)
 struct BiasRegs {
@@ -320,6 +363,51 @@ __device__ __forceinline__ void pending_fill(const GemmParams& p, const BiasRegs
         }
     }
     pd.left = 8;
+}
+
+// accumulators * QuickGELU'(pre) -> packed bf16 (+ column sums of what is stored): the d_pre GEMM of the tower backward
+__device__ __forceinline__ void pending_fill_dact(const GemmParams& p, const PreRegs& pr, f32x16 (&acc)[2][2], Pending<1>& pd, int bm0,
+                                                  int bn0, int wm, int wn, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) mfma_settle(acc[i][0]), mfma_settle(acc[i][1]);
+    const int frow = lane & 31, fh = lane >> 5;
+    const int n0 = bn0 + wn * 64 + 8 * fh;
+    float cs[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) cs[c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = bm0 + wm * 64 + i * 32 + frow;
+        const bool live = m < p.M;
+        pd.row[0][i] = (live && p.debug != 1) ? (uint32_t)(((long)m * p.ldc + n0) * 2) : OOB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x2_t out[4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                u32x2_t pre[2];
+                narrow_pair(pr.t[i][j][k], pre[0], pre[1]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = 2 * k + h;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                    v[0] *= quick_gelu_grad(bf_lo(pre[h].x)), v[1] *= quick_gelu_grad(bf_hi(pre[h].x));
+                    v[2] *= quick_gelu_grad(bf_lo(pre[h].y)), v[3] *= quick_gelu_grad(bf_hi(pre[h].y));
+                    if (live) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cs[16 * j + 4 * q + e] += v[e];
+                    }
+                    out[q] = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) pd.v[0][i][j][k] = widen_pair(out[2 * k], out[2 * k + 1]);
+        }
+    }
+    pd.left = 8;
+    if (p.colsum) colsum_wave(cs, p.colsum, bn0, wn, lane, p.N);
 }
 
 // bias_lds: the whole bias vector [N] staged in LDS once per block (or null: no bias).  Returns nothing; d.nst stores were issued.
@@ -571,11 +659,16 @@ __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_
     const int wm = (wave & 7) >> 1, wn = wave & 1;
     const int ntiles = p.tiles_n > 0 ? p.tiles_n * p.tiles_m : 1;
     const int tile_step = p.tiles_n > 0 ? (int)gridDim.x : 1;
-    const int batch = blockIdx.z;
+    // blockIdx.z = batch entry, or (split-K: batch 1) the K range whose partial product goes to slab z of the workspace
+    const int ks = p.splitk > 1 ? (int)blockIdx.z : 0;
+    const int batch = blockIdx.z;  // (split-K: strideA = strideB = 0, strideC = M * N: slab ks)
     const int gx = p.tiles_n > 0 ? p.tiles_n : (int)gridDim.x;
     const bf16_t* A = p.A + (long)batch * p.strideA;
     const bf16_t* B = p.B + (long)batch * p.strideB;
-    const int nt = p.debug == 2 ? 0 : (p.K + BK - 1) / BK;
+    const int ktiles_total = (p.K + BK - 1) / BK;
+    const int per = (ktiles_total + p.splitk - 1) / p.splitk;
+    const int kt0 = ks * per;
+    const int nt = p.debug == 2 ? 0 : (kt0 + per > ktiles_total ? (ktiles_total - kt0 > 0 ? ktiles_total - kt0 : 0) : per);
     float* bias_lds = nullptr;
     if (p.bias) {
         bias_lds = reinterpret_cast<float*>(smem + S::LDS_BYTES);
@@ -605,14 +698,14 @@ __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_
             if (!have) {
                 tile_origin(tile, bm0, bn0);
                 sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0);
-                loader_prologue<AKM, BKM>(sa, sb, smem, 0, nt, p.K, w, lane);
+                loader_prologue<AKM, BKM>(sa, sb, smem, kt0, nt, p.K, w, lane);
             }
-            k_loop_loader<AKM, BKM>(sa, sb, smem, 0, nt, p.K, w, lane, p.debug == 4);
+            k_loop_loader<AKM, BKM>(sa, sb, smem, kt0, nt, p.K, w, lane, p.debug == 4);
             have = false;
             if (tile + tile_step < ntiles) {  // every stage is free: stream the next output tile's first K tiles during the epilogue
                 tile_origin(tile + tile_step, bm0, bn0);
                 sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0);
-                loader_prologue<AKM, BKM>(sa, sb, smem, 0, nt, p.K, w, lane);
+                loader_prologue<AKM, BKM>(sa, sb, smem, kt0, nt, p.K, w, lane);
                 have = true;
             }
         }
@@ -638,10 +731,16 @@ __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        [[maybe_unused]] PreRegs pre_in;
+        if constexpr (EPI == 4) pre_load(p, de, bm0, bn0, wm, wn, lane, pre_in);
         if (stamp) stamp[5] = __builtin_readcyclecounter();  // shader clock (s_memtime), against the 100-MHz stamps: the actual frequency
         k_loop_consumer<AKM, BKM>(smem, nt, wave, lane, wm, wn, acc, stamp, p.debug == 4);
         if (stamp) stamp[2] = wall_clock64(), stamp[6] = __builtin_readcyclecounter(), stamp[7] = wall_clock64();
-        if constexpr (EPI >= 2) {
+        if constexpr (EPI == 4) {
+            if (stamp) stamp[3] = wall_clock64();
+            pending_fill_dact(p, pre_in, acc, pend, bm0, bn0, wm, wn, lane);
+            pending_flush<1>(de, pend);
+        } else if constexpr (EPI >= 2) {
             BiasRegs br;
             bias_load(bias_lds, bn0, wn, lane, br);
             if (stamp) stamp[3] = wall_clock64();
@@ -878,11 +977,27 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
         }
     }
     if constexpr (WM == 4 && PP == 2) {
-        if (mmvid_option(MMVID_OPT_GEMM_LOADER) && mmvid_option(MMVID_OPT_GEMM_EPI) >= 1 && direct_epilogue_ok(p, batch, true)) {
+        // the d_pre GEMM (dX of c_proj): packed bf16 result, QuickGELU' of the saved pre-activation, column sums = c_fc's bias gradient
+        const bool dact_packed = p.dact_pre && p.out_bf16 && !p.out_f32 && !p.residual && !p.accumulate && !p.save_pre && !p.bias &&
+                                 p.act == 0 && p.N % 128 == 0 && batch == 1 && p.ldp == p.ldc;
+        GemmParams pc = p;
+        if (dact_packed) pc.colsum = nullptr;  // (direct_epilogue_ok refuses column sums: the dact form reduces them in registers)
+        // split-K through a workspace (the dW GEMMs): slab ks = "batch entry" ks of an fp32 result without bias / accumulate
+        const bool slabs = p.splitk > 1 && p.partial && batch == 1 && !p.bias && !p.residual && !p.dact_pre && !p.save_pre && !p.colsum &&
+                           p.act == 0 && !p.out_bf16;
+        if (slabs) {
+            pc.out_f32 = p.partial, pc.partial = nullptr, pc.accumulate = 0, pc.ldc = p.N, pc.strideC = (long)p.M * p.N, pc.strideA = 0,
+            pc.strideB = 0, pc.splitk = 1;  // (for the eligibility test; the kernel gets splitk back below)
+        }
+        if (mmvid_option(MMVID_OPT_GEMM_LOADER) && mmvid_option(MMVID_OPT_GEMM_EPI) >= 1 &&
+            direct_epilogue_ok((dact_packed || slabs) ? pc : p, batch, true)) {
+            if (slabs) {
+                q.out_f32 = pc.out_f32, q.partial = nullptr, q.accumulate = 0, q.ldc = pc.ldc, q.strideC = pc.strideC, q.strideA = 0, q.strideB = 0;
+            }
             const bool packed = p.out_bf16 && !p.out_f32 && !p.residual && !p.dact_pre && !p.accumulate && p.N % 128 == 0 && batch == 1;
-            const int epi = packed ? (p.save_pre ? 3 : 2) : 1;
+            const int epi = dact_packed ? 4 : (packed ? (p.save_pre ? 3 : 2) : 1);
             const size_t lds = S::LDS_BYTES + BIAS_LDS_BYTES;
-            static bool attr[4] = {false, false, false, false};
+            static bool attr[5] = {false, false, false, false, false};
             auto go = [&](auto kern) {
                 if (!attr[epi]) {
                     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -890,7 +1005,9 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
                 }
                 hipLaunchKernelGGL(kern, grid, dim3(512 + 64 * NLOAD), lds, stream, q);
             };
-            if (epi == 3)
+            if (epi == 4)
+                go(gemm_bf16_lw_kernel<AKM, BKM, 4>);
+            else if (epi == 3)
                 go(gemm_bf16_lw_kernel<AKM, BKM, 3>);
             else if (epi == 2)
                 go(gemm_bf16_lw_kernel<AKM, BKM, 2>);

@@ -26,7 +26,7 @@ def cases():
             ('fc fwd    (bias, gelu, pre saved)', X, 4 * E, E, dict(bias=True, act=1, save=True)),
             ('proj fwd  (bias, +res, f32)', H, E, 4 * E, dict(bias=True, residual=res, out_dtype=torch.float32)),
             ('dX qkv    (NN, f32)', torch.randn(M, 3 * E, device=dev).to(bf), E, 3 * E, dict(km=True, out_dtype=torch.float32)),
-            ('dX proj   (NN, dact, bf16)', X, 4 * E, E, dict(km=True, dact=True)),
+            ('dX proj   (NN, dact, colsum, bf16)', X, 4 * E, E, dict(km=True, dact=True, colsum=True)),
             ('dX fc     (NN, acc f32)', H, E, 4 * E, dict(km=True, out_dtype=torch.float32, accumulate=True)),
     ):
         yield name, A, N, K, kw
@@ -45,12 +45,19 @@ for name, A, N, K, kw in cases():
         save = torch.zeros(M, N, device=dev, dtype=bf) if kw.get('save') else None
         base = torch.randn(M, N, device=dev, generator=torch.Generator(dev).manual_seed(3)) if kw.get('accumulate') else None
 
+        cs = torch.zeros(N, device=dev) if kw.get('colsum') else None
+
         def run(o=None):
             return ops.gemm(A, W, b_kmajor=bool(kw.get('km')), bias=bias, residual=kw.get('residual'), dact_pre=pre_in, save_pre=save,
-                            act=kw.get('act', 0), out_dtype=kw.get('out_dtype', bf), out=o, accumulate=bool(kw.get('accumulate')))
+                            act=kw.get('act', 0), out_dtype=kw.get('out_dtype', bf), out=o, accumulate=bool(kw.get('accumulate')), colsum=cs)
 
         y = run(base.clone() if base is not None else None)
         outs[epi] = (y.clone(), save.clone() if save is not None else None)
+        if cs is not None:
+            ref_cs = y.float().sum(0)  # (of the bf16-rounded result: ~1e-3 relative to the fp32 sums the kernel takes)
+            err = ((cs - ref_cs).abs().max() / ref_cs.abs().max()).item()
+            assert err < 5e-3, (name, epi, err)
+            row += f' [colsum err {err:.1e}]'
         scratch = base.clone() if base is not None else None
         t = timeit(lambda: run(scratch))
         fl = 2.0 * M * N * K
@@ -85,3 +92,22 @@ _lib.call('mmvid_set_option', b'gemm_tile', 0)
 _lib.call('mmvid_set_option', b'gemm_epi', 1)
 _lib.call('mmvid_set_option', b'gemm_loader', 1)
 print('ok')
+# dW GEMMs (k-major operands, split-K slabs + fixed-order reduce): LDS-staged block form vs the loader-wave form
+for name, N, K in (('dW in_proj', 2304, 768), ('dW out', 768, 768), ('dW fc', 3072, 768), ('dW proj', 768, 3072)):
+    dY = torch.randn(M, N, device=dev).to(bf)
+    Xk = torch.randn(M, K, device=dev).to(bf)
+    res = []
+    row = f'{name:34s} {N}x{K}x{M}:'
+    for loader in (0, 1):
+        _lib.call('mmvid_set_option', b'gemm_loader', loader)
+        dW = torch.zeros(N, K, device=dev)
+        ops.gemm_dw(dY, Xk, dW)
+        res.append(dW.clone())
+        t = timeit(lambda: ops.gemm_dw(dY, Xk, dW))
+        row += f'  {"LOADER" if loader else "lds"}: {t * 1e3:6.1f} us {2.0 * M * N * K / t / 1e9:6.1f} TF'
+    ref = dY.float().t() @ Xk.float()
+    err = ((res[1] - ref).abs().max() / ref.abs().max()).item()
+    print(row + f'  | bit-identical {torch.equal(res[0], res[1])} rel err vs fp32 torch {err:.1e}', flush=True)
+    assert torch.equal(res[0], res[1]) and err < 1e-2
+_lib.call('mmvid_set_option', b'gemm_loader', 1)
+print('dW ok')
