@@ -125,12 +125,29 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// max of the 16 accumulator registers of a 32x32 tile in 8 instructions: plain fmaxf() on MFMA outputs makes hipcc emit a
+// canonicalising v_max(x, x) per operand first (28 instructions for 16 values; the kernel is VALU-bound: 76 % VALU-busy per SIMD,
+// profiles/r03_pmc_attention_before_interleave.txt)
+__device__ __forceinline__ float max16(const f32x16& a) {
+    float m0, m1;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(a[0]), "v"(a[1]), "v"(a[2]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(a[3]), "v"(a[4]), "v"(a[5]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(m0), "v"(a[6]), "v"(a[7]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(m1), "v"(a[8]), "v"(a[9]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(m0), "v"(a[10]), "v"(a[11]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(m1), "v"(a[12]), "v"(a[13]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(m0), "v"(a[14]), "v"(a[15]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(m0), "v"(m1));
+    return m0;
+}
 // combine a value with the other 32-lane half's (v_permlane32_swap: VALU, no LDS round trip).  After the swap of
 // (v, v) one result register holds the lane's own value and the other its partner's, in every lane.
 __device__ __forceinline__ float half_max(float v) {
     const uint32_t u = __float_as_uint(v);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(__uint_as_float(r[0])), "v"(__uint_as_float(r[1])));
+    return m;
 }
 __device__ __forceinline__ float half_sum(float v) {
     const uint32_t u = __float_as_uint(v);
@@ -150,6 +167,31 @@ __device__ __forceinline__ float exp2_affine_sum(f32x16& a, float sc, float nb) 
         sum += v;
     }
     return sum[0] + sum[1];
+}
+
+// Row-per-lane epilogue stores, widened (cdna_hip_programming.md T21): a lane holds columns 8 g + 4 h .. +3 of its row for g = 0..3;
+// one v_permlane32_swap per dword on (g = 2k, 2k+1) leaves lanes 0-31 with columns 16k .. 16k+7 and lanes 32-63 with 16k+8 .. 16k+15,
+// so a 64-wide bf16 row segment goes out as 4 stores of 16 B per lane instead of 8 of 8 B (a store costs its issue slot).
+__device__ __forceinline__ uint4 widen_pair(uint2 lo, uint2 hi) {
+    const auto a = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+    return make_uint4(a[0], b[0], a[1], b[1]);
+}
+// acc[dt][r] * scale for one row of 64 values -> bf16 at `row_ptr` (the row's first element); h = lane >> 5
+__device__ __forceinline__ void store_row64(bf16_t* row_ptr, const f32x16 (&acc)[2], float scale, int h) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint2 pc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int g4 = 2 * k + u;
+                pc[u] = make_uint2(pack_bf2(acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale),
+                                   pack_bf2(acc[dt][4 * g4 + 2] * scale, acc[dt][4 * g4 + 3] * scale));
+            }
+            *reinterpret_cast<uint4*>(row_ptr + 32 * dt + 16 * k + 8 * h) = widen_pair(pc[0], pc[1]);
+        }
 }
 
 // Does any (q, key) pair of a 32x32 sub-tile need the mask predicate?  Wave-uniform.
@@ -198,6 +240,8 @@ __global__ __launch_bounds__(256, MINB) void attn_fwd_kernel(const bf16_t* __res
 
     float m_run = -INFINITY, lsum = 0.f;
     f32x16 oacc[2] = {zero16(), zero16()};
+    const int q_wave0 = qt * ROWS_PER_BLOCK + wave * 32;  // first query of the wave (wave-uniform)
+    const bool wave_has_row = mask.mode == 2 && ((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) || (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32));
 
     for (int t = 0; t < ntiles; ++t) {
         const char* Kt = smem[t & 1];
@@ -207,24 +251,32 @@ __global__ __launch_bounds__(256, MINB) void attn_fwd_kernel(const bf16_t* __res
             sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
         }
         if (!wave_active) continue;
+        // Both 32-key sub-tiles of the tile are in flight at once: the eight S = K Q^T MFMAs are issued back to back, and each
+        // sub-tile's softmax arithmetic (VALU: exp2 is quarter rate) runs while the matrix pipe still works on the other
+        // sub-tile's S or PV products.  Issued one sub-tile after the other (round 2), a wave sat in MFMA-result waits for 31 % of
+        // its cycles and parked for 41 % (profiles/r03_pmc_attention_before_interleave.txt).
+        const bool two = t * 64 + 32 < L;  // the second sub-tile holds live keys (block-uniform)
+        f32x16 sv[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sv[0] = mfma32(row_frag(Kt, l32, ks, h), qf[ks], sv[0]);
+        if (two) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) sv[1] = mfma32(row_frag(Kt, 32 + l32, ks, h), qf[ks], sv[1]);
+        }
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
+            if (ss == 1 && !two) break;
             const int key0 = t * 64 + 32 * ss;
-            if (key0 >= L) continue;  // a sub-tile of padding only (L = 579: keys 608..639): nothing to add (block-uniform)
-            f32x16 s = zero16();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = mfma32(row_frag(Kt, 32 * ss + l32, ks, h), qf[ks], s);
+            f32x16& s = sv[ss];
             mfma_settle(s);
             bf16x8_t vt[4];  // V^T fragments: requested now, consumed after the softmax arithmetic
             tr_frags4(ss, lds_addr(Vt) + trl, vt);
-            if (tile_needs_mask(mask, q, key0, L)) {
+            // mask needed?  padding keys, the causal diagonal band, or (wave-constant) a restricted query row in this wave
+            if (key0 + 32 > L || (mask.mode == 1 && key0 + 31 > q_wave0) || wave_has_row) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = is_masked(mask, q, key0 + acc_row(r, h), L) ? -INFINITY : s[r];
             }
-            float mx = fmaxf(s[0], s[1]);
-#pragma unroll
-            for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
-            mx = half_max(mx) * scale_log2;  // scale > 0
+            float mx = half_max(max16(s)) * scale_log2;  // scale > 0
             if (__any(mx > m_run + RESCALE_THR)) {        // rare after the first tiles
                 const float m_new = fmaxf(m_run, mx);
                 const float alpha = fast_exp2(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
@@ -248,16 +300,8 @@ __global__ __launch_bounds__(256, MINB) void attn_fwd_kernel(const bf16_t* __res
     if (!wave_active) return;
     lsum = half_sum(lsum);
     mfma_settle(oacc[0]), mfma_settle(oacc[1]);
-    if (q < L) {
-        const float inv = 1.0f / lsum;
-        bf16_t* op = out + ((long)b * L + q) * ldo + hd * 64 + 4 * h;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4) =
-                    make_uint2(pack_bf2(oacc[dt][4 * g4] * inv, oacc[dt][4 * g4 + 1] * inv),
-                               pack_bf2(oacc[dt][4 * g4 + 2] * inv, oacc[dt][4 * g4 + 3] * inv));
+    if (q < L) {  // (lanes l and l + 32 hold the same row: the half-wave exchange inside store_row64 pairs two active lanes)
+        store_row64(out + ((long)b * L + q) * ldo + hd * 64, oacc, 1.0f / lsum, h);
         if (h == 0) lse2[((long)b * H + hd) * L + q] = m_run + log2f(lsum);
     }
 }
@@ -313,6 +357,8 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dq_kernel(const bf16_t* __
     sk.issue(0, smem[0], wave), sv.issue(0, smem[0] + TILE, wave);
 
     f32x16 dq[2] = {zero16(), zero16()};
+    const int q_wave0 = qt * ROWS_PER_BLOCK + wave * 32;
+    const bool wave_has_row = mask.mode == 2 && ((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) || (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32));
     for (int t = 0; t < ntiles; ++t) {
         const char* Kt = smem[t & 1];
         const char* Vt = Kt + TILE;
@@ -334,7 +380,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dq_kernel(const bf16_t* __
             mfma_settle(s), mfma_settle(dp);
             bf16x8_t kt4[4];  // K^T fragments
             tr_frags4(ss, lds_addr(Kt) + trl, kt4);
-            if (tile_needs_mask(mask, q, key0, L)) {
+            if (key0 + 32 > L || (mask.mode == 1 && key0 + 31 > q_wave0) || wave_has_row) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = is_masked(mask, q, key0 + acc_row(r, h), L) ? -INFINITY : s[r];
             }
@@ -351,16 +397,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dq_kernel(const bf16_t* __
     }
     if (!wave_active) return;
     mfma_settle(dq[0]), mfma_settle(dq[1]);
-    if (q < L) {
-        bf16_t* op = dqkv + ((long)b * L + q) * ldg + hd * 64 + 4 * h;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4) =
-                    make_uint2(pack_bf2(dq[dt][4 * g4] * scale, dq[dt][4 * g4 + 1] * scale),
-                               pack_bf2(dq[dt][4 * g4 + 2] * scale, dq[dt][4 * g4 + 3] * scale));
-    }
+    if (q < L) store_row64(dqkv + ((long)b * L + q) * ldg + hd * 64, dq, scale, h);
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
@@ -411,6 +448,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* _
     if (tid < 128) reinterpret_cast<float*>(dsm + 2 * TILE)[tid] = stat;
 
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    const int key_wave0 = kt * ROWS_PER_BLOCK + wave * 32;
     for (int t = t0; t < nq_tiles; ++t) {
         const int bi = (t - t0) & 1;
         const char* Qt = dsm + bi * DKV_BUF;
@@ -440,10 +478,11 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* _
                 tr_frags4(ss, lds_addr(dOt) + trl, dot4);
                 tr_frags4(ss, lds_addr(Qt) + trl, qt4);
                 // mask needed?  (wave-uniform) key padding, causal diagonal region, or a restricted query row in range
-                bool nm = key >= L;
-                if (mask.mode == 1) nm = nm || (key > q0);
+                // (all wave-uniform: the wave's keys are key_wave0 .. key_wave0 + 31)
+                bool nm = key_wave0 + 32 > L;
+                if (mask.mode == 1) nm = nm || (key_wave0 + 31 > q0);
                 if (mask.mode == 2) nm = nm || (mask.r0 >= q0 && mask.r0 < q0 + 32) || (mask.r1 >= q0 && mask.r1 < q0 + 32);
-                if (__any(nm)) {
+                if (nm) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[r] = is_masked(mask, q0 + acc_row(r, h), key, L) ? -INFINITY : s[r];
                 }
@@ -482,18 +521,9 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* _
     if (!wave_active) return;
     mfma_settle(dk[0]), mfma_settle(dk[1]), mfma_settle(dv[0]), mfma_settle(dv[1]);
     if (key < L) {
-        bf16_t* kp = dqkv + ((long)b * L + key) * ldg + E + hd * 64 + 4 * h;
-        bf16_t* vp = kp + E;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                *reinterpret_cast<uint2*>(kp + 32 * dt + 8 * g4) =
-                    make_uint2(pack_bf2(dk[dt][4 * g4] * scale, dk[dt][4 * g4 + 1] * scale),
-                               pack_bf2(dk[dt][4 * g4 + 2] * scale, dk[dt][4 * g4 + 3] * scale));
-                *reinterpret_cast<uint2*>(vp + 32 * dt + 8 * g4) =
-                    make_uint2(pack_bf2(dv[dt][4 * g4], dv[dt][4 * g4 + 1]), pack_bf2(dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]));
-            }
+        bf16_t* kp = dqkv + ((long)b * L + key) * ldg + E + hd * 64;
+        store_row64(kp, dk, scale, h);
+        store_row64(kp + E, dv, 1.0f, h);
     }
 }
 
@@ -513,7 +543,7 @@ extern "C" int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, in
                                    int r0, int c0, int r1, int c1, void* out, int64_t ldo, float* lse2, void* stream) {
     MMVID_REQUIRE(qkv && out && lse2, "attention_fwd: null pointer");
     ATTN_COMMON_CHECKS("attention_fwd");
-    MMVID_REQUIRE(ld % 8 == 0 && ldo % 4 == 0, "attention_fwd: bad leading dims");
+    MMVID_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out & 15) == 0, "attention_fwd: leading dims must be multiples of 8, out 16-byte aligned");
     MMVID_REQUIRE((int64_t)L * ld * 2 < (1ll << 31), "attention_fwd: one batch entry of qkv must be smaller than 2 GiB");
     MmvidProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * 64, (hipStream_t)stream);
     const int nrt = cdiv(L, ROWS_PER_BLOCK);
@@ -535,7 +565,8 @@ extern "C" int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, i
                                    void* stream) {
     MMVID_REQUIRE(qkv && O && dO && lse2 && delta && dqkv, "attention_bwd: null pointer");
     ATTN_COMMON_CHECKS("attention_bwd");
-    MMVID_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldg % 4 == 0, "attention_bwd: bad leading dims");
+    MMVID_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldg % 8 == 0 && ((uintptr_t)dqkv & 15) == 0,
+                  "attention_bwd: leading dims must be multiples of 8, dqkv 16-byte aligned");
     MMVID_REQUIRE((int64_t)L * ld * 2 < (1ll << 31) && (int64_t)L * lddo * 2 < (1ll << 31),
                   "attention_bwd: one batch entry of qkv / dO must be smaller than 2 GiB");
     hipStream_t s = (hipStream_t)stream;
