@@ -95,6 +95,12 @@ int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, int H, int E,
 int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                         const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode,
                         int r0, int c0, int r1, int c1, void* dqkv, int64_t ldg, void* stream);
+/* The same, and dbias[3E] (optional) += column sums of dqkv: the bias gradient of the packed in-projection (nn.MultiheadAttention
+ * in_proj_bias), taken from the registers that hold dq / dk / dv right before they are stored (fp32 atomics, as the separate
+ * column-sum pass it replaces). */
+int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
+                             const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode, int r0,
+                             int c0, int r1, int c1, void* dqkv, int64_t ldg, float* dbias, void* stream);
 
 /* ---- sequence assembly + losses: dalle_bert.py:899-973,1030-1040; dalle_artv.py:441-491,526-539. */
 int mmvid_assemble_sequence(const float* const* tables, const int64_t* table_rows, int ntables, const int64_t* ids,

@@ -48,6 +48,7 @@ SIGNATURES = {
     'mmvid_groupnorm_swish_nhwc': [P, I, I, I64, I, P, P, F, I, P, I, P, P, P],
     'mmvid_attention_fwd': [P, I64, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
     'mmvid_attention_bwd': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P],
+    'mmvid_attention_bwd_bias': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
     'mmvid_assemble_sequence': [POINTER(P), POINTER(I64), I, P, P, P, I64, I, I, P, P],
     'mmvid_assemble_sequence_bwd': [POINTER(P), POINTER(I64), I, P, P, P, I64, I, I, P, I, P],
     'mmvid_cross_entropy_fwd': [P, I64, P, P, I64, I, P, P, P],

@@ -17,6 +17,7 @@
 // packed fp32 fma/add, hardware bf16 pack, v_permlane32_swap for the cross-half max, and a LAZY softmax
 // rescale (the running max is only raised when a tile exceeds it by 2^8; P <= 256 is exact enough in bf16).
 // exp2 with 1/sqrt(d)*log2(e) folded in; lse2 = m + log2(sum) is kept for the backward.  No atomics.
+#include "../../include/mmvid_hip.h"
 #include "gemm_core.h"
 #include "prof.h"
 
@@ -194,6 +195,31 @@ __device__ __forceinline__ void store_row64(bf16_t* row_ptr, const f32x16 (&acc)
         }
 }
 
+// Column sums of a wave's 32 rows x 64 values (row-per-lane accumulators, rows `live` only) added to dst[0..64): the bias gradient
+// of the in-projection is the column sum of dqkv, and each backward kernel holds its rows of dq / dk / dv in registers right
+// before storing them (the separate colsum pass over dqkv was 13 us per layer).  A halving exchange: after step s a lane keeps
+// half of its remaining columns, summed with its partner's; 31 cross-lane moves for 32 columns, then one atomic per lane.
+__device__ __forceinline__ void colsum_rows64(const f32x16 (&acc)[2], float scale, bool live, float* dst, int lane) {
+    float cs[32];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[16 * dt + r] = live ? acc[dt][r] * scale : 0.f;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int m = 1 << s;
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int t = 0; t < (16 >> s); ++t) {
+            const float keep = up ? cs[2 * t + 1] : cs[2 * t];
+            const float send = up ? cs[2 * t] : cs[2 * t + 1];
+            cs[t] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+    const int c = lane & 31, h = lane >> 5;  // lane l of half h ends with column index c = l: d = 32 dt + 8 g4 + 4 h + e
+    unsafeAtomicAdd(dst + 32 * (c >> 4) + 8 * ((c >> 2) & 3) + 4 * h + (c & 3), cs[0]);
+}
+
 // Does any (q, key) pair of a 32x32 sub-tile need the mask predicate?  Wave-uniform.
 __device__ __forceinline__ bool tile_needs_mask(const MaskSpec& m, int q_lane, int key0, int L) {
     bool need = key0 + 32 > L;
@@ -314,7 +340,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dq_kernel(const bf16_t* __
                                                              const float* __restrict__ lse2,
                                                              float* __restrict__ delta, int L, int H, int E,
                                                              int nrt, float scale, float scale_log2, MaskSpec mask,
-                                                             bf16_t* __restrict__ dqkv, long ldg) {
+                                                             bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias) {
     __shared__ __attribute__((aligned(16))) char smem[2][2 * TILE];  // K tile, V tile
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
     int qt, hd, b;
@@ -398,6 +424,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dq_kernel(const bf16_t* __
     if (!wave_active) return;
     mfma_settle(dq[0]), mfma_settle(dq[1]);
     if (q < L) store_row64(dqkv + ((long)b * L + q) * ldg + hd * 64, dq, scale, h);
+    if (dbias) colsum_rows64(dq, scale, q < L, dbias + hd * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
@@ -409,7 +436,7 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* _
                                                               const float* __restrict__ lse2,
                                                               const float* __restrict__ delta, int L, int H, int E,
                                                               int nrt, float scale, float scale_log2, MaskSpec mask,
-                                                              bf16_t* __restrict__ dqkv, long ldg) {
+                                                              bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias) {
     __shared__ __attribute__((aligned(16))) char dsm[2 * DKV_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
     int kt, hd, b;
@@ -525,6 +552,10 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* _
         store_row64(kp, dk, scale, h);
         store_row64(kp + E, dv, 1.0f, h);
     }
+    if (dbias) {
+        colsum_rows64(dk, scale, key < L, dbias + E + hd * 64, lane);
+        colsum_rows64(dv, 1.0f, key < L, dbias + 2 * E + hd * 64, lane);
+    }
 }
 
 static MaskSpec make_mask(int mode, int r0, int c0, int r1, int c1) {
@@ -563,6 +594,14 @@ extern "C" int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, i
                                    const float* lse2, float* delta, int B, int L, int H, int E, float scale,
                                    int mask_mode, int r0, int c0, int r1, int c1, void* dqkv, int64_t ldg,
                                    void* stream) {
+    return mmvid_attention_bwd_bias(qkv, ld, O, ldo, dO, lddo, lse2, delta, B, L, H, E, scale, mask_mode, r0, c0, r1, c1, dqkv, ldg,
+                                    nullptr, stream);
+}
+
+extern "C" int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
+                                        const float* lse2, float* delta, int B, int L, int H, int E, float scale,
+                                        int mask_mode, int r0, int c0, int r1, int c1, void* dqkv, int64_t ldg,
+                                        float* dbias, void* stream) {
     MMVID_REQUIRE(qkv && O && dO && lse2 && delta && dqkv, "attention_bwd: null pointer");
     ATTN_COMMON_CHECKS("attention_bwd");
     MMVID_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldg % 8 == 0 && ((uintptr_t)dqkv & 15) == 0,
@@ -576,16 +615,16 @@ extern "C" int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, i
     const int nrt = cdiv(L, ROWS_PER_BLOCK);
     if (mmvid_option(MMVID_OPT_ATTN_OCC) & 2)
         hipLaunchKernelGGL((attn_bwd_dq_kernel<4>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
+                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
     else
         hipLaunchKernelGGL((attn_bwd_dq_kernel<2>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
+                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
     if (mmvid_option(MMVID_OPT_ATTN_OCC) & 4)
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<3>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
+                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
     else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg);
+                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
     MMVID_LAUNCH_CHECK("attention_bwd");
     return MMVID_OK;
 }

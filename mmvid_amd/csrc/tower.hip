@@ -304,11 +304,12 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         const hipEvent_t ev_out = mark();
         TRY(linear_dx(d.M, d.E, d.E, gb, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
         wait(ev_in);  // the previous layer's in_proj dW still reads dqkv
-        TRY(mmvid_attention_bwd(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
-                                (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
-                                cfg->r1, cfg->c1, scr + sc.dqkv, 3 * d.E, stream));
+        // the in-projection's bias gradient (column sums of dqkv) comes out of the attention backward's registers
+        TRY(mmvid_attention_bwd_bias(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
+                                     (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
+                                     cfg->r1, cfg->c1, scr + sc.dqkv, 3 * d.E, ly.g_in_b, stream));
         fork();
-        TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, ly.g_in_b, ws, wst));
+        TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, nullptr, ws, wst));
         ev_in = mark();
         TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
         wait(ev_out);  // the LayerNorm backward overwrites gb

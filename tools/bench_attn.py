@@ -46,5 +46,9 @@ o2.backward(dO.float())
 err = lambda a, b: ((a.float() - b).abs().max() / b.abs().max()).item()
 g = torch.cat([t.grad.transpose(1, 2).reshape(B * L, E) for t in (q, k, v)], 1)
 bwd()
-print(f'rel err: out {err(out, o2):.2e} dqkv {err(dqkv, g):.2e}')
+db = torch.zeros(3 * E, device=dev)
+_lib.call('mmvid_attention_bwd_bias', ops._p(qkv), 3 * E, ops._p(out), E, ops._p(dO), E, ops._p(lse), ops._p(delta), B, L, H, E, 0.125, 2, 65,
+          65, 66, 66, ops._p(dqkv), 3 * E, ops._p(db), st())
+print(f'rel err: out {err(out, o2):.2e} dqkv {err(dqkv, g):.2e} fused in_proj bias gradient {err(db, g.sum(0)):.2e}')
+assert err(db, g.sum(0)) < 1e-2
 assert err(out, o2) < 2e-2 and err(dqkv, g) < 3e-2
