@@ -700,7 +700,7 @@ __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_
                 sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0);
                 loader_prologue<AKM, BKM>(sa, sb, smem, kt0, nt, p.K, w, lane);
             }
-            k_loop_loader<AKM, BKM>(sa, sb, smem, kt0, nt, p.K, w, lane, p.debug == 4);
+            k_loop_loader<AKM, BKM>(sa, sb, smem, kt0, nt, p.K, w, lane, p.debug == 4, p.debug == 6);
             have = false;
             if (tile + tile_step < ntiles) {  // every stage is free: stream the next output tile's first K tiles during the epilogue
                 tile_origin(tile + tile_step, bm0, bn0);

@@ -485,7 +485,7 @@ __device__ __forceinline__ void loader_prologue(const LoaderStage<AKM>& sa, cons
 // a loader wave's K loop: the prologue (its pieces of K tiles 0 and 1) has been requested
 template <bool AKM, bool BKM>
 __device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM>& sa, const LoaderStage<BKM>& sb, char* smem, int kt0, int nt, int K,
-                                              int w, int lane, bool half_barriers = false) {
+                                              int w, int lane, bool half_barriers = false, bool skip_half_dma = false) {
     using S = BlockShape<4>;
     constexpr int PER_TILE = 48 / NLOAD;  // this wave's pieces of a K tile
     char* b0 = smem;
@@ -503,11 +503,13 @@ __device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM>& sa, const 
         if (!half_barriers) __builtin_amdgcn_s_barrier();  // 1: the trailing group has finished its last read of tile t-1 (whose stage b2 is refilled)
         if (more) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 0, w, lane);
         __builtin_amdgcn_s_barrier();  // 2
-        if (more) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 1, w, lane);
+        if (more && !skip_half_dma) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 1, w, lane);
         if (!half_barriers) __builtin_amdgcn_s_barrier();  // 3
         if (more) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 2, w, lane);
         if (t + 1 < nt) {  // tile t+1 has landed before the barrier after which the leading group reads it
-            if (more)
+            if (more && skip_half_dma)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE - 16 / NLOAD) : "memory");  // (gemm_debug 6: timing experiment)
+            else if (more)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -92,12 +92,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DY* __restrict
     }
     for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
         const float mu = mean[r], rs = rstd[r];
-        float4 g[LN_MAXV], xh[LN_MAXV];
+        float4 g[LN_MAXV], xh[LN_MAXV], prev[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
+                // the residual-stream gradient this row's dx is added to: requested with the other operands (it used to be loaded
+                // after the two wave reductions: a third dependent memory round trip per row)
+                prev[i] = add ? reinterpret_cast<const float4*>(dx + r * lddx)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 d4;
                 if constexpr (sizeof(DY) == 4) {
                     d4 = reinterpret_cast<const float4*>(dy + r * lddy)[c];
@@ -125,10 +128,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DY* __restrict
                 o.z = rs * (g[i].z - m1 - xh[i].z * m2);
                 o.w = rs * (g[i].w - m1 - xh[i].w * m2);
                 float4* d = reinterpret_cast<float4*>(dx + r * lddx) + c;
-                if (add) {
-                    const float4 p = *d;
-                    o.x += p.x, o.y += p.y, o.z += p.z, o.w += p.w;
-                }
+                o.x += prev[i].x, o.y += prev[i].y, o.z += prev[i].z, o.w += prev[i].w;
                 *d = o;
                 pc[i].x += o.x, pc[i].y += o.y, pc[i].z += o.z, pc[i].w += o.w;
                 if (dx_bf16)  // bf16 copy of the updated residual gradient: the next backward GEMMs' operand

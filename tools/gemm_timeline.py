@@ -25,10 +25,10 @@ for name, N, K, kw in (('qkv fwd', 2304, 768, {}), ('fc fwd', 3072, 768, {'gelu'
             return ops.gemm(X, W, bias=bias, residual=res, out_dtype=torch.float32)
         return ops.gemm(X, W, bias=bias)
 
-    for epi in (1, 3, 4):
+    for epi in (3, 4, 6):
         _lib.call('mmvid_set_option', b'gemm_epi', 1)
         _lib.call('mmvid_set_option', b'gemm_loader', 1 if epi >= 3 else 0)
-        _lib.call('mmvid_set_option', b'gemm_debug', 4 if epi == 4 else 0)
+        _lib.call('mmvid_set_option', b'gemm_debug', epi if epi in (4, 6) else 0)
         for _ in range(3):
             run()
         nblk = 256 if N > 768 else 246
