@@ -102,6 +102,12 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   gemm_loader    MMVID_GEMM_LOADER    1 (default) = 256x128 GEMM blocks with a register-direct epilogue run 8 MFMA waves + 1 LOADER wave
 //                                       that issues every LDS-DMA request (the MFMA waves issue no vector-memory instruction in
 //                                       the K loop); 0 = every wave requests its own share between its MFMAs (round 2)
+//   gemm_groupn    MMVID_GEMM_GROUPN    1 (default) = persistent GEMM blocks walk the output tiles in column GROUPS sized so that one XCD round's
+//                                       B tiles + A panels fit its L2: fabric-side reads of the c_fc GEMM 179 -> 113 MB, qkv 109 -> 83 MB
+//                                       (PMC, profiles/r03_pmc_fetch_column_groups.txt); whole step 16.57 -> 16.52 ms
+//   gemm_loader    MMVID_GEMM_LOADER    1 (default) = 256x128 GEMM blocks with a register-direct epilogue run 8 MFMA waves + 1 LOADER wave
+//                                       that issues every LDS-DMA request (the MFMA waves issue no vector-memory instruction in
+//                                       the K loop); 0 = every wave requests its own share between its MFMAs (round 2)
 //   gemm_groupn    MMVID_GEMM_GROUPN    1 = persistent GEMM blocks walk the output tiles in column groups sized to the XCD L2 (default 0: measured
 //                                       no gain, profiles/r03_gemm_variants.log -- the K loop is not bound by L2 misses)
 enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_COUNT = 15 };

@@ -46,7 +46,7 @@ Opt g_opts[MMVID_OPT_COUNT] = {{"gemm_tile", "MMVID_GEMM_TILE", 0, 0, false},
                                {"gemm_epi", "MMVID_GEMM_EPI", 1, 0, false},
                                {"dh_bf16", "MMVID_DH_BF16", 1, 0, false},
                                {"gemm_loader", "MMVID_GEMM_LOADER", 1, 0, false},
-                               {"gemm_groupn", "MMVID_GEMM_GROUPN", 0, 0, false}};
+                               {"gemm_groupn", "MMVID_GEMM_GROUPN", 1, 0, false}};
 }  // namespace
 
 int mmvid_option(int which) {

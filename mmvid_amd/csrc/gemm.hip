@@ -964,13 +964,14 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
         // 34 % L2 misses, 2.4x the algorithmic reads.  Walking the tiles in column GROUPS keeps one group's B tiles resident:
         // the widest group whose B tiles plus the A panels of one round (32 tiles) fit ~3 MB.
         if (mmvid_option(MMVID_OPT_GEMM_GROUPN)) {
+            // working set of one round of an XCD (32 tiles) for a group width c: c B tiles + ceil(32 / c) A panels; take the width
+            // that minimises it, when that beats walking all column tiles and fits the 4-MB L2
             const double b_tile = 128.0 * p.K * 2, a_panel = 256.0 * p.K * 2;
-            int best = 0;
-            for (int c = 1; c <= q.tiles_n; ++c) {
-                const double rows_per_round = 32.0 / c < 1.0 ? 1.0 : 32.0 / c;
-                if (c * b_tile + (rows_per_round + 1.0) * a_panel <= 3.0e6) best = c;
-            }
-            if (best > 0 && best < q.tiles_n) {
+            auto wset = [&](int c) { return c * b_tile + cdiv(32, c) * a_panel; };
+            int best = q.tiles_n;
+            for (int c = 1; c < q.tiles_n; ++c)
+                if (wset(c) < wset(best)) best = c;
+            if (best < q.tiles_n && wset(best) <= 4.0e6) {
                 const int ngroups = cdiv(q.tiles_n, best);
                 q.group_n = cdiv(q.tiles_n, ngroups);  // equal-width groups
             }

@@ -14,7 +14,7 @@ namespace {
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 constexpr int kMaxSplitK = 16;  // == the cap of mmvid_gemm_dw_pick_splitk
-constexpr int kLnBwdBlocks = 1024;  // grid of the LayerNorm backward (its dw/db/colsum partial rows live in the scratch arena)
+constexpr int kLnBwdBlocks = 512;   // grid of the LayerNorm backward (its dw/db/colsum partial rows live in the scratch arena)
 
 struct Dims {
     int B, L, E, H, F, layers;
