@@ -86,8 +86,10 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   gemm_wshape    MMVID_GEMM_WSHAPE    forward / dX GEMMs on the 4-wave 256x128 shape with two blocks per CU (gemm.hip): 0 = off
 //                                       (default: measured 5-25 % slower, profiles/r02_gemm_anatomy.log), 1 = when the grid has
 //                                       >= 200 tiles, 2 = always
-//   attn_occ       MMVID_ATTN_OCC       attention kernels compiled for one more block per CU (registers capped, a few spilled):
-//                                       bit 0 forward (5 instead of 4), bit 1 dQ (4 instead of 3), bit 2 dK/dV (3 instead of 2)
+//   attn_occ       MMVID_ATTN_OCC       attention kernels compiled for one more block per CU than their register use gives (110 / 135 / 211
+//                                       registers = 4 / 3 / 2 blocks per CU by default; every kernel is launched as its <2> instance):
+//                                       bit 0 forward (<5>), bit 1 dQ (<4>), bit 2 dK/dV (<3>); registers capped, a few spilled --
+//                                       measured 1.1-1.6x SLOWER (profiles/r03_attention_microbench_occupancy_variants.log), default 0
 //   gemm_persist   MMVID_GEMM_PERSIST   1 (default) = GEMMs with more tiles than CUs run 256 persistent blocks that walk the tiles
 //                                       (whole-step A/B: 17.82 -> 17.77 ms; the block turnover is paid once per launch)
 //   gemm_debug     MMVID_GEMM_DEBUG     measurement only (tools/bench_gemm.py anatomy): 1 = the GEMM epilogue skips its global

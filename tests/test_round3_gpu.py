@@ -286,6 +286,8 @@ def test_sparse_exchange_with_simulated_peer_on_device(golden):
         tr._exchange_sparse()
         assert len(calls) == 2
         torch.testing.assert_close(W, mine + peer_dense, rtol=1e-6, atol=1e-6)
+        if tr._lazy is not None:  # the peer's rows carry a gradient here now: Adam must not skip them
+            assert bool(tr._lazy['flags'][peer_ids].all())
         touched = torch.zeros(W.shape[0], dtype=torch.bool, device=DEV)
         touched[ids] = True
         touched[peer_ids] = True
