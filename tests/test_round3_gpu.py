@@ -374,3 +374,74 @@ def test_lazy_table_rows_are_exact(golden):
     tr2 = FlatTrainer(load_synth(tiny_bert(), g, 17).train(), lr=1e-3, order=backward_order)
     tr2.load_state_dict(trs[1].state_dict())
     assert int(tr2._lazy['flags'].sum()) >= len(touched)
+
+
+# --------------------------------------------------------------------------- round-3 kernel forms against the round-2 forms
+@pytest.mark.parametrize('M,N,K', [(10422, 2304, 768), (10422, 768, 3072), (2561, 776, 200), (777, 2304, 128), (300, 3072, 768),
+                                   (70000, 256, 64)])
+def test_gemm_block_forms_are_bit_identical(M, N, K):
+    """The three forms of the 256x128 GEMM block -- LDS-staged epilogue (round 2), register-direct epilogue, loader-wave block
+    (+ column-group tile order) -- compute the same fp32 accumulators and apply the same epilogue arithmetic: bf16 / fp32 outputs
+    with bias, QuickGELU + saved pre-activation, and the dX form with QuickGELU' and column sums must be BIT-identical (ragged
+    M / N / K edges, single tile, several tiles per block); only the residual form may differ in summation order."""
+    from mmvid_amd import _lib, ops
+    torch.manual_seed(M + N + K)
+    bf = torch.bfloat16
+    A = torch.randn(M, K, device=DEV).to(bf)
+    W = (torch.randn(N, K, device=DEV) * 0.05).to(bf)
+    Wk = (torch.randn(K, N, device=DEV) * 0.05).to(bf)
+    bias = torch.randn(N, device=DEV) * 0.1
+    pre_in = torch.randn(M, N, device=DEV).to(bf)
+    forms = {'lds': (0, 0, 0), 'direct': (1, 0, 0), 'loader': (1, 1, 0), 'loader+groups': (1, 1, 1)}
+    outs = {}
+    try:
+        for name, (epi, loader, groups) in forms.items():
+            _lib.call('mmvid_set_option', b'gemm_epi', epi)
+            _lib.call('mmvid_set_option', b'gemm_loader', loader)
+            _lib.call('mmvid_set_option', b'gemm_groupn', groups)
+            _lib.call('mmvid_set_option', b'gemm_tile', 256)
+            save = torch.zeros(M, N, device=DEV, dtype=bf)
+            cs = torch.zeros(N, device=DEV)
+            outs[name] = (ops.gemm(A, W, bias=bias),                                     # qkv-like: packed bf16
+                          ops.gemm(A, W, bias=bias, out_dtype=torch.float32),            # fp32 result
+                          ops.gemm(A, W, bias=bias, act=1, save_pre=save), save,          # c_fc-like: two bf16 results
+                          ops.gemm(A, Wk, b_kmajor=True, dact_pre=pre_in, colsum=cs) if N % 8 == 0 else None, cs)
+    finally:
+        for k, v in ((b'gemm_epi', 1), (b'gemm_loader', 1), (b'gemm_groupn', 1), (b'gemm_tile', 0)):
+            _lib.call('mmvid_set_option', k, v)
+    ref = outs['lds']
+    want = (A.float() @ W.float().t() + bias)
+    assert relerr(ref[1].cpu(), want.cpu()) < 1e-5
+    for name, o in outs.items():
+        for i in (0, 1, 2, 3, 4):
+            if ref[i] is not None:
+                assert torch.equal(o[i], ref[i]), (name, i)
+        assert relerr(o[5].cpu(), ref[5].cpu()) < 1e-5, name  # column sums: fp32 atomics, order varies
+
+
+def test_attention_backward_with_fused_in_proj_bias_gradient():
+    """mmvid_attention_bwd_bias: dqkv as mmvid_attention_bwd, and dbias = column sums of dqkv (nn.MultiheadAttention
+    in_proj_bias gradient) taken from the kernels' registers; against fp32 torch autograd, with padded rows (L = 579)."""
+    from mmvid_amd import _lib, ops
+    B, L, H, E = 3, 579, 12, 768
+    torch.manual_seed(0)
+    qkv = (torch.randn(B * L, 3 * E, device=DEV) * 0.5).bfloat16()
+    dO = (torch.randn(B * L, E, device=DEV) * 0.1).bfloat16()
+    out = torch.empty(B * L, E, device=DEV, dtype=torch.bfloat16)
+    lse, delta = torch.empty(B * H * L, device=DEV), torch.empty(B * H * L, device=DEV)
+    dqkv = torch.empty(B * L, 3 * E, device=DEV, dtype=torch.bfloat16)
+    db = torch.zeros(3 * E, device=DEV)
+    st = ops._stream
+    _lib.call('mmvid_attention_fwd', ops._p(qkv), 3 * E, B, L, H, E, 0.125, 2, 65, 65, 66, 66, ops._p(out), E, ops._p(lse), st())
+    _lib.call('mmvid_attention_bwd_bias', ops._p(qkv), 3 * E, ops._p(out), E, ops._p(dO), E, ops._p(lse), ops._p(delta), B, L, H, E, 0.125,
+              2, 65, 65, 66, 66, ops._p(dqkv), 3 * E, ops._p(db), st())
+    q, k, v = [t.float().view(B, L, H, 64).transpose(1, 2).requires_grad_(True) for t in qkv.float().split(E, dim=1)]
+    mask = torch.zeros(L, L, device=DEV)
+    mask[65, :65] = float('-inf')
+    mask[66, :66] = float('-inf')
+    o = (torch.softmax(q @ k.transpose(-1, -2) * 0.125 + mask, -1) @ v).transpose(1, 2).reshape(B * L, E)
+    o.backward(dO.float())
+    g = torch.cat([t.grad.transpose(1, 2).reshape(B * L, E) for t in (q, k, v)], 1)
+    close(out, o, 2e-2, 'attention out')
+    close(dqkv, g, 3e-2, 'dqkv')
+    close(db, g.sum(0), 1e-2, 'fused in_proj bias gradient')
