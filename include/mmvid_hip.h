@@ -312,6 +312,10 @@ int mmvid_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C, int Cuse,
 /* single-head spatial attention of AttnBlock (model.py:180-205): q,k,v NHWC bf16 [N, HW, C] -> o bf16. */
 int mmvid_spatial_attention(const void* q, const void* k, const void* v, int N, int HW, int C, float scale,
                             float* scores_scratch, void* out_bf16, void* stream);
+/* The same with q, k, v rows `ld` elements apart: ld = 3C when they are the column blocks of one fused q|k|v 1x1 convolution
+ * (model.py:159-178 computes the three with separate convs of the same input). */
+int mmvid_spatial_attention_ld(const void* q, const void* k, const void* v, int64_t ld, int N, int HW, int C, float scale,
+                               float* scores_scratch, void* out_bf16, void* stream);
 
 /* ---- device-side samplers (csrc/sample.hip): BERT mask-predict, dalle_bert.py:514-714, and the ART-V token draw,
  * dalle_artv.py:61-67,274-281.  Randomness enters as tensors of Exp(1) variates E (what torch.multinomial draws

@@ -74,6 +74,7 @@ SIGNATURES = {
     'mmvid_image_to_nhwc8': [P, I, I, I, P, P],
     'mmvid_nhwc_to_nchw_f32': [P, I, I, I, I, I, P, P],
     'mmvid_spatial_attention': [P, P, P, I, I, I, F, P, P, P],
+    'mmvid_spatial_attention_ld': [P, P, P, I64, I, I, I, F, P, P, P],
     'mmvid_vqgan_run': [POINTER(VqganOp), I, P, P],
     'mmvid_sample_race': [P, I64, P, P, F, F, I64, I, I64, P, P, P],
     'mmvid_mp_select_keep': [P, P, P, I, I, I, I, P, P],

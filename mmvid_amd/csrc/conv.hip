@@ -506,17 +506,24 @@ extern "C" int mmvid_nhwc_to_nchw_f32(const float* x, int N, int H, int W, int C
 // scores_scratch: N*HW*HW fp32 followed by N*HW*HW bf16.
 extern "C" int mmvid_spatial_attention(const void* q, const void* k, const void* v, int N, int HW, int C, float scale,
                                        float* scores_scratch, void* out_bf16, void* stream) {
+    return mmvid_spatial_attention_ld(q, k, v, C, N, HW, C, scale, scores_scratch, out_bf16, stream);
+}
+
+// q, k, v rows `ld` elements apart (ld = 3C: the three of them are column blocks of ONE fused 1x1 convolution's output)
+extern "C" int mmvid_spatial_attention_ld(const void* q, const void* k, const void* v, int64_t ld, int N, int HW, int C, float scale,
+                                          float* scores_scratch, void* out_bf16, void* stream) {
     MMVID_REQUIRE(q && k && v && scores_scratch && out_bf16, "spatial_attention: null pointer");
-    MMVID_REQUIRE(HW % 8 == 0 && C % 8 == 0, "spatial_attention: HW=%d and C=%d must be multiples of 8", HW, C);
+    MMVID_REQUIRE(HW % 8 == 0 && C % 8 == 0 && ld % 8 == 0 && ld >= C, "spatial_attention: HW=%d, C=%d, ld=%lld must be multiples of 8", HW,
+                  C, (long long)ld);
     const long hw2 = (long)HW * HW;
     void* P = (void*)(scores_scratch + (long)N * hw2);
-    int rc = mmvid_gemm_bf16(0, 0, HW, HW, C, q, C, k, C, N, (long)HW * C, (long)HW * C, hw2, 1, 1.0f, nullptr, nullptr, 0,
+    int rc = mmvid_gemm_bf16(0, 0, HW, HW, C, q, ld, k, ld, N, (long)HW * ld, (long)HW * ld, hw2, 1, 1.0f, nullptr, nullptr, 0,
                              nullptr, nullptr, 0, 0, 0, scores_scratch, nullptr, HW, nullptr, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv((long)N * HW, 4)), dim3(256), 0, (hipStream_t)stream,
                        scores_scratch, (long)N * HW, HW, scale, (bf16_t*)P);
     MMVID_LAUNCH_CHECK("spatial_attention.softmax");
     // o[q][c] = sum_key P[q][key] v[key][c] : A = P row-major [HW, HW], B = v k-major [HW(red)][C]
-    return mmvid_gemm_bf16(0, 1, HW, C, HW, P, HW, v, C, N, hw2, (long)HW * C, (long)HW * C, 1, 1.0f, nullptr, nullptr, 0,
+    return mmvid_gemm_bf16(0, 1, HW, C, HW, P, HW, v, ld, N, hw2, (long)HW * ld, (long)HW * C, 1, 1.0f, nullptr, nullptr, 0,
                            nullptr, nullptr, 0, 0, 0, nullptr, out_bf16, C, nullptr, stream);
 }

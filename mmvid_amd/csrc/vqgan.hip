@@ -95,8 +95,8 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
                                             (int64_t)o.N * o.H * o.W * o.C, stream);
                 break;
             case MMVID_VQOP_SPATIAL_ATTN:
-                rc = mmvid_spatial_attention(at(arena, o.in0), at(arena, o.in1), at(arena, o.in2), o.N, o.H * o.W, o.C,
-                                             o.eps, (float*)at(arena, o.scratch), at(arena, o.out_bf16), stream);
+                rc = mmvid_spatial_attention_ld(at(arena, o.in0), at(arena, o.in1), at(arena, o.in2), o.pad > 0 ? o.pad : o.C, o.N,
+                                                o.H * o.W, o.C, o.eps, (float*)at(arena, o.scratch), at(arena, o.out_bf16), stream);
                 break;
             case MMVID_VQOP_VQ_ARGMIN:
                 rc = mmvid_vq_argmin_l2((const float*)at(arena, o.in0), (const float*)o.w, o.b, (int64_t)o.N * o.H * o.W,

@@ -137,6 +137,7 @@ _FUSE_GN = os.environ.get('MMVID_FUSE_GN', '1') != '0'
 _DUAL_OUT = os.environ.get('MMVID_DUAL_OUT', '1') != '0'
 _STRIP = os.environ.get('MMVID_CONV_STRIP', '1') != '0'
 _SPLITK = os.environ.get('MMVID_CONV_SPLITK', '1') != '0'
+_FUSE_QKV = os.environ.get('MMVID_FUSE_QKV', '1') != '0'  # AttnBlock q|k|v as one 1x1 conv (bf16 operator only)
 
 
 def _pow2_at_least8(c):
@@ -290,6 +291,27 @@ class _Planner:
         self._op(op=self.OP_CAST, N=n, H=h, W=wd, C=c, in0=x.off, out_bf16=out.off)
         return out
 
+    def conv_qkv(self, x, blk):
+        """AttnBlock q / k / v (model.py:159-178: three 1x1 convs of the same input) as ONE 1x1 conv with the three weights
+        stacked along Cout: one launch instead of three small ones.  Returns the [n, h, w, 3c] buffer (q, k, v are its column blocks)
+        and c."""
+        w, b = self.vae._cw_qkv(blk)
+        n, h, wd, cin = x.shape
+        c = w.shape[0] // 3
+        out = self.alloc((n, h, wd, 3 * c), bf16)
+        self._op(op=self.OP_CONV, mode=3, N=n, H=h, W=wd, C=cin, Cout=3 * c, flags=0, in0=x.off, in1=-1, out_bf16=out.off, out_f32=-1,
+                 scratch=-1, w=w.data_ptr(), b=b.data_ptr())
+        return out, c
+
+    def spatial_attention_fused(self, qkv, c):
+        n, h, wd, c3 = qkv.shape
+        hw = h * wd
+        out = self.alloc((n, h, wd, c), bf16)
+        sc = self.alloc((n * hw * hw * 3 // 2 + 64, ), f32)
+        self._op(op=self.OP_ATTN, N=n, H=h, W=wd, C=c, in0=qkv.off, in1=qkv.off + 2 * c, in2=qkv.off + 4 * c, out_bf16=out.off,
+                 scratch=sc.off, eps=float(c)**-0.5, pad=c3)
+        return out
+
     def spatial_attention(self, q, k, v):
         n, h, wd, c = q.shape
         hw = h * wd
@@ -395,6 +417,15 @@ class VQGanVAE1024(nn.Module):
             prep[k] = (wp.to(bf16).contiguous(), bp, cout)
         return prep[k]
 
+    def _cw_qkv(self, blk):
+        """q, k, v 1x1 conv holders of an AttnBlock -> (w bf16 [3C, 1, C], bias f32 [3C])."""
+        prep = self._prepared()
+        key = (id(blk), 'qkv')
+        if key not in prep:
+            ws, bs = zip(*[self._cw(hd)[:2] for hd in (blk.q, blk.k, blk.v)])
+            prep[key] = (torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous())
+        return prep[key]
+
     def _ee(self):
         prep = self._prepared()
         if 'ee' not in prep:
@@ -430,8 +461,12 @@ class VQGanVAE1024(nn.Module):
     def _plan_attn(self, pl, x32, blk, final='f32'):
         """model.py:180-205."""
         h = pl.gn(x32, blk.norm, swish=False)
-        q, k, v = pl.conv(h, blk.q, 3), pl.conv(h, blk.k, 3), pl.conv(h, blk.v, 3)
-        o = pl.spatial_attention(q, k, v)
+        if _FUSE_QKV and not pl.strict:
+            qkv, c = pl.conv_qkv(h, blk)
+            o = pl.spatial_attention_fused(qkv, c)
+        else:
+            q, k, v = pl.conv(h, blk.q, 3), pl.conv(h, blk.k, 3), pl.conv(h, blk.v, 3)
+            o = pl.spatial_attention(q, k, v)
         return pl.conv(o, blk.proj_out, 3, residual=x32, out32=final != 'bf16', feeds_gn=final != 'bf16',
                        also_bf16=final == 'both')
 

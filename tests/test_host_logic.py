@@ -338,7 +338,8 @@ def test_library_host_side_policies():
 
 
 def test_vqgan_plan_structure_config2(monkeypatch):
-    """The planned op list of one full-size encode (what mmvid_vqgan_run executes): 45 convolutions, no cast passes
+    """The planned op list of one full-size encode (what mmvid_vqgan_run executes): 39 convolutions (45 in the reference's
+    graph; the q, k, v 1x1 convs of each of the 3 AttnBlocks are one launch with stacked weights), no cast passes
     (convs store the precisions their consumers read), GroupNorm statistics fused into the producing conv wherever
     the geometry allows, and a matching stats area on both sides of every fused pair."""
     from mmvid_amd import vae as V
@@ -349,7 +350,12 @@ def test_vqgan_plan_structure_config2(monkeypatch):
     v._plan_encode(pl, 4, 128)
     ops_ = pl.ops
     kinds = [o.op for o in ops_]
-    assert kinds.count(pl.OP_CONV) == 45 and kinds.count(pl.OP_CAST) == 0
+    assert kinds.count(pl.OP_CONV) == 39 and kinds.count(pl.OP_CAST) == 0
+    attn = [o for o in ops_ if o.op == pl.OP_ATTN]
+    for o in attn:  # q | k | v are column blocks of one [n, hw, 3C] buffer: byte offsets 2C apart, row stride 3C
+        assert o.pad == 3 * o.C and o.in1 - o.in0 == 2 * o.C and o.in2 - o.in1 == 2 * o.C
+    qkv = [o for o in ops_ if o.op == pl.OP_CONV and o.mode == 3 and o.Cout == 3 * o.C]
+    assert len(qkv) == 3 and {o.out_bf16 for o in qkv} == {o.in0 for o in attn}
     assert kinds.count(pl.OP_GN) == 28 and kinds.count(pl.OP_ATTN) == 3 and kinds[-1] == pl.OP_VQ
     fused_gn = [o for o in ops_ if o.op == pl.OP_GN and o.flags & 2]
     emitting = [o for o in ops_ if o.op == pl.OP_CONV and o.flags & 4]
