@@ -392,7 +392,9 @@ def main():
     ap.add_argument('--layers', type=int, default=12, help=argparse.SUPPRESS)  # debugging only; 12 = the model
     ap.add_argument('--dry-run', action='store_true', help='rank plumbing only (gloo, no GPU work): start the ranks, all-reduce '
                     'one scalar, print the JSON skeleton')
-    ap.add_argument('--strict', action='store_true', help='run the VQGAN encoder in its exact-index mode (vae.strict)')
+    ap.add_argument('--strict', nargs='?', const='fp32', default=None, choices=['fp32', 'split'],
+                    help="run the VQGAN encoder in an exact-index mode: 'fp32' (vae.strict = True, fp32 matrix pipe) or 'split' "
+                    "(vae.strict = 'split': bf16-pair convolutions, 3 products each, on the bf16 pipe)")
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ:
         # started as plain `python bench.py --gpus N`: become the launcher (train.py:47-66 spawns its ranks from main() the
@@ -445,9 +447,9 @@ def main():
         return
     model = build_model(args.config, device, args.layers)
     if args.strict:  # exact-index tokenisation (vae.strict; 'split' = 3-term bf16 split on the MFMA pipe, True = f32 MFMA)
-        model.vae.strict = True
+        model.vae.strict = True if args.strict == 'fp32' else 'split'
         if model.cvae is not None:
-            model.cvae.strict = True
+            model.cvae.strict = model.vae.strict
     model.frontend.seed = seed  # every rank draws its own masks / warps
     broadcast_parameters(model)
     model.train()
@@ -552,8 +554,11 @@ def main():
             'metric': 'video-tokens/sec training step, 8-frame 128px text-to-video', 'value': value,
             'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16 (transformer) + fp32 (VQGAN encoder, exact token indices)' if args.strict else 'bf16', 'data': 'synthetic',
-            'config': {'workload': WORKLOADS[args.config] + (' [vae.strict: fp32 encoder]' if args.strict else ''),
+            'dtype': {None: 'bf16', 'fp32': 'bf16 (transformer) + fp32 (VQGAN encoder, exact token indices)',
+                      'split': 'bf16 (transformer) + bf16-pair convolutions / fp32 elsewhere (VQGAN encoder)'}[args.strict],
+            'data': 'synthetic',
+            'config': {'workload': WORKLOADS[args.config] + {None: '', 'fp32': ' [vae.strict: fp32 encoder]',
+                                                             'split': " [vae.strict = 'split': bf16-pair encoder]"}[args.strict],
                        'config_id': args.config, 'per_gpu_batch': B, 'global_batch': world * B,
                        'seq_len': L, 'parallelism': f'dp{world}', 'step_launch': step_launch, 'layers': args.layers},
             'loss': loss_value, 'roofline': roofline, 'kernels': kernels,

@@ -379,6 +379,27 @@ int mmvid_groupnorm_swish_nhwc_f32(const float* x, int N, int64_t hw, int C, con
 int mmvid_spatial_attention_f32(const float* q, const float* k, const float* v, int N, int HW, int C, float scale,
                                 float* scratch, float* out, void* stream);
 
+/* ---- the "split" VQGAN operators: `VQGanVAE1024.strict = 'split'` (csrc/conv.hip, conv_strip.hip, norm.hip).  The middle
+ * path between the bf16 operator and the fp32 one: every activation and weight that enters a convolution is a bf16 PAIR
+ * (x = x_hi + x_lo with hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits) and a convolution is the three products
+ * x_hi.w_hi + x_lo.w_hi + x_hi.w_lo accumulated in fp32 inside ONE K loop of three times the length on the bf16 matrix pipe
+ * (the dropped x_lo.w_lo term is 2^-18 relative).  Residual stream, GroupNorm (fp64 finalisation, expf swish), spatial
+ * attention (mmvid_spatial_attention_f32) and the VQ argmin stay fp32.  Same reference lines as the bf16 entry points.
+ * x_planes: [2][N,Hin,Win,Cin] bf16 (hi plane, lo plane); w3: [Cout][3][taps][Cin] bf16 = (w_hi | w_hi | w_lo). */
+int mmvid_conv2d_nhwc_split3(int mode, const void* x_planes, int N, int Hin, int Win, int Cin, const void* w3, const float* bias,
+                             int Cout, const float* residual_f32, int clamp01, float* out_f32, int splitk, float* workspace,
+                             void* stream);
+int mmvid_conv3x3_strip_nhwc_split3(const void* x_planes, int N, int H, int W, int Cin, const void* w3, const float* bias,
+                                    int Cout, const float* residual_f32, float* out_f32, void* stream);
+/* fp32 [n] -> bf16 pair planes [2][n] (n % 8 == 0). */
+int mmvid_split_f32_bf16x2(const float* x, int64_t n, void* planes_bf16, void* stream);
+/* img NCHW fp32 [N,3,H,W] in [0,1] -> bf16 pair planes [2][N,H,W,8] of 2x-1 (vae.py:41). */
+int mmvid_image_to_nhwc8_split(const float* img, int N, int H, int W, void* planes_bf16, void* stream);
+/* GroupNorm(32) [+ swish] (model.py:38-42): x fp32 NHWC -> bf16 pair planes [2][N,hw,C].
+ * stats_scratch: fp32 [N*(2*C + 64*ceil(hw/256))]. */
+int mmvid_groupnorm_swish_nhwc_split(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
+                                     int swish, float* stats_scratch, void* planes_bf16, void* stream);
+
 /* ---- native op-list executor for the VQGAN encoder / decoder (model.py:439-466, 551-582; vae.py:38-56): the host
  * plans the op sequence once per input shape, every call is then one host->native transition.  Offsets are bytes
  * into `arena` (-1 = unused); w/b/ext_* are device pointers. */
@@ -401,6 +422,10 @@ enum {
 /* flags & 16 (IMG2NHWC8, CONV, GROUPNORM, SPATIAL_ATTN, GATHER, EXT_CAST): the strict fp32 operator; every arena
  * tensor of such a plan is fp32 (out_f32 / in* are fp32), w is fp32 [Cout][taps][Cin]. */
 #define MMVID_VQFLAG_STRICT 16
+/* flags & 64 (IMG2NHWC8, CONV, GROUPNORM, CAST): the split operator.  IMG2NHWC8 / GROUPNORM / CAST write bf16 pair planes at
+ * out_bf16 (in0 fp32); CONV reads pair planes at in0, w = w3, residual in1 fp32, writes out_f32 (flags&2 clamp01, flags&8 strip
+ * form, flags&32 split-K by 4 through `scratch`). */
+#define MMVID_VQFLAG_SPLIT 64
 typedef struct {
     int32_t op, mode;
     int32_t N, H, W, C;

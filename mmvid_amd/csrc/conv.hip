@@ -22,7 +22,9 @@ struct ConvParams {
     const bf16_t* w;
     int N, Hin, Win, Cin, cin_log2, Hout, Wout, Cout, mode, taps;
     long M;
-    int K;
+    int K;         // reduction length the K loop runs over = terms * K1
+    int K1;        // taps * Cin
+    long x_plane;  // split operator (terms == 3): elements between the hi and lo planes of x; term 1 reads the lo plane
     const float* bias;
     const bf16_t* res_bf16;
     const float* res_f32;
@@ -77,10 +79,13 @@ struct ConvAStage<true> {
         }
     }
     __device__ __forceinline__ void issue(const ConvParams& p, int k0, char* tile, int wave) const {
-        const int tap = k0 >> p.cin_log2, ci0 = k0 & (p.Cin - 1);  // wave-uniform
+        // split operator: K = [x_hi.w_hi | x_lo.w_hi | x_hi.w_lo]; K1 % 64 == 0 here, so a K tile lies inside one term
+        const int term = (k0 >= p.K1 ? 1 : 0) + (k0 >= 2 * p.K1 ? 1 : 0);  // wave-uniform; 0 for the plain operator
+        k0 -= term * p.K1;
+        const int tap = k0 >> p.cin_log2, ci0 = k0 & (p.Cin - 1);
         const int ky = tap / 3, kx = tap - ky * 3;
         const int disp = p.mode == 0 ? (ky - 1) * p.Win + (kx - 1) : (p.mode == 1 ? ky * p.Win + kx : 0);
-        const long byte_disp = (((long)disp << p.cin_log2) + ci0) * 2;
+        const long byte_disp = (((long)disp << p.cin_log2) + ci0 + (term == 1 ? p.x_plane : 0)) * 2;
         const rsrc_t rsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + byte_disp, 0x7fffffffu);
         const uint32_t bit = 1u << tap;
 #pragma unroll
@@ -114,13 +119,16 @@ struct ConvAStage<false> {
     __device__ __forceinline__ void issue(const ConvParams& p, int k0, char* tile, int wave) const {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const int k = k0 + chunk[jj] * 8;
+            int k = k0 + chunk[jj] * 8;
+            bool ok = k < p.K && nbase[jj] >= 0;
+            const int term = (k >= p.K1 ? 1 : 0) + (k >= 2 * p.K1 ? 1 : 0);  // split operator: K1 % 8 == 0, a chunk lies in one term
+            k -= term * p.K1;
+            const bf16_t* xb = p.x + (term == 1 ? p.x_plane : 0);
             const int tap = k >> p.cin_log2;
             const int ci = k & (p.Cin - 1);
             const int ky = (p.mode == 3) ? 0 : tap / 3;
             const int kx = (p.mode == 3) ? 0 : tap - ky * 3;
             int iy, ix;
-            bool ok = k < p.K && nbase[jj] >= 0;
             if (p.mode == 0) {
                 iy = oy[jj] + ky - 1, ix = ox[jj] + kx - 1;
                 ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
@@ -134,7 +142,7 @@ struct ConvAStage<false> {
             } else {
                 iy = oy[jj], ix = ox[jj];
             }
-            const void* src = ok ? (const void*)(p.x + ((nbase[jj] + (long)iy * p.Win + ix) << p.cin_log2) + ci)
+            const void* src = ok ? (const void*)(xb + ((nbase[jj] + (long)iy * p.Win + ix) << p.cin_log2) + ci)
                                  : (const void*)g_zero16;
             glds16(src, tile + (wave * 4 + jj) * 1024);
         }
@@ -345,6 +353,36 @@ __global__ __launch_bounds__(256) void image_to_nhwc8_kernel(const float* __rest
     *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(pack_bf2(r, g), pack_bf2(b, 0.f), 0u, 0u);
 }
 
+// the same as a bf16 PAIR for the split operator: planes [2][N,H,W,8], hi = bf16(v), lo = bf16(v - hi)
+__global__ __launch_bounds__(256) void image_to_nhwc8_split_kernel(const float* __restrict__ img, long npix, long hw,
+                                                                   bf16_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const long n = i / hw, p = i - n * hw;
+    const float* s = img + n * 3 * hw + p;
+    const float v[3] = {2.f * s[0] - 1.f, 2.f * s[hw] - 1.f, 2.f * s[2 * hw] - 1.f};
+    const uint32_t h01 = pack_bf2(v[0], v[1]), h2 = pack_bf2(v[2], 0.f);
+    *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(h01, h2, 0u, 0u);
+    *reinterpret_cast<uint4*>(out + (npix + i) * 8) =
+        make_uint4(pack_bf2(v[0] - bf_lo(h01), v[1] - bf_hi(h01)), pack_bf2(v[2] - bf_lo(h2), 0.f), 0u, 0u);
+}
+
+// fp32 -> bf16 pair: hi = bf16(v), lo = bf16(v - hi); 8 elements per thread; planes [2][n]
+__global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ x, long n8, bf16_t* __restrict__ planes) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const float4 a = reinterpret_cast<const float4*>(x + i * 8)[0], b = reinterpret_cast<const float4*>(x + i * 8)[1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        l[e] = pack_bf2(v[2 * e] - bf_lo(h[e]), v[2 * e + 1] - bf_hi(h[e]));
+    }
+    *reinterpret_cast<uint4*>(planes + i * 8) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(planes + (n8 + i) * 8) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 // NHWC f32 -> NCHW f32 (first Cuse channels); small tensors only (decoder output, z)
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, long total, long hw, int C,
                                                            int Cuse, float* __restrict__ out) {
@@ -415,10 +453,32 @@ extern "C" int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Wi
 // splitk > 1: the reduction (taps x input channels) is cut into `splitk` ranges computed by separate blocks into
 // workspace [splitk][M][Cout] fp32, then added in order by conv_splitk_reduce_kernel together with bias / residual.  For the
 // deep, small-map layers (8x8 maps: M = 64 N rows, K = 4,608) whose 128x128 tiles would fill a fraction of the chip.
+static int conv2d_launch(int terms, int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w, const float* bias,
+                         int Cout, const void* residual_bf16, const float* residual_f32, int clamp01, void* out_bf16, float* out_f32,
+                         float* gn_partial, int splitk, float* workspace, void* stream);
+
 extern "C" int mmvid_conv2d_nhwc_splitk(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w,
                                         const float* bias, int Cout, const void* residual_bf16, const float* residual_f32,
                                         int clamp01, void* out_bf16, float* out_f32, float* gn_partial, int splitk,
                                         float* workspace, void* stream) {
+    return conv2d_launch(1, mode, x, N, Hin, Win, Cin, w, bias, Cout, residual_bf16, residual_f32, clamp01, out_bf16, out_f32,
+                         gn_partial, splitk, workspace, stream);
+}
+
+// The "split" operator (vae.strict = 'split'): activations and weights are bf16 PAIRS, x = x_hi + x_lo, w = w_hi + w_lo (16
+// mantissa bits each), and the convolution is the three products x_hi.w_hi + x_lo.w_hi + x_hi.w_lo accumulated in fp32 inside
+// ONE K loop of three times the length (the dropped x_lo.w_lo term is 2^-18 relative): ~1e-5 of the fp32 result on the bf16
+// matrix pipe.  x_planes: [2][N,Hin,Win,Cin] (hi plane, lo plane); w3: [Cout][3][taps][Cin] = (w_hi | w_hi | w_lo).
+extern "C" int mmvid_conv2d_nhwc_split3(int mode, const void* x_planes, int N, int Hin, int Win, int Cin, const void* w3,
+                                        const float* bias, int Cout, const float* residual_f32, int clamp01, float* out_f32,
+                                        int splitk, float* workspace, void* stream) {
+    return conv2d_launch(3, mode, x_planes, N, Hin, Win, Cin, w3, bias, Cout, nullptr, residual_f32, clamp01, nullptr, out_f32, nullptr,
+                         splitk, workspace, stream);
+}
+
+static int conv2d_launch(int terms, int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w, const float* bias,
+                         int Cout, const void* residual_bf16, const float* residual_f32, int clamp01, void* out_bf16, float* out_f32,
+                         float* gn_partial, int splitk, float* workspace, void* stream) {
     MMVID_REQUIRE(x && w && (out_bf16 || out_f32), "conv2d_nhwc: null pointer");
     MMVID_REQUIRE(splitk >= 1 && splitk <= 16 && (splitk == 1 || (workspace && !gn_partial && Cout % 4 == 0)),
                   "conv2d_nhwc: split-K (%d) needs a workspace and cannot emit GroupNorm statistics", splitk);
@@ -439,7 +499,8 @@ extern "C" int mmvid_conv2d_nhwc_splitk(int mode, const void* x, int N, int Hin,
         p.Hout = Hin, p.Wout = Win;
     }
     p.M = (long)N * p.Hout * p.Wout;
-    p.K = p.taps * Cin;
+    p.K1 = p.taps * Cin, p.K = terms * p.K1;
+    p.x_plane = terms > 1 ? (long)N * Hin * Win * Cin : 0;
     p.bias = bias, p.res_bf16 = (const bf16_t*)residual_bf16, p.res_f32 = residual_f32, p.clamp01 = clamp01;
     p.out_bf16 = (bf16_t*)out_bf16, p.out_f32 = out_f32, p.gn_partial = gn_partial;
     p.splitk = splitk, p.partial = splitk > 1 ? workspace : nullptr;
@@ -447,9 +508,9 @@ extern "C" int mmvid_conv2d_nhwc_splitk(int mode, const void* x, int N, int Hin,
         MMVID_REQUIRE(((long)p.Hout * p.Wout) % 128 == 0 && Cout % 128 == 0,
                       "conv2d_nhwc: fused GroupNorm statistics need Hout*Wout %% 128 == 0 and Cout %% 128 == 0");
     if (p.M == 0) return MMVID_OK;
-    MMVID_REQUIRE((long)N * Hin * Win * Cin * 2 < (1ll << 31) && (long)Cout * p.K * 2 < (1ll << 31),
+    MMVID_REQUIRE((long)N * Hin * Win * Cin * 2 * (terms > 1 ? 2 : 1) < (1ll << 31) && (long)Cout * p.K * 2 < (1ll << 31),
                   "conv2d_nhwc: input or weight of 2 GiB or more (32-bit buffer offsets)");
-    MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * p.K, (hipStream_t)stream);
+    MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * p.K, (hipStream_t)stream);  // executed MFMA work (3x for split)
     const int tile = mmvid_tile_override();
     bool big = false;
     // with fused GroupNorm statistics the block shape must not depend on the batch size: the order in which a
@@ -489,6 +550,25 @@ extern "C" int mmvid_image_to_nhwc8(const float* img, int N, int H, int W, void*
     hipLaunchKernelGGL(image_to_nhwc8_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, img, npix,
                        (long)H * W, (bf16_t*)out_bf16);
     MMVID_LAUNCH_CHECK("image_to_nhwc8");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_image_to_nhwc8_split(const float* img, int N, int H, int W, void* planes_bf16, void* stream) {
+    MMVID_REQUIRE(img && planes_bf16, "image_to_nhwc8_split: null pointer");
+    const long npix = (long)N * H * W;
+    if (npix == 0) return MMVID_OK;
+    hipLaunchKernelGGL(image_to_nhwc8_split_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, (hipStream_t)stream, img, npix,
+                       (long)H * W, (bf16_t*)planes_bf16);
+    MMVID_LAUNCH_CHECK("image_to_nhwc8_split");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_split_f32_bf16x2(const float* x, int64_t n, void* planes_bf16, void* stream) {
+    MMVID_REQUIRE(x && planes_bf16 && n % 8 == 0, "split_f32_bf16x2: null pointer or n=%lld not a multiple of 8", (long long)n);
+    if (n == 0) return MMVID_OK;
+    hipLaunchKernelGGL(split_f32_kernel, dim3(cdiv(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)(n / 8),
+                       (bf16_t*)planes_bf16);
+    MMVID_LAUNCH_CHECK("split_f32_bf16x2");
     return MMVID_OK;
 }
 

@@ -31,8 +31,10 @@ constexpr int ST_LDS = 2 * STAGE;
 
 struct StripParams {
     const bf16_t* x;
-    const bf16_t* w;  // [Cout][9][Cin]
+    const bf16_t* w;  // [Cout][terms][9][Cin]
     int N, H, W, Cin, Cout, w_log2;
+    int terms;        // 1, or 3 for the split operator (conv.hip): K = x_hi.w_hi | x_lo.w_hi | x_hi.w_lo
+    long x_plane;     // elements between the hi and lo planes of x
     long M;
     const float* bias;
     const bf16_t* res_bf16;
@@ -80,19 +82,24 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
     for (int jj = 0; jj < PB; ++jj) {
         const int row = (wave * PB + jj) * 4 + (lane >> 4), ps = lane & 15;
         const int q = ps ^ (row & 15);
-        bvoff[jj] = (q < 12 && cout0 + row < p.Cout) ? (uint32_t)((((long)(cout0 + row) * 9 + (q >> 2)) * Cin + (q & 3) * 8) * 2) : OOB;
+        bvoff[jj] = (q < 12 && cout0 + row < p.Cout)
+                        ? (uint32_t)((((long)(cout0 + row) * 9 * p.terms + (q >> 2)) * Cin + (q & 3) * 8) * 2)
+                        : OOB;
     }
-    const rsrc_t brsrc = make_rsrc(p.w, (uint32_t)((long)p.Cout * 9 * Cin * 2));
-    const int chunks = Cin >> 5, nt = 3 * chunks;
+    const rsrc_t brsrc = make_rsrc(p.w, (uint32_t)((long)p.Cout * 9 * p.terms * Cin * 2));
+    const int chunks = Cin >> 5, nt = 3 * chunks * p.terms;
+    // tile t = (term, kernel row ky, channel chunk ch), term outermost: A displacement and B offset in bytes (wave-uniform)
+    auto a_disp = [&](int term, int ky, int ch) { return ((long)(ky - 1) * W * Cin + ch * 32 + (term == 1 ? p.x_plane : 0)) * 2; };
+    auto b_soff = [&](int term, int ky, int ch) { return (uint32_t)((((term * 3 + ky) * 3) * Cin + ch * 32) * 2); };
     auto stage_tile = [&](int t, char* buf) {
-        const int ky = t / chunks, ch = t - ky * chunks;  // wave-uniform
-        const long disp = ((long)(ky - 1) * W * Cin + ch * 32) * 2;
-        const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + disp, 0x7fffffffu);
+        const int term = t / (3 * chunks), tt = t - term * 3 * chunks;
+        const int ky = tt / chunks, ch = tt - ky * chunks;
+        const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + a_disp(term, ky, ch), 0x7fffffffu);
         const uint32_t bit = 1u << ky;
 #pragma unroll
         for (int jj = 0; jj < PA; ++jj)
             blds16(arsrc, (amask[jj] & bit) ? avoff[jj] : OOB, 0, buf + (wave * PA + jj) * 1024);
-        const uint32_t bsoff = (uint32_t)((ky * 3 * Cin + ch * 32) * 2);
+        const uint32_t bsoff = b_soff(term, ky, ch);
 #pragma unroll
         for (int jj = 0; jj < PB; ++jj) blds16(brsrc, bvoff[jj], bsoff, buf + A_STAGE + (wave * PB + jj) * 1024);
     };
@@ -154,16 +161,18 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wave >= 4) __builtin_amdgcn_s_barrier();  // the trailing group starts one barrier late
-        int ky_n = 0, ch_n = 0;
+        int ky_n = 0, ch_n = 0, term_n = 0;
         for (int t = 0; t < nt; ++t) {
             const uint32_t st = (uint32_t)(t & 1) * STAGE;
             char* nxt = smem + ((t + 1) & 1) * STAGE;
-            if (++ch_n == chunks) ch_n = 0, ++ky_n;
+            if (++ch_n == chunks) {
+                ch_n = 0;
+                if (++ky_n == 3) ky_n = 0, ++term_n;
+            }
             const bool more = t + 1 < nt;
-            const long disp = ((long)(ky_n - 1) * W * Cin + ch_n * 32) * 2;
-            const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + (more ? disp : 0), 0x7fffffffu);
+            const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + (more ? a_disp(term_n, ky_n, ch_n) : 0), 0x7fffffffu);
             const uint32_t bit = 1u << ky_n;
-            const uint32_t bsoff = (uint32_t)((ky_n * 3 * Cin + ch_n * 32) * 2);
+            const uint32_t bsoff = b_soff(term_n, ky_n, ch_n);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 bf16x8_t fa[2][2], fb[2][4];
@@ -197,19 +206,21 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
         if (wave < 4) __builtin_amdgcn_s_barrier();  // the leading group waits for the trailing one
     } else {
     stage_tile(0, smem);
-        int ky_n = 0, ch_n = 0;  // (kernel row, channel chunk) of the NEXT tile, advanced without a division
+        int ky_n = 0, ch_n = 0, term_n = 0;  // (term, kernel row, channel chunk) of the NEXT tile, advanced without a division
         for (int t = 0; t < nt; ++t) {
             const uint32_t st = (uint32_t)(t & 1) * STAGE;
             char* nxt = smem + ((t + 1) & 1) * STAGE;
-            if (++ch_n == chunks) ch_n = 0, ++ky_n;
+            if (++ch_n == chunks) {
+                ch_n = 0;
+                if (++ky_n == 3) ky_n = 0, ++term_n;
+            }
             const bool more = t + 1 < nt;
             dma_publish_barrier();  // tile t has landed for every wave; buffer (t+1)&1 is free
             if (SCHED == 0 && more) stage_tile(t + 1, nxt);
             // descriptor / offsets of the next tile's requests: scalar work, once per tile
-            const long disp = ((long)(ky_n - 1) * W * Cin + ch_n * 32) * 2;
-            const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + (more ? disp : 0), 0x7fffffffu);
+            const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + (more ? a_disp(term_n, ky_n, ch_n) : 0), 0x7fffffffu);
             const uint32_t bit = 1u << ky_n;
-            const uint32_t bsoff = (uint32_t)((ky_n * 3 * Cin + ch_n * 32) * 2);
+            const uint32_t bsoff = b_soff(term_n, ky_n, ch_n);
             bf16x8_t fa[2][2], fb[2][4];
             load_frags(st, 0, fa[0], fb[0]);
     #pragma unroll
@@ -314,17 +325,34 @@ extern "C" int mmvid_conv3x3_strip_supported(int H, int W, int Cin, int Cout) {
     return (long)H * W >= 1024 ? 1 : 0;
 }
 
+static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
+                        const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32, float* gn_partial64,
+                        void* stream);
+
 extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
                                         const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32,
                                         float* gn_partial64, void* stream) {
+    return strip_launch(1, x, N, H, W, Cin, w, bias, Cout, residual_bf16, residual_f32, out_bf16, out_f32, gn_partial64, stream);
+}
+
+// the split operator of conv.hip (mmvid_conv2d_nhwc_split3) in strip form: x_planes [2][N,H,W,Cin], w3 [Cout][3][9][Cin]
+extern "C" int mmvid_conv3x3_strip_nhwc_split3(const void* x_planes, int N, int H, int W, int Cin, const void* w3, const float* bias,
+                                               int Cout, const float* residual_f32, float* out_f32, void* stream) {
+    return strip_launch(3, x_planes, N, H, W, Cin, w3, bias, Cout, nullptr, residual_f32, nullptr, out_f32, nullptr, stream);
+}
+
+static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
+                        const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32, float* gn_partial64,
+                        void* stream) {
     MMVID_REQUIRE(x && w && (out_bf16 || out_f32), "conv3x3_strip: null pointer");
     MMVID_REQUIRE(W >= 8 && W <= 128 && (W & (W - 1)) == 0 && Cin >= 32 && (Cin & (Cin - 1)) == 0 && Cout % 128 == 0 &&
                       ((long)H * W) % 64 == 0,
                   "conv3x3_strip: unsupported geometry H=%d W=%d Cin=%d Cout=%d", H, W, Cin, Cout);
-    MMVID_REQUIRE((long)N * H * W * Cin * 2 < (1ll << 31) && (long)Cout * 9 * Cin * 2 < (1ll << 31),
+    MMVID_REQUIRE((long)N * H * W * Cin * 2 * (terms > 1 ? 2 : 1) < (1ll << 31) && (long)Cout * 9 * terms * Cin * 2 < (1ll << 31),
                   "conv3x3_strip: input or weight of 2 GiB or more (32-bit buffer offsets)");
     StripParams p;
     p.x = (const bf16_t*)x, p.w = (const bf16_t*)w, p.N = N, p.H = H, p.W = W, p.Cin = Cin, p.Cout = Cout;
+    p.terms = terms, p.x_plane = terms > 1 ? (long)N * H * W * Cin : 0;
     p.w_log2 = 0;
     while ((1 << p.w_log2) < W) ++p.w_log2;
     p.M = (long)N * H * W;
@@ -338,7 +366,7 @@ extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int 
         (void)hipFuncSetAttribute((const void*)conv_strip_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
         attr = true;
     }
-    MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * 9 * Cin, (hipStream_t)stream);
+    MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * 9 * Cin * terms, (hipStream_t)stream);
     const int blocks = cdiv(p.M, ST_M) * (Cout / ST_N);
     if (mmvid_option(MMVID_OPT_STRIP_SCHED) >= 2)
         hipLaunchKernelGGL(conv_strip_kernel<2>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);

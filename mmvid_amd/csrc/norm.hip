@@ -339,6 +339,65 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
     }
 }
 
+// ---- split operator (vae.strict = 'split', conv.hip): fp32 input, statistics finalised in fp64, output as a bf16 PAIR
+// (mean, rstd) per (image, channel), stored per channel so the apply kernel reads them with the channel chunk: mr[n][C][2]
+__global__ __launch_bounds__(256) void groupnorm_finalize_f64_kernel(const float* __restrict__ partial, int nblk, int N, int C,
+                                                                     double cnt, float eps, float* __restrict__ mr) {
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);  // (n, grp)
+    if (item >= N * 32) return;
+    const int lane = threadIdx.x & 63;
+    const int n = item >> 5, grp = item & 31;
+    double sm = 0.0, sq = 0.0;
+    for (int k = lane; k < nblk; k += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(partial + (((long)n * nblk + k) * 32 + grp) * 2);
+        sm += (double)v.x, sq += (double)v.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64), sq += __shfl_xor(sq, o, 64);  // fixed butterfly
+    const double mu = sm / cnt;
+    double var = sq / cnt - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const int cpg = C >> 5;
+    if (lane < cpg) *reinterpret_cast<float2*>(mr + ((long)n * C + grp * cpg + lane) * 2) = make_float2((float)mu, (float)rstd);
+}
+
+// y = swish?(((x - mean) * rstd) * w + b) evaluated like ATen (expf, true division), stored as hi = bf16(y), lo = bf16(y - hi)
+// in planes [2][N*hw*C]; 8 channels per thread
+__global__ __launch_bounds__(256) void groupnorm_apply_split_kernel(const float* __restrict__ x, long hw, int C,
+                                                                    const float* __restrict__ mr, const float* __restrict__ w,
+                                                                    const float* __restrict__ b, int swish,
+                                                                    bf16_t* __restrict__ planes, long total_chunks) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total_chunks) return;
+    const int cchunks = C >> 3;
+    const int cc = (int)(t % cchunks);
+    const long pix = t / cchunks;
+    const int n = (int)(pix / hw);
+    float f[8], wv[8], bv[8];
+    load8<float>(x + pix * C + cc * 8, f);
+    load8<float>(w + cc * 8, wv);
+    load8<float>(b + cc * 8, bv);
+    const float4* q = reinterpret_cast<const float4*>(mr + ((long)n * C + cc * 8) * 2);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const float mu[8] = {q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.z};
+    const float rs[8] = {q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.y, q3.w};
+    uint32_t h[4], l[4];
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = ((f[e] - mu[e]) * rs[e]) * wv[e] + bv[e];
+        if (swish) v = v * (1.0f / (1.0f + expf(-v)));
+        o[e] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = pack_bf2(o[2 * e], o[2 * e + 1]);
+        l[e] = pack_bf2(o[2 * e] - bf_lo(h[e]), o[2 * e + 1] - bf_hi(h[e]));
+    }
+    *reinterpret_cast<uint4*>(planes + t * 8) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(planes + (total_chunks + t) * 8) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 }  // namespace
 
 extern "C" int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const float* w, const float* b,
@@ -459,5 +518,26 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
         hipLaunchKernelGGL(groupnorm_apply_kernel<float>, dim3(cdiv(chunks, 256)), dim3(256), 0, s, (const float*)x,
                            (long)hw, C, ab, swish, (bf16_t*)y_bf16, y_f32, chunks);
     MMVID_LAUNCH_CHECK("groupnorm");
+    return MMVID_OK;
+}
+
+// GroupNorm(32) [+ swish] of the split operator: x fp32 NHWC -> bf16 pair planes [2][N,hw,C].  Partial sums per 256 pixels in
+// fp32 (at most 4,096 addends each), combined and finalised in fp64.  stats_scratch: fp32 [N*(2*C + 64*ceil(hw/256))].
+extern "C" int mmvid_groupnorm_swish_nhwc_split(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
+                                                int swish, float* stats_scratch, void* planes_bf16, void* stream) {
+    MMVID_REQUIRE(x && w && b && stats_scratch && planes_bf16, "groupnorm_split: null pointer");
+    MMVID_REQUIRE(C % 32 == 0 && C <= 512 && 256 % (C / 8) == 0, "groupnorm_split: C=%d unsupported", C);
+    if (N == 0 || hw == 0) return MMVID_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int pix_per_block = 256, nblk = cdiv(hw, pix_per_block);
+    float* mr = stats_scratch;                         // [N][C][2]
+    float* partial = stats_scratch + (long)N * C * 2;  // [N][nblk][32][2]
+    hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3(nblk, N), dim3(256), 0, s, x, (long)hw, C, pix_per_block, partial);
+    hipLaunchKernelGGL(groupnorm_finalize_f64_kernel, dim3(cdiv((long)N * 32, 4)), dim3(256), 0, s, partial, nblk, N, C,
+                       (double)hw * (double)(C / 32), eps, mr);
+    const long chunks = (long)N * hw * (C / 8);
+    hipLaunchKernelGGL(groupnorm_apply_split_kernel, dim3(cdiv(chunks, 256)), dim3(256), 0, s, x, (long)hw, C, mr, w, b, swish,
+                       (bf16_t*)planes_bf16, chunks);
+    MMVID_LAUNCH_CHECK("groupnorm_split");
     return MMVID_OK;
 }

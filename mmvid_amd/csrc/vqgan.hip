@@ -55,6 +55,37 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
             if (rc) return rc;
             continue;
         }
+        if (o.flags & MMVID_VQFLAG_SPLIT) {  // the bf16-pair operator (conv.hip: mmvid_conv2d_nhwc_split3)
+            switch (o.op) {
+                case MMVID_VQOP_IMG2NHWC8:
+                    rc = mmvid_image_to_nhwc8_split((const float*)o.ext_in, o.N, o.H, o.W, at(arena, o.out_bf16), stream);
+                    break;
+                case MMVID_VQOP_CONV:
+                    if (o.flags & 8)
+                        rc = mmvid_conv3x3_strip_nhwc_split3(at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
+                                                             (const float*)at(arena, o.in1), (float*)at(arena, o.out_f32), stream);
+                    else
+                        rc = mmvid_conv2d_nhwc_split3(o.mode, at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
+                                                      (const float*)at(arena, o.in1), (o.flags >> 1) & 1, (float*)at(arena, o.out_f32),
+                                                      (o.flags & 32) ? 4 : 1, (o.flags & 32) ? (float*)at(arena, o.scratch) : nullptr,
+                                                      stream);
+                    break;
+                case MMVID_VQOP_GROUPNORM:
+                    rc = mmvid_groupnorm_swish_nhwc_split((const float*)at(arena, o.in0), o.N, (int64_t)o.H * o.W, o.C,
+                                                          (const float*)o.w, o.b, o.eps, o.mode, (float*)at(arena, o.scratch),
+                                                          at(arena, o.out_bf16), stream);
+                    break;
+                case MMVID_VQOP_CAST:
+                    rc = mmvid_split_f32_bf16x2((const float*)at(arena, o.in0), (int64_t)o.N * o.H * o.W * o.C, at(arena, o.out_bf16),
+                                                stream);
+                    break;
+                default:
+                    mmvid_set_error("vqgan_run: op %d at %d has no split form", o.op, i);
+                    return MMVID_ERR_ARG;
+            }
+            if (rc) return rc;
+            continue;
+        }
         switch (o.op) {
             case MMVID_VQOP_IMG2NHWC8:
                 rc = mmvid_image_to_nhwc8((const float*)o.ext_in, o.N, o.H, o.W, at(arena, o.out_bf16), stream);

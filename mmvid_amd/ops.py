@@ -335,6 +335,50 @@ def conv2d_nhwc(x, w, bias, mode, residual=None, clamp01=False, out_dtype=bf16, 
     return out
 
 
+# ---- the split operator (vae.strict = 'split'): bf16 pair planes, three products per convolution -------------------------
+def split_planes(x):
+    """fp32 [...] -> bf16 pair planes [2, ...]: hi = bf16(x), lo = bf16(x - hi)."""
+    _chk(x, f32, 'x')
+    out = torch.empty((2, ) + tuple(x.shape), device=x.device, dtype=bf16)
+    call('mmvid_split_f32_bf16x2', _p(x.contiguous()), x.numel(), _p(out), _stream())
+    return out
+
+
+def split_weights(w):
+    """fp32 [Cout, taps, Cin] -> bf16 [Cout, 3, taps, Cin] = (w_hi | w_hi | w_lo)."""
+    hi = w.to(bf16)
+    lo = (w - hi.float()).to(bf16)
+    return torch.stack([hi, hi, lo], 1).contiguous()
+
+
+def conv2d_nhwc_split3(x_planes, w3, bias, mode, residual=None, clamp01=False, splitk=1, strip=False):
+    """x_planes [2,N,H,W,Cin] bf16, w3 [Cout,3,taps,Cin] bf16 -> fp32 [N,Ho,Wo,Cout] = conv of (x_hi + x_lo) with (w_hi + w_lo)
+    without the lo.lo term, fp32 accumulate (mmvid_conv2d_nhwc_split3 / the strip form for mode 0)."""
+    _chk(x_planes, bf16, 'x_planes'), _chk(w3, bf16, 'w3')
+    _, N, H, W, Cin = x_planes.shape
+    Cout = w3.shape[0]
+    Ho, Wo = (H // 2, W // 2) if mode == 1 else ((2 * H, 2 * W) if mode == 2 else (H, W))
+    out = torch.empty(N, Ho, Wo, Cout, device=x_planes.device, dtype=f32)
+    if strip:
+        assert mode == 0 and not clamp01 and splitk == 1
+        call('mmvid_conv3x3_strip_nhwc_split3', _p(x_planes), N, H, W, Cin, _p(w3), _p(bias), Cout, _p(residual), _p(out), _stream())
+        return out
+    ws = torch.empty(splitk * N * Ho * Wo * Cout, device=out.device, dtype=f32) if splitk > 1 else None
+    call('mmvid_conv2d_nhwc_split3', mode, _p(x_planes), N, H, W, Cin, _p(w3), _p(bias), Cout, _p(residual), int(clamp01), _p(out),
+         int(splitk), _p(ws), _stream())
+    return out
+
+
+def groupnorm_swish_split(x, w, b, eps=1e-6, swish=True):
+    """x NHWC fp32 -> bf16 pair planes [2,N,H,W,C] of GroupNorm(32)(x) [* sigmoid]."""
+    _chk(x, f32, 'x')
+    N, H, W, C = x.shape
+    out = torch.empty(2, N, H, W, C, device=x.device, dtype=bf16)
+    st = torch.empty(N * (2 * C + 64 * ((H * W + 255) // 256)), device=x.device, dtype=f32)
+    call('mmvid_groupnorm_swish_nhwc_split', _p(x), N, H * W, C, _p(w), _p(b), float(eps), int(swish), _p(st), _p(out), _stream())
+    return out
+
+
 def image_to_nhwc8(img):
     _chk(img, f32, 'img')
     N, C, H, W = img.shape

@@ -173,11 +173,48 @@ class _Plan:
 class _Planner:
     OP_IMG, OP_CONV, OP_GN, OP_CAST, OP_ATTN, OP_VQ, OP_GATHER, OP_NCHW, OP_EXT = range(9)
     STRICT = 16  # MMVID_VQFLAG_STRICT: the fp32-accurate operator (csrc/strict.hip); all planned tensors are fp32
+    SPLIT = 64   # MMVID_VQFLAG_SPLIT: the bf16-pair operator; planned tensors are fp32 or pair planes [2][n,h,w,c] bf16
 
     def __init__(self, vae, strict=False):
         self.vae, self.ops, self.free, self.top, self.recording = vae, [], [], 0, True
         self.patches, self.kept = [], {}
-        self.strict = strict
+        self.split = strict == 'split'
+        self.strict = bool(strict) and not self.split
+
+    # ---- split operator (vae.strict = 'split'): fp32 tensors between ops, every conv input a bf16 pair ----------------------
+    def _planes(self, x):
+        """fp32 tensor -> pair planes (a no-op for a tensor that already is one)."""
+        if getattr(x, 'is_planes', False):
+            return x
+        n, h, wd, c = x.shape
+        assert x.dtype == f32 and c % 8 == 0, x.shape
+        out = self.alloc((2, n, h, wd, c), bf16)
+        out.is_planes, out.shape = True, (n, h, wd, c)
+        self._op(op=self.OP_CAST, N=n, H=h, W=wd, C=c, flags=self.SPLIT, in0=x.off, out_bf16=out.off)
+        return out
+
+    def _conv_split(self, x, holder, mode, residual, clamp01):
+        x = self._planes(x)
+        w3, b, _ = self.vae._cw_split(holder)
+        n, h, wd, cin = x.shape
+        assert cin == w3.shape[3], (x.shape, w3.shape)
+        ho, wo = (h // 2, wd // 2) if mode == 1 else ((2 * h, 2 * wd) if mode == 2 else (h, wd))
+        cout = w3.shape[0]
+        assert residual is None or residual.dtype == f32
+        out = self.alloc((n, ho, wo, cout), f32)
+        flags = self.SPLIT | (2 if clamp01 else 0)
+        scratch, ws = -1, None
+        if _STRIP and mode == 0 and not clamp01 and bool(_lib.load().mmvid_conv3x3_strip_supported(h, wd, cin, cout)):
+            flags |= 8
+        elif _SPLITK and mode == 0 and ho * wo <= 64 and 9 * cin >= 2304 and cout % 4 == 0:
+            ws = self.alloc((4 * n * ho * wo * cout, ), f32)
+            flags |= 32
+            scratch = ws.off
+        self._op(op=self.OP_CONV, mode=mode, N=n, H=h, W=wd, C=cin, Cout=cout, flags=flags, in0=x.off,
+                 in1=residual.off if residual is not None else -1, out_f32=out.off, scratch=scratch, w=w3.data_ptr(),
+                 b=b.data_ptr())
+        del ws
+        return out
 
     # arena allocation: first fit in the free list, else bump
     def alloc(self, shape, dtype):
@@ -205,6 +242,12 @@ class _Planner:
         return len(self.ops) - 1
 
     def image(self, n, s):
+        if self.split:
+            out = self.alloc((2, n, s, s, 8), bf16)
+            out.is_planes, out.shape = True, (n, s, s, 8)
+            i = self._op(op=self.OP_IMG, N=n, H=s, W=s, C=3, out_bf16=out.off, flags=self.SPLIT)
+            self.patches.append((i, 'ext_in', 'img'))
+            return out
         if self.strict:
             out = self.alloc((n, s, s, 4), f32)
             i = self._op(op=self.OP_IMG, N=n, H=s, W=s, C=3, out_f32=out.off, flags=self.STRICT)
@@ -219,6 +262,8 @@ class _Planner:
         """feeds_gn: a GroupNorm reads this output next -> the epilogue also emits its partial statistics (when the
         shape allows), into a stats area that lives as long as the output buffer.
         also_bf16 (with out32): the epilogue stores a bf16 copy too (`out.bf16`), instead of a later cast pass."""
+        if self.split:
+            return self._conv_split(x, holder, mode, residual, clamp01)
         w, b, _ = self.vae._cw(holder, self.strict)
         n, h, wd, cin = x.shape
         assert x.dtype == (f32 if self.strict else bf16) and cin == w.shape[2], (x.shape, w.shape)
@@ -266,6 +311,13 @@ class _Planner:
 
     def gn(self, x, holder, swish=True):
         n, h, wd, c = x.shape
+        if self.split:
+            out = self.alloc((2, n, h, wd, c), bf16)
+            out.is_planes, out.shape = True, (n, h, wd, c)
+            st = self.alloc((n * (2 * c + 64 * ((h * wd + 255) // 256)), ), f32)
+            self._op(op=self.OP_GN, mode=int(swish), N=n, H=h, W=wd, C=c, flags=self.SPLIT, in0=x.off, out_bf16=out.off,
+                     scratch=st.off, w=holder.weight.data_ptr(), b=holder.bias.data_ptr(), eps=1e-6)
+            return out
         if self.strict:
             out = self.alloc(x.shape, f32)
             st = self.alloc((n * 2 * c, ), f32)
@@ -282,6 +334,8 @@ class _Planner:
         return out
 
     def cast(self, x):
+        if self.split:
+            return self._planes(x)
         if x.dtype == bf16 or self.strict:
             return x
         if getattr(x, 'bf16', None) is not None:  # the producing conv already stored the bf16 copy
@@ -315,7 +369,7 @@ class _Planner:
     def spatial_attention(self, q, k, v):
         n, h, wd, c = q.shape
         hw = h * wd
-        if self.strict:
+        if self.strict or self.split:  # (split: q, k, v are fp32 conv outputs; the fp32 attention is 0.2 % of the encoder's work)
             out = self.alloc(q.shape, f32)
             sc = self.alloc((2 * n * hw * hw, ), f32)
             self._op(op=self.OP_ATTN, N=n, H=h, W=wd, C=c, flags=self.STRICT, in0=q.off, in1=k.off, in2=v.off,
@@ -336,17 +390,19 @@ class _Planner:
 
     def gather(self, n, hw):
         cb = self.vae.model.quantize.embedding.weight
-        out = self.alloc((n, hw, hw, cb.shape[1]), f32 if self.strict else bf16)
+        f32out = self.strict or self.split
+        out = self.alloc((n, hw, hw, cb.shape[1]), f32 if f32out else bf16)
         i = self._op(op=self.OP_GATHER, N=n, H=hw, W=hw, C=cb.shape[1], Cout=cb.shape[0], w=cb.data_ptr(),
-                     flags=self.STRICT if self.strict else 0, **{'out_f32' if self.strict else 'out_bf16': out.off})
+                     flags=self.STRICT if f32out else 0, **{'out_f32' if f32out else 'out_bf16': out.off})
         self.patches.append((i, 'ext_in', 'idx'))
         return out
 
     def external_z(self, n, hw, c):
         """decode_train: z [n*hw*hw, c] fp32 computed outside the plan (probs @ codebook) enters here."""
-        out = self.alloc((n, hw, hw, c), f32 if self.strict else bf16)
-        i = self._op(op=self.OP_EXT, N=n, H=hw, W=hw, C=c, flags=self.STRICT if self.strict else 0,
-                     **{'out_f32' if self.strict else 'out_bf16': out.off})
+        f32out = self.strict or self.split
+        out = self.alloc((n, hw, hw, c), f32 if f32out else bf16)
+        i = self._op(op=self.OP_EXT, N=n, H=hw, W=hw, C=c, flags=self.STRICT if f32out else 0,
+                     **{'out_f32' if f32out else 'out_bf16': out.off})
         self.patches.append((i, 'ext_in', 'z'))
         return out
 
@@ -382,7 +438,9 @@ class VQGanVAE1024(nn.Module):
         self.image_size = 256
         self.num_tokens = 1024
         # strict = True: fp32-accurate encoder / decoder (csrc/strict.hip) -- token indices equal the reference's; the
-        # default bf16 MFMA path is ~20x faster and differs on near-ties of the codebook distances
+        # default bf16 MFMA path is ~6x faster and differs on near-ties of the codebook distances.
+        # strict = 'split': the middle path -- bf16-pair convolutions on the bf16 matrix pipe (3 products per convolution,
+        # fp32 accumulate; ~1e-5 of the fp32 result), fp32 residual stream / GroupNorm / attention
         self.strict = False
         self._prep = {}
         self._prep_key = None
@@ -417,6 +475,24 @@ class VQGanVAE1024(nn.Module):
             prep[k] = (wp.to(bf16).contiguous(), bp, cout)
         return prep[k]
 
+    def _cw_split(self, holder):
+        """conv holder -> (w3 bf16 [Cout_p, 3, taps, Cin_p] = (w_hi | w_hi | w_lo), bias f32 [Cout_p], Cout): the weight side of
+        the split operator, w = w_hi + w_lo with w_hi = bf16(w), w_lo = bf16(w - w_hi)."""
+        prep = self._prepared()
+        k = (id(holder), 'split')
+        if k not in prep:
+            w, b = holder.weight.detach().float(), holder.bias.detach().float()
+            cout, cin, kh, kw = w.shape
+            cin_p, cout_p = _pow2_at_least8(cin), (cout + 7) // 8 * 8
+            wp = torch.zeros(cout_p, kh * kw, cin_p, device=w.device, dtype=f32)
+            wp[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+            hi = wp.to(bf16)
+            lo = (wp - hi.float()).to(bf16)
+            bp = torch.zeros(cout_p, device=w.device, dtype=f32)
+            bp[:cout] = b
+            prep[k] = (torch.stack([hi, hi, lo], 1).contiguous(), bp, cout)
+        return prep[k]
+
     def _cw_qkv(self, blk):
         """q, k, v 1x1 conv holders of an AttnBlock -> (w bf16 [3C, 1, C], bias f32 [3C])."""
         prep = self._prepared()
@@ -435,9 +511,10 @@ class VQGanVAE1024(nn.Module):
     # ---- planning: the op sequence of one encode / decode for a given batch shape ------------------------------
     def _plan(self, kind, n, size_or_hw):
         prep = self._prepared()
-        key = ('plan', kind, n, size_or_hw, bool(self.strict))
+        mode = 'split' if self.strict == 'split' else bool(self.strict)
+        key = ('plan', kind, n, size_or_hw, mode)
         if key not in prep:
-            pl = _Planner(self, strict=bool(self.strict))
+            pl = _Planner(self, strict=mode)
             if kind == 'enc':
                 self._plan_encode(pl, n, size_or_hw)
             elif kind == 'dec_z':
@@ -461,7 +538,7 @@ class VQGanVAE1024(nn.Module):
     def _plan_attn(self, pl, x32, blk, final='f32'):
         """model.py:180-205."""
         h = pl.gn(x32, blk.norm, swish=False)
-        if _FUSE_QKV and not pl.strict:
+        if _FUSE_QKV and not pl.strict and not pl.split:
             qkv, c = pl.conv_qkv(h, blk)
             o = pl.spatial_attention_fused(qkv, c)
         else:

@@ -369,3 +369,28 @@ def test_vqgan_plan_structure_config2(monkeypatch):
     # dual stores only where a 1x1 shortcut reads the stream in bf16 as well (the two channel-widening blocks)
     both = [o for o in ops_ if o.op == pl.OP_CONV and o.out_bf16 >= 0 and o.out_f32 >= 0]
     assert len(both) == 2
+
+
+def test_vqgan_plan_structure_split_mode(monkeypatch):
+    """vae.strict = 'split': every convolution is the pair operator (flag 64) on pair planes and writes fp32; GroupNorm and the
+    image layout write planes; attention is the fp32 operator; no bf16-operator op is left in the plan."""
+    from mmvid_amd import vae as V
+    v = V.VQGanVAE1024(None, 128)
+    v.image_size, v.strict = 128, 'split'
+    monkeypatch.setattr(v, '_ee', lambda: torch.zeros(1024))
+    pl = V._Planner(v, strict='split')
+    assert pl.split and not pl.strict
+    v._plan_encode(pl, 4, 128)
+    ops_ = pl.ops
+    convs = [o for o in ops_ if o.op == pl.OP_CONV]
+    assert len(convs) == 45 and all(o.flags & pl.SPLIT and o.out_f32 >= 0 and o.out_bf16 < 0 for o in convs)
+    assert sum(1 for o in convs if o.flags & 8) == 12          # the strip form at 32x32 and above
+    assert sum(1 for o in convs if o.flags & 32) >= 4          # split-K on the 8x8 layers
+    assert all(o.flags & pl.SPLIT for o in ops_ if o.op in (pl.OP_GN, pl.OP_CAST, pl.OP_IMG))
+    assert all(o.flags & pl.STRICT for o in ops_ if o.op == pl.OP_ATTN)
+    w3, b, cout = v._cw_split(v.model.encoder.conv_in)
+    assert w3.shape == (128, 3, 9, 8) and w3.dtype == torch.bfloat16 and cout == 128
+    w = v.model.encoder.conv_in.weight.detach().permute(0, 2, 3, 1).reshape(128, 9, 3)
+    assert torch.equal(w3[:, 0], w3[:, 1]) and (w3[:, 0, :, :3].float() + w3[:, 2, :, :3].float() - w).abs().max() < 2.0**-16
+    for o in ops_:
+        assert max(o.in0, o.in1, o.in2, o.out_bf16, o.out_f32, o.scratch) < pl.top

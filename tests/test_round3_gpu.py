@@ -2,6 +2,8 @@
 functions (tests/golden/frontend.npz, mask_predict_race.npz: tools/make_golden.py::case_frontend / case_mask_predict_race),
 the remaining BERT options (stable, motion_color, width-512 tower), and the data-parallel row-wise exchange with a
 simulated second rank."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -445,3 +447,118 @@ def test_attention_backward_with_fused_in_proj_bias_gradient():
     close(out, o, 2e-2, 'attention out')
     close(dqkv, g, 3e-2, 'dqkv')
     close(db, g.sum(0), 1e-2, 'fused in_proj bias gradient')
+
+
+# ------------------------------------------------------------------------------------------- vae.strict = 'split'
+def _conv_ref64(x, w, b, mode, residual=None):
+    """fp64 reference on the CPU: x [N,H,W,Cin], w [Cout,taps,Cin] -> [N,Ho,Wo,Cout] (modes of mmvid_conv2d_nhwc)."""
+    import torch.nn.functional as F
+    xd = x.double().cpu().permute(0, 3, 1, 2)
+    cout, taps, cin = w.shape
+    k = 3 if taps == 9 else 1
+    wd = w.double().cpu().view(cout, k, k, cin).permute(0, 3, 1, 2)
+    if mode == 1:
+        y = F.conv2d(F.pad(xd, (0, 1, 0, 1)), wd, b.double().cpu(), stride=2)
+    elif mode == 2:
+        y = F.conv2d(F.interpolate(xd, scale_factor=2.0, mode='nearest'), wd, b.double().cpu(), padding=1)
+    else:
+        y = F.conv2d(xd, wd, b.double().cpu(), padding=k // 2)
+    y = y.permute(0, 2, 3, 1)
+    return y + residual.double().cpu() if residual is not None else y
+
+
+@pytest.mark.parametrize('mode,n,h,cin,cout,strip,splitk', [
+    (0, 2, 32, 128, 128, True, 1),    # strip form (ResnetBlock convs at 32x32 and above)
+    (0, 3, 16, 256, 256, False, 1),   # implicit GEMM, fast A path
+    (0, 2, 8, 512, 512, False, 4),    # deep layer on a small map: split-K
+    (1, 2, 32, 128, 128, False, 1),   # Downsample
+    (2, 2, 8, 64, 64, False, 1),      # Upsample (decoder)
+    (3, 2, 16, 256, 256, False, 1),   # 1x1
+    (0, 2, 32, 8, 128, False, 1),     # conv_in: 3 real channels padded to 8
+])
+def test_split_convolution_vs_fp64(mode, n, h, cin, cout, strip, splitk):
+    """mmvid_conv2d_nhwc_split3 / mmvid_conv3x3_strip_nhwc_split3: x_hi.w_hi + x_lo.w_hi + x_hi.w_lo in one K loop.  Against an
+    fp64 convolution of the fp32 operands: the error must be what 16 mantissa bits per operand allow (~1e-5 of the output
+    scale), three orders of magnitude below the bf16 operator's."""
+    from mmvid_amd import ops
+    torch.manual_seed(mode * 7 + cin)
+    taps = 1 if mode == 3 else 9
+    x = torch.randn(n, h, h, cin, device=DEV)
+    if cin == 8:
+        x[..., 3:] = 0
+    w = torch.randn(cout, taps, cin, device=DEV) / math.sqrt(taps * cin)
+    b = torch.randn(cout, device=DEV)
+    ho = h // 2 if mode == 1 else (2 * h if mode == 2 else h)
+    res = torch.randn(n, ho, ho, cout, device=DEV)
+    y = ops.conv2d_nhwc_split3(ops.split_planes(x), ops.split_weights(w), b, mode, residual=res, splitk=splitk, strip=strip)
+    ref = _conv_ref64(x, w, b, mode, res)
+    err = (y.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    y16 = ops.conv2d_nhwc(x.to(torch.bfloat16), w.to(torch.bfloat16), b, mode, residual=res, out_dtype=torch.float32)
+    err16 = (y16.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f'split conv mode {mode} {h}x{h} {cin}->{cout}: max err / max |y| = {err:.2e} (bf16 operator: {err16:.2e})')
+    assert err < 1e-5 and err16 > 50 * err
+    # pair planes: hi + lo carries 16 mantissa bits of x
+    pl = ops.split_planes(x)
+    assert ((pl[0].float() + pl[1].float() - x).abs() <= x.abs() * 2.0**-16).all()
+
+
+def test_split_groupnorm_vs_fp64():
+    import torch.nn.functional as F
+    from mmvid_amd import ops
+    torch.manual_seed(5)
+    for (n, h, c, swish) in ((2, 32, 128, True), (3, 16, 256, False), (2, 8, 512, True)):
+        x = torch.randn(n, h, h, c, device=DEV) * 2 + 0.7
+        w, b = torch.randn(c, device=DEV), torch.randn(c, device=DEV)
+        pl = ops.groupnorm_swish_split(x, w, b, swish=swish)
+        ref = F.group_norm(x.double().cpu().permute(0, 3, 1, 2), 32, w.double().cpu(), b.double().cpu(), 1e-6)
+        if swish:
+            ref = ref * torch.sigmoid(ref)
+        ref = ref.permute(0, 2, 3, 1)
+        got = pl[0].double().cpu() + pl[1].double().cpu()
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        print(f'split GroupNorm {h}x{h}x{c} swish={swish}: max err / max |y| = {err:.2e}')
+        assert err < 2e-5
+
+
+@pytest.mark.parametrize('name,tiny', [('vqgan_tiny', True), ('vqgan_full', False)])
+def test_split_encoder_indices_equal_reference(golden, name, tiny):
+    """vae.strict = 'split' (bf16-pair convolutions on the bf16 matrix pipe): the indices equal the reference's on the VQGAN
+    goldens, z_e / decode agree to ~1e-4 (between the bf16 operator's 3e-2 and the fp32 operator's 4e-6)."""
+    from mmvid_amd.vae import VQGanVAE1024
+    from oracle.synth import synth_input
+    from test_host_logic import tiny_vae
+    from test_models_gpu import close, load_synth
+    g = golden(name)
+    s = g.meta['image_size']
+    vae = tiny_vae() if tiny else VQGanVAE1024(None, 128)
+    vae.image_size = s
+    load_synth(vae, g, 11)
+    vae.strict = 'split'
+    img = synth_input('img', (g.meta['n'], 3, s, s), 11, 'uniform').to(DEV)
+    z = vae.encode_z(img)
+    ref = g['z_e'].permute(0, 2, 3, 1)
+    print(f"{name} split z_e: max |dz| {(z.cpu() - ref).abs().max().item():.3e} (max |z| {ref.abs().max().item():.2f})")
+    close(z, ref, 2e-4, f'{name} split z_e')
+    idx = vae.get_codebook_indices(img).cpu()
+    assert torch.equal(idx, g['indices']), f'{name}: {(idx != g["indices"]).sum().item()} of {idx.numel()} indices differ'
+    dec = vae.decode(g['indices'].to(DEV))
+    print(f"{name} split decode: max |d| {(dec.cpu() - g['decoded']).abs().max().item():.3e}")
+    close(dec, g['decoded'], 2e-4, f'{name} split decode')
+    assert torch.equal(vae.get_codebook_indices(img[:1]).cpu(), idx[:1])  # batch composition does not matter
+    vae.strict = False
+    assert vae.get_codebook_indices(img).shape == idx.shape
+
+
+@pytest.mark.parametrize('name,nv,cvae', [('bert_tiny', 0, False), ('bert_tiny_visual', 1, True)])
+def test_split_tokens_of_bert_goldens(golden, name, nv, cvae):
+    from test_host_logic import tiny_bert
+    from test_models_gpu import load_synth
+    g = golden(name)
+    m = load_synth(tiny_bert(nv, cvae), g, 17)
+    m.vae.strict = 'split'
+    if m.cvae is not None:
+        m.cvae.strict = 'split'
+    assert torch.equal(m.get_image_tokens(g['frames'].to(DEV)).cpu(), g['target_tok'])
+    assert torch.equal(m.get_image_tokens(g['warped_frames'].to(DEV)).cpu(), g['warp_tok'])
+    if nv:
+        assert torch.equal(m.get_image_tokens(g['visual'].to(DEV), which_vae='cvae').cpu(), g['visual_tok'])
