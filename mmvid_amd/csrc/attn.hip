@@ -118,6 +118,11 @@ __device__ __forceinline__ bf16x8_t pack_half(const f32x16& a, int m) {
 __device__ __forceinline__ f32x16 mfma32(bf16x8_t a, bf16x8_t b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// first MFMA of an accumulation chain: C = 0 as an inline operand instead of 16 zeroing moves per tile (the loops are VALU-bound)
+__device__ __forceinline__ f32x16 mfma32z(bf16x8_t a, bf16x8_t b) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -237,44 +242,140 @@ __device__ __forceinline__ void block_coords(int nrt, int H, int& rt, int& hd, i
     b = bh / H;
 }
 
+// ---- "resident" form of the three kernels (L <= 608, i.e. the BERT configurations): ONE block of 8 waves per (batch, head) stages
+// the whole K and V (or Q and dO) of that head into LDS once -- 2 x 76 KiB of the 160 KiB -- and every wave then runs its 32-row units
+// (u = wave, wave + 8, wave + 16) against it without any further barrier or staging.  Why: the streaming kernels re-stage K/V once
+// per 128-row block (5x per head), park at one barrier per 64-key tile (41 % of a wave's cycles, profiles/
+// r03_pmc_attention_before_interleave.txt), and their grid of 1,080 blocks does not divide into the 1,024 / 768 / 512 resident
+// slots (a second or third round that is 5 % full).  Here the grid is B*H = 216 blocks, one round.  The first unit of every wave
+// starts while the later tiles are still in flight: all LDS-DMA requests are issued up front in tile order, and the first pass
+// waits per tile (counted vmcnt + barrier); passes two and three are barrier-free.  The per-row arithmetic and its order are the
+// streaming kernels' own (same code), so the results are bit-identical.
+constexpr int RES_WAVES = 8, RES_UNITS = 3, RES_MAX_L = 608;  // 19 units of 32 rows: 8 waves x up to 3 units
+
+// s_waitcnt vmcnt(n) for a wave-uniform even n in 0..40 (any other value: wait for everything, which never under-waits)
+__device__ __forceinline__ void wait_vm_even(int n) {
+    switch (n) {
+#define MMVID_VM_CASE(N) \
+    case N: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); break;
+        MMVID_VM_CASE(2) MMVID_VM_CASE(4) MMVID_VM_CASE(6) MMVID_VM_CASE(8) MMVID_VM_CASE(10) MMVID_VM_CASE(12) MMVID_VM_CASE(14)
+        MMVID_VM_CASE(16) MMVID_VM_CASE(18) MMVID_VM_CASE(20) MMVID_VM_CASE(22) MMVID_VM_CASE(24) MMVID_VM_CASE(26) MMVID_VM_CASE(28)
+        MMVID_VM_CASE(30) MMVID_VM_CASE(32) MMVID_VM_CASE(34) MMVID_VM_CASE(36) MMVID_VM_CASE(38) MMVID_VM_CASE(40)
+#undef MMVID_VM_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// Requests every 8-row piece of two token-major [rows x 64 d] operands (rows % 32 == 0) into resA / resB, in tile order: wave w owns
+// piece 8 t + w of tile t.  Returns whether this wave issued for the LAST tile (it may be a half tile: 4 pieces) -- the count of
+// requests that are younger than tile t's is then 2 * (ntiles - 1 - t), minus 2 if not.
+__device__ __forceinline__ bool res_stage(const bf16_t* A, long lda, const bf16_t* Bm, long ldb, int L, int rows, char* resA, char* resB,
+                                          int wave, int lane) {
+    const rsrc_t ra = make_rsrc(A, (uint32_t)(((long)(L - 1) * lda + 64) * 2));
+    const rsrc_t rb = make_rsrc(Bm, (uint32_t)(((long)(L - 1) * ldb + 64) * 2));
+    const int npieces = rows >> 3, ntiles = (rows + 63) >> 6;
+    bool last = false;
+    for (int t = 0; t < ntiles; ++t) {
+        const int p = 8 * t + wave;  // wave-uniform
+        if (p >= npieces) break;
+        const int row = p * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        blds16(ra, (uint32_t)(((long)row * lda + chunk * 8) * 2), 0, resA + p * 1024);
+        blds16(rb, (uint32_t)(((long)row * ldb + chunk * 8) * 2), 0, resB + p * 1024);
+        last = t == ntiles - 1;
+    }
+    return last;
+}
+// first pass, before tile t: this wave's requests for tiles 0..t have landed, then every wave's (barrier)
+__device__ __forceinline__ void res_wait_tile(int t, int ntiles, bool issued_last) {
+    const int younger = 2 * (ntiles - 1 - t) - ((issued_last || t == ntiles - 1) ? 0 : 2);
+    wait_vm_even(younger < 0 ? 0 : younger);
+    __builtin_amdgcn_s_barrier();
+}
+
 // ------------------------------------------------------------------------------------------ forward
-template <int MINB>
-__global__ __launch_bounds__(256, MINB) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int L, int H, int E,
-                                                          int nrt, float scale_log2, MaskSpec mask,
-                                                          bf16_t* __restrict__ out, long ldo, float* __restrict__ lse2) {
-    __shared__ __attribute__((aligned(16))) char smem[2][2 * TILE];  // K tile, V tile
+template <int MINB, bool RES>
+__global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int L,
+                                                                                         int H, int E, int nrt, float scale_log2,
+                                                                                         MaskSpec mask, bf16_t* __restrict__ out,
+                                                                                         long ldo, float* __restrict__ lse2) {
+    __shared__ __attribute__((aligned(16))) char smem[RES ? 1 : 2][RES ? 16 : 2 * TILE];  // streaming: K tile, V tile, two stages
+    extern __shared__ __attribute__((aligned(16))) char rsm[];                             // resident: K rows, V rows
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
-    int qt, hd, b;
-    block_coords(nrt, H, qt, hd, b);
-    const int q = qt * ROWS_PER_BLOCK + wave * 32 + l32;
-    const int qc = q < L ? q : L - 1;
-    const bool wave_active = qt * ROWS_PER_BLOCK + wave * 32 < L;
-    const bf16_t* Qp = qkv + ((long)b * L + qc) * ld + hd * 64;
-    bf16x8_t qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(Qp + 16 * s + 8 * h);
+    int qt = 0, hd, b;
+    if constexpr (RES)
+        hd = blockIdx.x % H, b = blockIdx.x / H;
+    else
+        block_coords(nrt, H, qt, hd, b);
     const bf16_t* Kbase = qkv + (long)b * L * ld + E + hd * 64;
     const bf16_t* Vbase = Kbase + E;
-    int kv_end = L;
-    if (mask.mode == 1 && (qt + 1) * ROWS_PER_BLOCK < L) kv_end = (qt + 1) * ROWS_PER_BLOCK;
-    const int ntiles = (kv_end + 63) >> 6;
     const int trl = tr_lane_off(lane);
+    const int rows = ((L + 31) >> 5) * 32, ntiles_all = (L + 63) >> 6;
+    const char* Kres = rsm;
+    const char* Vres = rsm + rows * 128;
+    bool issued_last = false;
+    // resident: the Q fragments of all of this wave's units first (they complete before the DMA requests are issued, so that no
+    // compiler-placed wait for them can end up waiting for the whole K/V as well)
+    bf16x8_t qres[RES ? RES_UNITS : 1][4];
+    if constexpr (RES) {
+#pragma unroll
+        for (int ui = 0; ui < RES_UNITS; ++ui) {
+            int qq = (wave + RES_WAVES * ui) * 32 + l32;
+            qq = qq < L ? qq : L - 1;
+            const bf16_t* Qp = qkv + ((long)b * L + qq) * ld + hd * 64;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qres[ui][s] = *reinterpret_cast<const bf16x8_t*>(Qp + 16 * s + 8 * h);
+        }
+#pragma unroll
+        for (int ui = 0; ui < RES_UNITS; ++ui)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(qres[ui][0]), "+v"(qres[ui][1]), "+v"(qres[ui][2]), "+v"(qres[ui][3])::"memory");
+        issued_last = res_stage(Kbase, ld, Vbase, ld, L, rows, rsm, rsm + rows * 128, wave, lane);
+    }
+#pragma unroll
+    for (int ui = 0; ui < (RES ? RES_UNITS : 1); ++ui) {
+    const int q_wave0 = RES ? (wave + RES_WAVES * ui) * 32 : qt * ROWS_PER_BLOCK + wave * 32;  // first query of the unit (wave-uniform)
+    if (RES && ui > 0 && q_wave0 >= L) break;
+    const int q = q_wave0 + l32;
+    const int qc = q < L ? q : L - 1;
+    const bool wave_active = q_wave0 < L;
+    bf16x8_t qf[4];
+    if constexpr (RES) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = qres[ui][s];
+    } else {
+        const bf16_t* Qp = qkv + ((long)b * L + qc) * ld + hd * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(Qp + 16 * s + 8 * h);
+    }
+    int kv_end = L;
+    if (mask.mode == 1) {
+        const int blk_end = RES ? q_wave0 + 32 : (qt + 1) * ROWS_PER_BLOCK;  // causal: the last key any of these queries may see, + 1
+        if (blk_end < L) kv_end = blk_end;
+    }
+    const int ntiles = (kv_end + 63) >> 6;
 
     TileStage sk, sv;
-    sk.init(Kbase, ld, L, wave, lane), sv.init(Vbase, ld, L, wave, lane);
-    sk.issue(0, smem[0], wave), sv.issue(0, smem[0] + TILE, wave);
+    if constexpr (!RES) {
+        sk.init(Kbase, ld, L, wave, lane), sv.init(Vbase, ld, L, wave, lane);
+        sk.issue(0, smem[0], wave), sv.issue(0, smem[0] + TILE, wave);
+    }
 
     float m_run = -INFINITY, lsum = 0.f;
     f32x16 oacc[2] = {zero16(), zero16()};
-    const int q_wave0 = qt * ROWS_PER_BLOCK + wave * 32;  // first query of the wave (wave-uniform)
     const bool wave_has_row = mask.mode == 2 && ((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) || (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32));
 
-    for (int t = 0; t < ntiles; ++t) {
-        const char* Kt = smem[t & 1];
-        const char* Vt = Kt + TILE;
-        dma_publish_barrier();  // tile t has landed for every wave; everyone is done with tile t-1
-        if (t + 1 < ntiles) {
-            sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
+    const int tloop = (RES && ui == 0) ? ntiles_all : ntiles;  // (first resident pass: every wave attends every tile's barrier)
+    for (int t = 0; t < tloop; ++t) {
+        const char* Kt = RES ? Kres + t * TILE : smem[t & 1];
+        const char* Vt = RES ? Vres + t * TILE : Kt + TILE;
+        if constexpr (RES) {
+            if (ui == 0) res_wait_tile(t, ntiles_all, issued_last);
+            if (t >= ntiles) continue;
+        } else {
+            dma_publish_barrier();  // tile t has landed for every wave; everyone is done with tile t-1
+            if (t + 1 < ntiles) {
+                sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
+            }
         }
         if (!wave_active) continue;
         // Both 32-key sub-tiles of the tile are in flight at once: the eight S = K Q^T MFMAs are issued back to back, and each
@@ -282,12 +383,14 @@ __global__ __launch_bounds__(256, MINB) void attn_fwd_kernel(const bf16_t* __res
         // sub-tile's S or PV products.  Issued one sub-tile after the other (round 2), a wave sat in MFMA-result waits for 31 % of
         // its cycles and parked for 41 % (profiles/r03_pmc_attention_before_interleave.txt).
         const bool two = t * 64 + 32 < L;  // the second sub-tile holds live keys (block-uniform)
-        f32x16 sv[2] = {zero16(), zero16()};
+        f32x16 sv[2];
+        sv[0] = mfma32z(row_frag(Kt, l32, 0, h), qf[0]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) sv[0] = mfma32(row_frag(Kt, l32, ks, h), qf[ks], sv[0]);
+        for (int ks = 1; ks < 4; ++ks) sv[0] = mfma32(row_frag(Kt, l32, ks, h), qf[ks], sv[0]);
         if (two) {
+            sv[1] = mfma32z(row_frag(Kt, 32 + l32, 0, h), qf[0]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) sv[1] = mfma32(row_frag(Kt, 32 + l32, ks, h), qf[ks], sv[1]);
+            for (int ks = 1; ks < 4; ++ks) sv[1] = mfma32(row_frag(Kt, 32 + l32, ks, h), qf[ks], sv[1]);
         }
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
@@ -323,83 +426,136 @@ __global__ __launch_bounds__(256, MINB) void attn_fwd_kernel(const bf16_t* __res
             oacc[1] = mfma32(vt[3], pf[1], oacc[1]);
         }
     }
-    if (!wave_active) return;
+    if (!wave_active) {
+        if constexpr (RES) continue; else return;
+    }
     lsum = half_sum(lsum);
     mfma_settle(oacc[0]), mfma_settle(oacc[1]);
     if (q < L) {  // (lanes l and l + 32 hold the same row: the half-wave exchange inside store_row64 pairs two active lanes)
         store_row64(out + ((long)b * L + q) * ldo + hd * 64, oacc, 1.0f / lsum, h);
         if (h == 0) lse2[((long)b * H + hd) * L + q] = m_run + log2f(lsum);
     }
+    }  // unit
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <int MINB>
-__global__ __launch_bounds__(256, MINB) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, long ld,
-                                                             const bf16_t* __restrict__ O, long ldo,
-                                                             const bf16_t* __restrict__ dO, long lddo,
-                                                             const float* __restrict__ lse2,
-                                                             float* __restrict__ delta, int L, int H, int E,
-                                                             int nrt, float scale, float scale_log2, MaskSpec mask,
-                                                             bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias) {
-    __shared__ __attribute__((aligned(16))) char smem[2][2 * TILE];  // K tile, V tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
-    int qt, hd, b;
-    block_coords(nrt, H, qt, hd, b);
-    const int q = qt * ROWS_PER_BLOCK + wave * 32 + l32;
+// the per-query operands of a dQ unit: Q and dO fragments of the lane's row, -lse2, delta = rowsum(dO * O)
+struct DqRow {
+    bf16x8_t qf[4], dof[4];
+    float neg_lse, delta;
+};
+// requests the row's operands (q clamped to L - 1); delta is finished by dq_row_finish() once the loads have landed
+__device__ __forceinline__ void dq_row_load(DqRow& r, uint4 (&o4)[4], const bf16_t* qkv, long ld, const bf16_t* O, long ldo, const bf16_t* dO,
+                                            long lddo, const float* lse2, int L, int H, int b, int hd, int q, int h) {
     const int qc = q < L ? q : L - 1;
-    const bool wave_active = qt * ROWS_PER_BLOCK + wave * 32 < L;
     const bf16_t* Qp = qkv + ((long)b * L + qc) * ld + hd * 64;
     const bf16_t* dOp = dO + ((long)b * L + qc) * lddo + hd * 64;
-    bf16x8_t qf[4], dof[4];
+    const bf16_t* Op = O + ((long)b * L + qc) * ldo + hd * 64;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        qf[s] = *reinterpret_cast<const bf16x8_t*>(Qp + 16 * s + 8 * h);
-        dof[s] = *reinterpret_cast<const bf16x8_t*>(dOp + 16 * s + 8 * h);
+        r.qf[s] = *reinterpret_cast<const bf16x8_t*>(Qp + 16 * s + 8 * h);
+        r.dof[s] = *reinterpret_cast<const bf16x8_t*>(dOp + 16 * s + 8 * h);
+        o4[s] = *reinterpret_cast<const uint4*>(Op + 16 * s + 8 * h);
     }
-    const float neg_lse = -lse2[((long)b * H + hd) * L + qc];
-    // delta[q] = sum_d dO[q][d] * O[q][d]: each half-lane holds 32 of the row's 64 d; also stored for the dK/dV kernel
-    float my_delta = 0.f;
-    {
-        const bf16_t* Op = O + ((long)b * L + qc) * ldo + hd * 64;
+    r.neg_lse = -lse2[((long)b * H + hd) * L + qc];
+}
+// delta[q] = sum_d dO[q][d] * O[q][d]: each half-lane holds 32 of the row's 64 d; also stored for the dK/dV kernel
+__device__ __forceinline__ void dq_row_finish(DqRow& r, const uint4 (&o4)[4], float* delta, int L, int H, int b, int hd, int q, int h) {
+    float d = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const uint4 o4 = *reinterpret_cast<const uint4*>(Op + 16 * s + 8 * h);
-            const uint4 d4 = __builtin_bit_cast(uint4, dof[s]);
-            my_delta += (bf_lo(o4.x) * bf_lo(d4.x) + bf_hi(o4.x) * bf_hi(d4.x)) + (bf_lo(o4.y) * bf_lo(d4.y) + bf_hi(o4.y) * bf_hi(d4.y)) +
-                        (bf_lo(o4.z) * bf_lo(d4.z) + bf_hi(o4.z) * bf_hi(d4.z)) + (bf_lo(o4.w) * bf_lo(d4.w) + bf_hi(o4.w) * bf_hi(d4.w));
-        }
-        my_delta = half_sum(my_delta);
-        if (h == 0 && q < L) delta[((long)b * H + hd) * L + q] = my_delta;
+    for (int s = 0; s < 4; ++s) {
+        const uint4 d4 = __builtin_bit_cast(uint4, r.dof[s]);
+        d += (bf_lo(o4[s].x) * bf_lo(d4.x) + bf_hi(o4[s].x) * bf_hi(d4.x)) + (bf_lo(o4[s].y) * bf_lo(d4.y) + bf_hi(o4[s].y) * bf_hi(d4.y)) +
+             (bf_lo(o4[s].z) * bf_lo(d4.z) + bf_hi(o4[s].z) * bf_hi(d4.z)) + (bf_lo(o4[s].w) * bf_lo(d4.w) + bf_hi(o4[s].w) * bf_hi(d4.w));
     }
+    r.delta = half_sum(d);
+    if (h == 0 && q < L) delta[((long)b * H + hd) * L + q] = r.delta;
+}
+
+template <int MINB, bool RES>
+__global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void attn_bwd_dq_kernel(
+    const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ O, long ldo, const bf16_t* __restrict__ dO, long lddo,
+    const float* __restrict__ lse2, float* __restrict__ delta, int L, int H, int E, int nrt, float scale, float scale_log2, MaskSpec mask,
+    bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias) {
+    __shared__ __attribute__((aligned(16))) char smem[RES ? 1 : 2][RES ? 16 : 2 * TILE];  // streaming: K tile, V tile, two stages
+    extern __shared__ __attribute__((aligned(16))) char rsm[];                             // resident: K rows, V rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
+    int qt = 0, hd, b;
+    if constexpr (RES)
+        hd = blockIdx.x % H, b = blockIdx.x / H;
+    else
+        block_coords(nrt, H, qt, hd, b);
     const bf16_t* Kbase = qkv + (long)b * L * ld + E + hd * 64;
     const bf16_t* Vbase = Kbase + E;
-    int kv_end = L;
-    if (mask.mode == 1 && (qt + 1) * ROWS_PER_BLOCK < L) kv_end = (qt + 1) * ROWS_PER_BLOCK;
-    const int ntiles = (kv_end + 63) >> 6;
     const int trl = tr_lane_off(lane);
+    const int rows = ((L + 31) >> 5) * 32, ntiles_all = (L + 63) >> 6;
+    const char* Kres = rsm;
+    const char* Vres = rsm + rows * 128;
+    bool issued_last = false;
+    auto unit_q0 = [&](int ui) { return RES ? (wave + RES_WAVES * ui) * 32 : qt * ROWS_PER_BLOCK + wave * 32; };
+    // row operands: `cur` for the unit being computed, `nxt` requested one unit ahead (resident form)
+    DqRow cur, nxt;
+    uint4 o4[4];
+    dq_row_load(cur, o4, qkv, ld, O, ldo, dO, lddo, lse2, L, H, b, hd, unit_q0(0) + l32, h);
+    dq_row_finish(cur, o4, delta, L, H, b, hd, unit_q0(0) + l32, h);
+    if constexpr (RES) {
+        dq_row_load(nxt, o4, qkv, ld, O, ldo, dO, lddo, lse2, L, H, b, hd, unit_q0(1) + l32, h);
+        dq_row_finish(nxt, o4, delta, L, H, b, hd, unit_q0(1) + l32, h);  // (every load has landed: none is left to be waited for
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  //  behind the DMA requests that follow)
+        issued_last = res_stage(Kbase, ld, Vbase, ld, L, rows, rsm, rsm + rows * 128, wave, lane);
+    }
+#pragma unroll 1
+    for (int ui = 0; ui < (RES ? RES_UNITS : 1); ++ui) {
+    const int q_wave0 = unit_q0(ui);
+    if (RES && ui > 0 && q_wave0 >= L) break;
+    const int q = q_wave0 + l32;
+    const bool wave_active = q_wave0 < L;
+    bool pend = false;  // the next unit's operands were requested at the start of this one: they fly under its work
+    if (RES && ui > 0) {
+        cur = nxt;
+        pend = ui + 1 < RES_UNITS && unit_q0(ui + 1) < L;
+        if (pend) dq_row_load(nxt, o4, qkv, ld, O, ldo, dO, lddo, lse2, L, H, b, hd, unit_q0(ui + 1) + l32, h);
+    }
+    const bf16x8_t (&qf)[4] = cur.qf;
+    const bf16x8_t (&dof)[4] = cur.dof;
+    const float neg_lse = cur.neg_lse, my_delta = cur.delta;
+    int kv_end = L;
+    if (mask.mode == 1) {
+        const int blk_end = RES ? q_wave0 + 32 : (qt + 1) * ROWS_PER_BLOCK;
+        if (blk_end < L) kv_end = blk_end;
+    }
+    const int ntiles = (kv_end + 63) >> 6;
 
     TileStage sk, sv;
-    sk.init(Kbase, ld, L, wave, lane), sv.init(Vbase, ld, L, wave, lane);
-    sk.issue(0, smem[0], wave), sv.issue(0, smem[0] + TILE, wave);
+    if constexpr (!RES) {
+        sk.init(Kbase, ld, L, wave, lane), sv.init(Vbase, ld, L, wave, lane);
+        sk.issue(0, smem[0], wave), sv.issue(0, smem[0] + TILE, wave);
+    }
 
     f32x16 dq[2] = {zero16(), zero16()};
-    const int q_wave0 = qt * ROWS_PER_BLOCK + wave * 32;
     const bool wave_has_row = mask.mode == 2 && ((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) || (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32));
-    for (int t = 0; t < ntiles; ++t) {
-        const char* Kt = smem[t & 1];
-        const char* Vt = Kt + TILE;
-        dma_publish_barrier();
-        if (t + 1 < ntiles) {
-            sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
+    const int tloop = (RES && ui == 0) ? ntiles_all : ntiles;
+    for (int t = 0; t < tloop; ++t) {
+        const char* Kt = RES ? Kres + t * TILE : smem[t & 1];
+        const char* Vt = RES ? Vres + t * TILE : Kt + TILE;
+        if constexpr (RES) {
+            if (ui == 0) res_wait_tile(t, ntiles_all, issued_last);
+            if (t >= ntiles) continue;
+        } else {
+            dma_publish_barrier();
+            if (t + 1 < ntiles) {
+                sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
+            }
         }
         if (!wave_active) continue;
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const int key0 = t * 64 + 32 * ss;
             if (key0 >= L) continue;  // padding-only sub-tile
-            f32x16 s = zero16(), dp = zero16();
+            f32x16 s = mfma32z(row_frag(Kt, 32 * ss + l32, 0, h), qf[0]);
+            f32x16 dp = mfma32z(row_frag(Vt, 32 * ss + l32, 0, h), dof[0]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 1; ks < 4; ++ks) {
                 s = mfma32(row_frag(Kt, 32 * ss + l32, ks, h), qf[ks], s);
                 dp = mfma32(row_frag(Vt, 32 * ss + l32, ks, h), dof[ks], dp);
             }
@@ -421,44 +577,57 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dq_kernel(const bf16_t* __
             dq[1] = mfma32(kt4[3], dsf[1], dq[1]);
         }
     }
-    if (!wave_active) return;
+    if (RES && pend) dq_row_finish(nxt, o4, delta, L, H, b, hd, unit_q0(ui + 1) + l32, h);
+    if (!wave_active) {
+        if constexpr (RES) continue; else return;
+    }
     mfma_settle(dq[0]), mfma_settle(dq[1]);
     if (q < L) store_row64(dqkv + ((long)b * L + q) * ldg + hd * 64, dq, scale, h);
     if (dbias) colsum_rows64(dq, scale, q < L, dbias + hd * 64, lane);
+    }  // unit
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
 constexpr int DKV_BUF = 2 * TILE + 512;  // Q tile, dO tile, lse2[64], delta[64]
 
-template <int MINB>
-__global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, long ld,
-                                                              const bf16_t* __restrict__ dO, long lddo,
-                                                              const float* __restrict__ lse2,
-                                                              const float* __restrict__ delta, int L, int H, int E,
-                                                              int nrt, float scale, float scale_log2, MaskSpec mask,
-                                                              bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias) {
-    __shared__ __attribute__((aligned(16))) char dsm[2 * DKV_BUF];
+template <int MINB, bool RES>
+__global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void attn_bwd_dkv_kernel(
+    const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ dO, long lddo, const float* __restrict__ lse2,
+    const float* __restrict__ delta, int L, int H, int E, int nrt, float scale, float scale_log2, MaskSpec mask,
+    bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias) {
+    __shared__ __attribute__((aligned(16))) char dsm[RES ? 16 : 2 * DKV_BUF];
+    extern __shared__ __attribute__((aligned(16))) char rsm[];  // resident: Q rows, dO rows, -lse2[rows], delta[rows]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
-    int kt, hd, b;
-    block_coords(nrt, H, kt, hd, b);
-    const int key = kt * ROWS_PER_BLOCK + wave * 32 + l32;
-    const int keyc = key < L ? key : L - 1;
-    const bool wave_active = kt * ROWS_PER_BLOCK + wave * 32 < L;
-    const bf16_t* Kp = qkv + ((long)b * L + keyc) * ld + E + hd * 64;
-    const bf16_t* Vp = Kp + E;
-    bf16x8_t kf[4], vf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        kf[s] = *reinterpret_cast<const bf16x8_t*>(Kp + 16 * s + 8 * h);
-        vf[s] = *reinterpret_cast<const bf16x8_t*>(Vp + 16 * s + 8 * h);
-    }
+    int kt = 0, hd, b;
+    if constexpr (RES)
+        hd = blockIdx.x % H, b = blockIdx.x / H;
+    else
+        block_coords(nrt, H, kt, hd, b);
     const bf16_t* Qbase = qkv + (long)b * L * ld + hd * 64;
     const bf16_t* dObase = dO + (long)b * L * lddo + hd * 64;
     const float* lse_b = lse2 + ((long)b * H + hd) * L;
     const float* del_b = delta + ((long)b * H + hd) * L;
     const int nq_tiles = (L + 63) >> 6;
-    const int t0 = (mask.mode == 1) ? (kt * ROWS_PER_BLOCK) >> 6 : 0;  // causal: only queries >= keys contribute
     const int trl = tr_lane_off(lane);
+    const int rows = ((L + 31) >> 5) * 32;
+    const char* Qres = rsm;
+    const char* dOres = rsm + rows * 128;
+    float* nlse_res = reinterpret_cast<float*>(rsm + rows * 256);
+    float* del_res = nlse_res + rows;
+    bool issued_last = false;
+    auto unit_k0 = [&](int ui) { return RES ? (wave + RES_WAVES * ui) * 32 : kt * ROWS_PER_BLOCK + wave * 32; };
+    auto load_kv = [&](int key, bf16x8_t (&kf)[4], bf16x8_t (&vf)[4]) {
+        const int keyc = key < L ? key : L - 1;
+        const bf16_t* Kp = qkv + ((long)b * L + keyc) * ld + E + hd * 64;
+        const bf16_t* Vp = Kp + E;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = *reinterpret_cast<const bf16x8_t*>(Kp + 16 * s + 8 * h);
+            vf[s] = *reinterpret_cast<const bf16x8_t*>(Vp + 16 * s + 8 * h);
+        }
+    };
+    bf16x8_t kf[4], vf[4], kn[4], vn[4];  // this unit's key rows; the next unit's (resident form), requested one unit ahead
+    load_kv(unit_k0(0) + l32, kf, vf);
 
     // per-query statistics of a tile: threads 0..63 carry -lse2 (-inf for padded queries: exp2(-inf) = 0),
     // threads 64..127 carry delta
@@ -468,35 +637,72 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* _
         if (tid < 64) return qq < L ? -lse_b[qq] : -INFINITY;
         return qq < L ? del_b[qq] : 0.f;
     };
+    if constexpr (RES) {
+        load_kv(unit_k0(1) + l32, kn, vn);
+        for (int r = tid; r < rows; r += RES_WAVES * 64) {
+            nlse_res[r] = r < L ? -lse_b[r] : -INFINITY;
+            del_res[r] = r < L ? del_b[r] : 0.f;
+        }
+        // every load has landed and this wave's statistics are in LDS before the DMA requests are issued (the first tile's barrier
+        // publishes them); nothing is left to be waited for behind the requests
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(kn[0]),
+                       "+v"(kn[1]), "+v"(kn[2]), "+v"(kn[3]), "+v"(vn[0]), "+v"(vn[1]), "+v"(vn[2]), "+v"(vn[3])
+                     :
+                     : "memory");
+        issued_last = res_stage(Qbase, ld, dObase, lddo, L, rows, rsm, rsm + rows * 128, wave, lane);
+    }
+#pragma unroll 1
+    for (int ui = 0; ui < (RES ? RES_UNITS : 1); ++ui) {
+    const int key_wave0 = unit_k0(ui);
+    if (RES && ui > 0 && key_wave0 >= L) break;
+    const int key = key_wave0 + l32;
+    const bool wave_active = key_wave0 < L;
+    if (RES && ui > 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = kn[s], vf[s] = vn[s];
+        if (ui + 1 < RES_UNITS && unit_k0(ui + 1) < L) load_kv(unit_k0(ui + 1) + l32, kn, vn);  // flies under this unit's work
+    }
+    const int t0 = (mask.mode == 1) ? key_wave0 >> 6 : 0;  // causal: only queries >= keys contribute
+    const int t_begin = RES ? (ui == 0 ? 0 : t0) : ((mask.mode == 1) ? (kt * ROWS_PER_BLOCK) >> 6 : 0);
+
     TileStage sq, sdo;
-    sq.init(Qbase, ld, L, wave, lane), sdo.init(dObase, lddo, L, wave, lane);
-    sq.issue(t0 * 64, dsm, wave), sdo.issue(t0 * 64, dsm + TILE, wave);
-    float stat = load_stat(t0);
-    if (tid < 128) reinterpret_cast<float*>(dsm + 2 * TILE)[tid] = stat;
+    float stat = 0.f;
+    if constexpr (!RES) {
+        sq.init(Qbase, ld, L, wave, lane), sdo.init(dObase, lddo, L, wave, lane);
+        sq.issue(t_begin * 64, dsm, wave), sdo.issue(t_begin * 64, dsm + TILE, wave);
+        stat = load_stat(t_begin);
+        if (tid < 128) reinterpret_cast<float*>(dsm + 2 * TILE)[tid] = stat;
+    }
 
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-    const int key_wave0 = kt * ROWS_PER_BLOCK + wave * 32;
-    for (int t = t0; t < nq_tiles; ++t) {
-        const int bi = (t - t0) & 1;
-        const char* Qt = dsm + bi * DKV_BUF;
-        const char* dOt = Qt + TILE;
-        const float* st_nlse = reinterpret_cast<const float*>(Qt + 2 * TILE);
-        const float* st_del = st_nlse + 64;
-        char* nx = dsm + (bi ^ 1) * DKV_BUF;
+    for (int t = t_begin; t < nq_tiles; ++t) {
+        const int bi = (t - t_begin) & 1;
+        const char* Qt = RES ? Qres + t * TILE : dsm + bi * DKV_BUF;
+        const char* dOt = RES ? dOres + t * TILE : Qt + TILE;
+        const float* st_nlse = RES ? nlse_res + t * 64 : reinterpret_cast<const float*>(Qt + 2 * TILE);
+        const float* st_del = RES ? del_res + t * 64 : st_nlse + 64;
+        char* nx = dsm + (RES ? 0 : (bi ^ 1) * DKV_BUF);
         const bool more = t + 1 < nq_tiles;
-        dma_publish_barrier();
-        if (more) {
-            sq.issue((t + 1) * 64, nx, wave), sdo.issue((t + 1) * 64, nx + TILE, wave);
-            stat = load_stat(t + 1);
+        if constexpr (RES) {
+            if (ui == 0) res_wait_tile(t, nq_tiles, issued_last);
+            if (t < t0) continue;
+        } else {
+            dma_publish_barrier();
+            if (more) {
+                sq.issue((t + 1) * 64, nx, wave), sdo.issue((t + 1) * 64, nx + TILE, wave);
+                stat = load_stat(t + 1);
+            }
         }
         if (wave_active) {
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 const int q0 = t * 64 + 32 * ss;
                 if (q0 >= L) continue;  // padding-only query sub-tile: P = 0 there
-                f32x16 s = zero16(), dp = zero16();
+                f32x16 s = mfma32z(row_frag(Qt, 32 * ss + l32, 0, h), kf[0]);
+                f32x16 dp = mfma32z(row_frag(dOt, 32 * ss + l32, 0, h), vf[0]);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = 1; ks < 4; ++ks) {
                     s = mfma32(row_frag(Qt, 32 * ss + l32, ks, h), kf[ks], s);
                     dp = mfma32(row_frag(dOt, 32 * ss + l32, ks, h), vf[ks], dp);
                 }
@@ -543,9 +749,13 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* _
                 dk[1] = mfma32(qt4[3], dsf[1], dk[1]);
             }
         }
-        if (more && tid < 128) reinterpret_cast<float*>(nx + 2 * TILE)[tid] = stat;
+        if constexpr (!RES) {
+            if (more && tid < 128) reinterpret_cast<float*>(nx + 2 * TILE)[tid] = stat;
+        }
     }
-    if (!wave_active) return;
+    if (!wave_active) {
+        if constexpr (RES) continue; else return;
+    }
     mfma_settle(dk[0]), mfma_settle(dk[1]), mfma_settle(dv[0]), mfma_settle(dv[1]);
     if (key < L) {
         bf16_t* kp = dqkv + ((long)b * L + key) * ldg + E + hd * 64;
@@ -556,7 +766,11 @@ __global__ __launch_bounds__(256, MINB) void attn_bwd_dkv_kernel(const bf16_t* _
         colsum_rows64(dk, scale, key < L, dbias + E + hd * 64, lane);
         colsum_rows64(dv, 1.0f, key < L, dbias + 2 * E + hd * 64, lane);
     }
+    }  // unit
 }
+
+// the resident kernels hold 2 x ceil32(L) x 128 B in LDS (+ 8 B per row of statistics in dK/dV): L <= 608.  Geometry only.
+static bool attn_resident(int L) { return L <= RES_MAX_L && mmvid_option(MMVID_OPT_ATTN_RES) != 0; }  // (default 0: measured slower)
 
 static MaskSpec make_mask(int mode, int r0, int c0, int r1, int c1) {
     MaskSpec m;
@@ -578,12 +792,22 @@ extern "C" int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, in
     MMVID_REQUIRE((int64_t)L * ld * 2 < (1ll << 31), "attention_fwd: one batch entry of qkv must be smaller than 2 GiB");
     MmvidProfScope prof(PROF_ATTN_FWD, 4.0 * B * H * (double)L * L * 64, (hipStream_t)stream);
     const int nrt = cdiv(L, ROWS_PER_BLOCK);
-    if (mmvid_option(MMVID_OPT_ATTN_OCC) & 1)
-        hipLaunchKernelGGL((attn_fwd_kernel<5>), dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
+    if (attn_resident(L)) {
+        const size_t lds = (size_t)cdiv(L, 32) * 32 * 256;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_L * 256);
+            attr = true;
+        }
+        hipLaunchKernelGGL((attn_fwd_kernel<1, true>), dim3(H * B), dim3(RES_WAVES * 64), lds, (hipStream_t)stream, (const bf16_t*)qkv,
+                           (long)ld, L, H, E, nrt, scale * 1.4426950408889634f, make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out,
+                           (long)ldo, lse2);
+    } else if (mmvid_option(MMVID_OPT_ATTN_OCC) & 1)
+        hipLaunchKernelGGL((attn_fwd_kernel<5, false>), dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
                        L, H, E, nrt, scale * 1.4426950408889634f, make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out,
                        (long)ldo, lse2);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<2>), dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
+        hipLaunchKernelGGL((attn_fwd_kernel<2, false>), dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
                        L, H, E, nrt, scale * 1.4426950408889634f, make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out,
                        (long)ldo, lse2);
     MMVID_LAUNCH_CHECK("attention_fwd");
@@ -613,17 +837,37 @@ extern "C" int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void*
     const float sl2 = scale * 1.4426950408889634f;
     MmvidProfScope prof(PROF_ATTN_BWD, 10.0 * B * H * (double)L * L * 64, s);  // 5 GEMM-equivalents (recompute counted once)
     const int nrt = cdiv(L, ROWS_PER_BLOCK);
-    if (mmvid_option(MMVID_OPT_ATTN_OCC) & 2)
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<4>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+    const bool res = attn_resident(L);
+    if (res) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_L * 256);
+            attr = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<1, true>), dim3(H * B), dim3(RES_WAVES * 64), (size_t)cdiv(L, 32) * 32 * 256, s,
+                           (const bf16_t*)qkv, (long)ld, (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt,
+                           scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
+    } else if (mmvid_option(MMVID_OPT_ATTN_OCC) & 2)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
                        (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
     else
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<2>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<2, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
                        (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
-    if (mmvid_option(MMVID_OPT_ATTN_OCC) & 4)
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<3>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+    if (res) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      RES_MAX_L * 264);
+            attr = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, true>), dim3(H * B), dim3(RES_WAVES * 64), (size_t)cdiv(L, 32) * 32 * 264, s,
+                           (const bf16_t*)qkv, (long)ld, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m,
+                           (bf16_t*)dqkv, (long)ldg, dbias);
+    } else if (mmvid_option(MMVID_OPT_ATTN_OCC) & 4)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<3, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
                        (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
     else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
                        (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
     MMVID_LAUNCH_CHECK("attention_bwd");
     return MMVID_OK;

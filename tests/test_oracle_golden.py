@@ -75,6 +75,34 @@ def test_tower_forward_backward(golden, tag, L, mt, idx):
         assert relerr(sd[k].grad, g[f'{tag}_d{nm}']) <= TOL
 
 
+def test_tower_12_layers_at_training_length(golden):
+    """The full-depth tower (12 layers, L = 579, restricted rows 65 / 66) against the reference's own forward + backward
+    (tests/golden/tower12.npz, tools/make_golden.py::case_tower12): output / input-gradient slices, the rows around the
+    restricted ones, norms, and parameter gradients of layers 0, 5 and 11."""
+    g = golden('tower12')
+    sd = synth_state_dict(g.manifest, 23)
+    for v in sd.values():
+        v.requires_grad_(True)
+    L = g.meta['L']
+    x = synth_input('x_t12', (2, L, 768), 23).requires_grad_(True)
+    gy = synth_input('g_t12', (2, L, 768), 23)
+    y = tower.tower(sd, x, tower.build_attention_mask(L, 'mask_prev', [65, 66]), 'transformer.')
+    y.backward(gy)
+    rows = [0, 64, 65, 66, 67, 578]
+    assert relerr(y[:, ::37, ::13], g['y_s']) <= TOL and relerr(x.grad[:, ::37, ::13], g['dx_s']) <= TOL
+    assert relerr(y[:, rows][..., ::7], g['y_rows']) <= TOL and relerr(x.grad[:, rows][..., ::7], g['dx_rows']) <= TOL
+    assert abs(y.double().norm().item() / g['y_norm'].item() - 1) < 1e-5
+    assert abs(x.grad.double().norm().item() / g['dx_norm'].item() - 1) < 1e-5
+    p = 'transformer.resblocks.'
+    for li in (0, 5, 11):
+        for nm, k in (('inw', 'attn.in_proj_weight'), ('outw', 'attn.out_proj.weight'), ('fcw', 'mlp.c_fc.weight'),
+                      ('pjw', 'mlp.c_proj.weight')):
+            assert relerr(sd[f'{p}{li}.{k}'].grad[::61, ::29], g[f'l{li}_d{nm}_s']) <= TOL
+        for nm, k in (('inb', 'attn.in_proj_bias'), ('ln1w', 'ln_1.weight'), ('ln2b', 'ln_2.bias'), ('fcb', 'mlp.c_fc.bias'),
+                      ('pjb', 'mlp.c_proj.bias')):
+            assert relerr(sd[f'{p}{li}.{k}'].grad, g[f'l{li}_d{nm}']) <= TOL
+
+
 @pytest.mark.parametrize('name,nv', [('bert_tiny', 0), ('bert_tiny_visual', 1)])
 def test_bert_losses_and_grads(golden, name, nv):
     g = golden(name)

@@ -449,6 +449,70 @@ def test_attention_backward_with_fused_in_proj_bias_gradient():
     close(db, g.sum(0), 1e-2, 'fused in_proj bias gradient')
 
 
+@pytest.mark.parametrize('B,L,mode,rows', [(3, 579, 2, (65, 65, 66, 66)), (2, 51, 2, (17, 17, 18, 18)), (2, 200, 1, (0, 0, 0, 0)),
+                                           (2, 608, 0, (0, 0, 0, 0)), (1, 33, 1, (0, 0, 0, 0))])
+def test_resident_attention_kernels_bit_identical_to_streaming(B, L, mode, rows):
+    """The resident form of the three attention kernels (one 8-wave block per (batch, head), K/V or Q/dO staged into LDS once;
+    L <= 608) runs the streaming kernels' own per-row arithmetic in the same order: out, lse2, delta and dqkv must be
+    bit-identical, the fused bias gradient (fp32 atomics) equal to round-off.  All three mask shapes, ragged and full L."""
+    from mmvid_amd import _lib, ops
+    H, E = 12, 768
+    torch.manual_seed(L)
+    qkv = (torch.randn(B * L, 3 * E, device=DEV) * 0.5).bfloat16()
+    dO = (torch.randn(B * L, E, device=DEV) * 0.1).bfloat16()
+    st = ops._stream
+    res = {}
+    try:
+        for flag in (0, 1):
+            _lib.call('mmvid_set_option', b'attn_res', flag)
+            out = torch.zeros(B * L, E, device=DEV, dtype=torch.bfloat16)
+            lse, delta = torch.zeros(B * H * L, device=DEV), torch.zeros(B * H * L, device=DEV)
+            dqkv = torch.zeros(B * L, 3 * E, device=DEV, dtype=torch.bfloat16)
+            db = torch.zeros(3 * E, device=DEV)
+            _lib.call('mmvid_attention_fwd', ops._p(qkv), 3 * E, B, L, H, E, 0.125, mode, *rows, ops._p(out), E, ops._p(lse), st())
+            _lib.call('mmvid_attention_bwd_bias', ops._p(qkv), 3 * E, ops._p(out), E, ops._p(dO), E, ops._p(lse), ops._p(delta), B, L, H, E,
+                      0.125, mode, *rows, ops._p(dqkv), 3 * E, ops._p(db), st())
+            torch.cuda.synchronize()
+            res[flag] = (out, lse, delta, dqkv, db)
+    finally:
+        _lib.call('mmvid_set_option', b'attn_res', 1)
+    for name, a, b in zip(('out', 'lse2', 'delta', 'dqkv'), res[0], res[1]):
+        assert torch.equal(a, b), f'{name}: resident differs from streaming in {(a != b).sum().item()} of {a.numel()} elements'
+    assert torch.isfinite(res[1][3].float()).all()
+    close(res[1][4], res[0][4], 1e-5, 'fused in_proj bias gradient, resident vs streaming')
+
+
+def test_tower_12_layers_at_training_length_vs_reference(golden):
+    """The HIP tower at full depth and the training shape (12 layers, L = 579, restricted rows 65 / 66) against the reference's own
+    forward + backward (tests/golden/tower12.npz): bf16 tolerances after 12 layers, norms within 2 %."""
+    from mmvid_amd.clip_tower import OpenAICLIPTransformer
+    from oracle.synth import synth_input
+    g = golden('tower12')
+    L = g.meta['L']
+    tw = load_synth(OpenAICLIPTransformer(L, 'openai_clip_visual', causal=True, mask_type='mask_prev', mask_kwargs={'index': [65, 66]},
+                                          layers=12), g, 23)
+    x = synth_input('x_t12', (2, L, 768), 23).to(DEV).requires_grad_(True)
+    gy = synth_input('g_t12', (2, L, 768), 23).to(DEV)
+    y = tw(x)
+    y.backward(gy)
+    rows = [0, 64, 65, 66, 67, 578]
+    close(y[:, ::37, ::13], g['y_s'], 3e-2, '12-layer tower y')
+    close(x.grad[:, ::37, ::13], g['dx_s'], 5e-2, '12-layer tower dx')
+    close(y[:, rows][..., ::7], g['y_rows'], 3e-2, '12-layer tower y, rows around the restricted ones')
+    close(x.grad[:, rows][..., ::7], g['dx_rows'], 5e-2, '12-layer tower dx, rows around the restricted ones')
+    assert abs(y.double().norm().item() / g['y_norm'].item() - 1) < 2e-2
+    assert abs(x.grad.double().norm().item() / g['dx_norm'].item() - 1) < 2e-2
+    blk = tw.transformer.resblocks
+    for li in (0, 5, 11):
+        for nm, prm in (('inw', blk[li].attn.in_proj_weight), ('outw', blk[li].attn.out_proj.weight), ('fcw', blk[li].mlp.c_fc.weight),
+                        ('pjw', blk[li].mlp.c_proj.weight)):
+            close(prm.grad[::61, ::29], g[f'l{li}_d{nm}_s'], 5e-2, f'layer {li} d{nm}')
+            assert abs(prm.grad.double().norm().item() / g[f'l{li}_d{nm}_norm'].item() - 1) < 2e-2
+        for nm, prm in (('inb', blk[li].attn.in_proj_bias), ('ln1w', blk[li].ln_1.weight), ('ln2b', blk[li].ln_2.bias),
+                        ('fcb', blk[li].mlp.c_fc.bias), ('pjb', blk[li].mlp.c_proj.bias)):
+            close(prm.grad, g[f'l{li}_d{nm}'], 5e-2, f'layer {li} d{nm}')
+
+
 # ------------------------------------------------------------------------------------------- vae.strict = 'split'
 def _conv_ref64(x, w, b, mode, residual=None):
     """fp64 reference on the CPU: x [N,H,W,Cin], w [Cout,taps,Cin] -> [N,Ho,Wo,Cout] (modes of mmvid_conv2d_nhwc)."""

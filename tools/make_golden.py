@@ -170,6 +170,35 @@ def case_tower():
     save('tower', meta=dict(seed=13, layers=2, width=768, heads=12), manifest=man, **res)
 
 
+def case_tower12():
+    """The full-depth tower at the training shape (12 layers, L = 579, mask_prev rows 65 / 66): slices and norms of the output,
+    the input gradient and parameter gradients of the first, a middle and the last layer."""
+    from mmvid_pytorch.transformers.clip_model import OpenAICLIPTransformer
+    ref_stubs.CLIP_STATE['sd'] = clip_state(12)
+    L = 579
+    tw = OpenAICLIPTransformer(L, 'openai_clip_visual', model_path='x', causal=True, mask_type='mask_prev',
+                               mask_kwargs={'index': [65, 66]})
+    man = load_synth(tw, 23)
+    assert len(tw.transformer.resblocks) == 12
+    x = synth_input('x_t12', (2, L, 768), 23).requires_grad_(True)
+    g = synth_input('g_t12', (2, L, 768), 23)
+    y = tw(x)
+    y.backward(g)
+    res = {'y_s': y[:, ::37, ::13], 'dx_s': x.grad[:, ::37, ::13], 'y_norm': y.double().norm().view(1),
+           'dx_norm': x.grad.double().norm().view(1), 'y_rows': y[:, [0, 64, 65, 66, 67, 578]][..., ::7],
+           'dx_rows': x.grad[:, [0, 64, 65, 66, 67, 578]][..., ::7]}
+    blk = tw.transformer.resblocks
+    for li in (0, 5, 11):
+        for nm, p in (('inw', blk[li].attn.in_proj_weight), ('outw', blk[li].attn.out_proj.weight),
+                      ('fcw', blk[li].mlp.c_fc.weight), ('pjw', blk[li].mlp.c_proj.weight)):
+            res[f'l{li}_d{nm}_s'] = p.grad[::61, ::29]
+            res[f'l{li}_d{nm}_norm'] = p.grad.double().norm().view(1)
+        for nm, p in (('inb', blk[li].attn.in_proj_bias), ('ln1w', blk[li].ln_1.weight), ('ln2b', blk[li].ln_2.bias),
+                      ('fcb', blk[li].mlp.c_fc.bias), ('pjb', blk[li].mlp.c_proj.bias)):
+            res[f'l{li}_d{nm}'] = p.grad
+    save('tower12', meta=dict(seed=23, layers=12, width=768, heads=12, L=L), manifest=man, **res)
+
+
 def _build_bert(num_visuals, use_cvae, seed, text_seq_len=16, num_targets=2):
     from mmvid_pytorch.dalle_bert import BERT
     ref_stubs.CLIP_STATE['sd'] = clip_state(2)
@@ -557,7 +586,7 @@ def case_mask_predict_race():
                                                    b=dict(videos=1, steps=9, dynamic=True, B=1))), **res)
 
 
-CASES = dict(vq=case_vq, vqgan_tiny=case_vqgan_tiny, vqgan_full=case_vqgan_full, tower=case_tower,
+CASES = dict(vq=case_vq, vqgan_tiny=case_vqgan_tiny, vqgan_full=case_vqgan_full, tower=case_tower, tower12=case_tower12,
              bert_tiny=case_bert_tiny, bert_tiny_visual=case_bert_tiny_visual, artv_tiny=case_artv_tiny,
              mask_predict=case_mask_predict, frontend=case_frontend, mask_predict_race=case_mask_predict_race)
 
