@@ -48,6 +48,8 @@ int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void*
 
 /* Measurement only (tools/gemm_timeline.py): per-block time stamps of the next 256x128 GEMM launches; NULL switches it off. */
 int mmvid_gemm_trace(void* dev_buf);
+/* the same for the streaming attention forward kernel: [2 blocks][4 waves][16 tiles][8] stamps (tools/attn_timeline.py). */
+int mmvid_attention_trace(void* dev_buf);
 
 /* Weight gradient dW[N][K] (+)= dY^T X over M tokens (autograd of nn.Linear); split-K through `workspace`
  * ([splitk][N][K] fp32) with a fixed-order reduction: deterministic. */

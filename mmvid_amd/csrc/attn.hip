@@ -269,8 +269,10 @@ __device__ __forceinline__ void wait_vm_even(int n) {
 // Requests every 8-row piece of two token-major [rows x 64 d] operands (rows % 32 == 0) into resA / resB, in tile order: wave w owns
 // piece 8 t + w of tile t.  Returns whether this wave issued for the LAST tile (it may be a half tile: 4 pieces) -- the count of
 // requests that are younger than tile t's is then 2 * (ntiles - 1 - t), minus 2 if not.
+template <int W = RES_WAVES>
 __device__ __forceinline__ bool res_stage(const bf16_t* A, long lda, const bf16_t* Bm, long ldb, int L, int rows, char* resA, char* resB,
                                           int wave, int lane) {
+    if (W > 8 && wave >= 8) return false;  // (a tile is 8 pieces: waves 8.. of a 16-wave block request nothing)
     const rsrc_t ra = make_rsrc(A, (uint32_t)(((long)(L - 1) * lda + 64) * 2));
     const rsrc_t rb = make_rsrc(Bm, (uint32_t)(((long)(L - 1) * ldb + 64) * 2));
     const int npieces = rows >> 3, ntiles = (rows + 63) >> 6;
@@ -287,18 +289,20 @@ __device__ __forceinline__ bool res_stage(const bf16_t* A, long lda, const bf16_
     return last;
 }
 // first pass, before tile t: this wave's requests for tiles 0..t have landed, then every wave's (barrier)
+template <int W = RES_WAVES>
 __device__ __forceinline__ void res_wait_tile(int t, int ntiles, bool issued_last) {
     const int younger = 2 * (ntiles - 1 - t) - ((issued_last || t == ntiles - 1) ? 0 : 2);
-    wait_vm_even(younger < 0 ? 0 : younger);
+    wait_vm_even(younger < 0 ? 0 : younger);  // (a wave that requested nothing passes at once: its counter is 0)
     __builtin_amdgcn_s_barrier();
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int MINB, bool RES>
-__global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int L,
+template <int MINB, bool RES, int W = RES_WAVES, bool TRACE = false>  // W: waves of the resident form (8: up to 3 units per wave; 16: up to 2)
+__global__ __launch_bounds__(RES ? W * 64 : 256, RES ? 1 : MINB) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int L,
                                                                                          int H, int E, int nrt, float scale_log2,
                                                                                          MaskSpec mask, bf16_t* __restrict__ out,
-                                                                                         long ldo, float* __restrict__ lse2) {
+                                                                                         long ldo, float* __restrict__ lse2,
+                                                                                         unsigned long long* trace) {
     __shared__ __attribute__((aligned(16))) char smem[RES ? 1 : 2][RES ? 16 : 2 * TILE];  // streaming: K tile, V tile, two stages
     extern __shared__ __attribute__((aligned(16))) char rsm[];                             // resident: K rows, V rows
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
@@ -311,37 +315,48 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
     const bf16_t* Vbase = Kbase + E;
     const int trl = tr_lane_off(lane);
     const int rows = ((L + 31) >> 5) * 32, ntiles_all = (L + 63) >> 6;
+    // measurement only (mmvid_attention_trace): blocks 100 and gridDim.x - 8 (a first-round and a tail-round block) stamp the
+    // 100-MHz wall clock at 7 points of every tile, per wave: [2 blocks][4 waves][16 tiles][8]
+    unsigned long long* tr = nullptr;
+    if (TRACE && trace && lane == 0 && (blockIdx.x == 100 || blockIdx.x == gridDim.x - 8))
+        tr = trace + ((blockIdx.x == 100 ? 0 : 4) + wave) * 16 * 8;
+    if (TRACE && trace && tid == 0) trace[1024 + 2 * blockIdx.x] = wall_clock64();  // block entry ([1024 + 2 b], exit at + 1)
+#define ATTN_STAMP(i) \
+    if constexpr (TRACE)  \
+        if (tr && t < 16) tr[t * 8 + (i)] = wall_clock64();
     const char* Kres = rsm;
     const char* Vres = rsm + rows * 128;
     bool issued_last = false;
     // resident: the Q fragments of all of this wave's units first (they complete before the DMA requests are issued, so that no
     // compiler-placed wait for them can end up waiting for the whole K/V as well)
-    bf16x8_t qres[RES ? RES_UNITS : 1][4];
+    constexpr int NU = (RES_MAX_L / 32 + W - 1) / W;  // units per wave
+    constexpr int NPRE = W >= 16 ? 1 : NU;            // (16 waves: 128 registers per wave -- only the first unit's Q is preloaded)
+    bf16x8_t qres[RES ? NPRE : 1][4];
     if constexpr (RES) {
 #pragma unroll
-        for (int ui = 0; ui < RES_UNITS; ++ui) {
-            int qq = (wave + RES_WAVES * ui) * 32 + l32;
+        for (int ui = 0; ui < NPRE; ++ui) {
+            int qq = (wave + W * ui) * 32 + l32;
             qq = qq < L ? qq : L - 1;
             const bf16_t* Qp = qkv + ((long)b * L + qq) * ld + hd * 64;
 #pragma unroll
             for (int s = 0; s < 4; ++s) qres[ui][s] = *reinterpret_cast<const bf16x8_t*>(Qp + 16 * s + 8 * h);
         }
 #pragma unroll
-        for (int ui = 0; ui < RES_UNITS; ++ui)
+        for (int ui = 0; ui < NPRE; ++ui)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(qres[ui][0]), "+v"(qres[ui][1]), "+v"(qres[ui][2]), "+v"(qres[ui][3])::"memory");
-        issued_last = res_stage(Kbase, ld, Vbase, ld, L, rows, rsm, rsm + rows * 128, wave, lane);
+        issued_last = res_stage<W>(Kbase, ld, Vbase, ld, L, rows, rsm, rsm + rows * 128, wave, lane);
     }
 #pragma unroll
-    for (int ui = 0; ui < (RES ? RES_UNITS : 1); ++ui) {
-    const int q_wave0 = RES ? (wave + RES_WAVES * ui) * 32 : qt * ROWS_PER_BLOCK + wave * 32;  // first query of the unit (wave-uniform)
+    for (int ui = 0; ui < (RES ? NU : 1); ++ui) {
+    const int q_wave0 = RES ? (wave + W * ui) * 32 : qt * ROWS_PER_BLOCK + wave * 32;  // first query of the unit (wave-uniform)
     if (RES && ui > 0 && q_wave0 >= L) break;
     const int q = q_wave0 + l32;
     const int qc = q < L ? q : L - 1;
     const bool wave_active = q_wave0 < L;
     bf16x8_t qf[4];
-    if constexpr (RES) {
+    if (RES && ui < NPRE) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = qres[ui][s];
+        for (int s = 0; s < 4; ++s) qf[s] = qres[ui < NPRE ? ui : 0][s];
     } else {
         const bf16_t* Qp = qkv + ((long)b * L + qc) * ld + hd * 64;
 #pragma unroll
@@ -362,17 +377,24 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
 
     float m_run = -INFINITY, lsum = 0.f;
     f32x16 oacc[2] = {zero16(), zero16()};
-    const bool wave_has_row = mask.mode == 2 && ((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) || (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32));
+    // restricted rows (mode 2): row r0 / r1 may not see keys below c0 / c1 -- only the wave that holds such a row, and only on key
+    // sub-tiles that begin below that bound, evaluates the predicate (it is ~200 instructions per sub-tile: applied to all 19
+    // sub-tiles it made the blocks holding rows 65 / 66 run 40 % longer than the rest, tools/attn_timeline.py)
+    const int row_kmax = mask.mode != 2 ? 0
+                                        : max((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) ? mask.c0 : 0,
+                                              (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32) ? mask.c1 : 0);
 
     const int tloop = (RES && ui == 0) ? ntiles_all : ntiles;  // (first resident pass: every wave attends every tile's barrier)
     for (int t = 0; t < tloop; ++t) {
         const char* Kt = RES ? Kres + t * TILE : smem[t & 1];
         const char* Vt = RES ? Vres + t * TILE : Kt + TILE;
         if constexpr (RES) {
-            if (ui == 0) res_wait_tile(t, ntiles_all, issued_last);
+            if (ui == 0) res_wait_tile<W>(t, ntiles_all, issued_last);
             if (t >= ntiles) continue;
         } else {
+            ATTN_STAMP(0)
             dma_publish_barrier();  // tile t has landed for every wave; everyone is done with tile t-1
+            ATTN_STAMP(1)
             if (t + 1 < ntiles) {
                 sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
             }
@@ -392,6 +414,7 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
 #pragma unroll
             for (int ks = 1; ks < 4; ++ks) sv[1] = mfma32(row_frag(Kt, 32 + l32, ks, h), qf[ks], sv[1]);
         }
+        ATTN_STAMP(2)
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             if (ss == 1 && !two) break;
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
             bf16x8_t vt[4];  // V^T fragments: requested now, consumed after the softmax arithmetic
             tr_frags4(ss, lds_addr(Vt) + trl, vt);
             // mask needed?  padding keys, the causal diagonal band, or (wave-constant) a restricted query row in this wave
-            if (key0 + 32 > L || (mask.mode == 1 && key0 + 31 > q_wave0) || wave_has_row) {
+            if (key0 + 32 > L || (mask.mode == 1 && key0 + 31 > q_wave0) || key0 < row_kmax) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = is_masked(mask, q, key0 + acc_row(r, h), L) ? -INFINITY : s[r];
             }
@@ -420,12 +443,15 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
             lsum += exp2_affine_sum(s, scale_log2, -m_ref);
             bf16x8_t pf[2] = {pack_half(s, 0), pack_half(s, 1)};
             lgkm_wait_tied<0>(vt[0], vt[1], vt[2], vt[3], pf[0], pf[1]);
+            ATTN_STAMP(3 + 2 * ss)
             oacc[0] = mfma32(vt[0], pf[0], oacc[0]);
             oacc[1] = mfma32(vt[1], pf[0], oacc[1]);
             oacc[0] = mfma32(vt[2], pf[1], oacc[0]);
             oacc[1] = mfma32(vt[3], pf[1], oacc[1]);
+            ATTN_STAMP(4 + 2 * ss)
         }
     }
+#undef ATTN_STAMP
     if (!wave_active) {
         if constexpr (RES) continue; else return;
     }
@@ -435,6 +461,7 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
         store_row64(out + ((long)b * L + q) * ldo + hd * 64, oacc, 1.0f / lsum, h);
         if (h == 0) lse2[((long)b * H + hd) * L + q] = m_run + log2f(lsum);
     }
+    if (TRACE && trace && tid == 0) trace[1024 + 2 * blockIdx.x + 1] = wall_clock64();
     }  // unit
 }
 
@@ -533,7 +560,12 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
     }
 
     f32x16 dq[2] = {zero16(), zero16()};
-    const bool wave_has_row = mask.mode == 2 && ((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) || (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32));
+    // restricted rows (mode 2): row r0 / r1 may not see keys below c0 / c1 -- only the wave that holds such a row, and only on key
+    // sub-tiles that begin below that bound, evaluates the predicate (it is ~200 instructions per sub-tile: applied to all 19
+    // sub-tiles it made the blocks holding rows 65 / 66 run 40 % longer than the rest, tools/attn_timeline.py)
+    const int row_kmax = mask.mode != 2 ? 0
+                                        : max((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) ? mask.c0 : 0,
+                                              (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32) ? mask.c1 : 0);
     const int tloop = (RES && ui == 0) ? ntiles_all : ntiles;
     for (int t = 0; t < tloop; ++t) {
         const char* Kt = RES ? Kres + t * TILE : smem[t & 1];
@@ -562,7 +594,7 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
             mfma_settle(s), mfma_settle(dp);
             bf16x8_t kt4[4];  // K^T fragments
             tr_frags4(ss, lds_addr(Kt) + trl, kt4);
-            if (key0 + 32 > L || (mask.mode == 1 && key0 + 31 > q_wave0) || wave_has_row) {
+            if (key0 + 32 > L || (mask.mode == 1 && key0 + 31 > q_wave0) || key0 < row_kmax) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = is_masked(mask, q, key0 + acc_row(r, h), L) ? -INFINITY : s[r];
             }
@@ -714,7 +746,8 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
                 // (all wave-uniform: the wave's keys are key_wave0 .. key_wave0 + 31)
                 bool nm = key_wave0 + 32 > L;
                 if (mask.mode == 1) nm = nm || (key_wave0 + 31 > q0);
-                if (mask.mode == 2) nm = nm || (mask.r0 >= q0 && mask.r0 < q0 + 32) || (mask.r1 >= q0 && mask.r1 < q0 + 32);
+                if (mask.mode == 2)  // a restricted row among these queries AND some of this wave's keys below its bound
+                    nm = nm || (mask.r0 >= q0 && mask.r0 < q0 + 32 && key_wave0 < mask.c0) || (mask.r1 >= q0 && mask.r1 < q0 + 32 && key_wave0 < mask.c1);
                 if (nm) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[r] = is_masked(mask, q0 + acc_row(r, h), key, L) ? -INFINITY : s[r];
@@ -772,6 +805,8 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
 // the resident kernels hold 2 x ceil32(L) x 128 B in LDS (+ 8 B per row of statistics in dK/dV): L <= 608.  Geometry only.
 static bool attn_resident(int L) { return L <= RES_MAX_L && mmvid_option(MMVID_OPT_ATTN_RES) != 0; }  // (default 0: measured slower)
 
+unsigned long long* g_attn_trace = nullptr;
+
 static MaskSpec make_mask(int mode, int r0, int c0, int r1, int c1) {
     MaskSpec m;
     m.mode = mode, m.r0 = r0, m.c0 = c0, m.r1 = r1, m.c1 = c1;
@@ -779,6 +814,13 @@ static MaskSpec make_mask(int mode, int r0, int c0, int r1, int c1) {
 }
 
 }  // namespace
+
+// Measurement only: device buffer of [2 blocks][4 waves][16 tiles][8] uint64 wall-clock stamps written by the next streaming
+// forward launches (tools/attn_timeline.py); NULL switches it off.
+extern "C" int mmvid_attention_trace(void* dev_buf) {
+    g_attn_trace = (unsigned long long*)dev_buf;
+    return MMVID_OK;
+}
 
 #define ATTN_COMMON_CHECKS(name)                                                                            \
     MMVID_REQUIRE(B > 0 && L > 0 && H > 0 && E == H * 64, name ": need E == H*64 (head_dim 64), got E=%d H=%d", E, H); \
@@ -799,17 +841,33 @@ extern "C" int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, in
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_L * 256);
             attr = true;
         }
-        hipLaunchKernelGGL((attn_fwd_kernel<1, true>), dim3(H * B), dim3(RES_WAVES * 64), lds, (hipStream_t)stream, (const bf16_t*)qkv,
-                           (long)ld, L, H, E, nrt, scale * 1.4426950408889634f, make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out,
-                           (long)ldo, lse2);
+        if (mmvid_option(MMVID_OPT_ATTN_RES) == 2) {  // 16 waves (4 per SIMD), up to 2 units each
+            static bool attr16 = false;
+            if (!attr16) {
+                (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          RES_MAX_L * 256);
+                attr16 = true;
+            }
+            hipLaunchKernelGGL((attn_fwd_kernel<1, true, 16>), dim3(H * B), dim3(1024), lds, (hipStream_t)stream, (const bf16_t*)qkv,
+                               (long)ld, L, H, E, nrt, scale * 1.4426950408889634f, make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out,
+                               (long)ldo, lse2, nullptr);
+        } else
+            hipLaunchKernelGGL((attn_fwd_kernel<1, true>), dim3(H * B), dim3(RES_WAVES * 64), lds, (hipStream_t)stream,
+                               (const bf16_t*)qkv, (long)ld, L, H, E, nrt, scale * 1.4426950408889634f,
+                               make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out, (long)ldo, lse2, nullptr);
     } else if (mmvid_option(MMVID_OPT_ATTN_OCC) & 1)
         hipLaunchKernelGGL((attn_fwd_kernel<5, false>), dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
                        L, H, E, nrt, scale * 1.4426950408889634f, make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out,
-                       (long)ldo, lse2);
+                       (long)ldo, lse2, nullptr);
     else
+        if (g_attn_trace)  // (measurement build of the same kernel, held to the production kernel's 4 waves per SIMD)
+            hipLaunchKernelGGL((attn_fwd_kernel<4, false, RES_WAVES, true>), dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t*)qkv, (long)ld, L, H, E, nrt, scale * 1.4426950408889634f,
+                               make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out, (long)ldo, lse2, g_attn_trace);
+        else
         hipLaunchKernelGGL((attn_fwd_kernel<2, false>), dim3(nrt * H * B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, (long)ld,
                        L, H, E, nrt, scale * 1.4426950408889634f, make_mask(mask_mode, r0, c0, r1, c1), (bf16_t*)out,
-                       (long)ldo, lse2);
+                       (long)ldo, lse2, nullptr);
     MMVID_LAUNCH_CHECK("attention_fwd");
     return MMVID_OK;
 }
