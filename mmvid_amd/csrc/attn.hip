@@ -321,6 +321,7 @@ __global__ __launch_bounds__(RES ? W * 64 : 256, RES ? 1 : MINB) void attn_fwd_k
     if (TRACE && trace && lane == 0 && (blockIdx.x == 100 || blockIdx.x == gridDim.x - 8))
         tr = trace + ((blockIdx.x == 100 ? 0 : 4) + wave) * 16 * 8;
     if (TRACE && trace && tid == 0) trace[1024 + 2 * blockIdx.x] = wall_clock64();  // block entry ([1024 + 2 b], exit at + 1)
+    if (TRACE && trace && tid == 0 && blockIdx.x == 100) trace[1000] = clock64(), trace[1001] = wall_clock64();  // shader clock vs wall clock
 #define ATTN_STAMP(i) \
     if constexpr (TRACE)  \
         if (tr && t < 16) tr[t * 8 + (i)] = wall_clock64();
@@ -369,10 +370,10 @@ __global__ __launch_bounds__(RES ? W * 64 : 256, RES ? 1 : MINB) void attn_fwd_k
     }
     const int ntiles = (kv_end + 63) >> 6;
 
-    TileStage sk, sv;
+    TileStage stK, stV;
     if constexpr (!RES) {
-        sk.init(Kbase, ld, L, wave, lane), sv.init(Vbase, ld, L, wave, lane);
-        sk.issue(0, smem[0], wave), sv.issue(0, smem[0] + TILE, wave);
+        stK.init(Kbase, ld, L, wave, lane), stV.init(Vbase, ld, L, wave, lane);
+        stK.issue(0, smem[0], wave), stV.issue(0, smem[0] + TILE, wave);
     }
 
     float m_run = -INFINITY, lsum = 0.f;
@@ -395,11 +396,14 @@ __global__ __launch_bounds__(RES ? W * 64 : 256, RES ? 1 : MINB) void attn_fwd_k
             ATTN_STAMP(0)
             dma_publish_barrier();  // tile t has landed for every wave; everyone is done with tile t-1
             ATTN_STAMP(1)
-            if (t + 1 < ntiles) {
-                sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
-            }
         }
-        if (!wave_active) continue;
+        // the next tile's LDS-DMA requests cost the wave 60-185 issue cycles per piece (4 pieces): they are issued right AFTER this
+        // tile's S MFMAs, so that this cost runs under the matrix pipe's 8 x 32 cycles instead of in front of them
+        const bool more = !RES && t + 1 < ntiles;
+        if (!wave_active) {
+            if (more) stK.issue((t + 1) * 64, smem[(t + 1) & 1], wave), stV.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
+            continue;
+        }
         // Both 32-key sub-tiles of the tile are in flight at once: the eight S = K Q^T MFMAs are issued back to back, and each
         // sub-tile's softmax arithmetic (VALU: exp2 is quarter rate) runs while the matrix pipe still works on the other
         // sub-tile's S or PV products.  Issued one sub-tile after the other (round 2), a wave sat in MFMA-result waits for 31 % of
@@ -413,6 +417,10 @@ __global__ __launch_bounds__(RES ? W * 64 : 256, RES ? 1 : MINB) void attn_fwd_k
             sv[1] = mfma32z(row_frag(Kt, 32 + l32, 0, h), qf[0]);
 #pragma unroll
             for (int ks = 1; ks < 4; ++ks) sv[1] = mfma32(row_frag(Kt, 32 + l32, ks, h), qf[ks], sv[1]);
+        }
+        if (more) {
+            __builtin_amdgcn_sched_barrier(0);
+            stK.issue((t + 1) * 64, smem[(t + 1) & 1], wave), stV.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
         }
         ATTN_STAMP(2)
 #pragma unroll
@@ -462,6 +470,7 @@ __global__ __launch_bounds__(RES ? W * 64 : 256, RES ? 1 : MINB) void attn_fwd_k
         if (h == 0) lse2[((long)b * H + hd) * L + q] = m_run + log2f(lsum);
     }
     if (TRACE && trace && tid == 0) trace[1024 + 2 * blockIdx.x + 1] = wall_clock64();
+    if (TRACE && trace && tid == 0 && blockIdx.x == 100) trace[1002] = clock64(), trace[1003] = wall_clock64();
     }  // unit
 }
 
@@ -499,11 +508,13 @@ __device__ __forceinline__ void dq_row_finish(DqRow& r, const uint4 (&o4)[4], fl
     if (h == 0 && q < L) delta[((long)b * H + hd) * L + q] = r.delta;
 }
 
-template <int MINB, bool RES>
+template <int MINB, bool RES, bool TRACE = false>
 __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ O, long ldo, const bf16_t* __restrict__ dO, long lddo,
     const float* __restrict__ lse2, float* __restrict__ delta, int L, int H, int E, int nrt, float scale, float scale_log2, MaskSpec mask,
-    bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias) {
+    bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias, unsigned long long* trace) {
+    // measurement only (mmvid_attention_trace): block entry / exit at trace[1024 + 4096 + 2 b], tile starts of blocks 100 and grid - 8
+    if (TRACE && trace && threadIdx.x == 0) trace[1024 + 4096 + 2 * blockIdx.x] = wall_clock64();
     __shared__ __attribute__((aligned(16))) char smem[RES ? 1 : 2][RES ? 16 : 2 * TILE];  // streaming: K tile, V tile, two stages
     extern __shared__ __attribute__((aligned(16))) char rsm[];                             // resident: K rows, V rows
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
@@ -574,12 +585,15 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
             if (ui == 0) res_wait_tile(t, ntiles_all, issued_last);
             if (t >= ntiles) continue;
         } else {
+            if (TRACE && trace && (threadIdx.x & 63) == 0 && t < 16 && (blockIdx.x == 100 || blockIdx.x == gridDim.x - 8))
+                trace[256 + ((blockIdx.x == 100 ? 0 : 4) + wave) * 16 + t] = wall_clock64();
             dma_publish_barrier();
-            if (t + 1 < ntiles) {
-                sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
-            }
         }
-        if (!wave_active) continue;
+        const bool more = !RES && t + 1 < ntiles;  // (the next tile's requests go out after the first eight MFMAs: see the forward kernel)
+        if (!wave_active) {
+            if (more) sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
+            continue;
+        }
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const int key0 = t * 64 + 32 * ss;
@@ -590,6 +604,10 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
             for (int ks = 1; ks < 4; ++ks) {
                 s = mfma32(row_frag(Kt, 32 * ss + l32, ks, h), qf[ks], s);
                 dp = mfma32(row_frag(Vt, 32 * ss + l32, ks, h), dof[ks], dp);
+            }
+            if (ss == 0 && more) {
+                __builtin_amdgcn_sched_barrier(0);
+                sk.issue((t + 1) * 64, smem[(t + 1) & 1], wave), sv.issue((t + 1) * 64, smem[(t + 1) & 1] + TILE, wave);
             }
             mfma_settle(s), mfma_settle(dp);
             bf16x8_t kt4[4];  // K^T fragments
@@ -616,17 +634,19 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
     mfma_settle(dq[0]), mfma_settle(dq[1]);
     if (q < L) store_row64(dqkv + ((long)b * L + q) * ldg + hd * 64, dq, scale, h);
     if (dbias) colsum_rows64(dq, scale, q < L, dbias + hd * 64, lane);
+    if (TRACE && trace && threadIdx.x == 0) trace[1024 + 4096 + 2 * blockIdx.x + 1] = wall_clock64();
     }  // unit
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
 constexpr int DKV_BUF = 2 * TILE + 512;  // Q tile, dO tile, lse2[64], delta[64]
 
-template <int MINB, bool RES>
+template <int MINB, bool RES, bool TRACE = false>
 __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ dO, long lddo, const float* __restrict__ lse2,
     const float* __restrict__ delta, int L, int H, int E, int nrt, float scale, float scale_log2, MaskSpec mask,
-    bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias) {
+    bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias, unsigned long long* trace) {
+    if (TRACE && trace && threadIdx.x == 0) trace[1024 + 8192 + 2 * blockIdx.x] = wall_clock64();
     __shared__ __attribute__((aligned(16))) char dsm[RES ? 16 : 2 * DKV_BUF];
     extern __shared__ __attribute__((aligned(16))) char rsm[];  // resident: Q rows, dO rows, -lse2[rows], delta[rows]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
@@ -720,8 +740,10 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
             if (ui == 0) res_wait_tile(t, nq_tiles, issued_last);
             if (t < t0) continue;
         } else {
+            if (TRACE && trace && (threadIdx.x & 63) == 0 && t < 16 && (blockIdx.x == 100 || blockIdx.x == gridDim.x - 8))
+                trace[512 + ((blockIdx.x == 100 ? 0 : 4) + wave) * 16 + t] = wall_clock64();
             dma_publish_barrier();
-            if (more) {
+            if (more && !wave_active) {
                 sq.issue((t + 1) * 64, nx, wave), sdo.issue((t + 1) * 64, nx + TILE, wave);
                 stat = load_stat(t + 1);
             }
@@ -737,6 +759,11 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
                 for (int ks = 1; ks < 4; ++ks) {
                     s = mfma32(row_frag(Qt, 32 * ss + l32, ks, h), kf[ks], s);
                     dp = mfma32(row_frag(dOt, 32 * ss + l32, ks, h), vf[ks], dp);
+                }
+                if (!RES && ss == 0 && more) {  // the next tile's requests, under the first eight MFMAs (see the forward kernel)
+                    __builtin_amdgcn_sched_barrier(0);
+                    sq.issue((t + 1) * 64, nx, wave), sdo.issue((t + 1) * 64, nx + TILE, wave);
+                    stat = load_stat(t + 1);
                 }
                 mfma_settle(s), mfma_settle(dp);
                 bf16x8_t dot4[4], qt4[4];  // dO^T and Q^T fragments, in consumption order
@@ -799,6 +826,7 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
         colsum_rows64(dk, scale, key < L, dbias + E + hd * 64, lane);
         colsum_rows64(dv, 1.0f, key < L, dbias + 2 * E + hd * 64, lane);
     }
+    if (TRACE && trace && threadIdx.x == 0) trace[1024 + 8192 + 2 * blockIdx.x + 1] = wall_clock64();
     }  // unit
 }
 
@@ -904,13 +932,16 @@ extern "C" int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void*
         }
         hipLaunchKernelGGL((attn_bwd_dq_kernel<1, true>), dim3(H * B), dim3(RES_WAVES * 64), (size_t)cdiv(L, 32) * 32 * 256, s,
                            (const bf16_t*)qkv, (long)ld, (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt,
-                           scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
+                           scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, nullptr);
     } else if (mmvid_option(MMVID_OPT_ATTN_OCC) & 2)
         hipLaunchKernelGGL((attn_bwd_dq_kernel<4, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
+                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, nullptr);
+    else if (g_attn_trace)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<3, false, true>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, g_attn_trace);
     else
         hipLaunchKernelGGL((attn_bwd_dq_kernel<2, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
+                       (const bf16_t*)O, (long)ldo, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, nullptr);
     if (res) {
         static bool attr = false;
         if (!attr) {
@@ -920,13 +951,16 @@ extern "C" int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void*
         }
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, true>), dim3(H * B), dim3(RES_WAVES * 64), (size_t)cdiv(L, 32) * 32 * 264, s,
                            (const bf16_t*)qkv, (long)ld, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m,
-                           (bf16_t*)dqkv, (long)ldg, dbias);
+                           (bf16_t*)dqkv, (long)ldg, dbias, nullptr);
     } else if (mmvid_option(MMVID_OPT_ATTN_OCC) & 4)
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<3, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
+                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, nullptr);
+    else if (g_attn_trace)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, false, true>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, g_attn_trace);
     else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias);
+                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, nullptr);
     MMVID_LAUNCH_CHECK("attention_bwd");
     return MMVID_OK;
 }
