@@ -50,6 +50,8 @@ int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void*
 int mmvid_gemm_trace(void* dev_buf);
 /* the same for the streaming attention forward kernel: [2 blocks][4 waves][16 tiles][8] stamps (tools/attn_timeline.py). */
 int mmvid_attention_trace(void* dev_buf);
+/* and for the decode gemv (csrc/decode.hip): [512 blocks][8] stamps of the next mmvid_gemv_rows launches (tools/bench_decode_step.py). */
+int mmvid_decode_trace(void* dev_buf);
 
 /* Weight gradient dW[N][K] (+)= dY^T X over M tokens (autograd of nn.Linear); split-K through `workspace`
  * ([splitk][N][K] fp32) with a fixed-order reduction: deterministic. */
@@ -443,7 +445,8 @@ typedef struct {
 } mmvid_vqgan_op_t;
 int mmvid_vqgan_run(const mmvid_vqgan_op_t* ops, int nops, void* arena, void* stream);
 
-/* hardware probe (tools/gpu_probe.py): which = 0 -> ds_read_b64_tr_b16 lane layout. */
+/* hardware probe (tools/gpu_probe.py): which = 0 -> ds_read_b64_tr_b16 lane layout | 1 -> LDS-DMA through a buffer descriptor |
+ * 2 -> store-pattern bandwidth | 3 -> the DPP / permlane wave reductions (in float[64] -> out float[3][64]). */
 int mmvid_probe(int which, const void* in, void* out, void* stream);
 
 /* ---- optional HIP-event timing of the MFMA kernel families on their launch stream (bench.py roofline line).

@@ -81,6 +81,7 @@ SIGNATURES = {
     'mmvid_image_to_nhwc8_split': [P, I, I, I, P, P],
     'mmvid_groupnorm_swish_nhwc_split': [P, I, I64, I, P, P, F, I, P, P, P],
     'mmvid_attention_trace': [P],
+    'mmvid_decode_trace': [P],
     'mmvid_vqgan_run': [POINTER(VqganOp), I, P, P],
     'mmvid_sample_race': [P, I64, P, P, F, F, I64, I, I64, P, P, P],
     'mmvid_mp_select_keep': [P, P, P, I, I, I, I, P, P],

@@ -62,6 +62,40 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// The same reductions without the LDS crossbar: __shfl_xor is ds_bpermute_b32 (an LDS-pipe round trip of ~100+ cycles per step, six
+// dependent steps); here four DPP steps inside a row of 16 lanes (quad xor 1, xor 2, row_half_mirror, row_mirror) and the gfx950
+// row / half-wave swaps (v_permlane16_swap, v_permlane32_swap) -- all VALU, ~8 cycles a step.  Every lane ends with the total.  The
+// summation ORDER differs from wave_sum's, so kernels whose results are pinned bit-for-bit keep the old form; the latency-bound decode
+// kernels (csrc/decode.hip: a gemv spent 3.8 us of 11 in LayerNorm reductions, tools/decode_gemv_timeline.py) use this one.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the 8-lane group
+    v += dpp_mov<0x140>(v);  // row_mirror: the other 8-lane group of the row
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // rows 0|1 and 2|3
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const uint32_t w = __float_as_uint(v);
+    const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);  // the two half-waves
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float wave_max_fast(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const uint32_t w = __float_as_uint(v);
+    const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+
 // Guard against reading MFMA results too early.  v_mfma_f32_32x32x16_bf16 needs 12 wait states before a VALU may
 // read its destination; hipcc (ROCm 7.2) counts them along the fall-through path only, so a conditional branch
 // right after an MFMA chain can reach the first reader after ~7 (observed: intermittent stale accumulators in the

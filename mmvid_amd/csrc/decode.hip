@@ -7,6 +7,7 @@
 // the twelve layers' GEMMs at M = B.
 #include "../../include/mmvid_hip.h"
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         sc[k] = d;
         mx = fmaxf(mx, d);
     }
-    mx = wave_max(mx);
+    mx = wave_max_fast(mx);
     if (lane == 0) stat[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(stat[0], stat[1]), fmaxf(stat[2], stat[3]));
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         sc[k] = p;
         sum += p;
     }
-    sum = wave_sum(sum);
+    sum = wave_sum_fast(sum);
     if (lane == 0) stat[4 + wave] = sum;
     __syncthreads();
     sum = (stat[4] + stat[5]) + (stat[6] + stat[7]);
@@ -146,15 +147,77 @@ struct GemvArgs {
 // KIT = ceil(K / 512): 16-byte weight loads per lane and output feature.  The kernel is latency-bound (a decode step is a
 // chain of ~60 of these), so the two global round trips it needs are overlapped: every weight load of the wave is issued
 // FIRST, into registers, and the input rows are fetched / normalised / staged in LDS while those are in flight.
-template <int KIT, int XV = 12>  // XV float4 of the input block per thread: NB * K <= 1024 * XV floats
-__global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a) {
+// ---- reduce-scatter of a short list of per-lane partial sums over the 64 lanes of a wave.  A gemv wave ends with 2 * NB partial dot
+// products per lane (2 output features x NB rows); summing each with a full butterfly costs 6 cross-lane steps per value.  Here the
+// list is HALVED per lane bit instead: at bit 5 (v_permlane32_swap) a lane hands one half of its list to its partner and keeps the
+// sum of the other half, then bit 4 (v_permlane16_swap), bit 3 (row_mirror), bit 2 (row_half_mirror) -- N - 1 exchanges for N values
+// -- and the remaining lane bits are a butterfly on the ONE value left.  Value j of the list ends, complete, in lanes
+// [j << (6 - LOGN), (j + 1) << (6 - LOGN)).
+template <int BIT>
+__device__ __forceinline__ float xchg_add(float x, float y, int lane) {  // lanes with BIT clear: x over the pair; set: y over the pair
+    if constexpr (BIT == 5) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (BIT == 4) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+        const bool up = (lane >> BIT) & 1;
+        const float keep = up ? y : x, send = up ? x : y;
+        return keep + dpp_mov<BIT == 3 ? 0x140 : (BIT == 2 ? 0x141 : (BIT == 1 ? 0x4E : 0xB1))>(send);
+    }
+}
+template <int BIT>
+__device__ __forceinline__ float bfly_add(float v) {  // all-reduce step over lane bit BIT
+    if constexpr (BIT == 5) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (BIT == 4) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+        return v + dpp_mov<BIT == 3 ? 0x140 : (BIT == 2 ? 0x141 : (BIT == 1 ? 0x4E : 0xB1))>(v);
+    }
+}
+template <int LOGN>
+__device__ __forceinline__ float reduce_scatter(float (&v)[1 << LOGN], int lane) {
+    if constexpr (LOGN >= 1) {
+#pragma unroll
+        for (int i = 0; i < (1 << LOGN) / 2; ++i) v[i] = xchg_add<5>(v[i], v[i + (1 << LOGN) / 2], lane);
+    }
+    if constexpr (LOGN >= 2) {
+#pragma unroll
+        for (int i = 0; i < (1 << LOGN) / 4; ++i) v[i] = xchg_add<4>(v[i], v[i + (1 << LOGN) / 4], lane);
+    }
+    if constexpr (LOGN >= 3) {
+#pragma unroll
+        for (int i = 0; i < (1 << LOGN) / 8; ++i) v[i] = xchg_add<3>(v[i], v[i + (1 << LOGN) / 8], lane);
+    }
+    if constexpr (LOGN >= 4) v[0] = xchg_add<2>(v[0], v[1], lane);
+    float r = v[0];
+    if constexpr (LOGN < 1) r = bfly_add<5>(r);
+    if constexpr (LOGN < 2) r = bfly_add<4>(r);
+    if constexpr (LOGN < 3) r = bfly_add<3>(r);
+    if constexpr (LOGN < 4) r = bfly_add<2>(r);
+    r = bfly_add<1>(r);
+    return bfly_add<0>(r);
+}
+
+unsigned long long* g_decode_trace = nullptr;  // measurement only (mmvid_decode_trace): [blocks][8] wall-clock stamps of the next gemv
+
+// BF: the staged rows are bf16-exact (round_in) -> LDS holds them as bf16 (half the LDS traffic, 16-byte conflict-free reads) and the
+// products go through v_dot2c_f32_bf16 (two multiply-adds per instruction, fp32 accumulate)
+template <int KIT, bool TRACE = false, int FPW = 2, bool BF = false>  // FPW: output features per wave (1 for the narrow outputs: twice the blocks)
+__global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned long long* trace = nullptr) {
+#define GV_STAMP(i) \
+    if constexpr (TRACE)  \
+        if (threadIdx.x == 0 && blockIdx.x < 512) trace[blockIdx.x * 8 + (i)] = wall_clock64();
+    GV_STAMP(0)
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][K]
-    __shared__ float red[4][GV_MAXB];
-    __shared__ float stats[GV_MAXB][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, NB = a.NB;
-    const int n0 = blockIdx.x * GV_COLS + wave * 2;
-    const bool have = n0 < a.N, two = n0 + 1 < a.N;
+    const int n0 = blockIdx.x * (4 * FPW) + wave * FPW;
+    const bool have = n0 < a.N, two = FPW == 2 && n0 + 1 < a.N;
     // ---- 1. weights of this wave's two output features -> registers
     uint4 w[2][KIT];
     {
@@ -164,92 +227,95 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a) {
         for (int it = 0; it < KIT; ++it) {
             const int k0 = (it * 64 + lane) * 8;
             w[0][it] = k0 < K ? *reinterpret_cast<const uint4*>(w0 + k0) : make_uint4(0u, 0u, 0u, 0u);
-            w[1][it] = k0 < K ? *reinterpret_cast<const uint4*>(w1 + k0) : make_uint4(0u, 0u, 0u, 0u);
+            w[1][it] = (FPW == 2 && k0 < K) ? *reinterpret_cast<const uint4*>(w1 + k0) : make_uint4(0u, 0u, 0u, 0u);
         }
     }
-    // epilogue operands of lane l = (feature c = l >> 3, row b = l & 7): requested now, consumed at the very end
-    const int ec = lane >> 3, eb = lane & 7;
-    const bool elane = lane < 16 && eb < NB && n0 + ec < a.N;
+    // epilogue operands: value (feature c, row b) of the reduce-scatter below ends in the lanes [j << esh, (j + 1) << esh) with
+    // j = c * NBP + b (NBP = NB rounded up to a power of two); the first lane of each group finishes that output.  Requested now,
+    // consumed at the very end.
+    const int elog = NB <= 1 ? 0 : (NB <= 2 ? 1 : (NB <= 4 ? 2 : 3)), esh = (FPW == 2 ? 5 : 6) - elog;
+    const int ec = FPW == 2 ? lane >> 5 : 0, eb = (lane >> esh) & ((1 << elog) - 1);
+    const bool elane = (lane & ((1 << esh) - 1)) == 0 && eb < NB && n0 + ec < a.N;
     const int en = n0 + ec;
     const float ebias = (elane && a.bias) ? a.bias[en] : 0.f;
     const float eres = (elane && a.residual) ? a.residual[eb * a.ldr + en] : 0.f;
     const int epos = a.kv_cache ? (a.pos_dev ? *a.pos_dev : a.pos0) : 0;
-    // ---- 2. input rows: one pass of 16-byte loads into registers, LayerNorm statistics by block reduction, then LDS
-    const int kq = K >> 2, total4 = NB * kq;  // float4 per row / in all rows
-    float4 xv[XV];
-    int xrow[XV];
+    GV_STAMP(1)
+    // ---- 2. input rows: wave w owns rows w and w + 4 (NB <= 8) -- a row is K/256 coalesced 16-byte loads per lane, its LayerNorm
+    // statistics are two in-wave reductions (no cross-wave step, no barrier), and the normalised row goes to LDS.  (The first form
+    // spread the rows' float4 over all 256 threads: per-row partial sums through eight-way selects, a cross-wave LDS reduction and
+    // four barriers -- 3.8 us of an 11-us kernel at batch 4, tools/decode_gemv_timeline.py.)
+    constexpr int XR = 2 * KIT;  // float4 per lane and row: K <= 512 * KIT
+    float4 xr[2][XR];
 #pragma unroll
-    for (int j = 0; j < XV; ++j) {
-        const int i = tid + 256 * j;
-        xrow[j] = i < total4 ? i / kq : -1;
-        xv[j] = i < total4 ? *reinterpret_cast<const float4*>(a.x + (long)xrow[j] * a.ldx + (i - xrow[j] * kq) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    constexpr int XL = 6;  // with LayerNorm NB * K <= 6144: gain / bias of this thread's elements, requested with the rows
-    float4 lg[XL], lb[XL];
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = wave + 4 * rr;
 #pragma unroll
-    for (int j = 0; j < XL; ++j) {
-        const bool on = a.ln_w && xrow[j] >= 0;
-        const int k = on ? (tid + 256 * j - xrow[j] * kq) * 4 : 0;
-        lg[j] = on ? *reinterpret_cast<const float4*>(a.ln_w + k) : make_float4(1.f, 1.f, 1.f, 1.f);
-        lb[j] = on ? *reinterpret_cast<const float4*>(a.ln_b + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (a.ln_w) {
-        for (int pass = 0; pass < 2; ++pass) {
-            float part[GV_MAXB];
-#pragma unroll
-            for (int b = 0; b < GV_MAXB; ++b) part[b] = 0.f;
-#pragma unroll
-            for (int j = 0; j < XV; ++j) {
-                if (xrow[j] < 0) continue;
-                float v;
-                if (pass == 0) {
-                    v = (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
-                } else {
-                    const float mu = stats[xrow[j]][0];
-                    const float d0 = xv[j].x - mu, d1 = xv[j].y - mu, d2 = xv[j].z - mu, d3 = xv[j].w - mu;
-                    v = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                }
-#pragma unroll
-                for (int b = 0; b < GV_MAXB; ++b) part[b] += (xrow[j] == b) ? v : 0.f;
-            }
-#pragma unroll
-            for (int b = 0; b < GV_MAXB; ++b) {
-                if (b < NB) {
-                    const float sw = wave_sum(part[b]);
-                    if (lane == 0) red[wave][b] = sw;
-                }
-            }
-            __syncthreads();
-            if (tid < NB) {
-                const float t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-                if (pass == 0)
-                    stats[tid][0] = t / (float)K;
-                else
-                    stats[tid][1] = rsqrtf(t / (float)K + a.eps);
-            }
-            __syncthreads();
+        for (int jj = 0; jj < XR; ++jj) {
+            const int k = (jj * 64 + lane) * 4;
+            xr[rr][jj] = (r < NB && k < K) ? *reinterpret_cast<const float4*>(a.x + (long)r * a.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    float4 lg[XR], lb[XR];  // LayerNorm gain / bias of this lane's columns (requested with the rows)
 #pragma unroll
-    for (int j = 0; j < XV; ++j) {
-        if (xrow[j] < 0) continue;
-        const int i = tid + 256 * j;
-        const int k = (i - xrow[j] * kq) * 4;
-        float v[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-        if (a.ln_w && j < XL) {
-            const float mu = stats[xrow[j]][0], rs = stats[xrow[j]][1];
-            const float4 g4 = lg[j < XL ? j : 0], b4 = lb[j < XL ? j : 0];
-            v[0] = (v[0] - mu) * rs * g4.x + b4.x, v[1] = (v[1] - mu) * rs * g4.y + b4.y;
-            v[2] = (v[2] - mu) * rs * g4.z + b4.z, v[3] = (v[3] - mu) * rs * g4.w + b4.w;
-        }
-        if (a.round_in) {
+    for (int jj = 0; jj < XR; ++jj) {
+        const int k = (jj * 64 + lane) * 4;
+        const bool on = a.ln_w && k < K;
+        lg[jj] = on ? *reinterpret_cast<const float4*>(a.ln_w + k) : make_float4(1.f, 1.f, 1.f, 1.f);
+        lb[jj] = on ? *reinterpret_cast<const float4*>(a.ln_b + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if constexpr (TRACE) {  // (the stamp is taken when the input rows have ARRIVED: it consumes one of them)
+        float probe = xr[0][0].x;
+        asm volatile("" : "+v"(probe));
+    }
+    GV_STAMP(2)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]);
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = wave + 4 * rr;
+        if (r >= NB) break;  // wave-uniform
+        float mu = 0.f, rs = 1.f;
+        if (a.ln_w) {
+            float t = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < XR; ++jj) t += (xr[rr][jj].x + xr[rr][jj].y) + (xr[rr][jj].z + xr[rr][jj].w);  // (columns >= K hold 0)
+            mu = wave_sum_fast(t) / (float)K;
+            float q = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < XR; ++jj) {
+                if ((jj * 64 + lane) * 4 >= K) continue;
+                const float d0 = xr[rr][jj].x - mu, d1 = xr[rr][jj].y - mu, d2 = xr[rr][jj].z - mu, d3 = xr[rr][jj].w - mu;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            rs = rsqrtf(wave_sum_fast(q) / (float)K + a.eps);
         }
-        *reinterpret_cast<float4*>(xs + (long)xrow[j] * K + k) = make_float4(v[0], v[1], v[2], v[3]);
+        if (rr == 0) { GV_STAMP(3) }
+#pragma unroll
+        for (int jj = 0; jj < XR; ++jj) {
+            const int k = (jj * 64 + lane) * 4;
+            if (k >= K) continue;
+            float v[4] = {xr[rr][jj].x, xr[rr][jj].y, xr[rr][jj].z, xr[rr][jj].w};
+            if (a.ln_w) {
+                v[0] = (v[0] - mu) * rs * lg[jj].x + lb[jj].x, v[1] = (v[1] - mu) * rs * lg[jj].y + lb[jj].y;
+                v[2] = (v[2] - mu) * rs * lg[jj].z + lb[jj].z, v[3] = (v[3] - mu) * rs * lg[jj].w + lb[jj].w;
+            }
+            if (a.round_in) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]);
+            }
+            if constexpr (BF)
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(xs) + (long)r * K + k) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            else
+                *reinterpret_cast<float4*>(xs + (long)r * K + k) = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
     __syncthreads();
+    GV_STAMP(4)
     if (!have) return;
+    if constexpr (TRACE) {  // the weights have arrived
+        asm volatile("" : "+v"(w[0][0].x), "+v"(w[0][KIT - 1].x));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    GV_STAMP(5)
     // ---- 3. dot products: weights from registers, rows from LDS
     float acc[2][GV_MAXB];
 #pragma unroll
@@ -265,28 +331,66 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a) {
         const float f1[8] = {bf_lo(u1.x), bf_hi(u1.x), bf_lo(u1.y), bf_hi(u1.y), bf_lo(u1.z), bf_hi(u1.z), bf_lo(u1.w), bf_hi(u1.w)};
 #pragma unroll
         for (int b = 0; b < GV_MAXB; ++b) {
+            if constexpr (BF) {
+                if (b < NB) {
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+                    const uint4 x8 = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(xs) + b * K + k0);
+                    const uint32_t xw[4] = {x8.x, x8.y, x8.z, x8.w}, w0[4] = {u0.x, u0.y, u0.z, u0.w}, w1[4] = {u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0][b] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w0[e]), __builtin_bit_cast(bf2_t, xw[e]), acc[0][b], false);
+                        if constexpr (FPW == 2)
+                            acc[1][b] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w1[e]), __builtin_bit_cast(bf2_t, xw[e]), acc[1][b], false);
+                    }
+                }
+                continue;
+            }
             if (b < NB) {
                 const float4 xa = *reinterpret_cast<const float4*>(xs + b * K + k0);
                 const float4 xb = *reinterpret_cast<const float4*>(xs + b * K + k0 + 4);
                 acc[0][b] += (f0[0] * xa.x + f0[1] * xa.y) + (f0[2] * xa.z + f0[3] * xa.w) + (f0[4] * xb.x + f0[5] * xb.y) +
                              (f0[6] * xb.z + f0[7] * xb.w);
-                acc[1][b] += (f1[0] * xa.x + f1[1] * xa.y) + (f1[2] * xa.z + f1[3] * xa.w) + (f1[4] * xb.x + f1[5] * xb.y) +
-                             (f1[6] * xb.z + f1[7] * xb.w);
+                if constexpr (FPW == 2)
+                    acc[1][b] += (f1[0] * xa.x + f1[1] * xa.y) + (f1[2] * xa.z + f1[3] * xa.w) + (f1[4] * xb.x + f1[5] * xb.y) +
+                                 (f1[6] * xb.z + f1[7] * xb.w);
             }
         }
     }
+    // 2 * NBP partial sums per lane -> the complete sum (c, b) in lane group c * NBP + b (see reduce_scatter above)
+    float v;
+    if constexpr (FPW == 2) {
+        if (elog == 0) {
+            float l2[2] = {acc[0][0], acc[1][0]};
+            v = reduce_scatter<1>(l2, lane);
+        } else if (elog == 1) {
+            float l4[4] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
+            v = reduce_scatter<2>(l4, lane);
+        } else if (elog == 2) {
+            float l8[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+            v = reduce_scatter<3>(l8, lane);
+        } else {
+            float l16[16];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < 16; ++j) l16[j] = acc[j >> 3][j & 7];
+            v = reduce_scatter<4>(l16, lane);
+        }
+    } else {
+        if (elog == 0) {
+            float l1[1] = {acc[0][0]};
+            v = reduce_scatter<0>(l1, lane);
+        } else if (elog == 1) {
+            float l2[2] = {acc[0][0], acc[0][1]};
+            v = reduce_scatter<1>(l2, lane);
+        } else if (elog == 2) {
+            float l4[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+            v = reduce_scatter<2>(l4, lane);
+        } else {
+            float l8[8];
 #pragma unroll
-        for (int b = 0; b < GV_MAXB; ++b)
-            if (b < NB) acc[c][b] = wave_sum(acc[c][b]);
-    // every lane holds every sum: lane (c, b) finishes its own output (one parallel round of stores)
-    float v = 0.f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int b = 0; b < GV_MAXB; ++b)
-            if (lane == c * 8 + b) v = acc[c][b];
+            for (int j = 0; j < 8; ++j) l8[j] = acc[0][j];
+            v = reduce_scatter<3>(l8, lane);
+        }
+    }
     if (elane) {
         v += ebias;
         if (a.act == 1) v = v * sigmoidf_(1.702f * v);  // QuickGELU (clip_model.py:196-198)
@@ -296,6 +400,8 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a) {
         if (a.kv_cache && en >= a.kv_lo && en < a.kv_lo + a.kv_width && epos < a.Lmax)
             a.kv_cache[((long)eb * a.Lmax + epos) * a.kv_width + (en - a.kv_lo)] = f2bf(v);
     }
+    GV_STAMP(6)
+#undef GV_STAMP
 }
 
 // One block per (head, batch): q fp32 [B][ldq] (already bf16-rounded), K|V rows from the cache (position `pos` included).
@@ -342,7 +448,7 @@ __global__ __launch_bounds__(256) void attn_decode2_kernel(const float* __restri
         const int k = kg + 32 * j;
         u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E + dc * 8) : make_uint4(0u, 0u, 0u, 0u);
     }
-    mx = wave_max(mx);
+    mx = wave_max_fast(mx);
     if (lane == 0) stat[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(stat[0], stat[1]), fmaxf(stat[2], stat[3]));
@@ -352,7 +458,7 @@ __global__ __launch_bounds__(256) void attn_decode2_kernel(const float* __restri
         sc[k] = p;
         sum += p;
     }
-    sum = wave_sum(sum);
+    sum = wave_sum_fast(sum);
     if (lane == 0) stat[4 + wave] = sum;
     __syncthreads();
     sum = (stat[4] + stat[5]) + (stat[6] + stat[7]);
@@ -396,32 +502,53 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const long long* __restr
 }
 
 int gemv_launch(GemvArgs a, hipStream_t s) {
-    if (a.NB > GV_MAXB || a.K % 8 != 0 || (long)a.NB * a.K > 24576 || a.K > 3072 || a.ldx % 4 != 0 ||
-        (a.ln_w && (long)a.NB * a.K > 6144)) {
-        mmvid_set_error("decode gemv: NB=%d (<= %d), K=%d (multiple of 8, <= 3072, NB*K <= 24576; <= 6144 with LayerNorm), ldx %% 4 == 0",
-                        a.NB, GV_MAXB, a.K);
+    if (a.NB > GV_MAXB || a.K % 8 != 0 || (long)a.NB * a.K > 24576 || a.K > 3072 || a.ldx % 4 != 0) {
+        mmvid_set_error("decode gemv: NB=%d (<= %d), K=%d (multiple of 8, <= 3072, NB*K <= 24576), ldx %% 4 == 0", a.NB, GV_MAXB, a.K);
         return MMVID_ERR_ARG;
     }
-    const dim3 grid(cdiv(a.N, GV_COLS));
-    const size_t lds = (size_t)a.NB * a.K * 4;
+    // 8 output features per block, or 4 (one per wave) for the narrow outputs (out-proj, c_proj: N = 768 would be 96 blocks on 256 CUs)
+    const bool narrow = a.N <= 1024;
+    const dim3 grid(cdiv(a.N, narrow ? 4 : GV_COLS));
+    const size_t lds = (size_t)a.NB * a.K * (a.round_in ? 2 : 4);
     const int kit = cdiv(a.K, 512);
-    if ((long)a.NB * a.K > 12288) {  // 5..8 rows of a 3,072-wide input (c_proj): 96 KiB of LDS, 24 float4 staged per thread
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)gemv_rows_kernel<6, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
-            attr = true;
+    static bool attr = false;
+    if (!attr) {  // up to 8 rows of a 3,072-wide fp32 input: 96 KiB of LDS (48 KiB as bf16)
+        (void)hipFuncSetAttribute((const void*)(gemv_rows_kernel<6, false, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
+        (void)hipFuncSetAttribute((const void*)(gemv_rows_kernel<6, false, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
+        (void)hipFuncSetAttribute((const void*)(gemv_rows_kernel<6, true, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
+        (void)hipFuncSetAttribute((const void*)(gemv_rows_kernel<6, true, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
+        attr = true;
+    }
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, g_decode_trace); };
+    const bool bf = a.round_in != 0;  // (the staged rows are then bf16-exact)
+    auto pick = [&](auto kit_c) {
+        constexpr int KITC = decltype(kit_c)::value;
+        if (g_decode_trace) {
+            if (narrow)
+                bf ? go(gemv_rows_kernel<KITC, true, 1, true>) : go(gemv_rows_kernel<KITC, true, 1, false>);
+            else
+                bf ? go(gemv_rows_kernel<KITC, true, 2, true>) : go(gemv_rows_kernel<KITC, true, 2, false>);
+        } else if (narrow) {
+            bf ? go(gemv_rows_kernel<KITC, false, 1, true>) : go(gemv_rows_kernel<KITC, false, 1, false>);
+        } else {
+            bf ? go(gemv_rows_kernel<KITC, false, 2, true>) : go(gemv_rows_kernel<KITC, false, 2, false>);
         }
-        hipLaunchKernelGGL((gemv_rows_kernel<6, 24>), grid, dim3(256), lds, s, a);
-    } else if (kit <= 2)
-        hipLaunchKernelGGL(gemv_rows_kernel<2>, grid, dim3(256), lds, s, a);
+    };
+    if (kit <= 2)
+        pick(std::integral_constant<int, 2>{});
     else if (kit <= 4)
-        hipLaunchKernelGGL(gemv_rows_kernel<4>, grid, dim3(256), lds, s, a);
+        pick(std::integral_constant<int, 4>{});
     else
-        hipLaunchKernelGGL(gemv_rows_kernel<6>, grid, dim3(256), lds, s, a);
+        pick(std::integral_constant<int, 6>{});
     return MMVID_OK;
 }
 
 }  // namespace
+
+extern "C" int mmvid_decode_trace(void* dev_buf) {
+    g_decode_trace = (unsigned long long*)dev_buf;
+    return MMVID_OK;
+}
 
 extern "C" int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const float* ln_w, const float* ln_b, float eps,
                                const void* W, const float* bias, int N, int act, const float* residual, int64_t ldr,
@@ -484,7 +611,7 @@ extern "C" int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvi
                            0.125f * 1.4426950408889634f, o, (long)E);
         GemvArgs g2 = {};
         g2.NB = B, g2.x = o, g2.ldx = E, g2.W = (const bf16_t*)ly.out_w, g2.bias = ly.out_b, g2.N = E, g2.K = E, g2.residual = x,
-        g2.ldr = E, g2.out = xmid, g2.ldo = E;
+        g2.ldr = E, g2.out = xmid, g2.ldo = E, g2.round_in = 1;  // (o is bf16-exact already: rounding is a no-op, LDS holds bf16)
         rc = gemv_launch(g2, s);
         if (rc) return rc;
         GemvArgs g3 = {};
@@ -494,7 +621,7 @@ extern "C" int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvi
         if (rc) return rc;
         GemvArgs g4 = {};
         g4.NB = B, g4.x = act, g4.ldx = F, g4.W = (const bf16_t*)ly.pj_w, g4.bias = ly.pj_b, g4.N = E, g4.K = F, g4.residual = xmid,
-        g4.ldr = E, g4.out = xnext, g4.ldo = E;
+        g4.ldr = E, g4.out = xnext, g4.ldo = E, g4.round_in = 1;  // (the rounded GELU output)
         rc = gemv_launch(g4, s);
         if (rc) return rc;
         x = xnext;

@@ -76,10 +76,24 @@ __global__ __launch_bounds__(512) void probe_store_kernel(int M, int N, int vari
             if (bm0 + ml < M && bn0 + c < N) *reinterpret_cast<uint2*>(out + (long)(bm0 + ml) * N + bn0 + c) = v2;
         }
 }
+// which = 3: the DPP / permlane wave reductions of common.h.  in: float[64]; out: float[3][64] = wave_sum_fast, wave_max_fast and
+// wave_sum (the ds_bpermute form) as every lane sees them.
+__global__ void probe_wave_reduce_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const float v = in[lane];
+    out[lane] = wave_sum_fast(v);
+    out[64 + lane] = wave_max_fast(v);
+    out[128 + lane] = wave_sum(v);
+}
 }  // namespace
 
 extern "C" int mmvid_probe(int which, const void* in, void* out, void* stream) {
-    MMVID_REQUIRE((which >= 0 && which <= 2) && in && out, "probe: bad arguments");
+    MMVID_REQUIRE((which >= 0 && which <= 3) && in && out, "probe: bad arguments");
+    if (which == 3) {
+        hipLaunchKernelGGL(probe_wave_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)in, (float*)out);
+        MMVID_LAUNCH_CHECK("probe");
+        return MMVID_OK;
+    }
     if (which == 2) {  // in = HOST int32[3]: M, N, variant
         const int* a = (const int*)in;
         const int M = a[0], N = a[1], variant = a[2];

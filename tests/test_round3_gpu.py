@@ -514,6 +514,45 @@ def test_tower_12_layers_at_training_length_vs_reference(golden):
             close(prm.grad, g[f'l{li}_d{nm}'], 5e-2, f'layer {li} d{nm}')
 
 
+@pytest.mark.parametrize('B', [1, 4, 8])
+def test_decode_step_on_a_long_cache(B):
+    """Decode steps deep into a long cache (position 643..647 of 704): the gemv rows live in LDS as bf16 and are reduced by the DPP
+    reduce-scatter (csrc/decode.hip), for 1 / 4 / 8 rows -- against the full-prefix causal forward at the same positions."""
+    from mmvid_amd.clip_tower import OpenAICLIPTransformer
+    torch.manual_seed(B)
+    L, P, steps = 704, 643, 5
+    tw = OpenAICLIPTransformer(seq_len=L, which_model='openai_clip_visual', causal=True, layers=2).to(DEV).eval()
+    x = torch.randn(B, P + steps, 768, device=DEV) * 0.5
+    with torch.no_grad():
+        full = tw(x)
+        cache = tw.new_kv_cache(B, L, DEV)
+        tw.prefill(x[:, :P].contiguous(), cache)
+        sess = tw.decode_session(cache, P)
+        for k in range(steps):
+            h = sess.step(x[:, P + k].contiguous())
+            close(h, full[:, P + k], 1e-2, f'B={B}: incremental vs full forward at position {P + k}')
+
+
+def test_dpp_wave_reductions():
+    """wave_sum_fast / wave_max_fast (csrc/common.h: DPP inside a row, v_permlane16_swap / v_permlane32_swap across rows): every lane
+    holds the total; equal to the ds_bpermute butterfly up to fp32 summation order."""
+    from mmvid_amd import _lib, ops
+    torch.manual_seed(3)
+    for scale in (1.0, 1e3):
+        v = (torch.randn(64, device=DEV) * scale).contiguous()
+        out = torch.empty(3, 64, device=DEV)
+        _lib.call('mmvid_probe', 3, ops._p(v), ops._p(out), ops._stream())
+        ref = v.double().sum().item()
+        assert torch.all(out[0] == out[0, 0]) and torch.all(out[1] == out[1, 0])
+        assert abs(out[0, 0].item() - ref) <= 1e-5 * v.abs().sum().item()
+        assert out[1, 0].item() == v.max().item()
+        assert abs(out[2, 0].item() - ref) <= 1e-5 * v.abs().sum().item()
+    # exact on integers: the order of the additions cannot matter
+    v = torch.arange(64, device=DEV, dtype=torch.float32)
+    _lib.call('mmvid_probe', 3, ops._p(v), ops._p(out), ops._stream())
+    assert torch.all(out[0] == 2016.0) and torch.all(out[1] == 63.0)
+
+
 # ------------------------------------------------------------------------------------------- vae.strict = 'split'
 def _conv_ref64(x, w, b, mode, residual=None):
     """fp64 reference on the CPU: x [N,H,W,Cin], w [Cout,taps,Cin] -> [N,Ho,Wo,Cout] (modes of mmvid_conv2d_nhwc)."""
