@@ -144,8 +144,12 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   gemm_loader    MMVID_GEMM_LOADER    1 (default) = 256x128 GEMM blocks with a register-direct epilogue run 8 MFMA waves + 1 LOADER wave
 //                                       that issues every LDS-DMA request (the MFMA waves issue no vector-memory instruction in
 //                                       the K loop); 0 = every wave requests its own share between its MFMAs (round 2)
-//   gemm_groupn    MMVID_GEMM_GROUPN    1 = persistent GEMM blocks walk the output tiles in column groups sized to the XCD L2 (default 0: measured
-//                                       no gain, profiles/r03_gemm_variants.log -- the K loop is not bound by L2 misses)
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_ATTN_RES = 15, MMVID_OPT_COUNT = 16 };
+//   attn_res       MMVID_ATTN_RES       0 (default) = streaming attention kernels; 1 = "resident" forms (one 8-wave block per (batch, head), K/V
+//                                       or Q/dO staged into LDS once, L <= 608; bit-identical; measured 16 % SLOWER: 2 waves per SIMD cannot
+//                                       hide a wave's ~1.7-us per-tile dependency chain); 2 = the forward kernel with 16 waves (equal to 0)
+//   gemm_fused_reduce MMVID_GEMM_FUSED_REDUCE 0 (default) = split-K slabs of the weight-gradient GEMM added by splitk_reduce_kernel; 1 = by the last
+//                                       block of each output tile inside the GEMM (bit-identical; measured +5 ms per step: the device-scope
+//                                       release writes back the XCD's whole L2)
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_ATTN_RES = 15, MMVID_OPT_GEMM_FUSED_REDUCE = 16, MMVID_OPT_COUNT = 17 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

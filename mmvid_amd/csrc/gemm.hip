@@ -53,7 +53,19 @@ struct GemmParams {
     int group_n;     // persistent blocks: tiles are walked column-GROUP-major (groups of group_n column tiles), see launch_shape
     int defer;       // EPI >= 2: issue a tile's stores from inside the next tile's K loop (persistent blocks)
     unsigned long long* trace;  // measurement only (mmvid_gemm_trace): per block, wave group and tile 8 time stamps (100 MHz)
+    // split-K slabs reduced inside the GEMM (option gemm_fused_reduce): the block that finishes a tile LAST adds the tile's slabs in
+    // slab order (+ red_out when red_accumulate) into red_out [M][red_ld]; counters = one int per output tile, zero between launches
+    float* red_out;
+    long red_ld;
+    int red_accumulate;
+    int* counters;
 };
+// counters of the fused split-K reduction: a ring (every launch takes the next `tiles` entries), zero-initialised with the module
+// and left zero by every launch, so neither an allocation nor a memset is ever needed (graph capture safe)
+constexpr int RED_RING = 16384;
+__device__ int g_red_counters[RED_RING];
+int g_red_cursor = 0;
+thread_local bool g_last_launch_fused = false;
 unsigned long long* g_gemm_trace = nullptr;
 constexpr int TRACE_TILES = 8;
 
@@ -752,6 +764,42 @@ __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_
         }
         if (stamp) stamp[4] = wall_clock64();
     }
+    // ---- split-K slabs (option gemm_fused_reduce, default OFF): the last block to finish this tile adds its slabs in slab order (the
+    // arithmetic of splitk_reduce_kernel, bit for bit) -- no reduce launch.  Release: this block's slab stores, device-wide, before
+    // its count; acquire: the counter value before any slab is read.  MEASURED NEGATIVE on this 8-XCD part: the device-scope
+    // release is a write-back of the XCD's whole L2 (buffer_wbl2), paid by every block -- the captured training step went from
+    // 16.03 to 21.17 ms (+105 us per weight-gradient GEMM) against the 0.4 ms the 49 reduce launches cost (tools/ab_graph.py).
+    if constexpr (EPI == 1) {
+        if (p.red_out) {
+            // (the flag lives in the first stage: the K loop is over, and the dynamic LDS of this kernel is already the CU's 160 KiB)
+            volatile int* s_last = reinterpret_cast<volatile int*>(smem);
+            __threadfence();
+            __syncthreads();  // (the loader waves have returned: the barrier counts the eight MFMA waves)
+            const int tile = blockIdx.x + gridDim.x * blockIdx.y;
+            if (tid == 0) *s_last = atomicAdd(p.counters + tile, 1) == p.splitk - 1;
+            __syncthreads();
+            if (*s_last) {
+                __threadfence();
+                int bm0, bn0;
+                tile_origin(0, bm0, bn0);
+                const long mn = (long)p.M * p.N;
+#pragma unroll 4
+                for (int k = 0; k < 16; ++k) {
+                    const int idx = tid + 512 * k, r = idx >> 5, c = (idx & 31) * 4;
+                    const int m = bm0 + r, n = bn0 + c;
+                    if (m >= p.M || n >= p.N) continue;
+                    float4 a = p.red_accumulate ? *reinterpret_cast<const float4*>(p.red_out + (long)m * p.red_ld + n) : make_float4(0, 0, 0, 0);
+                    const float* src = p.out_f32 + (long)m * p.N + n;
+                    for (int sidx = 0; sidx < p.splitk; ++sidx) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + sidx * mn);
+                        a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+                    }
+                    *reinterpret_cast<float4*>(p.red_out + (long)m * p.red_ld + n) = a;
+                }
+                if (tid == 0) p.counters[tile] = 0;
+            }
+        }
+    }
 }
 
 // ================================================================================================================
@@ -956,6 +1004,7 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     GemmParams q = p;
     q.tiles_n = q.tiles_m = 0;
     q.defer = 0, q.group_n = 0;
+    q.red_out = nullptr, q.counters = nullptr;  // (set below when the split-K slabs are reduced inside the kernel)
     if (WM == 4 && mmvid_option(MMVID_OPT_GEMM_PERSIST) && (long)grid.x * grid.y > 256) {  // more than one tile per CU
         q.tiles_n = (int)grid.x, q.tiles_m = (int)grid.y;
         grid = dim3(256, 1, grid.z);
@@ -994,6 +1043,15 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
             direct_epilogue_ok((dact_packed || slabs) ? pc : p, batch, true)) {
             if (slabs) {
                 q.out_f32 = pc.out_f32, q.partial = nullptr, q.accumulate = 0, q.ldc = pc.ldc, q.strideC = pc.strideC, q.strideA = 0, q.strideB = 0;
+                const int tiles = (int)(grid.x * grid.y);
+                if (mmvid_option(MMVID_OPT_GEMM_FUSED_REDUCE) && p.red_out && tiles <= RED_RING && p.N % 4 == 0 && p.tiles_n == 0 && q.tiles_n == 0) {
+                    if (g_red_cursor + tiles > RED_RING) g_red_cursor = 0;
+                    void* base = nullptr;
+                    (void)hipGetSymbolAddress(&base, HIP_SYMBOL(g_red_counters));
+                    q.counters = (int*)base + g_red_cursor, q.red_out = p.red_out;
+                    g_red_cursor += tiles;
+                    g_last_launch_fused = true;
+                }
             }
             const bool packed = p.out_bf16 && !p.out_f32 && !p.residual && !p.dact_pre && !p.accumulate && p.N % 128 == 0 && batch == 1;
             const int epi = dact_packed ? 4 : (packed ? (p.save_pre ? 3 : 2) : 1);
@@ -1145,6 +1203,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
     p.tiles_n = p.tiles_m = 0;
     p.trace = g_gemm_trace;
+    p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor)
         launch<false, false>(p, batch, s);
@@ -1188,9 +1247,13 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
     p.tiles_n = p.tiles_m = 0;
     p.trace = nullptr;
+    // split-K: the slabs are added in slab order either by the last block of each output tile inside the GEMM (option
+    // gemm_fused_reduce, the 256x128 loader-wave kernel) or by splitk_reduce_kernel -- the same additions in the same order
+    p.red_out = splitk > 1 ? dW : nullptr, p.red_ld = K, p.red_accumulate = accumulate, p.counters = nullptr;
     hipStream_t s = (hipStream_t)stream;
+    g_last_launch_fused = false;
     launch<true, true>(p, 1, s);
-    if (splitk > 1) {
+    if (splitk > 1 && !g_last_launch_fused) {
         const long mn = (long)N * K;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(mn / 4, 256)), dim3(256), 0, s, workspace, splitk, mn, dW, accumulate);
     }

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             v[i] = make_float4(0, 0, 0, 0);
         }
     }
-    const float mean = wave_sum(s) / (float)E;
+    const float mean = wave_sum_fast(s) / (float)E;  // (DPP / permlane reduction: no LDS-crossbar round trips, common.h)
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             q += (a * a + b2 * b2) + (c2 * c2 + d * d);
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)E + eps);
+    const float rstd = rsqrtf(wave_sum_fast(q) / (float)E + eps);
     if (lane == 0) {
         if (mean_out) mean_out[r] = mean;
         if (rstd_out) rstd_out[r] = rstd;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DY* __restrict
                 pb[i].x += d4.x, pb[i].y += d4.y, pb[i].z += d4.z, pb[i].w += d4.w;
             }
         }
-        const float m1 = wave_sum(s1) / (float)E, m2 = wave_sum(s2) / (float)E;
+        const float m1 = wave_sum_fast(s1) / (float)E, m2 = wave_sum_fast(s2) / (float)E;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + 64 * i;

@@ -533,6 +533,37 @@ def test_decode_step_on_a_long_cache(B):
             close(h, full[:, P + k], 1e-2, f'B={B}: incremental vs full forward at position {P + k}')
 
 
+@pytest.mark.parametrize('M,N,K,acc', [(10422, 2304, 768, False), (10422, 768, 768, True), (10422, 3072, 768, True),
+                                          (10422, 768, 3072, False), (3000, 520, 264, True)])
+def test_split_k_slabs_reduced_by_the_last_block(M, N, K, acc):
+    """The weight-gradient GEMM's split-K slabs can be added in slab order by the block that finishes an output tile last (option
+    gemm_fused_reduce, csrc/gemm.hip; OFF by default: its device-scope release costs more than the reduce launch it saves) -- the
+    additions of splitk_reduce_kernel in the same order: bit-identical results, with and without accumulation, launch after launch
+    (the tile counters return to zero), and against torch."""
+    from mmvid_amd import _lib, ops
+    torch.manual_seed(N + K)
+    dY = (torch.randn(M, N, device=DEV) * 0.1).bfloat16()
+    X = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
+    base = torch.randn(N, K, device=DEV)
+    res = {}
+    try:
+        for flag in (0, 1):
+            _lib.call('mmvid_set_option', b'gemm_fused_reduce', flag)
+            outs = []
+            for rep in range(3):
+                dW = base.clone()
+                ops.gemm_dw(dY, X, dW, accumulate=acc)
+                outs.append(dW)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+            res[flag] = outs[0]
+    finally:
+        _lib.call('mmvid_set_option', b'gemm_fused_reduce', 0)
+    assert torch.equal(res[0], res[1]), f'{(res[0] != res[1]).sum().item()} of {res[0].numel()} elements differ'
+    ref = dY.float().t() @ X.float() + (base if acc else 0)
+    close(res[1], ref, 2e-3, 'dW vs torch')
+
+
 def test_dpp_wave_reductions():
     """wave_sum_fast / wave_max_fast (csrc/common.h: DPP inside a row, v_permlane16_swap / v_permlane32_swap across rows): every lane
     holds the total; equal to the ds_bpermute butterfly up to fp32 summation order."""
