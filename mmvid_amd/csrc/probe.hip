@@ -85,10 +85,65 @@ __global__ void probe_wave_reduce_kernel(const float* __restrict__ in, float* __
     out[64 + lane] = wave_max_fast(v);
     out[128 + lane] = wave_sum(v);
 }
+// which = 4: LDS read throughput of the attention kernels' access patterns.  One block of 1024 threads (16 waves) on one CU reads a
+// [64 rows][128 B] tile 2048 times per wave with pattern in[0]:
+//   0  ds_read_b128, lane -> 16 consecutive bytes (the ideal)          1  ds_read_b128, row = lane&31, chunk = (2 ks + h) ^ ((row>>1)&7)
+//   2  ds_read_b128, row = lane&31, chunk = (2 ks + h) ^ (row & 7)      3  ds_read_b64_tr_b16 as attn.hip's tr_frag issues it
+//   4  ds_read_b64, lane -> 8 consecutive bytes (the ideal for 3)
+// out: uint64[4] = shader clocks per wave; the host derives bytes per clock.
+__global__ __launch_bounds__(1024) void probe_lds_pattern_kernel(const int* __restrict__ in, unsigned long long* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char tile[2 * 8192];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4096; i += (int)blockDim.x) reinterpret_cast<int*>(tile)[i] = i;
+    __syncthreads();
+    const int pat = in[0];
+    const int l32 = lane & 31, h = lane >> 5;
+    typedef __attribute__((address_space(3))) char lds_c;
+    const unsigned base = (unsigned)(uintptr_t)(lds_c*)tile;
+    unsigned addr[4];
+    for (int ks = 0; ks < 4; ++ks) {
+        if (pat == 0) addr[ks] = base + ks * 1024 + lane * 16;
+        else if (pat == 1) addr[ks] = base + l32 * 128 + (((2 * ks + h) ^ ((l32 >> 1) & 7)) << 4);
+        else if (pat == 2) addr[ks] = base + l32 * 128 + (((2 * ks + h) ^ (l32 & 7)) << 4);
+        else if (pat == 4) addr[ks] = base + ks * 512 + lane * 8;
+        else {
+            const int G = lane >> 4, si = lane & 15;
+            const int rowl = 4 * (G >> 1) + (si >> 2), cl = 2 * (G & 1) + ((si & 3) >> 1);
+            addr[ks] = base + rowl * 128 + ((cl ^ (rowl >> 1)) << 4) + 8 * (si & 1) + ks * 2048;
+        }
+    }
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < 512; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (pat <= 2) {
+                uint4 v;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr[ks]) : "memory");
+            } else if (pat == 3) {
+                uint2 v;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr[ks]) : "memory");
+            } else {
+                uint2 v;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr[ks]) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t1 = clock64();
+    if (lane == 0 && wave < 4) out[wave] = t1 - t0;
+    if (acc.x == 0x12345678u) out[4] = acc.x;
+}
 }  // namespace
 
 extern "C" int mmvid_probe(int which, const void* in, void* out, void* stream) {
-    MMVID_REQUIRE((which >= 0 && which <= 3) && in && out, "probe: bad arguments");
+    MMVID_REQUIRE((which >= 0 && which <= 4) && in && out, "probe: bad arguments");
+    if (which == 4) {
+        hipLaunchKernelGGL(probe_lds_pattern_kernel, dim3(1), dim3(((const int*)in == nullptr) ? 256 : 1024), 0, (hipStream_t)stream, (const int*)in, (unsigned long long*)out);
+        MMVID_LAUNCH_CHECK("probe");
+        return MMVID_OK;
+    }
     if (which == 3) {
         hipLaunchKernelGGL(probe_wave_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)in, (float*)out);
         MMVID_LAUNCH_CHECK("probe");
