@@ -14,12 +14,16 @@ echo "== bench"; timeout 900 python bench.py > gpurun_out/bench.log 2> gpurun_ou
 echo "== smoke"; timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke.log | cut -c1-220
 echo "== gpu tests"; timeout 1500 python -m pytest tests -m gpu -v -s --timeout 400 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 gpurun_out/pytest_gpu.log; grep -E "^(FAILED|ERROR)" gpurun_out/pytest_gpu.log | cut -c1-200
 echo "== strict"; timeout 600 python bench.py --strict --steps 20 --no-cpu-baseline > gpurun_out/bench_strict.log 2> gpurun_out/bench_strict.err; grep "bench\]" gpurun_out/bench_strict.err | cut -c1-200
+echo "== strict split"; timeout 600 python bench.py --strict split --steps 20 --no-cpu-baseline --no-exact > gpurun_out/bench_split.log 2> gpurun_out/bench_split.err; grep "bench\]" gpurun_out/bench_split.err | cut -c1-200
 echo "== config 4"; timeout 600 python bench.py --config 4 --steps 20 --warmup 3 > gpurun_out/bench_c4.log 2> gpurun_out/bench_c4.err; grep "bench\]" gpurun_out/bench_c4.err | cut -c1-200
 echo "== config 5"; timeout 900 python bench.py --config 5 --steps 2 --warmup 1 > gpurun_out/bench_c5.log 2> gpurun_out/bench_c5.err; echo "rc=$?"
 echo "== BERT sampling (mask-predict)"; timeout 900 python bench.py --sample --steps 3 --warmup 1 > gpurun_out/bench_bert_sampling.log 2> gpurun_out/bench_bert_sampling.err; grep "bench\]" gpurun_out/bench_bert_sampling.err | cut -c1-200
 echo "== launcher, forced exchange"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --force-exchange > gpurun_out/bench_ddp1.log 2> gpurun_out/bench_ddp1.err; grep "bench\]" gpurun_out/bench_ddp1.err | cut -c1-200
 echo "== self-launch on a 1-GPU box"; timeout 300 python bench.py --gpus 2 --steps 1 --warmup 0 > gpurun_out/bench_gpus2.log 2> gpurun_out/bench_gpus2.err; echo "rc=$? (expected non-zero)"; grep -o "only [0-9]* device(s) visible[^;]*" gpurun_out/bench_gpus2.err | head -1
-echo "== gemm / attention microbench"; timeout 600 python tools/bench_gemm_epi.py 2>&1 | grep -v amdgpu > gpurun_out/gemm_epi.log; timeout 300 python tools/gemm_timeline.py 2>&1 | grep -v amdgpu > gpurun_out/gemm_timeline.log; timeout 300 python tools/bench_attn.py 2>&1 | grep -v amdgpu > gpurun_out/attn.log; cat gpurun_out/attn.log
+echo "== attention / decode microbench + timelines"; timeout 300 python tools/bench_attn.py 2>&1 | grep -v amdgpu > gpurun_out/attn.log; cat gpurun_out/attn.log
+timeout 300 python tools/attn_timeline.py 2>&1 | grep -v amdgpu > gpurun_out/attn_timeline.log; timeout 300 python tools/bench_decode_step.py 4 2>&1 | grep -v "amdgpu\|fused=False" > gpurun_out/decode_step_b4.log
+timeout 300 python tools/bench_decode_step.py 1 2>&1 | grep -v "amdgpu\|fused=False" > gpurun_out/decode_step_b1.log; timeout 300 python tools/decode_gemv_timeline.py 4 2>&1 | grep -v amdgpu > gpurun_out/decode_gemv_timeline.log
+timeout 300 python tools/conv_layer_profile.py 54 2>&1 | grep -v amdgpu > gpurun_out/conv_layers_54.log
 echo "== rocprofv3 kernel stats"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -o bench -- python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --eager > $ROOT/gpurun_out/prof.log 2>&1; echo "rocprof rc=$?")
 find gpurun_out/prof -type f ! -name "*kernel_stats*" -delete
@@ -30,7 +34,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - <<'PY'
 import json
-for f in ('bench','bench_strict','bench_c4','bench_c5','bench_ddp1'):
+for f in ('bench','bench_strict','bench_split','bench_c4','bench_c5','bench_ddp1'):
     try:
         d=json.loads(open(f'gpurun_out/{f}.log').read().strip().splitlines()[-1])
         print(f, 'ms/step',round(d['ms_per_step'],3),'value',round(d['value']),d['config'].get('step_launch',''), 'roof', d['roofline'] and {k:d['roofline'][k] for k in ('kernel','achieved','frac','traffic')})
