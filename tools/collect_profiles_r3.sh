@@ -13,6 +13,7 @@ cp $g/decode_step_b4.log $p/${r}_artv_decode_step_b4.log; cp $g/decode_step_b1.l
 cp $g/conv_layers_54.log $p/${r}_vqgan_encoder_per_layer_54_frames.log
 cp $g/pmc_FETCH_SIZE.csv $p/${r}_pmc_fetch_size.csv; cp $g/pmc_WRITE_SIZE.csv $p/${r}_pmc_write_size.csv
 cp $g/prof/bench_kernel_stats.csv $p/${r}_rocprofv3_kernel_stats.csv
+cp $g/stress.log $p/${r}_graph_replay_stress.log
 cp $g/host.txt $p/${r}_host.txt; cp $g/rocm_smi.txt $p/${r}_rocm_smi.txt
 grep -o "only [0-9]* device(s) visible[^;]*" $g/bench_gpus2.err | head -1 > $p/${r}_bench_gpus2_on_one_gpu_box.txt
 ls -la $p | grep ${r}_ | wc -l

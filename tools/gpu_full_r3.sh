@@ -24,6 +24,7 @@ echo "== attention / decode microbench + timelines"; timeout 300 python tools/be
 timeout 300 python tools/attn_timeline.py 2>&1 | grep -v amdgpu > gpurun_out/attn_timeline.log; timeout 300 python tools/bench_decode_step.py 4 2>&1 | grep -v "amdgpu\|fused=False" > gpurun_out/decode_step_b4.log
 timeout 300 python tools/bench_decode_step.py 1 2>&1 | grep -v "amdgpu\|fused=False" > gpurun_out/decode_step_b1.log; timeout 300 python tools/decode_gemv_timeline.py 4 2>&1 | grep -v amdgpu > gpurun_out/decode_gemv_timeline.log
 timeout 300 python tools/conv_layer_profile.py 54 2>&1 | grep -v amdgpu > gpurun_out/conv_layers_54.log
+echo "== graph-replay stress"; for sd in 42 7; do timeout 300 python tools/stress_nan.py 300 $sd 1000 2>&1 | grep -v amdgpu | tail -2; done > gpurun_out/stress.log; cat gpurun_out/stress.log
 echo "== rocprofv3 kernel stats"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -o bench -- python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --eager > $ROOT/gpurun_out/prof.log 2>&1; echo "rocprof rc=$?")
 find gpurun_out/prof -type f ! -name "*kernel_stats*" -delete
