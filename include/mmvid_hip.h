@@ -391,18 +391,18 @@ int mmvid_spatial_attention_f32(const float* q, const float* k, const float* v, 
  * attention (mmvid_spatial_attention_f32) and the VQ argmin stay fp32.  Same reference lines as the bf16 entry points.
  * x_planes: [2][N,Hin,Win,Cin] bf16 (hi plane, lo plane); w3: [Cout][3][taps][Cin] bf16 = (w_hi | w_hi | w_lo). */
 int mmvid_conv2d_nhwc_split3(int mode, const void* x_planes, int N, int Hin, int Win, int Cin, const void* w3, const float* bias,
-                             int Cout, const float* residual_f32, int clamp01, float* out_f32, int splitk, float* workspace,
-                             void* stream);
+                             int Cout, const float* residual_f32, int clamp01, float* out_f32, float* gn_partial, int splitk,
+                             float* workspace, void* stream);
 int mmvid_conv3x3_strip_nhwc_split3(const void* x_planes, int N, int H, int W, int Cin, const void* w3, const float* bias,
-                                    int Cout, const float* residual_f32, float* out_f32, void* stream);
+                                    int Cout, const float* residual_f32, float* out_f32, float* gn_partial64, void* stream);
 /* fp32 [n] -> bf16 pair planes [2][n] (n % 8 == 0). */
 int mmvid_split_f32_bf16x2(const float* x, int64_t n, void* planes_bf16, void* stream);
 /* img NCHW fp32 [N,3,H,W] in [0,1] -> bf16 pair planes [2][N,H,W,8] of 2x-1 (vae.py:41). */
 int mmvid_image_to_nhwc8_split(const float* img, int N, int H, int W, void* planes_bf16, void* stream);
-/* GroupNorm(32) [+ swish] (model.py:38-42): x fp32 NHWC -> bf16 pair planes [2][N,hw,C].
- * stats_scratch: fp32 [N*(2*C + 64*ceil(hw/256))]. */
+/* GroupNorm(32) [+ swish] (model.py:38-42): x fp32 NHWC -> bf16 pair planes [2][N,hw,C].  partial_blocks as in
+ * mmvid_groupnorm_swish_nhwc (0: a statistics pass runs here).  stats_scratch: fp32 [N*(2*C + 64*ceil(hw/64))]. */
 int mmvid_groupnorm_swish_nhwc_split(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
-                                     int swish, float* stats_scratch, void* planes_bf16, void* stream);
+                                     int swish, float* stats_scratch, int partial_blocks, void* planes_bf16, void* stream);
 
 /* ---- native op-list executor for the VQGAN encoder / decoder (model.py:439-466, 551-582; vae.py:38-56): the host
  * plans the op sequence once per input shape, every call is then one host->native transition.  Offsets are bytes
@@ -428,7 +428,8 @@ enum {
 #define MMVID_VQFLAG_STRICT 16
 /* flags & 64 (IMG2NHWC8, CONV, GROUPNORM, CAST): the split operator.  IMG2NHWC8 / GROUPNORM / CAST write bf16 pair planes at
  * out_bf16 (in0 fp32); CONV reads pair planes at in0, w = w3, residual in1 fp32, writes out_f32 (flags&2 clamp01, flags&8 strip
- * form, flags&32 split-K by 4 through `scratch`). */
+ * form, flags&32 split-K by 4 through `scratch`, flags&4 GroupNorm partial sums of the output into the stats area `scratch`);
+ * GROUPNORM flags&2 / flags&8 as for the bf16 operator (partial sums written by the producing CONV). */
 #define MMVID_VQFLAG_SPLIT 64
 typedef struct {
     int32_t op, mode;

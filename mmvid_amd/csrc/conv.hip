@@ -471,8 +471,8 @@ extern "C" int mmvid_conv2d_nhwc_splitk(int mode, const void* x, int N, int Hin,
 // matrix pipe.  x_planes: [2][N,Hin,Win,Cin] (hi plane, lo plane); w3: [Cout][3][taps][Cin] = (w_hi | w_hi | w_lo).
 extern "C" int mmvid_conv2d_nhwc_split3(int mode, const void* x_planes, int N, int Hin, int Win, int Cin, const void* w3,
                                         const float* bias, int Cout, const float* residual_f32, int clamp01, float* out_f32,
-                                        int splitk, float* workspace, void* stream) {
-    return conv2d_launch(3, mode, x_planes, N, Hin, Win, Cin, w3, bias, Cout, nullptr, residual_f32, clamp01, nullptr, out_f32, nullptr,
+                                        float* gn_partial, int splitk, float* workspace, void* stream) {
+    return conv2d_launch(3, mode, x_planes, N, Hin, Win, Cin, w3, bias, Cout, nullptr, residual_f32, clamp01, nullptr, out_f32, gn_partial,
                          splitk, workspace, stream);
 }
 

@@ -337,8 +337,8 @@ extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int 
 
 // the split operator of conv.hip (mmvid_conv2d_nhwc_split3) in strip form: x_planes [2][N,H,W,Cin], w3 [Cout][3][9][Cin]
 extern "C" int mmvid_conv3x3_strip_nhwc_split3(const void* x_planes, int N, int H, int W, int Cin, const void* w3, const float* bias,
-                                               int Cout, const float* residual_f32, float* out_f32, void* stream) {
-    return strip_launch(3, x_planes, N, H, W, Cin, w3, bias, Cout, nullptr, residual_f32, nullptr, out_f32, nullptr, stream);
+                                               int Cout, const float* residual_f32, float* out_f32, float* gn_partial64, void* stream) {
+    return strip_launch(3, x_planes, N, H, W, Cin, w3, bias, Cout, nullptr, residual_f32, nullptr, out_f32, gn_partial64, stream);
 }
 
 static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,

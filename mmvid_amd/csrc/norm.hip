@@ -521,18 +521,24 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
     return MMVID_OK;
 }
 
-// GroupNorm(32) [+ swish] of the split operator: x fp32 NHWC -> bf16 pair planes [2][N,hw,C].  Partial sums per 256 pixels in
-// fp32 (at most 4,096 addends each), combined and finalised in fp64.  stats_scratch: fp32 [N*(2*C + 64*ceil(hw/256))].
+// GroupNorm(32) [+ swish] of the split operator: x fp32 NHWC -> bf16 pair planes [2][N,hw,C].  Partial sums in fp32 -- per 256
+// pixels by a statistics pass here (partial_blocks = 0), or per 128 / 64 pixels by the producing convolution's epilogue
+// (partial_blocks = hw/128 or hw/64) -- combined and finalised in fp64.  stats_scratch: fp32 [N*(2*C + 64*ceil(hw/64))].
 extern "C" int mmvid_groupnorm_swish_nhwc_split(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
-                                                int swish, float* stats_scratch, void* planes_bf16, void* stream) {
+                                                int swish, float* stats_scratch, int partial_blocks, void* planes_bf16, void* stream) {
     MMVID_REQUIRE(x && w && b && stats_scratch && planes_bf16, "groupnorm_split: null pointer");
     MMVID_REQUIRE(C % 32 == 0 && C <= 512 && 256 % (C / 8) == 0, "groupnorm_split: C=%d unsupported", C);
+    MMVID_REQUIRE(partial_blocks >= 0 && partial_blocks <= cdiv(hw, 64), "groupnorm_split: partial_blocks %d", partial_blocks);
     if (N == 0 || hw == 0) return MMVID_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int pix_per_block = 256, nblk = cdiv(hw, pix_per_block);
+    const int pix_per_block = 256;
+    int nblk = partial_blocks;  // > 0: the producing convolution's epilogue already wrote that many partial blocks per image
     float* mr = stats_scratch;                         // [N][C][2]
     float* partial = stats_scratch + (long)N * C * 2;  // [N][nblk][32][2]
-    hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3(nblk, N), dim3(256), 0, s, x, (long)hw, C, pix_per_block, partial);
+    if (partial_blocks == 0) {
+        nblk = cdiv(hw, pix_per_block);
+        hipLaunchKernelGGL(groupnorm_stats_kernel<float>, dim3(nblk, N), dim3(256), 0, s, x, (long)hw, C, pix_per_block, partial);
+    }
     hipLaunchKernelGGL(groupnorm_finalize_f64_kernel, dim3(cdiv((long)N * 32, 4)), dim3(256), 0, s, partial, nblk, N, C,
                        (double)hw * (double)(C / 32), eps, mr);
     const long chunks = (long)N * hw * (C / 8);

@@ -63,16 +63,20 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
                 case MMVID_VQOP_CONV:
                     if (o.flags & 8)
                         rc = mmvid_conv3x3_strip_nhwc_split3(at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
-                                                             (const float*)at(arena, o.in1), (float*)at(arena, o.out_f32), stream);
+                                                             (const float*)at(arena, o.in1), (float*)at(arena, o.out_f32),
+                                                             (o.flags & 4) ? (float*)at(arena, o.scratch) + (int64_t)o.N * o.Cout * 2 : nullptr,
+                                                             stream);
                     else
                         rc = mmvid_conv2d_nhwc_split3(o.mode, at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
                                                       (const float*)at(arena, o.in1), (o.flags >> 1) & 1, (float*)at(arena, o.out_f32),
+                                                      (o.flags & 4) ? (float*)at(arena, o.scratch) + (int64_t)o.N * o.Cout * 2 : nullptr,
                                                       (o.flags & 32) ? 4 : 1, (o.flags & 32) ? (float*)at(arena, o.scratch) : nullptr,
                                                       stream);
                     break;
                 case MMVID_VQOP_GROUPNORM:
                     rc = mmvid_groupnorm_swish_nhwc_split((const float*)at(arena, o.in0), o.N, (int64_t)o.H * o.W, o.C,
                                                           (const float*)o.w, o.b, o.eps, o.mode, (float*)at(arena, o.scratch),
+                                                          (o.flags & 2) ? (o.H * o.W) / ((o.flags & 8) ? 64 : 128) : 0,
                                                           at(arena, o.out_bf16), stream);
                     break;
                 case MMVID_VQOP_CAST:

@@ -361,11 +361,11 @@ def conv2d_nhwc_split3(x_planes, w3, bias, mode, residual=None, clamp01=False, s
     out = torch.empty(N, Ho, Wo, Cout, device=x_planes.device, dtype=f32)
     if strip:
         assert mode == 0 and not clamp01 and splitk == 1
-        call('mmvid_conv3x3_strip_nhwc_split3', _p(x_planes), N, H, W, Cin, _p(w3), _p(bias), Cout, _p(residual), _p(out), _stream())
+        call('mmvid_conv3x3_strip_nhwc_split3', _p(x_planes), N, H, W, Cin, _p(w3), _p(bias), Cout, _p(residual), _p(out), None, _stream())
         return out
     ws = torch.empty(splitk * N * Ho * Wo * Cout, device=out.device, dtype=f32) if splitk > 1 else None
     call('mmvid_conv2d_nhwc_split3', mode, _p(x_planes), N, H, W, Cin, _p(w3), _p(bias), Cout, _p(residual), int(clamp01), _p(out),
-         int(splitk), _p(ws), _stream())
+         None, int(splitk), _p(ws), _stream())
     return out
 
 
@@ -374,8 +374,8 @@ def groupnorm_swish_split(x, w, b, eps=1e-6, swish=True):
     _chk(x, f32, 'x')
     N, H, W, C = x.shape
     out = torch.empty(2, N, H, W, C, device=x.device, dtype=bf16)
-    st = torch.empty(N * (2 * C + 64 * ((H * W + 255) // 256)), device=x.device, dtype=f32)
-    call('mmvid_groupnorm_swish_nhwc_split', _p(x), N, H * W, C, _p(w), _p(b), float(eps), int(swish), _p(st), _p(out), _stream())
+    st = torch.empty(N * (2 * C + 64 * ((H * W + 63) // 64)), device=x.device, dtype=f32)
+    call('mmvid_groupnorm_swish_nhwc_split', _p(x), N, H * W, C, _p(w), _p(b), float(eps), int(swish), _p(st), 0, _p(out), _stream())
     return out
 
 

@@ -193,7 +193,7 @@ class _Planner:
         self._op(op=self.OP_CAST, N=n, H=h, W=wd, C=c, flags=self.SPLIT, in0=x.off, out_bf16=out.off)
         return out
 
-    def _conv_split(self, x, holder, mode, residual, clamp01):
+    def _conv_split(self, x, holder, mode, residual, clamp01, feeds_gn=False):
         x = self._planes(x)
         w3, b, _ = self.vae._cw_split(holder)
         n, h, wd, cin = x.shape
@@ -204,9 +204,15 @@ class _Planner:
         out = self.alloc((n, ho, wo, cout), f32)
         flags = self.SPLIT | (2 if clamp01 else 0)
         scratch, ws = -1, None
-        if _STRIP and mode == 0 and not clamp01 and bool(_lib.load().mmvid_conv3x3_strip_supported(h, wd, cin, cout)):
+        strip = _STRIP and mode == 0 and not clamp01 and bool(_lib.load().mmvid_conv3x3_strip_supported(h, wd, cin, cout))
+        if strip:
             flags |= 8
-        elif _SPLITK and mode == 0 and ho * wo <= 64 and 9 * cin >= 2304 and cout % 4 == 0:
+        if feeds_gn and _FUSE_GN and (ho * wo) % 128 == 0 and cout % 128 == 0:  # the epilogue emits the GroupNorm partial sums
+            out.gn_stats = self._gn_stats(n, ho * wo, cout)
+            out.gn_stats.blocks64 = strip
+            flags |= 4
+            scratch = out.gn_stats.off
+        elif not strip and _SPLITK and mode == 0 and ho * wo <= 64 and 9 * cin >= 2304 and cout % 4 == 0:
             ws = self.alloc((4 * n * ho * wo * cout, ), f32)
             flags |= 32
             scratch = ws.off
@@ -263,7 +269,7 @@ class _Planner:
         shape allows), into a stats area that lives as long as the output buffer.
         also_bf16 (with out32): the epilogue stores a bf16 copy too (`out.bf16`), instead of a later cast pass."""
         if self.split:
-            return self._conv_split(x, holder, mode, residual, clamp01)
+            return self._conv_split(x, holder, mode, residual, clamp01, feeds_gn)
         w, b, _ = self.vae._cw(holder, self.strict)
         n, h, wd, cin = x.shape
         assert x.dtype == (f32 if self.strict else bf16) and cin == w.shape[2], (x.shape, w.shape)
@@ -314,8 +320,11 @@ class _Planner:
         if self.split:
             out = self.alloc((2, n, h, wd, c), bf16)
             out.is_planes, out.shape = True, (n, h, wd, c)
-            st = self.alloc((n * (2 * c + 64 * ((h * wd + 255) // 256)), ), f32)
-            self._op(op=self.OP_GN, mode=int(swish), N=n, H=h, W=wd, C=c, flags=self.SPLIT, in0=x.off, out_bf16=out.off,
+            st = getattr(x, 'gn_stats', None)  # partial sums already written by the producing convolution's epilogue
+            flags = self.SPLIT | (2 if st is not None else 0) | (8 if getattr(st, 'blocks64', False) else 0)
+            if st is None:
+                st = self._gn_stats(n, h * wd, c)
+            self._op(op=self.OP_GN, mode=int(swish), N=n, H=h, W=wd, C=c, flags=flags, in0=x.off, out_bf16=out.off,
                      scratch=st.off, w=holder.weight.data_ptr(), b=holder.bias.data_ptr(), eps=1e-6)
             return out
         if self.strict:
