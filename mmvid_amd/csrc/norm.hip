@@ -8,58 +8,72 @@ namespace {
 
 constexpr int LN_MAXV = 4;  // float4 per lane -> E <= 1024
 
-// y = (x - mean) * rstd * w + b ; writes bf16 and/or f32; saves mean/rstd.
+// y = (x - mean) * rstd * w + b ; writes bf16 and/or f32; saves mean/rstd.  A wave owns TWO rows (r, r + rows/2 rounded): both rows'
+// loads are in flight before either is reduced and the two reductions interleave -- the kernel is bound by a wave's load -> reduce
+// -> reduce -> store chain (2,606 short blocks), not by HBM.
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx, long rows, int E,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ b, float eps,
                                                             bf16_t* __restrict__ y_bf16, float* __restrict__ y_f32,
                                                             long ldy, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out) {
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
+    const long half = (rows + 1) >> 1;
+    const long r0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r0 >= half) return;
+    const long rr[2] = {r0, r0 + half};
+    const bool live1 = rr[1] < rows;
     const int lane = threadIdx.x & 63;
     const int nv = E >> 2;  // float4 count
-    const float4* xr = reinterpret_cast<const float4*>(x + r * ldx);
-    float4 v[LN_MAXV];
-    float s = 0.f;
+    float4 v[2][LN_MAXV];
+    float s[2] = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            v[i] = xr[c];
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        } else {
-            v[i] = make_float4(0, 0, 0, 0);
+    for (int k = 0; k < 2; ++k) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (k == 0 || live1 ? rr[k] : rr[0]) * ldx);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            v[k][i] = c < nv ? xr[c] : make_float4(0, 0, 0, 0);
         }
     }
-    const float mean = wave_sum_fast(s) / (float)E;  // (DPP / permlane reduction: no LDS-crossbar round trips, common.h)
-    float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            float a = v[i].x - mean, b2 = v[i].y - mean, c2 = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + b2 * b2) + (c2 * c2 + d * d);
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) s[k] += (v[k][i].x + v[k][i].y) + (v[k][i].z + v[k][i].w);  // (columns >= E hold 0)
+    const float mean[2] = {wave_sum_fast(s[0]) / (float)E, wave_sum_fast(s[1]) / (float)E};  // (DPP / permlane reductions, common.h)
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float a = v[k][i].x - mean[k], b2 = v[k][i].y - mean[k], c2 = v[k][i].z - mean[k], d = v[k][i].w - mean[k];
+                q[k] += (a * a + b2 * b2) + (c2 * c2 + d * d);
+            }
         }
-    }
-    const float rstd = rsqrtf(wave_sum_fast(q) / (float)E + eps);
-    if (lane == 0) {
-        if (mean_out) mean_out[r] = mean;
-        if (rstd_out) rstd_out[r] = rstd;
-    }
+    const float rstd[2] = {rsqrtf(wave_sum_fast(q[0]) / (float)E + eps), rsqrtf(wave_sum_fast(q[1]) / (float)E + eps)};
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            const float4 w4 = reinterpret_cast<const float4*>(w)[c];
-            const float4 b4 = reinterpret_cast<const float4*>(b)[c];
-            float4 o;
-            o.x = (v[i].x - mean) * rstd * w4.x + b4.x;
-            o.y = (v[i].y - mean) * rstd * w4.y + b4.y;
-            o.z = (v[i].z - mean) * rstd * w4.z + b4.z;
-            o.w = (v[i].w - mean) * rstd * w4.w + b4.w;
-            if (y_f32) reinterpret_cast<float4*>(y_f32 + r * ldy)[c] = o;
-            if (y_bf16) reinterpret_cast<uint2*>(y_bf16 + r * ldy)[c] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !live1) break;
+        const long r = rr[k];
+        if (lane == 0) {
+            if (mean_out) mean_out[r] = mean[k];
+            if (rstd_out) rstd_out[r] = rstd[k];
+        }
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 w4 = reinterpret_cast<const float4*>(w)[c];
+                const float4 b4 = reinterpret_cast<const float4*>(b)[c];
+                float4 o;
+                o.x = (v[k][i].x - mean[k]) * rstd[k] * w4.x + b4.x;
+                o.y = (v[k][i].y - mean[k]) * rstd[k] * w4.y + b4.y;
+                o.z = (v[k][i].z - mean[k]) * rstd[k] * w4.z + b4.z;
+                o.w = (v[k][i].w - mean[k]) * rstd[k] * w4.w + b4.w;
+                if (y_f32) reinterpret_cast<float4*>(y_f32 + r * ldy)[c] = o;
+                if (y_bf16) reinterpret_cast<uint2*>(y_bf16 + r * ldy)[c] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+            }
         }
     }
 }
@@ -408,7 +422,7 @@ extern "C" int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, in
                   "layernorm_fwd: E=%d must be a multiple of 4 and <= %d; row strides multiples of 4", E,
                   64 * 4 * LN_MAXV);
     if (rows == 0) return MMVID_OK;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv((rows + 1) / 2, 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
                        (long)rows, E, w, b, eps, (bf16_t*)y_bf16, y_f32, (long)ldy, mean, rstd);
     MMVID_LAUNCH_CHECK("layernorm_fwd");
     return MMVID_OK;
