@@ -223,10 +223,69 @@ class TextVideoDataset(torch.utils.data.Dataset):
 
 
 # ------------------------------------------------------------------------------------------------ output side
+def _box(kind, *payload):
+    body = b''.join(payload)
+    return (8 + len(body)).to_bytes(4, 'big') + kind + body
+
+
+def _u(value, nbytes=4):
+    return int(value).to_bytes(nbytes, 'big')
+
+
+_UNITY = b''.join(_u(v) for v in (0x00010000, 0, 0, 0, 0x00010000, 0, 0, 0, 0x40000000))  # the identity transformation matrix
+
+
+def write_mjpeg_mp4(path, frames_u8, fps=4, quality=95):
+    """frames_u8 [T, H, W, 3] uint8 -> an ISO base-media (.mp4) file whose video track is Motion-JPEG: every frame a baseline JPEG
+    (PIL), all samples in one chunk of `mdat`, constant frame duration.  The reference writes H.264 through
+    torchvision.io.write_video (utils_html.py:178-184: PyAV, absent from this image); Motion-JPEG needs no codec library, is
+    intra-only (every frame a key frame) and is read by ffmpeg / VLC / QuickTime.  Returns the list of (offset, size) of the frames."""
+    import io
+
+    from PIL import Image
+    T, H, W, _ = frames_u8.shape
+    jpegs = []
+    for f in frames_u8:
+        buf = io.BytesIO()
+        Image.fromarray(f.numpy() if hasattr(f, 'numpy') else f).save(buf, format='JPEG', quality=quality, subsampling=0)
+        jpegs.append(buf.getvalue())
+    scale = 1000
+    delta = max(1, round(scale / fps))
+    duration = delta * T
+    ftyp = _box(b'ftyp', b'isom', _u(0x200), b'isom', b'iso2', b'mp41')
+    first = len(ftyp) + 8  # the frames follow the mdat header, which follows ftyp
+    mdat = _box(b'mdat', *jpegs)
+    mvhd = _box(b'mvhd', _u(0), _u(0), _u(0), _u(scale), _u(duration), _u(0x00010000), _u(0x0100, 2), bytes(10), _UNITY, bytes(24), _u(2))
+    tkhd = _box(b'tkhd', _u(3), _u(0), _u(0), _u(1), _u(0), _u(duration), bytes(8), _u(0, 2), _u(0, 2), _u(0, 2), _u(0, 2), _UNITY,
+                _u(W << 16), _u(H << 16))
+    mdhd = _box(b'mdhd', _u(0), _u(0), _u(0), _u(scale), _u(duration), _u(0x55C4, 2), _u(0, 2))
+    hdlr = _box(b'hdlr', _u(0), _u(0), b'vide', bytes(12), b'VideoHandler\x00')
+    name = b'Motion JPEG'
+    entry = _box(b'jpeg', bytes(6), _u(1, 2), bytes(16), _u(W, 2), _u(H, 2), _u(0x00480000), _u(0x00480000), _u(0), _u(1, 2),
+                 bytes([len(name)]) + name + bytes(31 - len(name)), _u(0x0018, 2), _u(0xFFFF, 2))
+    stsd = _box(b'stsd', _u(0), _u(1), entry)
+    stts = _box(b'stts', _u(0), _u(1), _u(T), _u(delta))
+    stsc = _box(b'stsc', _u(0), _u(1), _u(1), _u(T), _u(1))
+    stsz = _box(b'stsz', _u(0), _u(0), _u(T), *[_u(len(j)) for j in jpegs])
+    stco = _box(b'stco', _u(0), _u(1), _u(first))
+    stbl = _box(b'stbl', stsd, stts, stsc, stsz, stco)
+    dinf = _box(b'dinf', _box(b'dref', _u(0), _u(1), _box(b'url ', _u(1))))
+    minf = _box(b'minf', _box(b'vmhd', _u(1), bytes(8)), dinf, stbl)
+    moov = _box(b'moov', mvhd, _box(b'trak', tkhd, _box(b'mdia', mdhd, hdlr, minf)))
+    with open(path, 'wb') as fh:
+        fh.write(ftyp + mdat + moov)
+    spans, off = [], first
+    for j in jpegs:
+        spans.append((off, len(j)))
+        off += len(j)
+    return spans
+
+
 @torch.no_grad()
 def save_image_tensor(tensor, path, video_format='gif', fps=4):
-    """utils/utils_html.py:157-186.  [3,H,W] / [1,3,H,W] -> `<path>.png`; [T,3,H,W] / [1,T,3,H,W] -> `<path>.gif`.  Values are
-    clamped to [0, 1] and quantised by truncation (`* 255` then uint8), as the reference does.  Returns the file name."""
+    """utils/utils_html.py:157-186.  [3,H,W] / [1,3,H,W] -> `<path>.png`; [T,3,H,W] / [1,T,3,H,W] -> `<path>.gif` or, with
+    video_format='mp4', `<path>.mp4` (Motion-JPEG, `write_mjpeg_mp4`; the reference: H.264 at the same 4 frames per second).
+    Values are clamped to [0, 1] and quantised by truncation (`* 255` then uint8), as the reference does.  Returns the file name."""
     from PIL import Image
     t = tensor.squeeze(0) if tensor.dim() in (4, 5) and tensor.shape[0] == 1 else tensor
     u8 = (t.detach().float().cpu().clamp(0, 1) * 255).to(torch.uint8)
@@ -234,11 +293,13 @@ def save_image_tensor(tensor, path, video_format='gif', fps=4):
         out = str(path) + '.png'
         Image.fromarray(u8.permute(1, 2, 0).numpy()).save(out)
     elif u8.dim() == 4:
-        if video_format != 'gif':
-            raise NotImplementedError("video_format='mp4' needs torchvision.io.write_video (utils_html.py:178-184)")
-        out = str(path) + '.gif'
-        frames = [Image.fromarray(f.permute(1, 2, 0).numpy()) for f in u8]
-        frames[0].save(out, save_all=True, append_images=frames[1:], duration=int(1000 / fps), loop=0)
+        if video_format == 'gif':
+            out = str(path) + '.gif'
+            frames = [Image.fromarray(f.permute(1, 2, 0).numpy()) for f in u8]
+            frames[0].save(out, save_all=True, append_images=frames[1:], duration=int(1000 / fps), loop=0)
+        else:
+            out = str(path) + '.mp4'
+            write_mjpeg_mp4(out, u8.permute(0, 2, 3, 1).contiguous(), fps=fps)
     else:
         raise RuntimeError(f'save_image_tensor: unsupported shape {tuple(tensor.shape)}')
     return os.path.basename(out)

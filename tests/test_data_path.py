@@ -101,8 +101,63 @@ def test_save_image_tensor_gif_and_png(tmp_path):
         import numpy as np
         px = torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1)
     assert torch.equal(px, (img * 255).to(torch.uint8))  # truncation, as `(x * 255).type(torch.uint8)` in the reference
-    with pytest.raises(NotImplementedError):
-        save_image_tensor(video, tmp_path / 'x', video_format='mp4')
+
+
+def _boxes(buf, start=0, end=None):
+    """[(type, payload offset, payload size)] of the ISO base-media boxes in buf[start:end]."""
+    out, pos, end = [], start, len(buf) if end is None else end
+    while pos < end:
+        size, kind = int.from_bytes(buf[pos:pos + 4], 'big'), buf[pos + 4:pos + 8].decode('latin1')
+        assert size >= 8 and pos + size <= end, (kind, size)
+        out.append((kind, pos + 8, size - 8))
+        pos += size
+    return out
+
+
+def test_save_image_tensor_mp4_is_motion_jpeg_in_iso_bmff(tmp_path):
+    """utils_html.py:178-184 (`video_format='mp4'`, 4 fps): the file is parsed back box by box -- ftyp / mdat / moov, one video
+    track whose sample table (stts / stsc / stsz / stco) locates every frame -- and each sample decodes (PIL) to the frame written,
+    within JPEG quality-95 error."""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    from mmvid_amd.data import save_image_tensor
+    torch.manual_seed(0)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 32), torch.linspace(0, 1, 48), indexing='ij')
+    video = torch.stack([torch.stack([(xx + 0.1 * t) % 1.0, yy, 0.5 * (xx + yy)]) for t in range(6)])  # smooth content [6,3,32,48]
+    assert save_image_tensor(video.unsqueeze(0), tmp_path / 'clip', video_format='mp4') == 'clip.mp4'
+    buf = (tmp_path / 'clip.mp4').read_bytes()
+    top = {k: (o, n) for k, o, n in _boxes(buf)}
+    assert list(top) == ['ftyp', 'mdat', 'moov'] and buf[top['ftyp'][0]:top['ftyp'][0] + 4] == b'isom'
+    moov = {k: (o, n) for k, o, n in _boxes(buf, top['moov'][0], sum(top['moov']))}
+    o, n = moov['mvhd']
+    scale, duration = int.from_bytes(buf[o + 12:o + 16], 'big'), int.from_bytes(buf[o + 16:o + 20], 'big')
+    assert duration / scale == 6 / 4  # six frames at four per second
+    trak = {k: (o, n) for k, o, n in _boxes(buf, moov['trak'][0], sum(moov['trak']))}
+    o, n = trak['tkhd']
+    assert int.from_bytes(buf[o + 76:o + 80], 'big') >> 16 == 48 and int.from_bytes(buf[o + 80:o + 84], 'big') >> 16 == 32
+    mdia = {k: (o, n) for k, o, n in _boxes(buf, trak['mdia'][0], sum(trak['mdia']))}
+    assert buf[mdia['hdlr'][0] + 8:mdia['hdlr'][0] + 12] == b'vide'
+    minf = {k: (o, n) for k, o, n in _boxes(buf, mdia['minf'][0], sum(mdia['minf']))}
+    stbl = {k: (o, n) for k, o, n in _boxes(buf, minf['stbl'][0], sum(minf['stbl']))}
+    o, n = stbl['stsd']
+    assert buf[o + 12:o + 16] == b'jpeg' and int.from_bytes(buf[o + 40:o + 42], 'big') == 48 and int.from_bytes(buf[o + 42:o + 44], 'big') == 32
+    o, n = stbl['stts']
+    assert [int.from_bytes(buf[o + 4 * i:o + 4 * i + 4], 'big') for i in range(1, 4)] == [1, 6, scale // 4]
+    o, n = stbl['stsz']
+    sizes = [int.from_bytes(buf[o + 12 + 4 * i:o + 16 + 4 * i], 'big') for i in range(int.from_bytes(buf[o + 8:o + 12], 'big'))]
+    o, n = stbl['stco']
+    pos = int.from_bytes(buf[o + 8:o + 12], 'big')
+    assert len(sizes) == 6 and pos == top['mdat'][0] and sum(sizes) == top['mdat'][1]
+    want = (video.clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1).numpy().astype(np.int16)
+    for t, size in enumerate(sizes):
+        with Image.open(io.BytesIO(buf[pos:pos + size])) as im:
+            assert im.format == 'JPEG' and im.size == (48, 32)
+            got = np.asarray(im.convert('RGB')).astype(np.int16)
+        assert np.abs(got - want[t]).mean() < 2.0 and np.abs(got - want[t]).max() < 24
+        pos += size
 
 
 def test_reference_import_paths():
@@ -111,3 +166,169 @@ def test_reference_import_paths():
     from mmvid_amd.loader import TextVideoDataset
     from mmvid_amd.tokenizer import SimpleTokenizer
     assert TextVideoDataset is data.TextVideoDataset and SimpleTokenizer is data.SimpleTokenizer
+    from mmvid_amd.loader_ext import VoxDataset  # utils_train.py:17 `from mmvid_pytorch.loader_ext import VoxDataset`
+    assert VoxDataset.__init__.__code__.co_varnames[1:22] == (
+        'folder', 'text_len', 'image_size', 'truncate_captions', 'resize_ratio', 'tokenizer', 'shuffle', 'mode', 'frame_step', 'frame_num',
+        'deterministic', 'cache', 'return_vc', 'video_only', 'keys', 'return_neg', 'attr_mode', 'sample_label', 'cat1', 'args', 'rng')
+
+
+# ------------------------------------------------------------------------------------------------ VoxCeleb loader (loader_ext.py)
+def _make_vox(root, spec, with_aux=True):
+    """spec: {key: (frames, label flags set)} -> video / txt / label / mask / draw trees of mm_vox_celeb/README.md:12-42.  Frame t
+    of every video is a flat grey level 9 t, masks are 200, drawings 100."""
+    import numpy as np
+    from PIL import Image
+    for key, (nframes, flags) in spec.items():
+        for sub, level in (('video', None), ('mask', 200), (os.path.join('draw', 'style1'), 100)):
+            if sub != 'video' and not with_aux:
+                continue
+            d = root / sub / key
+            d.mkdir(parents=True, exist_ok=True)
+            for t in range(nframes if sub == 'video' else 3):
+                v = min(9 * t, 255) if level is None else level
+                Image.fromarray(np.full((40, 56, 3), v, np.uint8)).save(d / f'{t:07d}.png')
+        (root / 'txt').mkdir(exist_ok=True)
+        (root / 'label').mkdir(exist_ok=True)
+        (root / 'txt' / f'{key}.txt').write_text(f'{key[:4]} talks.\n\nzz second line.\n')
+        (root / 'label' / f'{key}.txt').write_text(','.join('1' if i in flags else '0' for i in range(40)))
+
+
+VOX = {'id01#aaa#0001.txt#000.mp4': (20, {20, 39}), 'id01#aaa#0002.txt#000.mp4': (12, {20}), 'id02#bbb#0001.txt#000.mp4': (16, {4, 15, 39}),
+       'id03#ccc#0001.txt#000.mp4': (5, {13})}
+
+
+def test_vox_dataset_index_caches_and_contract(tmp_path):
+    """loader_ext.py:143-311: the index (and its two pickle caches, in the reference's format), the short-video filter, the person /
+    attribute tables, and the (text, frames, visuals) contract in the default attr_mode."""
+    import pickle
+
+    from mmvid_amd.loader_ext import VoxDataset, person_id
+    root = tmp_path / 'mmvox'
+    root.mkdir()
+    _make_vox(root, VOX)
+    ds = VoxDataset(root, text_len=16, image_size=32, tokenizer=_FakeTok(), frame_step=2, frame_num=4, deterministic=True, attr_mode='mask+text')
+    assert sorted(ds.keys) == sorted(k for k, (n, _) in VOX.items() if n >= 8) and ds.min_len == 8
+    idx = pickle.load(open(tmp_path / 'mmvox_local.pkl', 'rb'))
+    assert set(idx) == {'root', 'keys', 'texts', 'videos', 'lengths'} and len(idx['keys']) == 4  # the cache holds every video
+    k0 = 'id01#aaa#0001.txt#000.mp4'
+    assert idx['texts'][k0] == os.path.join('txt', k0 + '.txt') and idx['videos'][k0][10] == os.path.join('video', k0, '0000010.png')
+    attr = pickle.load(open(tmp_path / 'mmvox_attr_dict_vox2.pkl', 'rb'))
+    assert set(attr) == {'pid', 'attr', 'cat1'} and sorted(attr['pid']['id01#aaa']) == sorted(k for k in VOX if k.startswith('id01'))
+    assert person_id(k0) == 'id01#aaa' and sorted(ds.attr_dict['cat1'][39]) == sorted([k0, 'id02#bbb#0001.txt#000.mp4'])
+    assert ds.attr_dict['cat1'][13] == []  # its only holder is the 5-frame video, filtered out
+    i = ds.keys.index(k0)
+    tokens, frames, visuals = ds[i]
+    assert tokens.shape == (16, ) and tokens[0] == ord('i') % 251 + 1  # deterministic: the first caption line
+    assert frames.shape == (4, 3, 32, 32) and [round(float(f[0, 0, 0]) * 255) for f in frames] == [0, 18, 36, 54]
+    assert visuals.shape == (1, 3, 32, 32) and round(float(visuals[0, 0, 5, 5]) * 255) == 200  # the mask frame
+    # a second instance reads both caches instead of scanning (the folder can even be gone)
+    import shutil
+    shutil.rmtree(root / 'txt')
+    again = VoxDataset(root, text_len=16, image_size=32, tokenizer=_FakeTok(), frame_step=2, frame_num=4, deterministic=True, video_only=True)
+    assert sorted(again.keys) == sorted(ds.keys)
+    tok, fr, vis = again[0]
+    assert tok[0] == ord('d') % 251 + 1 and fr.shape == (4, 3, 32, 32) and vis.shape == (3, 32, 32)  # 'dummy text', own frame 0
+
+
+def test_vox_dataset_attr_modes(tmp_path):
+    """The control images and captions of every attr_mode (loader_ext.py:470-787): sources by their grey level (video frames < 180,
+    masks 200, drawings 100), the two-image sentences name what sits in which slot, dropout yields 'null', cat1 / cat2 return stacks."""
+    import random
+
+    from mmvid_amd.loader_ext import _RECIPES, VoxDataset
+    root = tmp_path / 'mmvox'
+    root.mkdir()
+    _make_vox(root, VOX)
+
+    def level(img):
+        return round(float(img[0, 4, 4]) * 255)
+
+    def kind(img):
+        return {200: 'mask', 100: 'draw'}.get(level(img), 'appearance')
+
+    for mode, recipe in _RECIPES.items():
+        seen = set()
+        for seed in range(24):
+            ds = VoxDataset(root, text_len=96, image_size=32, tokenizer=None, frame_step=2, frame_num=4, attr_mode=mode, rng=random.Random(seed))
+            text, frames, visuals = ds[seed % len(ds)]
+            assert frames.shape == (4, 3, 32, 32) and visuals.dim() == 4 and visuals.shape[1:] == (3, 32, 32)
+            if recipe['caption'] == 'pair':
+                assert visuals.shape[0] == 2
+                a, b = kind(visuals[0]), kind(visuals[1])
+                assert text in (f'A person with {a} in image one and {b} in image two is talking',
+                                f'A person with {b} in image two and {a} in image one is talking'), (mode, text)
+                seen.add((a, b, text.startswith(f'A person with {a}')))
+            elif recipe['caption'] == 'one':
+                assert text == 'A person in image one is talking' and kind(visuals[0]) == mode
+            elif recipe['caption'] == 'motion':
+                assert visuals.shape[0] == 1 + len(frames[:9:3]) and text.endswith('motion in the following frames is talking.')
+                assert torch.equal(visuals[1:], frames[:9:3])  # every third frame of the clip (3 of them with the usual 8-frame clips)
+            else:
+                assert text in ('null', 'id01 talks.', 'id02 talks.', 'zz second line.')
+                seen.add(text)
+        if recipe['caption'] == 'pair':
+            orders = {s[:2] for s in seen}
+            assert len(orders) == (2 if recipe.get('shuffle') else 1) and {s[2] for s in seen} == {True, False}, (mode, seen)
+    # dropout: about one caption in ten becomes 'null'
+    ds = VoxDataset(root, text_len=96, image_size=32, tokenizer=None, frame_step=2, frame_num=4, attr_mode='mask+text_dropout', rng=random.Random(5))
+    nulls = sum(ds[i % len(ds)][0] == 'null' for i in range(300))
+    assert 10 <= nulls <= 55
+    # negative captions: a video with different attribute flags
+    ds = VoxDataset(root, text_len=16, image_size=32, tokenizer=_FakeTok(), frame_step=2, frame_num=4, attr_mode='text', return_neg=True,
+                    rng=random.Random(1))
+    out = ds[0]
+    assert len(out) == 5 and out[3] == 0 and out[4].shape == (16, ) and out[2].shape == (1, 3, 32, 32)
+    # cat1 / cat2: one clip per attribute with a sentence about it
+    ds = VoxDataset(root, text_len=96, image_size=32, tokenizer=None, frame_step=2, frame_num=4, attr_mode='cat1', cat1=[39, 15], rng=random.Random(2))
+    clips, texts = ds[0]
+    assert clips.shape == (2, 4, 3, 32, 32) and texts == ['A person is young.', texts[1]] and texts[1] in ('A person wears eyeglasses.', 'A person is wearing eyeglasses.')
+    ds = VoxDataset(root, text_len=96, image_size=32, tokenizer=None, frame_step=2, frame_num=4, attr_mode='cat2', rng=random.Random(2))
+    with pytest.raises((KeyError, ZeroDivisionError)):  # no kept video is chubby: the attribute's list is empty (as in the reference)
+        ds[0]
+    _make_vox(root, {'id04#ddd#0001.txt#000.mp4': (10, {4, 13, 15, 39})})
+    for f in (tmp_path / 'mmvox_local.pkl', tmp_path / 'mmvox_attr_dict_vox2.pkl'):
+        f.unlink()
+    ds = VoxDataset(root, text_len=96, image_size=32, tokenizer=None, frame_step=2, frame_num=4, attr_mode='cat2', rng=random.Random(2))
+    clips, texts = ds[ds.keys.index('id01#aaa#0001.txt#000.mp4')]
+    assert clips.shape == (5, 4, 3, 32, 32) and texts[0] in ('A boy.', 'A guy.') and texts[1:] == [
+        'A person is youthful.', 'A person has no hair.', 'A person wears spectacles.', 'A person is plump.']
+
+
+def test_vox_text_grammar():
+    """mm_vox_celeb/pcfg.py restated (mmvid_amd/vox_text.py): sentence forms, attribute grouping, negated 'No_' labels, exclusive hair
+    colours.  (The attribute tables themselves are compared with the reference's module when it is importable.)"""
+    import random
+    import re
+
+    from mmvid_amd import vox_text as vt
+    r = random.Random(0)
+    forms = re.compile(r"^(He|She|A (male|man|female|woman|person)|This (male|man|female|woman|person)) (is|has|wears|is wearing) [a-z' ,0-9]+\.$")
+    for _ in range(200):
+        verb = r.choice(['is', 'has', 'wear'])
+        s = vt.generate_phrase((r.random() < 0.5, r.random()), (verb, 'wavy hair'), r)
+        assert forms.match(s), s
+    assert vt.generate_phrase((True, 1.0), ('has', 'bangs'), r) == 'He has bangs.' and vt.generate_phrase((False, 1.0), ('is', 'young'), r) == 'She is young.'
+    pred = [False] * 40
+    for a in ('Male', 'Young', 'Eyeglasses', 'Wavy_Hair', 'Bangs', 'Big_Nose', 'No_Beard'):
+        pred[vt.ATTR.index(a)] = True
+    text = vt.generate(pred, 3, r)
+    assert len(text) == 3 and all('beard' not in t for t in text)  # No_Beard = 1 means no beard: negated away
+    for t in text:
+        assert all(forms.match(s + '.') for s in t.rstrip('.').split('. ')), t
+        for word in ('young', 'eyeglasses', 'wavy hair', 'bangs', 'big nose'):
+            assert t.count(word) == 1
+        assert 'She' not in t and 'woman' not in t and 'female' not in t
+    pred[vt.ATTR.index('No_Beard')] = False
+    assert all('beard' in t for t in vt.generate(pred, 2, r))
+    many = [vt.mutual_exclusive([True] * 40, vt.HAIR_COLOURS, r) for _ in range(20)]
+    assert all(sum(m[vt.ATTR.index(a)] for a in vt.HAIR_COLOURS) == 1 for m in many)
+    sents = vt.generate_random_sentences(8, 12, r)
+    assert len(sents) == 12 and all('smiling' not in s and 'blurry' not in s and 'brown hair' not in s for s in sents)
+    ref_dir = '/root/reference/mm_vox_celeb'
+    if os.path.exists(os.path.join(ref_dir, 'pcfg.py')):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('ref_pcfg', os.path.join(ref_dir, 'pcfg.py'))
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+        assert list(ref.ATTR) == vt.ATTR and list(ref.NAME) == vt.NAME and dict(ref.ATTR_VERB) == vt.ATTR_VERB
+        assert ref.NEGATE_IDX == vt.NEGATE_IDX and ref.GENDER_IDX == vt.GENDER_IDX
