@@ -13,9 +13,12 @@
 // with ds_read_b128; operands whose REDUCTION index is the position (V^T, K^T, Q^T, dO^T) are read from the
 // same row-major tile with the hardware transpose read ds_read_b64_tr_b16 -- there are no transposed copies
 // in HBM.  One 16-B-chunk XOR swizzle (chunk ^= (row>>1)&7, applied on the DMA source address) serves both.
-// The inner loops are VALU-bound (exp2 is quarter rate), so they are written for instruction count:
-// packed fp32 fma/add, hardware bf16 pack, v_permlane32_swap for the cross-half max, and a LAZY softmax
-// rescale (the running max is only raised when a tile exceeds it by 2^8; P <= 256 is exact enough in bf16).
+// The inner loops are written for instruction count: packed fp32 fma/add, hardware bf16 pack, v_permlane32_swap for
+// the cross-half max, and a LAZY softmax rescale (the running max is only raised when a tile exceeds it by 2^8;
+// P <= 256 is exact enough in bf16).  What bounds them, measured with time stamps from inside (tools/attn_timeline.py,
+// DESIGN.md section 3): a wave's own MFMA -> softmax -> MFMA chain, 1.65-2.45 us per 64-position tile whatever shares
+// its SIMD (matrix pipe ~20 %, VALU ~25 %, LDS ~50 % busy), so a block lasts ~25 us and every partly filled round of
+// the 1,080-block grid costs a whole one.
 // exp2 with 1/sqrt(d)*log2(e) folded in; lse2 = m + log2(sum) is kept for the backward.  No atomics.
 #include "../../include/mmvid_hip.h"
 #include "gemm_core.h"
