@@ -59,9 +59,9 @@ for cfg in (2, 4):
         run(f'BERT config {cfg} generate_images b={B} candidates={cand} dynamic={dyn}',
             lambda: m.generate_images(b['text'], mask_predict_steps=0, mp_config=dict(bench.MP_CONFIG, B=cand, T=6), dynamic=dyn, **kw)[0])
     vae = m.vae
-    for strict in (False, True):
+    for strict in (False, True, 'split'):
         vae.strict = strict
-        for N in (1, 2, 7, 54) if not strict else (1, 3):
+        for N in (1, 2, 7, 54) if strict is not True else (1, 3):
             img = torch.rand(N, 3, 128, 128, device=dev)
             run(f'VQGAN encode+decode N={N} strict={strict}', lambda: vae.decode(vae.get_codebook_indices(img)))
         vae.strict = False
