@@ -1,3 +1,4 @@
-"""`from mmvid_pytorch.loader import TextVideoDataset` (utils_train.py:25) -> the same import path here.  The other dataset
-classes of the reference's loader.py / loader_ext.py (mp4, image stacks, shape-attribute, VoxCeleb, iPER) are not built."""
+"""`from mmvid_pytorch.loader import TextVideoDataset` / `TextMP4Dataset` / `TextImageStackDataset` (utils_train.py:25, 46, 64) -> the
+same import path here.  (`TextImageDataset`, the shape-attribute and iPER loaders of the reference are not built.)"""
 from .data import TextVideoDataset  # noqa: F401
+from .loader_files import TextImageStackDataset, TextMP4Dataset  # noqa: F401

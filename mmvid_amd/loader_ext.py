@@ -93,6 +93,25 @@ def _resize_short_side(x, size):
     return y.reshape(*lead, *y.shape[-3:])
 
 
+def clip_transform(x, size, deterministic, resize_ratio, rng):
+    """The image transform shared by the reference's clip data sets (loader.py:352-367, 716-731, 977-996; loader_ext.py:296-311):
+    Resize(size) then CenterCrop(size) when deterministic, else RandomResizedCrop(size, scale=(resize_ratio, 1), ratio=(1, 1)) -- a
+    square of that share of the image area, anywhere -- with ONE crop for the whole stack [..., 3, H, W]."""
+    S = size
+    x = _resize_short_side(x, S)
+    h, w = x.shape[-2:]
+    if deterministic:
+        top, left = (h - S) // 2, (w - S) // 2
+        return x[..., top:top + S, left:left + S].contiguous()
+    side = int(round((rng.uniform(resize_ratio, 1.0) * h * w)**0.5))
+    side = max(1, min(side, h, w))
+    top, left = rng.randint(0, h - side), rng.randint(0, w - side)
+    lead = x.shape[:-3]
+    y = torch.nn.functional.interpolate(x[..., top:top + side, left:left + side].reshape(-1, *x.shape[-3:-2], side, side), size=(S, S),
+                                        mode='bilinear', align_corners=False, antialias=True)
+    return y.reshape(*lead, *y.shape[-3:])
+
+
 class VoxDataset(torch.utils.data.Dataset):
 
     def __init__(self, folder, text_len=256, image_size=128, truncate_captions=False, resize_ratio=0.75, tokenizer=None, shuffle=False,
@@ -173,20 +192,7 @@ class VoxDataset(torch.utils.data.Dataset):
     # ---- images -------------------------------------------------------------------------------------------------------------
     def _transform(self, x):
         """[..., 3, H, W] in [0, 1] -> [..., 3, S, S]: one crop for the whole stack (loader_ext.py:296-311)."""
-        S = self.image_size
-        x = _resize_short_side(x, S)
-        h, w = x.shape[-2:]
-        if self.deterministic:
-            top, left = (h - S) // 2, (w - S) // 2
-            return x[..., top:top + S, left:left + S].contiguous()
-        # RandomResizedCrop(S, scale=(resize_ratio, 1), ratio=(1, 1)): a square of that share of the image area, anywhere
-        side = int(round((self.rng.uniform(self.resize_ratio, 1.0) * h * w)**0.5))
-        side = max(1, min(side, h, w))
-        top, left = self.rng.randint(0, h - side), self.rng.randint(0, w - side)
-        lead = x.shape[:-3]
-        y = torch.nn.functional.interpolate(x[..., top:top + side, left:left + side].reshape(-1, *x.shape[-3:-2], side, side), size=(S, S),
-                                            mode='bilinear', align_corners=False, antialias=True)
-        return y.reshape(*lead, *y.shape[-3:])
+        return clip_transform(x, self.image_size, self.deterministic, self.resize_ratio, self.rng)
 
     def _frame(self, rel_path):
         return self._transform(_open_rgb(os.path.join(self.root, rel_path)))

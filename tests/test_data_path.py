@@ -332,3 +332,101 @@ def test_vox_text_grammar():
         spec.loader.exec_module(ref)
         assert list(ref.ATTR) == vt.ATTR and list(ref.NAME) == vt.NAME and dict(ref.ATTR_VERB) == vt.ATTR_VERB
         assert ref.NEGATE_IDX == vt.NEGATE_IDX and ref.GENDER_IDX == vt.GENDER_IDX
+
+
+# ------------------------------------------------------------------------------------------------ one file per video (loader.py)
+def _make_stacks(root, lengths, vertical=()):
+    """video/<id>.png = n square frames of side 24 side by side (or stacked), frame t a flat grey 10 t; txt, label, visual beside."""
+    import numpy as np
+    from PIL import Image
+    for sub in ('video', 'txt', 'label', 'visual'):
+        (root / sub).mkdir(parents=True, exist_ok=True)
+    for vid, n in lengths.items():
+        strip = np.concatenate([np.full((24, 24, 3), min(10 * t, 255), np.uint8) for t in range(n)], axis=0 if vid in vertical else 1)
+        Image.fromarray(strip).save(root / 'video' / f'{vid}.png')
+        Image.fromarray(255 - strip).save(root / 'visual' / f'{vid}.png')
+        (root / 'txt' / f'{vid}.txt').write_text(f'{vid} caption\n')
+        (root / 'label' / f'{vid}.txt').write_text('0,1,1,0')
+
+
+def test_text_image_stack_dataset(tmp_path):
+    """loader.py:852-1110: frames split out of one image (horizontal or vertical strip), the index cache, the length filter and the
+    four return forms."""
+    import pickle
+    import random
+
+    import numpy as np
+
+    from mmvid_amd.loader import TextImageStackDataset
+    root = tmp_path / 'stacks'
+    _make_stacks(root, {'wide': 16, 'tall': 12, 'tiny': 4}, vertical=('tall', ))
+    (root / 'video' / 'stray.txt').write_text('not an image')
+    ds = TextImageStackDataset(root, text_len=12, image_size=16, tokenizer=_FakeTok(), frame_step=2, frame_num=4, deterministic=True,
+                               rng=random.Random(0))
+    assert sorted(ds.keys) == ['tall', 'wide'] and ds.lengths == {'wide': 16, 'tall': 12} and ds.has_label and ds.has_visual
+    idx = pickle.load(open(tmp_path / 'stacks_local.pkl', 'rb'))
+    assert sorted(idx['keys']) == ['tall', 'tiny', 'wide'] and idx['videos']['wide'] == os.path.join('video', 'wide.png')
+    for key in ('wide', 'tall'):
+        tokens, frames = ds[ds.keys.index(key)]
+        assert tokens.shape == (12, ) and tokens[0] == ord(key[0]) % 251 + 1 and frames.shape == (4, 3, 16, 16)
+        levels = [round(float(f[0, 3, 3]) * 255) for f in frames]
+        assert all(b - a == 20 for a, b in zip(levels, levels[1:])) and levels[0] % 10 == 0  # every second frame of the strip
+    vc = TextImageStackDataset(root, text_len=12, image_size=16, tokenizer=_FakeTok(), frame_num=4, deterministic=True, return_vc=True,
+                               rng=random.Random(1))
+    tokens, frames, visual = vc[0]
+    assert visual.shape == (3, 16, 16) and round(float(visual[0, 2, 2]) * 255) % 10 == 5  # 255 - 10 t: a frame of visual/<id>.png
+    lab = TextImageStackDataset(root, text_len=12, image_size=16, tokenizer=_FakeTok(), frame_num=4, return_label=True, rng=random.Random(2))[0]
+    assert isinstance(lab[2], np.ndarray) and lab[2].tolist() == [0, 1, 1, 0]
+    txt = TextImageStackDataset(root, text_len=12, image_size=16, tokenizer=None, frame_num=4, return_text=True, rng=random.Random(2))[1]
+    assert txt[0] == txt[2] and txt[2].endswith(' caption')
+    img = TextImageStackDataset(root, text_len=12, image_size=16, tokenizer=None, frame_num=4, image_only=True, mode='1frame',
+                                rng=random.Random(3))[0]
+    assert img[1] == 0 and img[0].shape == (3, 16, 16)
+    # no_cache: nothing is written
+    (tmp_path / 'stacks_local.pkl').unlink()
+    TextImageStackDataset(root, text_len=12, image_size=16, tokenizer=None, frame_num=4, no_cache=True)
+    assert not (tmp_path / 'stacks_local.pkl').exists()
+
+
+def test_text_mp4_dataset_with_an_injected_frame_source(tmp_path):
+    """loader.py:597-849 without a decoder: the class takes any source with count(path) / read(path, idxs); without decord and
+    without one it says what is missing."""
+    import random
+
+    from mmvid_amd.loader import TextMP4Dataset
+    from mmvid_amd.loader_files import VID_EXT
+
+    class FakeSource:
+        extensions = VID_EXT
+
+        def count(self, path):
+            return int(open(path).read())
+
+        def read(self, path, idxs=None):
+            n = self.count(path)
+            idxs = list(range(n)) if idxs is None else list(idxs)
+            return torch.stack([torch.full((3, 20, 28), t / 100.0) for t in idxs])
+
+    root = tmp_path / 'clips'
+    for sub in ('video', 'txt', 'label'):
+        (root / sub).mkdir(parents=True)
+    for vid, n in (('a', 30), ('b', 9), ('c', 5)):
+        (root / 'video' / f'{vid}.mp4').write_text(str(n))
+        (root / 'txt' / f'{vid}.txt').write_text(f'{vid} words\n')
+        (root / 'label' / f'{vid}.txt').write_text('7')
+    ds = TextMP4Dataset(root, text_len=10, image_size=16, tokenizer=_FakeTok(), frame_step=2, frame_num=4, source=FakeSource(), rng=random.Random(0))
+    assert sorted(ds.keys) == ['a', 'b'] and (tmp_path / 'clips_local.pkl').exists()
+    tokens, frames, visual = ds[ds.keys.index('a')]
+    assert tokens.shape == (10, ) and frames.shape == (4, 3, 16, 16) and visual.shape == (3, 16, 16)
+    t = [round(float(f[0, 0, 0]) * 100) for f in frames]
+    assert t == [t[0], t[0] + 2, t[0] + 4, t[0] + 6] and 0 <= t[0] <= 30 - 6 - 1
+    assert TextMP4Dataset(root, text_len=10, image_size=16, tokenizer=_FakeTok(), frame_num=4, source=FakeSource(), return_label=True,
+                          rng=random.Random(1))[0][2] == 7
+    vo = TextMP4Dataset(root, text_len=10, image_size=16, tokenizer=_FakeTok(), frame_num=4, source=FakeSource(), video_only=True, mode='1frame',
+                        rng=random.Random(1))[0]
+    assert vo[0][0] == ord('d') % 251 + 1 and vo[1].shape == (3, 16, 16) and vo[2].shape == (3, 16, 16)
+    try:
+        import decord  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match='decord'):
+            TextMP4Dataset(root, tokenizer=_FakeTok())
