@@ -24,7 +24,7 @@ from torch import nn
 from . import ops, sampling
 from .clip_tower import OpenAICLIPTransformer
 from .frontend import Frontend, face_choices
-from .functional import PosTable, AssembleSequence, BertHeads, LNLinear
+from .functional import PosTable, AssembleSequence, BertHeads, LNLinear, Linear, LayerNormRows
 from .modules import AxialPositionalEmbedding, AxialPositionalEmbeddingList
 
 
@@ -66,9 +66,6 @@ class BERT(nn.Module):
                  num_targets=1, use_separate_visual_emb=False, insert_sep=False, text_emb_bottleneck=False,
                  **kwargs):
         super().__init__()
-        if fixed_language_model is not None:
-            raise NotImplementedError('fixed_language_model (RoBERTa features, dalle_bert.py:306-322) is outside '
-                                      'the hot path of this build')
         image_size = vae.image_size
         num_image_tokens = vae.num_tokens
         image_fmap_size = vae.image_size // (2**vae.num_layers)
@@ -79,9 +76,32 @@ class BERT(nn.Module):
         self.random_erasing = dict(p=1.0, scale=(0.2, 0.8), ratio=(0.5, 2.0))
         self.visual_eraser = dict(p=0.95, scale=(0.55, 0.85), ratio=(0.5, 2.0))
 
-        num_text_tokens = num_text_tokens + text_seq_len  # unique pad id per position (dalle_bert.py:299)
-        self.text_emb = nn.Embedding(num_text_tokens, dim)
-        self.text_pos_emb = nn.Embedding(text_seq_len, dim)
+        if fixed_language_model is None:
+            num_text_tokens = num_text_tokens + text_seq_len  # unique pad id per position (dalle_bert.py:299)
+            self.text_emb = nn.Embedding(num_text_tokens, dim)
+            self.text_pos_emb = nn.Embedding(text_seq_len, dim)
+            self.text_feature_mapping = None
+        else:
+            # dalle_bert.py:307-322: the text is ONE token, a sentence feature of a frozen language model (computed by the driver,
+            # utils_train.py:194-215) mapped to `dim`; there is no text table and no text position.
+            assert text_feature_dim > 0
+            text_seq_len, num_text_tokens = 1, 1
+            self.text_emb = self.text_pos_emb = None
+            if text_emb_bottleneck is not None:  # (sic) the class default False reaches int(False) = 0 in the reference
+                nf = int(text_emb_bottleneck)
+                if nf <= 0 or nf % 8 or text_feature_dim % 8 or max(nf, text_feature_dim, dim) > 1024:
+                    raise ValueError(f'text_emb_bottleneck={text_emb_bottleneck!r}, text_feature_dim={text_feature_dim}: the mapping '
+                                     'kernels take widths that are multiples of 8, at most 1024 (pass text_emb_bottleneck=None '
+                                     'for the single Linear)')
+                self.text_feature_mapping = nn.Sequential(nn.LayerNorm(text_feature_dim), nn.Linear(text_feature_dim, nf),
+                                                          nn.LayerNorm(nf), nn.Linear(nf, dim), nn.LayerNorm(dim))
+            else:
+                if text_feature_dim % 8:
+                    raise ValueError(f'text_feature_dim={text_feature_dim} must be a multiple of 8')
+                self.text_feature_mapping = nn.Linear(text_feature_dim, dim)
+            # what the text segment reads from the (absent) table and position: a zero row, the mapped feature is added on top
+            self.register_buffer('_no_text_row', torch.zeros(1, dim), persistent=False)
+        self.text_feature_dim = text_feature_dim
         self.image_emb = nn.Embedding(num_image_tokens + 2, dim)
         self.target_pos_emb = AxialPositionalEmbedding(dim, axial_shape=(num_targets, image_fmap_size, image_fmap_size))
         if cvae is not None:
@@ -113,7 +133,7 @@ class BERT(nn.Module):
         self.vae, self.cvae = vae, cvae
         set_requires_grad(self.vae, False)
         set_requires_grad(self.cvae, False)
-        self.fixed_language_model = None
+        self.fixed_language_model = fixed_language_model
         self.which_transformer = which_transformer
         assert which_transformer != 'default'
         if not which_transformer.startswith('openai_clip'):
@@ -173,15 +193,20 @@ class BERT(nn.Module):
 
     def head_shadow_targets(self):
         """Linear layers whose weight the MFMA kernels read in bf16 (engine.FlatTrainer attaches shadow views)."""
-        return [self.to_logits[1]]
+        m = self.text_feature_mapping
+        extra = [] if m is None else ([m] if isinstance(m, nn.Linear) else [m[1], m[3]])
+        return [self.to_logits[1]] + extra
 
     def _tables(self):
         vis = self.visual_emb.weight if (self.num_visuals > 0 and self.visual_emb is not None) else self.image_emb.weight
-        return (self.special_emb.weight, self.text_emb.weight, vis, self.image_emb.weight)
+        text = self.text_emb.weight if self.text_emb is not None else self._no_text_row
+        return (self.special_emb.weight, text, vis, self.image_emb.weight)
 
     def sparse_grad_rows(self):
         """Tables whose gradient has few non-zero rows per step, with the row ids of the last forward (engine.FlatTrainer
         exchanges them row-wise instead of all-reducing 152 MB of mostly zeros)."""
+        if self.text_emb is None:
+            return {}
         log = self._text_id_log
         if not log or self._text_id_overflow:  # nothing logged / more forwards since zero_grad than the log holds: the
             return {'text_emb.weight': None}   # trainer falls back to the dense all-reduce for this table
@@ -195,7 +220,7 @@ class BERT(nn.Module):
         """Every text-segment id of a grad-enabled forward: the only rows of text_emb its backward can touch.  Logged per
         forward since the last zero_grad so gradient accumulation stays covered; past TEXT_ID_LOG_MAX forwards the log is
         declared incomplete (sparse_grad_rows -> None -> dense all-reduce) rather than silently dropping the oldest."""
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() or self.text_emb is None:
             return
         if len(self._text_id_log) >= self.TEXT_ID_LOG_MAX:
             self._text_id_overflow = True
@@ -205,7 +230,8 @@ class BERT(nn.Module):
     def _pos_layout(self):
         """Segments of the positional table for functional.PosTable: (dst0, rows, src0, params, axial dims)."""
         sp, f = self.special_pos_emb.weight, self.image_fmap_size
-        lay = [(0, 1, 0, (sp, ), ()), (1, self.text_seq_len, 0, (self.text_pos_emb.weight, ), ())]
+        text_pos = self.text_pos_emb.weight if self.text_pos_emb is not None else self._no_text_row
+        lay = [(0, 1, 0, (sp, ), ()), (1, self.text_seq_len, 0, (text_pos, ), ())]
         at = 1 + self.text_seq_len
         if self.num_visuals > 0:
             for m in self.visual_pos_emb.module_list:  # one (h, w) axial table per visual frame, + a zero [SEP] row each
@@ -224,7 +250,7 @@ class BERT(nn.Module):
             lay, L = self._pos_layout()
             params = [w for seg in lay for w in seg[3]]
             return PosTable.apply(lay, L, *params)
-        parts = [sp[0:1], self.text_pos_emb.weight[:self.text_seq_len]]
+        parts = [sp[0:1], (self.text_pos_emb.weight if self.text_pos_emb is not None else self._no_text_row)[:self.text_seq_len]]
         if self.num_visuals > 0:
             parts.append(self.visual_pos_emb.table(insert_sep=bool(self.insert_sep)))
         parts += [sp[1:3], self.target_pos_emb.table()]
@@ -336,9 +362,21 @@ class BERT(nn.Module):
             tok = self.erase_codebook_face(tok, vc_mode, face_mode)
         return tok
 
-    def _assemble(self, ids, length):
+    def _assemble(self, ids, length, text_rows=None):
         pos = self._pos_table()[:length]
-        return AssembleSequence.apply(pos, ids.contiguous(), self._seg[:length].contiguous(), *self._tables())
+        x = AssembleSequence.apply(pos, ids.contiguous(), self._seg[:length].contiguous(), *self._tables())
+        if text_rows is not None:  # fixed language model: the text position holds the mapped feature (dalle_bert.py:924-925)
+            x[:, self.txt_tok_index].add_(text_rows)
+        return x
+
+    def _map_text_feature(self, feat):
+        """text_feature_mapping (dalle_bert.py:312-322) on [B, text_feature_dim] fp32 rows -> [B, dim]."""
+        m = self.text_feature_mapping
+        if isinstance(m, nn.Linear):
+            return Linear.apply(feat, m.weight, m.bias, self._w16(m))
+        h = LNLinear.apply(feat, m[0].weight, m[0].bias, m[1].weight, m[1].bias, self._w16(m[1]))
+        h = LNLinear.apply(h, m[2].weight, m[2].bias, m[3].weight, m[3].bias, self._w16(m[3]))
+        return LayerNormRows.apply(h, m[4].weight, m[4].bias)
 
     def _head_rows(self, B, nseq, device):
         """Row numbers (into the [nseq*B*L, dim] tower output) and labels of the REL / VID heads: positives from the MSM
@@ -362,11 +400,21 @@ class BERT(nn.Module):
                 vc_mode=None, face_mode=None, visual_aug_mode=None, _mask1=None, _target_warp=None, **kwargs):
         device = text.device
         B = text.shape[0]
-        assert text.shape[-1] == self.text_seq_len, \
-            f'the length {text.shape[-1]} of the text tokens you passed in does not have the correct length ({self.text_seq_len})'
+        text_rows = None
+        if self.fixed_language_model is None:
+            assert text.shape[-1] == self.text_seq_len, \
+                f'the length {text.shape[-1]} of the text tokens you passed in does not have the correct length ({self.text_seq_len})'
+            text = ops._chk(text.contiguous(), torch.int64, 'text')
+        else:  # `text` is the sentence feature [B, text_feature_dim] (dalle_bert.py:897-898, 924-925); its one token reads row 0
+            if negvc:
+                raise NotImplementedError('negvc with a fixed language model: the reference indexes a text table it does not '
+                                          'have in this mode (dalle_bert.py:930-932)')
+            assert text.dim() == 2 and text.shape[-1] == self.text_feature_dim, \
+                f'expected text features of shape [B, {self.text_feature_dim}], got {tuple(text.shape)}'
+            text_rows = self._map_text_feature(ops._chk(text.contiguous().float(), torch.float32, 'text'))
+            text = torch.zeros(B, 1, dtype=torch.int64, device=device)
         MASK = self.image_token_lut['[MASK]']
         pad_base = self.num_text_tokens - self.text_seq_len
-        text = ops._chk(text.contiguous(), torch.int64, 'text')
         vis_tok = self._visual_tokens(visual, erase_visual, erase_visual_half, vc_mode, face_mode, visual_aug_mode)
         if not return_loss:  # control embedding only (dalle_bert.py:977-978)
             empty = torch.empty(B, 0, dtype=torch.long, device=device)
@@ -374,7 +422,7 @@ class BERT(nn.Module):
                                      pad_base, MASK, False, False)[0]
             self.frontend.advance(device)
             self._log_text_ids(ids)
-            return self._assemble(ids, self.control_seq_len)
+            return self._assemble(ids, self.control_seq_len, text_rows)
 
         T, f = self.num_targets, self.image_fmap_size
         do_vid = vid and T > 1
@@ -424,7 +472,12 @@ class BERT(nn.Module):
         ids, sel, tfull, cnt = ops.bert_build_ids(text, vis_tok, self.visual_seq_len, target, target_warp, mask1, pad_base, MASK,
                                                   bool(rel), bool(do_vid), text_neg=text_neg_ids)
         self._log_text_ids(ids)  # rows of text_emb this forward's backward can touch (sparse_grad_rows)
-        x_seq = self._assemble(ids, self.total_seq_len)
+        if text_rows is not None and (rel or do_vid):  # one row per sequence of the batched pass: MSM, REL (halves swapped), VID
+            half = B // 2
+            per_pass = [text_rows] + ([torch.cat((text_rows[half:], text_rows[:half]))] if rel else []) + \
+                ([text_rows] if do_vid else [])
+            text_rows = torch.cat(per_pass)
+        x_seq = self._assemble(ids, self.total_seq_len, text_rows)
         y = self.transformer_forward(x_seq)  # [nseq*B, L, dim]
         if self._debug_keep is not None:  # tools/stress_nan2.py: the stage tensors of the last (replayed) forward
             self._debug_keep.update(mask1=mask1, nfm=not_fully_masked, target=target, target_warp=target_warp, ids=ids, sel=sel,

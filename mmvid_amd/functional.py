@@ -173,6 +173,52 @@ class LNLinear(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class Linear(torch.autograd.Function):
+    """nn.Linear(K, N) on rows x [R, K] fp32 -> [R, N] fp32 (bf16 MFMA GEMM, fp32 accumulate): the `text_feature_mapping` of the
+    fixed-language-model branch (dalle_bert.py:322)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, w_bf16):
+        _note_params(ctx, (x, w, b, w_bf16))
+        x16 = ops.cast_bf16(x.contiguous())
+        ctx.save_for_backward(x16)
+        ctx.params = (w, b, w_bf16)
+        return ops.gemm(x16, w_bf16, bias=b.detach(), out_dtype=f32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, = ctx.saved_tensors
+        w, b, w_bf16 = ctx.params
+        d16 = ops.cast_bf16(dy.contiguous())
+        if w.requires_grad:
+            ops.gemm_dw(d16, x16, _grad_buf(w), accumulate=True)
+        if b.requires_grad:
+            ops.colsum_bf16(d16, _grad_buf(b))
+        dx = ops.gemm(d16, w_bf16, b_kmajor=True, out_dtype=f32) if ctx.needs_input_grad[0] else None
+        return _with_param_zeros(ctx, (dx, None, None, None))
+
+
+class LayerNormRows(torch.autograd.Function):
+    """nn.LayerNorm(E) on rows [R, E] fp32 -> fp32 (the closing norm of the bottleneck mapping, dalle_bert.py:319)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _note_params(ctx, (x, w, b))
+        x = x.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x, w.detach(), b.detach(), 1e-5, out_dtype=f32)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.params = (w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        w, b = ctx.params
+        dx = ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, w.detach(), dw=_grad_buf(w) if w.requires_grad else None,
+                               db=_grad_buf(b) if b.requires_grad else None)
+        return _with_param_zeros(ctx, (dx, None, None))
+
+
 class LNLinearCrossEntropy(torch.autograd.Function):
     """to_logits + F.cross_entropy(logits[select], target[select]) (dalle_bert.py:1038-1040) fused at the autograd
     level: the bf16 dlogits go straight into the backward GEMMs.  Returns (loss, logits).

@@ -24,7 +24,11 @@ class Cfg:
         self.fmap = image_size // 16
         self.image_seq_len = self.fmap**2
         self.num_image_tokens = sd['vae.model.quantize.embedding.weight'].shape[0]
-        self.num_text_tokens = sd['text_emb.weight'].shape[0]  # already + text_seq_len
+        # fixed language model (dalle_bert.py:307-322): no text table, ONE text token = a mapped sentence feature
+        self.fixed_language_model = 'text_emb.weight' not in sd
+        if self.fixed_language_model:
+            assert text_seq_len == 1
+        self.num_text_tokens = 1 if self.fixed_language_model else sd['text_emb.weight'].shape[0]  # already + text_seq_len
         self.visual_seq_len = num_visuals * self.image_seq_len
         self.target_seq_len = num_targets * self.image_seq_len
         self.MASK = self.num_image_tokens
@@ -44,14 +48,29 @@ def get_image_tokens(sd, cfg, frames, which='vae'):
     return idx.view(b, -1)
 
 
+def text_feature_mapping(sd, feat):
+    """dalle_bert.py:312-322: nn.Linear, or LayerNorm-Linear-LayerNorm-Linear-LayerNorm with a bottleneck."""
+    p = 'text_feature_mapping.'
+    if p + 'weight' in sd:
+        return F.linear(feat, sd[p + 'weight'], sd[p + 'bias'])
+    h = feat
+    for i in range(5):
+        w, b = sd[f'{p}{i}.weight'], sd[f'{p}{i}.bias']
+        h = F.layer_norm(h, (h.shape[-1], ), w, b, 1e-5) if i % 2 == 0 else F.linear(h, w, b)
+    return h
+
+
 def control_embedding(sd, cfg, text, visual_tok=None):
     """dalle_bert.py:899-978 -> [B, 1+Ttxt+Nvis+2, dim]."""
     B = text.shape[0]
     sp, spp = sd['special_emb.weight'], sd['special_pos_emb.weight']
     rel = (sp[0] + spp[0]).expand(B, 1, -1)
-    text_range = torch.arange(cfg.text_seq_len) + (cfg.num_text_tokens - cfg.text_seq_len)
-    text = torch.where(text == 0, text_range, text)  # unique pad id per position, 917-919
-    te = sd['text_emb.weight'][text] + sd['text_pos_emb.weight'][:cfg.text_seq_len]
+    if cfg.fixed_language_model:  # 924-925: `text` is the feature [B, text_feature_dim]
+        te = text_feature_mapping(sd, text).unsqueeze(1)
+    else:
+        text_range = torch.arange(cfg.text_seq_len) + (cfg.num_text_tokens - cfg.text_seq_len)
+        text = torch.where(text == 0, text_range, text)  # unique pad id per position, 917-919
+        te = sd['text_emb.weight'][text] + sd['text_pos_emb.weight'][:cfg.text_seq_len]
     parts = [rel, te]
     if cfg.num_visuals > 0:
         if visual_tok is None:

@@ -47,6 +47,28 @@ def test_tower_state_dict_layout_matches_reference(golden):
     assert c.mask_spec == 'causal' and torch.equal(c.dense_attention_mask(), build_attention_mask(40, 'causal'))
 
 
+@pytest.mark.parametrize('name,bn', [('bert_flm', None), ('bert_flm_bottleneck', '256')])
+def test_bert_fixed_language_model_layout(golden, name, bn):
+    """dalle_bert.py:307-322: one text token fed by `text_feature_mapping`; no text table, no text position."""
+    import torch.nn as nn
+    m = tiny_bert(fixed_language_model='roberta-large', text_feature_dim=1024, text_emb_bottleneck=bn)
+    assert manifest(m) == golden(name).manifest
+    assert m.text_seq_len == 1 and m.num_text_tokens == 1 and m.text_emb is None and m.text_pos_emb is None
+    assert m.total_seq_len == 1 + 1 + 2 + 32 and m.st1_tok_index == 2 and m.vid_tok_index == 3
+    assert m._seg.tolist()[:4] == [0, 1, 0, 0]
+    assert m.sparse_grad_rows() == {}
+    extra = [m.text_feature_mapping] if bn is None else [m.text_feature_mapping[1], m.text_feature_mapping[3]]
+    assert m.head_shadow_targets() == [m.to_logits[1]] + extra and all(isinstance(x, nn.Linear) for x in extra)
+    pos = m._pos_table()
+    assert pos.shape == (m.total_seq_len, 768) and float(pos[1].detach().abs().max()) == 0.0
+    for bad in (dict(text_feature_dim=1020), dict(text_feature_dim=1024, text_emb_bottleneck='0'),
+                dict(text_feature_dim=1024, text_emb_bottleneck=False), dict(text_feature_dim=2048, text_emb_bottleneck='256')):
+        with pytest.raises(ValueError):
+            tiny_bert(fixed_language_model='roberta-large', **bad)
+    with pytest.raises(AssertionError):
+        tiny_bert(fixed_language_model='roberta-large')  # text_feature_dim > 0 (dalle_bert.py:308)
+
+
 @pytest.mark.parametrize('name,nv,cvae', [('bert_tiny', 0, False), ('bert_tiny_visual', 1, True)])
 def test_bert_state_dict_layout_and_indices(golden, name, nv, cvae):
     m = tiny_bert(nv, cvae)

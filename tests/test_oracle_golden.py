@@ -137,6 +137,39 @@ def test_bert_losses_and_grads(golden, name, nv):
     assert abs(tn.item() / g['g_total_norm'].item() - 1) < 1e-5
 
 
+@pytest.mark.parametrize('name', ['bert_flm', 'bert_flm_bottleneck'])
+def test_bert_fixed_language_model(golden, name):
+    """dalle_bert.py:307-322, 924-925: the text is one mapped sentence feature (single Linear / LayerNorm-Linear bottleneck)."""
+    g = golden(name)
+    sd = synth_model_sd(g, 23)
+    for k in sd:
+        sd[k].requires_grad_(not k.startswith('vae.'))
+    assert 'text_emb.weight' not in sd and any(k.startswith('text_feature_mapping.') for k in sd)
+    cfg = bert.Cfg(sd, 1, 0, 2, 64)
+    assert cfg.total_seq_len == 1 + 1 + 2 + 2 * 16
+    feat = g['text_feat']
+    with torch.no_grad():
+        tt = bert.get_image_tokens(sd, cfg, g['frames'])
+    assert torch.equal(tt, g['target_tok'])
+    r = bert.forward_losses(sd, cfg, feat, tt, g['mask1'], g['warp_tok'], None)
+    assert relerr(r['control_emb'], g['control_emb']) <= TOL
+    assert relerr(r['out_msm'][:, ::3, ::7], g['out_msm_s']) <= TOL
+    assert relerr(r['out_rel'][:, ::3, ::7], g['out_rel_s']) <= TOL and relerr(r['out_vid'][:, ::3, ::7], g['out_vid_s']) <= TOL
+    losses = torch.stack([r['loss_msm'], r['loss_rel'], r['loss_vid']])
+    assert torch.allclose(losses, g['losses'], rtol=1e-5)
+    (7 * r['loss_msm'] + .5 * r['loss_rel'] + .5 * r['loss_vid']).backward()
+    G = {k: v.grad for k, v in sd.items() if v.grad is not None}
+    n = 0
+    for k, v in G.items():
+        if k.startswith('text_feature_mapping.'):
+            assert relerr(v if v.dim() == 1 else v[::4, ::8], g['g_' + k]) <= TOL, k
+            n += 1
+    assert n == (2 if name == 'bert_flm' else 10)
+    assert relerr(G['image_emb.weight'][::3, ::5], g['g_image_emb']) <= TOL
+    tn = torch.sqrt(sum((v.double()**2).sum() for v in G.values()))
+    assert abs(tn.item() / g['g_total_norm'].item() - 1) < 1e-5
+
+
 def test_mask_predict_trajectory(golden):
     g, gb = golden('mask_predict'), golden('bert_tiny')
     sd = synth_model_sd(gb, 17)

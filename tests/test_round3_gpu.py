@@ -697,3 +697,62 @@ def test_split_tokens_of_bert_goldens(golden, name, nv, cvae):
     assert torch.equal(m.get_image_tokens(g['warped_frames'].to(DEV)).cpu(), g['warp_tok'])
     if nv:
         assert torch.equal(m.get_image_tokens(g['visual'].to(DEV), which_vae='cvae').cpu(), g['visual_tok'])
+
+
+# ------------------------------------------------------------------------------ BERT with a fixed language model
+@pytest.mark.parametrize('name,bn', [('bert_flm', None), ('bert_flm_bottleneck', '256')])
+def test_bert_fixed_language_model_vs_reference(golden, name, bn):
+    """dalle_bert.py:307-322, 924-925 on the HIP path: the sentence feature goes through text_feature_mapping (MFMA GEMMs +
+    LayerNorm kernels) into the one text token; REL swaps it with the rest of the control.  Losses / gradients vs the
+    reference's with its tokens, mask and warped tokens injected; tokens of the frames exact in the pair-operator mode."""
+    from mmvid_amd.engine import FlatTrainer, backward_order
+    g = golden(name)
+    m = load_synth(tiny_bert(fixed_language_model='roberta-large', text_feature_dim=1024, text_emb_bottleneck=bn), g, 23).train()
+    feat = g['text_feat'].to(DEV)
+    with torch.no_grad():
+        ctrl = m(feat, return_loss=False)
+    close(ctrl, g['control_emb'], 1e-2, 'control_emb (text row through the bf16 mapping)')
+    close(torch.cat((ctrl[:, :1], ctrl[:, 2:]), 1), torch.cat((g['control_emb'][:, :1], g['control_emb'][:, 2:]), 1), 1e-6,
+          'control_emb without the text row')
+    m.vae.strict = 'split'
+    assert torch.equal(m.get_image_tokens(g['frames'].to(DEV)).cpu(), g['target_tok'])
+    m.vae.strict = False
+
+    def run(model):
+        return model(feat, target=g['target_tok'].to(DEV), return_loss=True, rel=True, vid=True, rel_no_fully_masked=True,
+                     _mask1=g['mask1'], _target_warp=g['warp_tok'])
+    lm, lr, lv = run(m)
+    losses = torch.stack([lm, lr, lv]).detach().cpu()
+    print('losses', losses.tolist(), 'ref', g['losses'].tolist())
+    assert torch.allclose(losses, g['losses'], rtol=2e-2, atol=2e-2)
+    (7 * lm + 0.5 * lr + 0.5 * lv).backward()
+    G = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    n = 0
+    for k, v in G.items():
+        if k.startswith('text_feature_mapping.'):
+            close(v if v.dim() == 1 else v[::4, ::8], g['g_' + k], 6e-2, 'g ' + k)
+            assert abs(v.double().norm().item() / g['gn_' + k].item() - 1) < 5e-2, k
+            n += 1
+    assert n == (2 if bn is None else 10)
+    close(G['image_emb.weight'][::3, ::5], g['g_image_emb'], 5e-2, 'g image_emb')
+    close(G['special_emb.weight'], g['g_special_emb'], 5e-2, 'g special_emb')
+    tn = torch.sqrt(sum((v.double()**2).sum() for v in G.values())).item()
+    print('total grad norm', tn, 'ref', g['g_total_norm'].item())
+    assert abs(tn / g['g_total_norm'].item() - 1) < 3e-2
+    # the flat engine: the mapping's Linear weights are read through bf16 shadows the fused optimiser keeps current
+    m2 = load_synth(tiny_bert(fixed_language_model='roberta-large', text_feature_dim=1024, text_emb_bottleneck=bn), g, 23).train()
+    tr = FlatTrainer(m2, lr=2e-5, order=backward_order)
+    first = None
+    for it in range(3):
+        tr.zero_grad()
+        a, b, c = run(m2)
+        (7 * a + 0.5 * b + 0.5 * c).backward()
+        tr.step()
+        first = first if first is not None else float(a.detach())
+    assert abs(first - float(lm.detach())) < 1e-6 * max(1.0, abs(first)) and float(a.detach()) < first, (first, float(a.detach()))
+    for lin in m2.head_shadow_targets():
+        assert torch.equal(m2._w16(lin), lin.weight.detach().to(torch.bfloat16)), 'stale bf16 shadow'
+    m2.eval()
+    torch.manual_seed(3)
+    images, _, seq = m2.generate_images(feat[:1], mask_predict_steps=3, mp_config=golden('mask_predict').meta['mp_config'], dynamic=False)
+    assert images.shape == (1, 2, 3, 64, 64) and seq.shape == (2, 16) and torch.isfinite(images).all()

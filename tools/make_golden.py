@@ -8,7 +8,8 @@ layout), and the reference's outputs.  Run:
 
     PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [case ...]
 
-Cases: vq vqgan_tiny vqgan_full tower bert_tiny bert_tiny_visual artv_tiny mask_predict frontend mask_predict_race
+Cases: vq vqgan_tiny vqgan_full tower tower12 bert_tiny bert_tiny_visual bert_flm bert_flm_bottleneck artv_tiny mask_predict
+       frontend mask_predict_race
 """
 import json
 import os
@@ -199,14 +200,14 @@ def case_tower12():
     save('tower12', meta=dict(seed=23, layers=12, width=768, heads=12, L=L), manifest=man, **res)
 
 
-def _build_bert(num_visuals, use_cvae, seed, text_seq_len=16, num_targets=2):
+def _build_bert(num_visuals, use_cvae, seed, text_seq_len=16, num_targets=2, **extra):
     from mmvid_pytorch.dalle_bert import BERT
     ref_stubs.CLIP_STATE['sd'] = clip_state(2)
     vae, _ = build_vae(True, 11)
     cvae = build_vae(True, 12)[0] if use_cvae else None
     m = BERT(dim=768, vae=vae, cvae=cvae, num_text_tokens=49408, text_seq_len=text_seq_len,
              which_transformer='openai_clip_visual', num_visuals=num_visuals, num_targets=num_targets,
-             openai_clip_path='x')
+             openai_clip_path='x', **extra)
     man = manifest_of(m)
     sd = synth_state_dict(man, seed)
     # keep the per-VAE seeds used above so vae / cvae differ
@@ -293,6 +294,61 @@ def _bert_case(name, num_visuals, use_cvae):
         res['g_vpos0'] = g['visual_pos_emb.module_list.0.weights_0'].reshape(-1, 768)
     save(name, meta=dict(seed=17, vae_seed=11, cvae_seed=12, B=B, T=T, image_size=S, text_seq_len=TL,
                          num_visuals=num_visuals, layers=2, py_seed=123), manifest=man, **res)
+
+
+def _bert_flm_case(name, bottleneck):
+    """BERT with a fixed language model (dalle_bert.py:307-322, 924-925): the text is one sentence feature per sample (what
+    utils_train.py:194-215 takes from RoBERTa-large, 1024 wide); the model maps it to one token."""
+    import mmvid_pytorch.dalle_bert as db
+    FD = 1024
+    m, man = _build_bert(0, False, 23, fixed_language_model='roberta-large', text_feature_dim=FD, text_emb_bottleneck=bottleneck)
+    B, T, S = 2, 2, 64
+    feat = synth_input('text_feat', (B, FD), 23, 'normal')
+    frames = synth_input('frames', (B, T, 3, S, S), 23, 'uniform')
+    cap = {'emb_in': [], 'tf_out': [], 'warp': []}
+    h1 = m.image_emb.register_forward_hook(lambda mod, i, o: cap['emb_in'].append(i[0].clone()))
+    h2 = m.transformer.register_forward_hook(lambda mod, i, o: cap['tf_out'].append(o.detach().clone()))
+    warp_orig = db.warp
+
+    def warp_cap(x, p):
+        y = warp_orig(x, p)
+        cap['warp'].append(y.clone())
+        return y
+
+    db.warp = warp_cap
+    m.train()
+    with torch.no_grad():
+        ctrl = m(feat, return_loss=False)
+    seed_all(321)
+    losses = m(feat, target=frames, return_loss=True, rel=True, vid=True, msm_strategy_prob=np.array([0.7, 0.1, 0.1, 0.1]),
+               msm_bernoulli_prob=[0.2, 0.5], rel_no_fully_masked=True, vid_strategy_prob=np.array([0.25, 0.25, 0.25, 0.25]))
+    (7 * losses[0] + 0.5 * losses[1] + 0.5 * losses[2]).backward()
+    db.warp = warp_orig
+    h1.remove(), h2.remove()
+    with torch.no_grad():
+        target_tok = m.get_image_tokens(frames)
+        warp_tok = m.get_image_tokens(cap['warp'][0])
+    mask1 = cap['emb_in'][0] != m.image_token_lut['[MASK]']
+    g = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    res = dict(text_feat=feat, frames=frames, control_emb=ctrl, target_tok=target_tok, warp_tok=warp_tok, mask1=mask1,
+               out_msm_s=cap['tf_out'][0][:, ::3, ::7], out_rel_s=cap['tf_out'][1][:, ::3, ::7], out_vid_s=cap['tf_out'][2][:, ::3, ::7],
+               losses=torch.stack(list(losses)).detach(), g_image_emb=g['image_emb.weight'][::3, ::5],
+               g_special_emb=g['special_emb.weight'],
+               g_total_norm=torch.sqrt(sum((v.double()**2).sum() for v in g.values())).view(1))
+    for k, v in g.items():
+        if k.startswith('text_feature_mapping.'):
+            res['g_' + k] = v if v.dim() == 1 else v[::4, ::8]
+            res['gn_' + k] = v.double().norm().view(1)
+    save(name, meta=dict(seed=23, vae_seed=11, B=B, T=T, image_size=S, text_feature_dim=FD, bottleneck=bottleneck, layers=2,
+                         py_seed=321), manifest=man, **res)
+
+
+def case_bert_flm():
+    _bert_flm_case('bert_flm', None)
+
+
+def case_bert_flm_bottleneck():
+    _bert_flm_case('bert_flm_bottleneck', '256')
 
 
 def case_bert_tiny():
@@ -587,7 +643,8 @@ def case_mask_predict_race():
 
 
 CASES = dict(vq=case_vq, vqgan_tiny=case_vqgan_tiny, vqgan_full=case_vqgan_full, tower=case_tower, tower12=case_tower12,
-             bert_tiny=case_bert_tiny, bert_tiny_visual=case_bert_tiny_visual, artv_tiny=case_artv_tiny,
+             bert_tiny=case_bert_tiny, bert_tiny_visual=case_bert_tiny_visual, bert_flm=case_bert_flm,
+             bert_flm_bottleneck=case_bert_flm_bottleneck, artv_tiny=case_artv_tiny,
              mask_predict=case_mask_predict, frontend=case_frontend, mask_predict_race=case_mask_predict_race)
 
 if __name__ == '__main__':
