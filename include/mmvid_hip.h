@@ -59,6 +59,15 @@ int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64_t ldy, con
                        float* workspace, float* dW, int accumulate, void* stream);
 /* The split factor this library would choose for that GEMM on MI355X (1..16): size `workspace` with it. */
 int mmvid_gemm_dw_pick_splitk(int64_t M, int N, int K);
+/* The same weight gradient for `groups` Linear layers of one shape in ONE launch, without split-K (the autograd of the twelve
+ * ResidualAttentionBlocks' nn.Linear / in_proj weights, clip_model.py:196-227, taken after the layer loop): dW_list[g][N][K] (+)=
+ * dY_g^T X_g with dY_g = dY + g * strideY ([M][ldy]) and X_g = X + g * strideX ([M][ldx]), strides in elements; dW_list is a HOST
+ * array of `groups` device pointers (copied into the launch), a null entry is skipped.  Every block reduces over all M tokens
+ * in fp32: deterministic, no workspace.  mmvid_gemm_dw_grouped_fill = tiles / (whole rounds of the 256 CUs), the share of the
+ * chip such a launch keeps busy (the tower groups a kind of weight when it is >= 0.7). */
+int mmvid_gemm_bf16_dw_grouped(int64_t M, int N, int K, const void* dY, int64_t ldy, int64_t strideY, const void* X, int64_t ldx,
+                               int64_t strideX, int groups, float* const* dW_list, int accumulate, void* stream);
+double mmvid_gemm_dw_grouped_fill(int N, int K, int groups);
 
 /* ---- LayerNorm: clip_model.py:188-193 (fp32 statistics, eps 1e-5) and the nn.LayerNorm of the heads. */
 int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const float* w, const float* b, float eps,
@@ -250,7 +259,10 @@ int mmvid_tower_workspace(const mmvid_tower_cfg_t* cfg, int64_t* saved_bytes, in
 /* saved == NULL: inference (activations are not kept).  x_out may alias x_in only when saved == NULL. */
 int mmvid_tower_forward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                         float* x_out, void* saved, void* scratch, void* stream);
-/* g: dL/dx_out on entry, dL/dx_in on exit (in place, fp32 [B*L, E]). */
+/* g: dL/dx_out on entry, dL/dx_in on exit (in place, fp32 [B*L, E]).  With option dw_grouped (default) each layer's slice of the
+ * saved arena ends in room for that layer's four dY tensors (bf16): the backward writes them there -- `saved` is const only in its
+ * forward part -- and computes the weight gradients of all `cfg->layers` layers of a kind in one launch after the layer loop
+ * (mmvid_gemm_bf16_dw_grouped).  The option must not change between a forward and its backward (the slice size follows it). */
 int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
                          const void* saved, void* scratch, void* stream);
 

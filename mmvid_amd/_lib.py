@@ -41,6 +41,7 @@ SIGNATURES = {
     'mmvid_gemm_bf16': [I, I, I, I, I, P, I64, P, I64, I, I64, I64, I64, I, F, P, P, I64, P, P, I64, I, I, P, P, I64, P, P],
     'mmvid_gemm_bf16_dw': [I64, I, I, P, I64, P, I64, I, P, P, I, P],
     'mmvid_gemm_dw_pick_splitk': [I64, I, I],
+    'mmvid_gemm_bf16_dw_grouped': [I64, I, I, P, I64, I64, P, I64, I64, I, P, I, P],
     'mmvid_layernorm_fwd': [P, I64, I64, I, P, P, F, P, P, I64, P, P, P],
     'mmvid_layernorm_bwd': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P],
     'mmvid_layernorm_bwd_ws': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P, I64, P],
@@ -123,7 +124,7 @@ SIGNATURES = {
     'mmvid_prof_end': [P, P, P, P, I],
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I),
-         'mmvid_warp_params_bytes': ([], I)}
+         'mmvid_warp_params_bytes': ([], I), 'mmvid_gemm_dw_grouped_fill': ([I, I, I], ctypes.c_double)}
 
 class PosSegment(ctypes.Structure):
     """mmvid_pos_segment_t (include/mmvid_hip.h)."""

@@ -26,6 +26,8 @@ namespace {
 using namespace mmvid_core;
 
 
+constexpr int GROUP_MAX = 16;  // batch entries of one grouped launch (their output pointers travel in the kernel arguments)
+
 struct GemmParams {
     const bf16_t* A;
     const bf16_t* B;
@@ -59,6 +61,10 @@ struct GemmParams {
     long red_ld;
     int red_accumulate;
     int* counters;
+    // grouped launch (mmvid_gemm_bf16_dw_grouped): batch entry z writes the fp32 result at out_list[z] instead of out_f32 + z * strideC
+    // (the weight gradients of the layers are separate allocations); a null entry = nothing to do for that z (a frozen weight)
+    int n_out_list;
+    float* out_list[GROUP_MAX];
 };
 // counters of the fused split-K reduction: a ring (every launch takes the next `tiles` entries), zero-initialised with the module
 // and left zero by every launch, so neither an allocation nor a memset is ever needed (graph capture safe)
@@ -205,15 +211,16 @@ struct DirectEpi {
     int nst;  // vector-memory STORES per wave and tile (16 per output tensor)
     __device__ __forceinline__ void init(const GemmParams& p, int batch) {
         const long cb = (long)batch * p.strideC;
-        const float* addbase = p.residual ? p.residual + cb : ((p.accumulate && p.out_f32) ? p.out_f32 + cb : nullptr);
+        float* const of32 = p.n_out_list > 0 ? p.out_list[batch] : (p.out_f32 ? p.out_f32 + cb : nullptr);
+        const float* addbase = p.residual ? p.residual + cb : ((p.accumulate && of32) ? of32 : nullptr);
         const long ldadd = p.residual ? p.ldr : p.ldc;
         has_add = addbase != nullptr, has_dact = p.dact_pre != nullptr, has_save = p.save_pre != nullptr;
-        has_f32 = p.out_f32 != nullptr, has_bf16 = p.out_bf16 != nullptr;
-        const void* any = p.out_f32 ? (const void*)p.out_f32 : (const void*)p.out_bf16;
+        has_f32 = of32 != nullptr, has_bf16 = p.out_bf16 != nullptr;
+        const void* any = of32 ? (const void*)of32 : (const void*)p.out_bf16;
         r_add = make_rsrc(has_add ? (const void*)addbase : any, has_add ? (uint32_t)(((long)(p.M - 1) * ldadd + p.N) * 4) : 0u);
         r_pre_in = make_rsrc(has_dact ? (const void*)(p.dact_pre + cb) : any, has_dact ? (uint32_t)(((long)(p.M - 1) * p.ldp + p.N) * 2) : 0u);
         r_pre_out = make_rsrc(has_save ? (const void*)(p.save_pre + cb) : any, has_save ? (uint32_t)(((long)(p.M - 1) * p.ldp + p.N) * 2) : 0u);
-        r_f32 = make_rsrc(has_f32 ? (const void*)(p.out_f32 + cb) : any, has_f32 ? (uint32_t)(((long)(p.M - 1) * p.ldc + p.N) * 4) : 0u);
+        r_f32 = make_rsrc(has_f32 ? (const void*)of32 : any, has_f32 ? (uint32_t)(((long)(p.M - 1) * p.ldc + p.N) * 4) : 0u);
         r_bf16 = make_rsrc(has_bf16 ? (const void*)(p.out_bf16 + cb) : any, has_bf16 ? (uint32_t)(((long)(p.M - 1) * p.ldc + p.N) * 2) : 0u);
         nst = 16 * ((has_save ? 1 : 0) + (has_f32 ? 1 : 0) + (has_bf16 ? 1 : 0));
     }
@@ -674,6 +681,7 @@ __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_
     // blockIdx.z = batch entry, or (split-K: batch 1) the K range whose partial product goes to slab z of the workspace
     const int ks = p.splitk > 1 ? (int)blockIdx.z : 0;
     const int batch = blockIdx.z;  // (split-K: strideA = strideB = 0, strideC = M * N: slab ks)
+    if (p.n_out_list > 0 && p.out_list[batch] == nullptr) return;  // grouped launch: this entry has no output (block-uniform)
     const int gx = p.tiles_n > 0 ? p.tiles_n : (int)gridDim.x;
     const bf16_t* A = p.A + (long)batch * p.strideA;
     const bf16_t* B = p.B + (long)batch * p.strideB;
@@ -1204,6 +1212,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.tiles_n = p.tiles_m = 0;
     p.trace = g_gemm_trace;
     p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
+    p.n_out_list = 0;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor)
         launch<false, false>(p, batch, s);
@@ -1250,6 +1259,7 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     // split-K: the slabs are added in slab order either by the last block of each output tile inside the GEMM (option
     // gemm_fused_reduce, the 256x128 loader-wave kernel) or by splitk_reduce_kernel -- the same additions in the same order
     p.red_out = splitk > 1 ? dW : nullptr, p.red_ld = K, p.red_accumulate = accumulate, p.counters = nullptr;
+    p.n_out_list = 0;
     hipStream_t s = (hipStream_t)stream;
     g_last_launch_fused = false;
     launch<true, true>(p, 1, s);
@@ -1258,5 +1268,63 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(mn / 4, 256)), dim3(256), 0, s, workspace, splitk, mn, dW, accumulate);
     }
     MMVID_LAUNCH_CHECK("gemm_bf16_dw");
+    return MMVID_OK;
+}
+
+// How full the chip is when `groups` weight gradients [N][K] go out as ONE launch of 256x128 tiles without split-K: tiles over
+// whole rounds of the 256 CUs.  The tower backward groups a kind of weight gradient when this is >= 0.7, and otherwise keeps the
+// per-layer split-K launches (a group of few small matrices would leave most of the chip idle for a whole token reduction).
+extern "C" double mmvid_gemm_dw_grouped_fill(int N, int K, int groups) {
+    const long tiles = (long)cdiv(N, 256) * cdiv(K, BN) * groups;
+    const long rounds = cdiv(tiles, 256);
+    return tiles > 0 ? (double)tiles / (double)(rounds * 256) : 0.0;
+}
+
+// dW_g[N][K] (+)= dY_g^T X_g for g = 0 .. groups-1 in ONE launch (no split-K, no workspace: every block reduces over all M tokens in
+// fp32): dY_g = dY + g * strideY [M][ldy], X_g = X + g * strideX [M][ldx] (strides in elements), dW_list[g] = that group's output
+// [N][K] or null (skipped).  Deterministic.  MI355X-first: with 288 GB the backward can keep every layer's dY, and the weight
+// gradients of ALL layers then fill the chip without the split-K slabs (tools/bench_dw_grouped.py: 1.92 vs 2.82 ms per backward).
+extern "C" int mmvid_gemm_bf16_dw_grouped(int64_t M, int N, int K, const void* dY, int64_t ldy, int64_t strideY, const void* X,
+                                          int64_t ldx, int64_t strideX, int groups, float* const* dW_list, int accumulate,
+                                          void* stream) {
+    MMVID_REQUIRE(dY && X && dW_list && M > 0 && N > 0 && K > 0 && groups > 0, "gemm_bf16_dw_grouped: bad arguments");
+    MMVID_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && strideY % 8 == 0 && strideX % 8 == 0,
+                  "gemm_bf16_dw_grouped: N, K, ldy, ldx and the group strides must be multiples of 8");
+    MMVID_REQUIRE(M * ldy * 2 < (1ll << 31) && M * ldx * 2 < (1ll << 31), "gemm_bf16_dw_grouped: an operand of 2 GiB or more per group");
+    MMVID_REQUIRE((int64_t)(N - 1) * K + K < (1ll << 29), "gemm_bf16_dw_grouped: an output of 2 GiB or more");
+    using S = BlockShape<4>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_lw_kernel<true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(S::LDS_BYTES + BIAS_LDS_BYTES));
+        attr = true;
+    }
+    for (int g0 = 0; g0 < groups; g0 += GROUP_MAX) {
+        const int n = groups - g0 < GROUP_MAX ? groups - g0 : GROUP_MAX;
+        GemmParams p;
+        p.A = (const bf16_t*)dY + (int64_t)g0 * strideY, p.B = (const bf16_t*)X + (int64_t)g0 * strideX;
+        p.M = N, p.N = K, p.K = (int)M, p.lda = ldy, p.ldb = ldx;
+        p.strideA = strideY, p.strideB = strideX, p.strideC = 0, p.splitk = 1;
+        p.bias = nullptr, p.residual = nullptr, p.ldr = 0, p.dact_pre = nullptr, p.save_pre = nullptr, p.ldp = 0;
+        p.act = 0, p.accumulate = accumulate, p.alpha = 1.0f;
+        p.out_f32 = nullptr, p.out_bf16 = nullptr, p.ldc = K;
+        p.partial = nullptr, p.colsum = nullptr;
+        p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
+        p.tiles_n = p.tiles_m = 0, p.group_n = 0, p.defer = 0;
+        p.trace = nullptr;
+        p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
+        p.n_out_list = n;
+        bool any = false;
+        for (int g = 0; g < GROUP_MAX; ++g) {
+            p.out_list[g] = g < n ? dW_list[g0 + g] : nullptr;
+            any = any || p.out_list[g] != nullptr;
+        }
+        if (!any) continue;
+        MmvidProfScope prof(PROF_GEMM_TN, 2.0 * M * N * (double)K * n, (hipStream_t)stream);
+        const dim3 grid(cdiv(K, BN), cdiv(N, S::ROWS), n);
+        hipLaunchKernelGGL((gemm_bf16_lw_kernel<true, true, 1>), grid, dim3(512 + 64 * NLOAD), S::LDS_BYTES + BIAS_LDS_BYTES,
+                           (hipStream_t)stream, p);
+    }
+    MMVID_LAUNCH_CHECK("gemm_bf16_dw_grouped");
     return MMVID_OK;
 }

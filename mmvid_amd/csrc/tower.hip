@@ -27,8 +27,12 @@ Dims dims_of(const mmvid_tower_cfg_t& c) {
     return d;
 }
 
+// Grouped weight gradients (option dw_grouped, default on): the backward keeps every layer's four dY tensors -- bf16(g) in front
+// of c_proj (k_gpj) and of out_proj (k_gout), d_pre (k_dpre), dqkv (k_dqkv): M * (E + F + E + 3E) * 2 bytes per layer, 1.7 GB for
+// the 12-layer training step -- in the layer's slice of the saved arena (which exists only for a forward that will be
+// differentiated), so that the weight gradients of ALL layers of a kind go out as one launch after the layer loop.
 struct SavedLayer {  // byte offsets inside one layer's slice of the saved arena
-    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1, qkv, o, lse2, h2, pre, act, total;
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1, qkv, o, lse2, h2, pre, act, k_gpj, k_dpre, k_gout, k_dqkv, total;
 };
 SavedLayer saved_layout(const Dims& d) {
     SavedLayer s;
@@ -48,6 +52,9 @@ SavedLayer saved_layout(const Dims& d) {
     s.h2 = take(d.M * d.E * 2);
     s.pre = take(d.M * d.F * 2);
     s.act = take(d.M * d.F * 2);
+    const int64_t keep = mmvid_option(MMVID_OPT_DW_GROUPED) ? 1 : 0;  // (written by the backward only)
+    s.k_gpj = take(keep * d.M * d.E * 2), s.k_dpre = take(keep * d.M * d.F * 2);
+    s.k_gout = take(keep * d.M * d.E * 2), s.k_dqkv = take(keep * d.M * 3 * d.E * 2);
     s.total = off;
     return s;
 }
@@ -238,6 +245,81 @@ static SideStream& side_stream() {
     return ss;
 }
 
+// The layer loop with the weight gradients taken out of it: every layer writes its four dY tensors into its own slice of the
+// scratch arena's `keep` region (no copies: the kernels that produce them are pointed there), and after the loop the weight
+// gradients of each kind -- c_proj, c_fc, out_proj, in_proj -- are ONE launch over all layers of this call, each block reducing
+// over all tokens (no split-K slabs, no reduce launches).  A kind whose group would leave the chip mostly idle (few layers per
+// call: the chunked backward of the multi-GPU engine) keeps the per-layer split-K launches, run after the loop on the same data.
+// Same arithmetic per element up to the fp32 summation order of the token reduction (one chain instead of split-K slabs).
+static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g, const void* saved,
+                                  void* scratch, void* stream) {
+    const Dims d = dims_of(*cfg);
+    const SavedLayer sl = saved_layout(d);
+    const Scratch sc = scratch_layout(d);
+    char* scr = (char*)scratch;
+    char* keep = (char*)saved;  // (the kept tensors are the backward's own: written here, read by the launches after the loop)
+    struct { int64_t g_pj, d_pre, g_out, dqkv, total; } kl = {sl.k_gpj, sl.k_dpre, sl.k_gout, sl.k_dqkv, sl.total};
+    const float scale = 0.125f;
+    const bool dh16 = mmvid_option(MMVID_OPT_DH_BF16) != 0;
+    const bool fuse_fc_bias = mmvid_option(MMVID_OPT_FUSE_COLSUM) != 0;
+    void* d_h = scr + sc.d_h;
+    float* ws = (float*)(scr + sc.splitk_ws);
+    float* ln_ws = (float*)(scr + sc.ln_ws);
+    const int64_t ln_ws_floats = (int64_t)kLnBwdBlocks * 3 * d.E;
+    for (int i = d.layers - 1; i >= 0; --i) {
+        const mmvid_tower_layer_t& ly = layers[i];
+        const char* sv = (const char*)saved + (int64_t)i * sl.total;
+        char* kp = keep + (int64_t)i * kl.total;
+        void* g_pj = kp + kl.g_pj;  // bf16(g) in front of c_proj: the cast below (top layer of the call) or the layer above's LN1 backward
+        if (i == d.layers - 1) {
+            TRY(mmvid_cast_f32_to_bf16(g, g_pj, d.M * d.E, stream));
+            if (ly.g_pj_b) TRY(mmvid_colsum_bf16(g_pj, d.E, d.M, d.E, ly.g_pj_b, stream));
+        }
+        TRY(linear_dx(d.M, d.E, d.F, g_pj, ly.pj_w, sv + sl.pre, nullptr, kp + kl.d_pre, stream, fuse_fc_bias ? ly.g_fc_b : nullptr));
+        if (!fuse_fc_bias && ly.g_fc_b) TRY(mmvid_colsum_bf16(kp + kl.d_pre, d.F, d.M, d.F, ly.g_fc_b, stream));
+        TRY(linear_dx(d.M, d.F, d.E, kp + kl.d_pre, ly.fc_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
+        TRY(mmvid_layernorm_bwd_ex(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
+                                   (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, kp + kl.g_out, ly.g_ln2_w, ly.g_ln2_b,
+                                   ly.g_out_b, ln_ws, ln_ws_floats, stream));
+        TRY(linear_dx(d.M, d.E, d.E, kp + kl.g_out, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
+        TRY(mmvid_attention_bwd_bias(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
+                                     (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
+                                     cfg->r1, cfg->c1, kp + kl.dqkv, 3 * d.E, ly.g_in_b, stream));
+        TRY(linear_dx(d.M, 3 * d.E, d.E, kp + kl.dqkv, ly.in_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
+        TRY(mmvid_layernorm_bwd_ex(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
+                                   (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1,
+                                   i > 0 ? (void*)(keep + (int64_t)(i - 1) * kl.total + kl.g_pj) : nullptr, ly.g_ln1_w, ly.g_ln1_b,
+                                   i > 0 ? layers[i - 1].g_pj_b : nullptr, ln_ws, ln_ws_floats, stream));
+    }
+    // ---- the weight gradients: dW[N][K] += dY^T X per kind
+    struct Kind {
+        int N, K;
+        int64_t dy_off, x_off;  // inside a layer's keep slice / saved slice
+        float* mmvid_tower_layer_t::*gw;
+    };
+    const Kind kinds[4] = {{d.E, d.F, kl.g_pj, sl.act, &mmvid_tower_layer_t::g_pj_w},
+                           {d.F, d.E, kl.d_pre, sl.h2, &mmvid_tower_layer_t::g_fc_w},
+                           {d.E, d.E, kl.g_out, sl.o, &mmvid_tower_layer_t::g_out_w},
+                           {3 * d.E, d.E, kl.dqkv, sl.h1, &mmvid_tower_layer_t::g_in_w}};
+    // (The four launches are independent; putting two of them on a second stream so that their partial last rounds overlap was
+    // measured SLOWER on the captured step, 15.69 vs 15.56 ms: profiles/r03_ab_whole_step_dw_grouped.log.)
+    std::vector<float*> outs((size_t)d.layers);
+    for (const Kind& k : kinds) {
+        bool any = false;
+        for (int i = 0; i < d.layers; ++i) outs[(size_t)i] = layers[i].*(k.gw), any = any || outs[(size_t)i];
+        if (!any) continue;  // a frozen tower under trainable embeddings
+        if (mmvid_gemm_dw_grouped_fill(k.N, k.K, d.layers) >= 0.7) {
+            TRY(mmvid_gemm_bf16_dw_grouped(d.M, k.N, k.K, keep + k.dy_off, k.N, kl.total / 2, (const char*)saved + k.x_off, k.K,
+                                           sl.total / 2, d.layers, outs.data(), /*accumulate=*/1, stream));
+        } else {
+            for (int i = d.layers - 1; i >= 0; --i)
+                TRY(linear_dw(d.M, k.N, k.K, keep + (int64_t)i * kl.total + k.dy_off, (const char*)saved + (int64_t)i * sl.total + k.x_off,
+                              outs[(size_t)i], nullptr, ws, stream));
+        }
+    }
+    return MMVID_OK;
+}
+
 static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
                                   const void* saved, void* scratch, void* stream) {
     const Dims d = dims_of(*cfg);
@@ -273,6 +355,7 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
     auto wait = [&](hipEvent_t e) {
         if (e) hip_ok = hip_ok && hipStreamWaitEvent(s0, e, 0) == hipSuccess;
     };
+    if (mmvid_option(MMVID_OPT_DW_GROUPED) && !ss.ok) return tower_backward_grouped(cfg, layers, g, saved, scratch, stream);
     hipEvent_t ev_fc = nullptr, ev_in = nullptr;  // previous layer's dW chains that read d_pre / dqkv
     for (int i = d.layers - 1; i >= 0; --i) {
         const mmvid_tower_layer_t& ly = layers[i];

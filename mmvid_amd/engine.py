@@ -103,7 +103,9 @@ class FlatTrainer:
                 i = int(n.split('.')[3])
                 self._layer_start[i] = min(o, self._layer_start.get(i, tot))
         tw = getattr(model, 'transformer', None)
-        if tw is not None and hasattr(tw, 'on_layers_done') and self._layer_start:
+        # (only when there is something to exchange: a chunked backward returns to the host every few layers, and a group of one
+        # would pay for that -- the weight gradients of all layers could no longer go out as one launch per kind, csrc/tower.hip)
+        if tw is not None and hasattr(tw, 'on_layers_done') and self._layer_start and (self.world > 1 or self.force_exchange):
             tw.on_layers_done = self.layers_done
         self._init_lazy_rows(lazy_rows and os.environ.get('MMVID_LAZY_ROWS', '1') != '0')
 

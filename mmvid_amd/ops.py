@@ -108,6 +108,19 @@ def gemm_dw(dY, X, dW, accumulate=True, splitk=None):
     return dW
 
 
+def gemm_dw_grouped(dY, X, dWs, accumulate=True):
+    """dWs[g][N,K] (+)= dY[g]^T X[g] for all groups in one launch, no split-K (the tower backward's weight gradients of all layers of
+    a kind).  dY [G,M,N], X [G,M,K] bf16, contiguous; dWs: list of G fp32 [N,K] tensors or None (skipped)."""
+    _chk(dY, bf16, 'dY'), _chk(X, bf16, 'X')
+    G, M, N = dY.shape
+    K = X.shape[2]
+    assert X.shape[:2] == (G, M) and len(dWs) == G
+    ptrs = (ctypes.c_void_p * G)(*[(_chk(w, f32, 'dW').data_ptr() if w is not None else None) for w in dWs])
+    call('mmvid_gemm_bf16_dw_grouped', M, N, K, _p(dY), dY.stride(1), dY.stride(0), _p(X), X.stride(1), X.stride(0), G, ptrs,
+         int(accumulate), _stream())
+    return dWs
+
+
 def gemm_f32(A, B, *, b_kmajor=False, bias=None, residual=None, alpha=1.0):
     """Exact-fp32 GEMM (k-ordered fmaf chains on the f32 matrix pipe): C = alpha * A @ (B if b_kmajor else B^T).
     A [M,K] f32; B [N,K] (row-major) or [K,N] (b_kmajor)."""

@@ -756,3 +756,70 @@ def test_bert_fixed_language_model_vs_reference(golden, name, bn):
     torch.manual_seed(3)
     images, _, seq = m2.generate_images(feat[:1], mask_predict_steps=3, mp_config=golden('mask_predict').meta['mp_config'], dynamic=False)
     assert images.shape == (1, 2, 3, 64, 64) and seq.shape == (2, 16) and torch.isfinite(images).all()
+
+
+# ------------------------------------------------------------------------------ grouped weight gradients
+def test_grouped_weight_gradient_gemm():
+    """mmvid_gemm_bf16_dw_grouped: G weight gradients in one launch without split-K vs the per-layer split-K GEMM and an fp64
+    product; a skipped (null) entry, more groups than one launch holds, accumulate on / off, ragged tiles."""
+    from mmvid_amd import ops
+    torch.manual_seed(0)
+    for G, M, N, K in ((18, 1000, 768, 256), (3, 2317, 264, 776), (12, 579, 2304, 768)):
+        dY = (torch.randn(G, M, N, device=DEV) * 0.1).to(torch.bfloat16)
+        X = (torch.randn(G, M, K, device=DEV) * 0.1).to(torch.bfloat16)
+        ref = torch.einsum('gmn,gmk->gnk', dY.double(), X.double())
+        base = torch.randn(G, N, K, device=DEV)
+        for acc in (False, True):
+            outs = [base[g].clone() for g in range(G)]
+            skip = G // 2
+            outs_arg = [o if g != skip else None for g, o in enumerate(outs)]
+            ops.gemm_dw_grouped(dY, X, outs_arg, accumulate=acc)
+            per = [base[g].clone() for g in range(G)]
+            for g in range(G):
+                ops.gemm_dw(dY[g], X[g], per[g], accumulate=acc)
+            for g in range(G):
+                if g == skip:
+                    assert torch.equal(outs[g], base[g]), 'a null entry must leave its output alone'
+                    continue
+                want = ref[g] + (base[g].double() if acc else 0)
+                e = ((outs[g].double() - want).abs().max() / want.abs().max()).item()
+                e2 = ((outs[g] - per[g]).abs().max() / want.abs().max()).item()
+                assert e < 2e-5 and e2 < 2e-5, (G, M, N, K, acc, g, e, e2)
+            again = [base[g].clone() if g != skip else None for g in range(G)]
+            ops.gemm_dw_grouped(dY, X, again, accumulate=acc)
+            assert all(torch.equal(a, o) for a, o in zip(again, outs_arg) if a is not None), 'not deterministic'
+
+
+@pytest.mark.parametrize('chunked', [False, True])
+def test_tower_backward_grouped_weight_gradients(chunked):
+    """Option dw_grouped (default on): the layer loop keeps every layer's dY and the weight gradients of a kind are one launch after
+    it.  Against the per-layer split-K path: the input gradient is bit-identical (nothing on that chain changed), every parameter
+    gradient agrees to fp32 summation order; with the chunked backward of the multi-GPU engine (3 layers per call) only the kinds
+    that fill the chip are grouped."""
+    from mmvid_amd import _lib
+    from mmvid_amd.clip_tower import OpenAICLIPTransformer
+    from oracle.synth import synth_input
+    L = 579
+    res = {}
+    for opt in (0, 1):
+        _lib.call('mmvid_set_option', b'dw_grouped', opt)
+        torch.manual_seed(5)
+        tw = OpenAICLIPTransformer(L, 'openai_clip_visual', causal=True, mask_type='mask_prev', mask_kwargs={'index': [65, 66]}, layers=6).to(DEV)
+        done = []
+        if chunked:
+            tw.on_layers_done = done.append
+        x = synth_input('x', (4, L, 768), 13).to(DEV).requires_grad_(True)
+        y = tw(x)
+        y.backward(synth_input('gy', (4, L, 768), 14).to(DEV))
+        res[opt] = (x.grad.clone(), {k: p.grad.clone() for k, p in tw.named_parameters()})
+        if chunked:
+            assert done == [3, 0]
+    _lib.call('mmvid_set_option', b'dw_grouped', 1)
+    assert torch.equal(res[0][0], res[1][0]), 'the input gradient must not depend on where the weight gradients are computed'
+    worst = 0.0
+    for k, a in res[0][1].items():
+        b = res[1][1][k]
+        e = ((a - b).abs().max() / a.abs().max().clamp_min(1e-20)).item()
+        worst = max(worst, e)
+        assert e < 5e-5, (k, e)  # (bias gradients are atomically accumulated column sums: not bit-stable run to run either way)
+    print('worst relative difference of a parameter gradient, grouped vs per-layer split-K:', worst)
