@@ -59,15 +59,25 @@ int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64_t ldy, con
                        float* workspace, float* dW, int accumulate, void* stream);
 /* The split factor this library would choose for that GEMM on MI355X (1..16): size `workspace` with it. */
 int mmvid_gemm_dw_pick_splitk(int64_t M, int N, int K);
-/* The same weight gradient for `groups` Linear layers of one shape in ONE launch, without split-K (the autograd of the twelve
- * ResidualAttentionBlocks' nn.Linear / in_proj weights, clip_model.py:196-227, taken after the layer loop): dW_list[g][N][K] (+)=
- * dY_g^T X_g with dY_g = dY + g * strideY ([M][ldy]) and X_g = X + g * strideX ([M][ldx]), strides in elements; dW_list is a HOST
- * array of `groups` device pointers (copied into the launch), a null entry is skipped.  Every block reduces over all M tokens
- * in fp32: deterministic, no workspace.  mmvid_gemm_dw_grouped_fill = tiles / (whole rounds of the 256 CUs), the share of the
- * chip such a launch keeps busy (the tower groups a kind of weight when it is >= 0.7). */
+/* The same weight gradients for `groups` layers x `nkinds` Linear shapes in ONE launch, without split-K (the autograd of the twelve
+ * ResidualAttentionBlocks' in_proj / out_proj / c_fc / c_proj weights, clip_model.py:196-227, taken after the layer loop):
+ * dW_list[g][N][K] (+)= dY_g^T X_g with dY_g = dY + g * strideY ([M][ldy]) and X_g = X + g * strideX ([M][ldx]), strides in
+ * elements; dW_list is a HOST array of `groups` device pointers (copied into the launch; a null entry is skipped).  Every block
+ * reduces over all M tokens in fp32: deterministic, no workspace.  nkinds <= 4; any number of groups (several launches beyond
+ * 48 / nkinds).  mmvid_gemm_bf16_dw_grouped is the one-kind form.  mmvid_gemm_dw_multi_fill = output tiles / (whole rounds of
+ * the 256 CUs): the share of the chip such a launch keeps busy (the tower groups its weight gradients when it is >= 0.7). */
+typedef struct {
+    int N, K;              /* dW is [N][K] */
+    const void* dY;        /* bf16 [groups][M][ldy >= N] */
+    int64_t ldy, strideY;
+    const void* X;         /* bf16 [groups][M][ldx >= K] */
+    int64_t ldx, strideX;
+    float* const* dW_list; /* host array [groups] of device pointers */
+} mmvid_dw_kind_t;
+int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_kind_t* kinds, int groups, int accumulate, void* stream);
 int mmvid_gemm_bf16_dw_grouped(int64_t M, int N, int K, const void* dY, int64_t ldy, int64_t strideY, const void* X, int64_t ldx,
                                int64_t strideX, int groups, float* const* dW_list, int accumulate, void* stream);
-double mmvid_gemm_dw_grouped_fill(int N, int K, int groups);
+double mmvid_gemm_dw_multi_fill(int nkinds, const mmvid_dw_kind_t* kinds, int groups);
 
 /* ---- LayerNorm: clip_model.py:188-193 (fp32 statistics, eps 1e-5) and the nn.LayerNorm of the heads. */
 int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int E, const float* w, const float* b, float eps,

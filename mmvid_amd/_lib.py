@@ -42,6 +42,7 @@ SIGNATURES = {
     'mmvid_gemm_bf16_dw': [I64, I, I, P, I64, P, I64, I, P, P, I, P],
     'mmvid_gemm_dw_pick_splitk': [I64, I, I],
     'mmvid_gemm_bf16_dw_grouped': [I64, I, I, P, I64, I64, P, I64, I64, I, P, I, P],
+    'mmvid_gemm_bf16_dw_multi': [I64, I, P, I, I, P],
     'mmvid_layernorm_fwd': [P, I64, I64, I, P, P, F, P, P, I64, P, P, P],
     'mmvid_layernorm_bwd': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P],
     'mmvid_layernorm_bwd_ws': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P, I64, P],
@@ -124,7 +125,13 @@ SIGNATURES = {
     'mmvid_prof_end': [P, P, P, P, I],
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I),
-         'mmvid_warp_params_bytes': ([], I), 'mmvid_gemm_dw_grouped_fill': ([I, I, I], ctypes.c_double)}
+         'mmvid_warp_params_bytes': ([], I), 'mmvid_gemm_dw_multi_fill': ([I, P, I], ctypes.c_double)}
+
+class DwKind(ctypes.Structure):
+    """mmvid_dw_kind_t (include/mmvid_hip.h)."""
+    _fields_ = [('N', ctypes.c_int32), ('K', ctypes.c_int32), ('dY', ctypes.c_void_p), ('ldy', ctypes.c_int64), ('strideY', ctypes.c_int64),
+                ('X', ctypes.c_void_p), ('ldx', ctypes.c_int64), ('strideX', ctypes.c_int64), ('dW_list', ctypes.c_void_p)]
+
 
 class PosSegment(ctypes.Structure):
     """mmvid_pos_segment_t (include/mmvid_hip.h)."""

@@ -19,6 +19,7 @@
 // filled by LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds; ragged edges zero-filled by the range
 // check).  MFMA operands are swapped (a = B-frag, b = A-frag) so that each lane ends up with 4 consecutive n for one
 // m: 16-B epilogue loads/stores.  Roofline: bf16 MFMA (2.5 PFLOP/s dense); algorithmic FLOPs = 2*M*N*K.
+#include "../../include/mmvid_hip.h"
 #include "gemm_core.h"
 #include "prof.h"
 
@@ -26,7 +27,16 @@ namespace {
 using namespace mmvid_core;
 
 
-constexpr int GROUP_MAX = 16;  // batch entries of one grouped launch (their output pointers travel in the kernel arguments)
+constexpr int GROUP_MAX = 48;  // outputs of one grouped launch (their pointers travel in the kernel arguments)
+constexpr int KIND_MAX = 4;    // shapes of one grouped launch (mmvid_gemm_bf16_dw_multi: the four Linear weights of a ResidualAttentionBlock)
+struct GroupKind {             // one shape of a multi-shape grouped launch: `groups` products dW[M][N] = A_g^T B_g
+    const unsigned short* A;   // (bf16) group g at A + g * strideA, k-major [K][lda]
+    const unsigned short* B;
+    long strideA, strideB, lda, ldb;
+    int M, N, tiles_n, tiles_m;
+    int first;  // first tile (in the launch's linear tile order) of this kind
+    int out0;   // its outputs are out_list[out0 + g]
+};
 
 struct GemmParams {
     const bf16_t* A;
@@ -61,9 +71,13 @@ struct GemmParams {
     long red_ld;
     int red_accumulate;
     int* counters;
-    // grouped launch (mmvid_gemm_bf16_dw_grouped): batch entry z writes the fp32 result at out_list[z] instead of out_f32 + z * strideC
-    // (the weight gradients of the layers are separate allocations); a null entry = nothing to do for that z (a frozen weight)
-    int n_out_list;
+};
+// Second kernel argument of the grouped launch (mmvid_gemm_bf16_dw_multi): grid.x = all tiles of all kinds and groups; a block finds
+// its (kind, group, tile) here and patches its private copy of GemmParams (A, B, M, N, lda, ldb, ldc, out_f32).  The outputs are
+// separate allocations (the layers' weight gradients): their pointers travel in the kernel arguments; null = skipped (frozen weight).
+struct GroupTable {
+    int n_kinds;
+    GroupKind kinds[KIND_MAX];
     float* out_list[GROUP_MAX];
 };
 // counters of the fused split-K reduction: a ring (every launch takes the next `tiles` entries), zero-initialised with the module
@@ -211,16 +225,15 @@ struct DirectEpi {
     int nst;  // vector-memory STORES per wave and tile (16 per output tensor)
     __device__ __forceinline__ void init(const GemmParams& p, int batch) {
         const long cb = (long)batch * p.strideC;
-        float* const of32 = p.n_out_list > 0 ? p.out_list[batch] : (p.out_f32 ? p.out_f32 + cb : nullptr);
-        const float* addbase = p.residual ? p.residual + cb : ((p.accumulate && of32) ? of32 : nullptr);
+        const float* addbase = p.residual ? p.residual + cb : ((p.accumulate && p.out_f32) ? p.out_f32 + cb : nullptr);
         const long ldadd = p.residual ? p.ldr : p.ldc;
         has_add = addbase != nullptr, has_dact = p.dact_pre != nullptr, has_save = p.save_pre != nullptr;
-        has_f32 = of32 != nullptr, has_bf16 = p.out_bf16 != nullptr;
-        const void* any = of32 ? (const void*)of32 : (const void*)p.out_bf16;
+        has_f32 = p.out_f32 != nullptr, has_bf16 = p.out_bf16 != nullptr;
+        const void* any = p.out_f32 ? (const void*)p.out_f32 : (const void*)p.out_bf16;
         r_add = make_rsrc(has_add ? (const void*)addbase : any, has_add ? (uint32_t)(((long)(p.M - 1) * ldadd + p.N) * 4) : 0u);
         r_pre_in = make_rsrc(has_dact ? (const void*)(p.dact_pre + cb) : any, has_dact ? (uint32_t)(((long)(p.M - 1) * p.ldp + p.N) * 2) : 0u);
         r_pre_out = make_rsrc(has_save ? (const void*)(p.save_pre + cb) : any, has_save ? (uint32_t)(((long)(p.M - 1) * p.ldp + p.N) * 2) : 0u);
-        r_f32 = make_rsrc(has_f32 ? (const void*)of32 : any, has_f32 ? (uint32_t)(((long)(p.M - 1) * p.ldc + p.N) * 4) : 0u);
+        r_f32 = make_rsrc(has_f32 ? (const void*)(p.out_f32 + cb) : any, has_f32 ? (uint32_t)(((long)(p.M - 1) * p.ldc + p.N) * 4) : 0u);
         r_bf16 = make_rsrc(has_bf16 ? (const void*)(p.out_bf16 + cb) : any, has_bf16 ? (uint32_t)(((long)(p.M - 1) * p.ldc + p.N) * 2) : 0u);
         nst = 16 * ((has_save ? 1 : 0) + (has_f32 ? 1 : 0) + (has_bf16 ? 1 : 0));
     }
@@ -669,9 +682,27 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
 // k_loop_loader / k_loop_consumer), register-direct epilogues only (EPI 1: general, 2 / 3: packed bf16 with one / two outputs).
 // The loader requests the next output tile's first two K tiles while the MFMA waves are in their epilogue, so a persistent block
 // streams operands continuously; the MFMA waves never wait on vmcnt (their epilogue stores drain on their own).
-template <bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_kernel(GemmParams p) {
+template <bool AKM, bool BKM, int EPI, bool GROUPED>
+__device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt) {
     using S = BlockShape<4>;
+    int multi_bm0 = 0, multi_bn0 = 0;
+    if constexpr (GROUPED) {  // this block's (kind, group, tile): every XCD walks a contiguous stretch of the (kind, group, row, column) order
+        const int wg = xcd_remap(blockIdx.x, gridDim.x);
+        GroupKind kd = gt->kinds[0];  // (static indices + selects: a dynamically indexed copy would live in scratch memory)
+#pragma unroll
+        for (int i = 1; i < KIND_MAX; ++i)
+            if (wg >= gt->kinds[i].first) kd = gt->kinds[i];  // (unused kinds carry first = INT_MAX)
+        const int rem = wg - kd.first, per = kd.tiles_n * kd.tiles_m;
+        const int g = rem / per, t = rem - g * per;
+        float* const out = gt->out_list[kd.out0 + g];
+        if (out == nullptr) return;  // (block-uniform, before any barrier)
+        const int tm = t / kd.tiles_n, tn = t - tm * kd.tiles_n;
+        multi_bm0 = tm * S::ROWS, multi_bn0 = tn * BN;
+        p.A = kd.A + (long)g * kd.strideA, p.B = kd.B + (long)g * kd.strideB;
+        p.strideA = p.strideB = p.strideC = 0;
+        p.M = kd.M, p.N = kd.N, p.lda = kd.lda, p.ldb = kd.ldb, p.ldc = kd.N;
+        p.out_f32 = out;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];  // three stages, then the bias vector
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -681,7 +712,6 @@ __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_
     // blockIdx.z = batch entry, or (split-K: batch 1) the K range whose partial product goes to slab z of the workspace
     const int ks = p.splitk > 1 ? (int)blockIdx.z : 0;
     const int batch = blockIdx.z;  // (split-K: strideA = strideB = 0, strideC = M * N: slab ks)
-    if (p.n_out_list > 0 && p.out_list[batch] == nullptr) return;  // grouped launch: this entry has no output (block-uniform)
     const int gx = p.tiles_n > 0 ? p.tiles_n : (int)gridDim.x;
     const bf16_t* A = p.A + (long)batch * p.strideA;
     const bf16_t* B = p.B + (long)batch * p.strideB;
@@ -696,6 +726,10 @@ __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_
         __syncthreads();
     }
     auto tile_origin = [&](int tile, int& bm0, int& bn0) {
+        if constexpr (GROUPED) {
+            bm0 = multi_bm0, bn0 = multi_bn0;
+            return;
+        }
         const int wg = p.tiles_n > 0 ? xcd_remap(tile, ntiles) : xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
         int tn = wg % gx, tm = wg / gx;
         if (p.tiles_n > 0 && p.group_n > 0) {  // column-group-major: group g = column tiles [g * group_n, ...), rows inside it, columns fastest
@@ -808,6 +842,15 @@ __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_
             }
         }
     }
+}
+
+template <bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_kernel(GemmParams p) {
+    gemm_lw_body<AKM, BKM, EPI, false>(p, nullptr);
+}
+// the grouped weight-gradient launch: both operands k-major, general register-direct epilogue (fp32 += result)
+__global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_grouped_kernel(GemmParams p, GroupTable gt) {
+    gemm_lw_body<true, true, 1, true>(p, &gt);
 }
 
 // ================================================================================================================
@@ -1212,7 +1255,6 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.tiles_n = p.tiles_m = 0;
     p.trace = g_gemm_trace;
     p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
-    p.n_out_list = 0;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor)
         launch<false, false>(p, batch, s);
@@ -1259,7 +1301,6 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     // split-K: the slabs are added in slab order either by the last block of each output tile inside the GEMM (option
     // gemm_fused_reduce, the 256x128 loader-wave kernel) or by splitk_reduce_kernel -- the same additions in the same order
     p.red_out = splitk > 1 ? dW : nullptr, p.red_ld = K, p.red_accumulate = accumulate, p.counters = nullptr;
-    p.n_out_list = 0;
     hipStream_t s = (hipStream_t)stream;
     g_last_launch_fused = false;
     launch<true, true>(p, 1, s);
@@ -1271,60 +1312,95 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     return MMVID_OK;
 }
 
-// How full the chip is when `groups` weight gradients [N][K] go out as ONE launch of 256x128 tiles without split-K: tiles over
-// whole rounds of the 256 CUs.  The tower backward groups a kind of weight gradient when this is >= 0.7, and otherwise keeps the
-// per-layer split-K launches (a group of few small matrices would leave most of the chip idle for a whole token reduction).
-extern "C" double mmvid_gemm_dw_grouped_fill(int N, int K, int groups) {
-    const long tiles = (long)cdiv(N, 256) * cdiv(K, BN) * groups;
-    const long rounds = cdiv(tiles, 256);
-    return tiles > 0 ? (double)tiles / (double)(rounds * 256) : 0.0;
-}
-
-// dW_g[N][K] (+)= dY_g^T X_g for g = 0 .. groups-1 in ONE launch (no split-K, no workspace: every block reduces over all M tokens in
-// fp32): dY_g = dY + g * strideY [M][ldy], X_g = X + g * strideX [M][ldx] (strides in elements), dW_list[g] = that group's output
-// [N][K] or null (skipped).  Deterministic.  MI355X-first: with 288 GB the backward can keep every layer's dY, and the weight
-// gradients of ALL layers then fill the chip without the split-K slabs (tools/bench_dw_grouped.py: 1.92 vs 2.82 ms per backward).
-extern "C" int mmvid_gemm_bf16_dw_grouped(int64_t M, int N, int K, const void* dY, int64_t ldy, int64_t strideY, const void* X,
-                                          int64_t ldx, int64_t strideX, int groups, float* const* dW_list, int accumulate,
-                                          void* stream) {
-    MMVID_REQUIRE(dY && X && dW_list && M > 0 && N > 0 && K > 0 && groups > 0, "gemm_bf16_dw_grouped: bad arguments");
-    MMVID_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && strideY % 8 == 0 && strideX % 8 == 0,
-                  "gemm_bf16_dw_grouped: N, K, ldy, ldx and the group strides must be multiples of 8");
-    MMVID_REQUIRE(M * ldy * 2 < (1ll << 31) && M * ldx * 2 < (1ll << 31), "gemm_bf16_dw_grouped: an operand of 2 GiB or more per group");
-    MMVID_REQUIRE((int64_t)(N - 1) * K + K < (1ll << 29), "gemm_bf16_dw_grouped: an output of 2 GiB or more");
+// dW_{k,g}[N_k][K_k] (+)= dY_{k,g}^T X_{k,g} for every kind k < nkinds (a shape) and group g < groups (a layer) in ONE launch: no
+// split-K, no workspace, every block reduces over all M tokens in fp32 (deterministic).  The grid is the list of all output tiles;
+// XCD x walks a contiguous stretch of it (tiles of one layer share their operand panels in that XCD's L2).  MI355X-first: with
+// 288 GB the backward can keep every layer's dY, and the weight gradients of ALL layers then fill the chip without split-K slabs
+// (tools/bench_dw_grouped.py; captured step 16.36 -> 15.56 ms, profiles/r03_ab_whole_step_dw_grouped.log).
+extern "C" int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_kind_t* kinds, int groups, int accumulate, void* stream) {
+    MMVID_REQUIRE(kinds && M > 0 && nkinds > 0 && nkinds <= KIND_MAX && groups > 0, "gemm_bf16_dw_multi: bad arguments");
     using S = BlockShape<4>;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_lw_kernel<true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_lw_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(S::LDS_BYTES + BIAS_LDS_BYTES));
         attr = true;
     }
-    for (int g0 = 0; g0 < groups; g0 += GROUP_MAX) {
-        const int n = groups - g0 < GROUP_MAX ? groups - g0 : GROUP_MAX;
+    for (int k = 0; k < nkinds; ++k) {
+        const mmvid_dw_kind_t& kd = kinds[k];
+        MMVID_REQUIRE(kd.dY && kd.X && kd.dW_list && kd.N > 0 && kd.K > 0, "gemm_bf16_dw_multi: kind %d: null pointer / bad size", k);
+        MMVID_REQUIRE(kd.N % 8 == 0 && kd.K % 8 == 0 && kd.ldy % 8 == 0 && kd.ldx % 8 == 0 && kd.strideY % 8 == 0 && kd.strideX % 8 == 0,
+                      "gemm_bf16_dw_multi: kind %d: N, K, ldy, ldx and the group strides must be multiples of 8", k);
+        MMVID_REQUIRE(M * kd.ldy * 2 < (1ll << 31) && M * kd.ldx * 2 < (1ll << 31), "gemm_bf16_dw_multi: an operand of 2 GiB or more per group");
+        MMVID_REQUIRE((int64_t)kd.N * kd.K < (1ll << 29), "gemm_bf16_dw_multi: an output of 2 GiB or more");
+    }
+    const int per_launch = GROUP_MAX / nkinds;  // groups whose output pointers fit one launch
+    for (int g0 = 0; g0 < groups; g0 += per_launch) {
+        const int n = groups - g0 < per_launch ? groups - g0 : per_launch;
+        GroupTable gt;
+        gt.n_kinds = nkinds;
+        int tiles = 0;
+        bool any = false;
+        double flops = 0;
+        for (int g = 0; g < GROUP_MAX; ++g) gt.out_list[g] = nullptr;
+        for (int k = 0; k < KIND_MAX; ++k) {
+            GroupKind& o = gt.kinds[k];
+            if (k >= nkinds) {
+                o = gt.kinds[0];
+                o.first = 0x7fffffff;
+                continue;
+            }
+            const mmvid_dw_kind_t& kd = kinds[k];
+            o.A = (const unsigned short*)kd.dY + (int64_t)g0 * kd.strideY, o.B = (const unsigned short*)kd.X + (int64_t)g0 * kd.strideX;
+            o.strideA = kd.strideY, o.strideB = kd.strideX, o.lda = kd.ldy, o.ldb = kd.ldx;
+            o.M = kd.N, o.N = kd.K, o.tiles_n = cdiv(kd.K, BN), o.tiles_m = cdiv(kd.N, S::ROWS);
+            o.first = tiles, o.out0 = k * n;
+            tiles += o.tiles_n * o.tiles_m * n;
+            for (int g = 0; g < n; ++g) {
+                gt.out_list[o.out0 + g] = kd.dW_list[g0 + g];
+                if (kd.dW_list[g0 + g]) any = true, flops += 2.0 * M * kd.N * (double)kd.K;
+            }
+        }
+        if (!any) continue;
         GemmParams p;
-        p.A = (const bf16_t*)dY + (int64_t)g0 * strideY, p.B = (const bf16_t*)X + (int64_t)g0 * strideX;
-        p.M = N, p.N = K, p.K = (int)M, p.lda = ldy, p.ldb = ldx;
-        p.strideA = strideY, p.strideB = strideX, p.strideC = 0, p.splitk = 1;
+        p.A = gt.kinds[0].A, p.B = gt.kinds[0].B;
+        p.M = gt.kinds[0].M, p.N = gt.kinds[0].N, p.K = (int)M, p.lda = gt.kinds[0].lda, p.ldb = gt.kinds[0].ldb;
+        p.strideA = p.strideB = p.strideC = 0, p.splitk = 1;
         p.bias = nullptr, p.residual = nullptr, p.ldr = 0, p.dact_pre = nullptr, p.save_pre = nullptr, p.ldp = 0;
         p.act = 0, p.accumulate = accumulate, p.alpha = 1.0f;
-        p.out_f32 = nullptr, p.out_bf16 = nullptr, p.ldc = K;
+        p.out_f32 = nullptr, p.out_bf16 = nullptr, p.ldc = gt.kinds[0].N;
         p.partial = nullptr, p.colsum = nullptr;
         p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
         p.tiles_n = p.tiles_m = 0, p.group_n = 0, p.defer = 0;
         p.trace = nullptr;
         p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
-        p.n_out_list = n;
-        bool any = false;
-        for (int g = 0; g < GROUP_MAX; ++g) {
-            p.out_list[g] = g < n ? dW_list[g0 + g] : nullptr;
-            any = any || p.out_list[g] != nullptr;
-        }
-        if (!any) continue;
-        MmvidProfScope prof(PROF_GEMM_TN, 2.0 * M * N * (double)K * n, (hipStream_t)stream);
-        const dim3 grid(cdiv(K, BN), cdiv(N, S::ROWS), n);
-        hipLaunchKernelGGL((gemm_bf16_lw_kernel<true, true, 1>), grid, dim3(512 + 64 * NLOAD), S::LDS_BYTES + BIAS_LDS_BYTES,
-                           (hipStream_t)stream, p);
+        MmvidProfScope prof(PROF_GEMM_TN, flops, (hipStream_t)stream);
+        hipLaunchKernelGGL(gemm_bf16_lw_grouped_kernel, dim3(tiles), dim3(512 + 64 * NLOAD), S::LDS_BYTES + BIAS_LDS_BYTES,
+                           (hipStream_t)stream, p, gt);
     }
-    MMVID_LAUNCH_CHECK("gemm_bf16_dw_grouped");
+    MMVID_LAUNCH_CHECK("gemm_bf16_dw_multi");
     return MMVID_OK;
+}
+
+// one kind: dW_list[g][N][K] (+)= dY_g^T X_g
+extern "C" int mmvid_gemm_bf16_dw_grouped(int64_t M, int N, int K, const void* dY, int64_t ldy, int64_t strideY, const void* X,
+                                          int64_t ldx, int64_t strideX, int groups, float* const* dW_list, int accumulate,
+                                          void* stream) {
+    mmvid_dw_kind_t kd;
+    kd.N = N, kd.K = K, kd.dY = dY, kd.ldy = ldy, kd.strideY = strideY, kd.X = X, kd.ldx = ldx, kd.strideX = strideX, kd.dW_list = dW_list;
+    return mmvid_gemm_bf16_dw_multi(M, 1, &kd, groups, accumulate, stream);
+}
+
+// How full the chip is when `tiles` output tiles of 256x128 go out as one launch of whole-token-reduction blocks: tiles over whole
+// rounds of the 256 CUs.  The tower backward groups its weight gradients when this is >= 0.7 and otherwise keeps the per-layer
+// split-K launches (a few small matrices would leave most of the chip idle for a whole token reduction).
+extern "C" double mmvid_gemm_dw_multi_fill(int nkinds, const mmvid_dw_kind_t* kinds, int groups) {
+    long tiles = 0;
+    for (int k = 0; k < nkinds; ++k) {
+        long live = 0;
+        for (int g = 0; g < groups; ++g) live += kinds[k].dW_list == nullptr || kinds[k].dW_list[g] != nullptr;
+        tiles += (long)cdiv(kinds[k].N, 256) * cdiv(kinds[k].K, BN) * live;
+    }
+    const long rounds = cdiv(tiles, 256);
+    return tiles > 0 ? (double)tiles / (double)(rounds * 256) : 0.0;
 }

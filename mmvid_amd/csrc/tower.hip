@@ -301,22 +301,32 @@ static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_towe
                            {d.F, d.E, kl.d_pre, sl.h2, &mmvid_tower_layer_t::g_fc_w},
                            {d.E, d.E, kl.g_out, sl.o, &mmvid_tower_layer_t::g_out_w},
                            {3 * d.E, d.E, kl.dqkv, sl.h1, &mmvid_tower_layer_t::g_in_w}};
-    // (The four launches are independent; putting two of them on a second stream so that their partial last rounds overlap was
-    // measured SLOWER on the captured step, 15.69 vs 15.56 ms: profiles/r03_ab_whole_step_dw_grouped.log.)
-    std::vector<float*> outs((size_t)d.layers);
+    // ONE launch for the four kinds (one launch per kind left three partial last rounds; putting two of the four on a second stream
+    // so that those overlap was measured SLOWER on the captured step, 15.69 vs 15.56 ms: profiles/r03_ab_whole_step_dw_grouped.log).
+    std::vector<float*> outs((size_t)d.layers * 4);
+    mmvid_dw_kind_t kd[4];
+    int nk = 0;
     for (const Kind& k : kinds) {
+        float** o = outs.data() + (size_t)nk * d.layers;
         bool any = false;
-        for (int i = 0; i < d.layers; ++i) outs[(size_t)i] = layers[i].*(k.gw), any = any || outs[(size_t)i];
-        if (!any) continue;  // a frozen tower under trainable embeddings
-        if (mmvid_gemm_dw_grouped_fill(k.N, k.K, d.layers) >= 0.7) {
-            TRY(mmvid_gemm_bf16_dw_grouped(d.M, k.N, k.K, keep + k.dy_off, k.N, kl.total / 2, (const char*)saved + k.x_off, k.K,
-                                           sl.total / 2, d.layers, outs.data(), /*accumulate=*/1, stream));
-        } else {
-            for (int i = d.layers - 1; i >= 0; --i)
-                TRY(linear_dw(d.M, k.N, k.K, keep + (int64_t)i * kl.total + k.dy_off, (const char*)saved + (int64_t)i * sl.total + k.x_off,
-                              outs[(size_t)i], nullptr, ws, stream));
-        }
+        for (int i = 0; i < d.layers; ++i) o[i] = layers[i].*(k.gw), any = any || o[i];
+        if (!any) continue;  // a frozen weight (a frozen tower under trainable embeddings: none at all)
+        kd[nk].N = k.N, kd[nk].K = k.K;
+        kd[nk].dY = keep + k.dy_off, kd[nk].ldy = k.N, kd[nk].strideY = kl.total / 2;
+        kd[nk].X = (const char*)saved + k.x_off, kd[nk].ldx = k.K, kd[nk].strideX = sl.total / 2;
+        kd[nk].dW_list = o;
+        ++nk;
     }
+    if (nk == 0) return MMVID_OK;
+    if (mmvid_option(MMVID_OPT_DW_GROUPED) == 2) {  // measurement: one launch per kind (each with its own partial last round)
+        for (int k = 0; k < nk; ++k) TRY(mmvid_gemm_bf16_dw_multi(d.M, 1, kd + k, d.layers, 1, stream));
+        return MMVID_OK;
+    }
+    if (mmvid_gemm_dw_multi_fill(nk, kd, d.layers) >= 0.7) return mmvid_gemm_bf16_dw_multi(d.M, nk, kd, d.layers, /*accumulate=*/1, stream);
+    for (int k = 0; k < nk; ++k)  // few tiles (short calls of a chunked backward on a small model): per layer, split-K
+        for (int i = d.layers - 1; i >= 0; --i)
+            TRY(linear_dw(d.M, kd[k].N, kd[k].K, (const char*)kd[k].dY + (int64_t)i * kl.total, (const char*)kd[k].X + (int64_t)i * sl.total,
+                          kd[k].dW_list[i], nullptr, ws, stream));
     return MMVID_OK;
 }
 

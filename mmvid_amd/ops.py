@@ -121,6 +121,36 @@ def gemm_dw_grouped(dY, X, dWs, accumulate=True):
     return dWs
 
 
+def _dw_kinds(kinds):
+    """[(dY [G,M,N], X [G,M,K], [dW or None] * G)] -> (mmvid_dw_kind_t array, keep-alive list, M, G)."""
+    arr = (_lib.DwKind * len(kinds))()
+    keep = []
+    G, M = kinds[0][0].shape[:2]
+    for a, (dY, X, dWs) in zip(arr, kinds):
+        _chk(dY, bf16, 'dY'), _chk(X, bf16, 'X')
+        assert dY.shape[:2] == (G, M) and X.shape[:2] == (G, M) and len(dWs) == G
+        ptrs = (ctypes.c_void_p * G)(*[(_chk(w, f32, 'dW').data_ptr() if w is not None else None) for w in dWs])
+        keep.append(ptrs)
+        a.N, a.K, a.dY, a.ldy, a.strideY = dY.shape[2], X.shape[2], dY.data_ptr(), dY.stride(1), dY.stride(0)
+        a.X, a.ldx, a.strideX, a.dW_list = X.data_ptr(), X.stride(1), X.stride(0), ctypes.cast(ptrs, ctypes.c_void_p)
+    return arr, keep, M, G
+
+
+def gemm_dw_multi(kinds, accumulate=True):
+    """Weight gradients of several Linear shapes x several layers in one launch: kinds = [(dY [G,M,N_k], X [G,M,K_k], [dW [N_k,K_k]
+    fp32 or None] * G)], at most 4 kinds.  dW (+)= dY[g]^T X[g]."""
+    arr, keep, M, G = _dw_kinds(kinds)
+    call('mmvid_gemm_bf16_dw_multi', M, len(kinds), arr, G, int(accumulate), _stream())
+
+
+def gemm_dw_multi_fill(shapes, groups):
+    """[(N, K)] -> share of the chip one grouped launch of those weight gradients x `groups` layers keeps busy (host-side policy)."""
+    arr = (_lib.DwKind * len(shapes))()
+    for a, (N, K) in zip(arr, shapes):
+        a.N, a.K, a.dW_list = N, K, None
+    return _lib.load().mmvid_gemm_dw_multi_fill(len(shapes), arr, groups)
+
+
 def gemm_f32(A, B, *, b_kmajor=False, bias=None, residual=None, alpha=1.0):
     """Exact-fp32 GEMM (k-ordered fmaf chains on the f32 matrix pipe): C = alpha * A @ (B if b_kmajor else B^T).
     A [M,K] f32; B [N,K] (row-major) or [K,N] (b_kmajor)."""

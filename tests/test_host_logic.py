@@ -354,11 +354,13 @@ def test_library_host_side_policies():
     assert lib.mmvid_gemm_dw_pick_splitk(10422, 3072, 768) == 3    # 72 tiles
     assert lib.mmvid_gemm_dw_pick_splitk(100, 768, 768) == 1       # too few tokens to split
     assert lib.mmvid_gemm_dw_pick_splitk(10 ** 6, 8192, 8192) == 1  # already more tiles than CUs
-    # grouped weight gradients: tiles over whole rounds of the 256 CUs; the tower groups a kind at >= 0.7
-    fill = lib.mmvid_gemm_dw_grouped_fill
-    assert abs(fill(768, 768, 12) - 216 / 256) < 1e-12 and abs(fill(2304, 768, 12) - 648 / 768) < 1e-12
-    assert abs(fill(3072, 768, 12) - 864 / 1024) < 1e-12 and abs(fill(768, 3072, 12) - 864 / 1024) < 1e-12
-    assert fill(768, 768, 3) < 0.7 and fill(2304, 768, 3) < 0.7 and fill(3072, 768, 3) >= 0.7  # chunks of 3 layers (multi-GPU engine)
+    # grouped weight gradients: output tiles over whole rounds of the 256 CUs; the tower groups them at >= 0.7
+    from mmvid_amd import ops
+    four = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]  # c_proj, c_fc, out_proj, in_proj of ViT-B/32
+    assert abs(ops.gemm_dw_multi_fill(four, 12) - 2592 / (11 * 256)) < 1e-12   # the training step: 10.1 -> 11 rounds
+    assert abs(ops.gemm_dw_multi_fill(four, 3) - 648 / (3 * 256)) < 1e-12     # chunks of 3 layers (multi-GPU engine)
+    assert abs(ops.gemm_dw_multi_fill([(768, 768)], 12) - 216 / 256) < 1e-12
+    assert ops.gemm_dw_multi_fill([(768, 768)], 3) < 0.7 and ops.gemm_dw_multi_fill([(512, 512)], 2) < 0.7
     _lib.call('mmvid_set_option', b'dw_grouped', 1)
     _lib.call('mmvid_set_option', b'gemm_tile', 0)
     with pytest.raises(_lib.MMVIDError, match='unknown option'):

@@ -790,12 +790,50 @@ def test_grouped_weight_gradient_gemm():
             assert all(torch.equal(a, o) for a, o in zip(again, outs_arg) if a is not None), 'not deterministic'
 
 
+def test_multi_shape_grouped_weight_gradient_gemm():
+    """mmvid_gemm_bf16_dw_multi: the four Linear shapes of a ResidualAttentionBlock x several layers in ONE launch (what the tower
+    backward issues after its layer loop), against fp64 products; a frozen kind (all outputs null), a frozen layer, 13 layers
+    (more than one launch's pointer table holds for four kinds), ragged shapes."""
+    from mmvid_amd import ops
+    torch.manual_seed(1)
+    for G, M, shapes in ((13, 700, [(256, 1024), (1024, 256), (256, 256), (768, 256)]), (3, 1237, [(264, 520), (520, 264)]),
+                         (12, 579, [(768, 3072), (3072, 768), (768, 768), (2304, 768)])):
+        kinds, refs, bases = [], [], []
+        for ki, (N, K) in enumerate(shapes):
+            dY = (torch.randn(G, M, N, device=DEV) * 0.1).to(torch.bfloat16)
+            X = (torch.randn(G, M, K, device=DEV) * 0.1).to(torch.bfloat16)
+            base = torch.randn(G, N, K, device=DEV)
+            outs = [base[g].clone() for g in range(G)]
+            frozen_kind = ki == 2 and len(shapes) == 4 and G == 13
+            arg = [None if (frozen_kind or (g == 1 and ki == 0)) else o for g, o in enumerate(outs)]
+            kinds.append((dY, X, arg))
+            refs.append(torch.einsum('gmn,gmk->gnk', dY.double(), X.double()))
+            bases.append((base, outs))
+        ops.gemm_dw_multi(kinds, accumulate=True)
+        for (dY, X, arg), ref, (base, outs) in zip(kinds, refs, bases):
+            for g in range(G):
+                if arg[g] is None:
+                    assert torch.equal(outs[g], base[g])
+                    continue
+                want = ref[g] + base[g].double()
+                e = ((outs[g].double() - want).abs().max() / want.abs().max()).item()
+                assert e < 2e-5, (G, M, tuple(dY.shape), g, e)
+        first = [[o.clone() if o is not None else None for o in arg] for _, _, arg in kinds]
+        for (dY, X, arg), (base, outs) in zip(kinds, bases):
+            for g, o in enumerate(arg):
+                if o is not None:
+                    o.copy_(base[g])
+        ops.gemm_dw_multi(kinds, accumulate=True)
+        for (_, _, arg), f in zip(kinds, first):
+            assert all(torch.equal(a, b) for a, b in zip(arg, f) if a is not None), 'not deterministic'
+
+
 @pytest.mark.parametrize('chunked', [False, True])
 def test_tower_backward_grouped_weight_gradients(chunked):
     """Option dw_grouped (default on): the layer loop keeps every layer's dY and the weight gradients of a kind are one launch after
     it.  Against the per-layer split-K path: the input gradient is bit-identical (nothing on that chain changed), every parameter
-    gradient agrees to fp32 summation order; with the chunked backward of the multi-GPU engine (3 layers per call) only the kinds
-    that fill the chip are grouped."""
+    gradient agrees to fp32 summation order; the same with the chunked backward of the multi-GPU engine (3 layers per call and
+    launch)."""
     from mmvid_amd import _lib
     from mmvid_amd.clip_tower import OpenAICLIPTransformer
     from oracle.synth import synth_input
