@@ -100,6 +100,20 @@ int mmvid_layernorm_bwd_ex(const void* dy, int dy_is_bf16, int64_t lddy, const f
                            const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx, int add_into_dx,
                            void* dx_bf16, float* dw, float* db, float* dx_colsum, float* workspace, int64_t workspace_floats,
                            void* stream);
+/* The two stages apart, for a caller that runs several LayerNorm backwards and reduces their parameter gradients together (the
+ * tower backward: ln_1 / ln_2 of clip_model.py:188-193, 224-227 for all layers): _partial computes dx and leaves the weight / bias /
+ * column-sum gradients as *blocks_out partial rows [blocks][3][E] in `workspace` (>= 64 * 3 * E floats, this call's own);
+ * _reduce_multi adds the rows of n such calls into their targets (null targets skipped) in one launch, in the fixed order of the
+ * single-call reduction: deterministic, bit-identical to mmvid_layernorm_bwd_ex with a workspace. */
+typedef struct {
+    const float* partial; /* [blocks][3][E] */
+    float *dw, *db, *dx_colsum;
+} mmvid_ln_reduce_t;
+int mmvid_layernorm_bwd_partial(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx, int add_into_dx,
+                                void* dx_bf16, int want_dw, int want_db, int want_colsum, float* workspace,
+                                int64_t workspace_floats, int* blocks_out, void* stream);
+int mmvid_layernorm_bwd_reduce_multi(int n, const mmvid_ln_reduce_t* items, int blocks, int E, void* stream);
 /* GroupNorm(32, eps) [+ swish] on NHWC: taming/modules/diffusionmodules/model.py:38-42, 33-35.
  * stats_scratch: fp32 [N * (2*C + 64 * ceil(hw / 128))] = the per-channel affine [N][C][2], then partial sums
  * [N][blocks][32][2].  partial_blocks = 0: the statistics pass runs here; = hw/128: the producing convolution

@@ -46,6 +46,8 @@ SIGNATURES = {
     'mmvid_layernorm_fwd': [P, I64, I64, I, P, P, F, P, P, I64, P, P, P],
     'mmvid_layernorm_bwd': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P],
     'mmvid_layernorm_bwd_ws': [P, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P, I64, P],
+    'mmvid_layernorm_bwd_partial': [P, I, I64, P, I64, P, P, P, I64, I, P, I64, I, P, I, I, I, P, I64, P, P],
+    'mmvid_layernorm_bwd_reduce_multi': [I, P, I, I, P],
     'mmvid_layernorm_bwd_ex': [P, I, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P, I64, P],
     'mmvid_groupnorm_swish_nhwc': [P, I, I, I64, I, P, P, F, I, P, I, P, P, P],
     'mmvid_attention_fwd': [P, I64, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
@@ -131,6 +133,11 @@ class DwKind(ctypes.Structure):
     """mmvid_dw_kind_t (include/mmvid_hip.h)."""
     _fields_ = [('N', ctypes.c_int32), ('K', ctypes.c_int32), ('dY', ctypes.c_void_p), ('ldy', ctypes.c_int64), ('strideY', ctypes.c_int64),
                 ('X', ctypes.c_void_p), ('ldx', ctypes.c_int64), ('strideX', ctypes.c_int64), ('dW_list', ctypes.c_void_p)]
+
+
+class LnReduce(ctypes.Structure):
+    """mmvid_ln_reduce_t (include/mmvid_hip.h)."""
+    _fields_ = [('partial', ctypes.c_void_p), ('dw', ctypes.c_void_p), ('db', ctypes.c_void_p), ('dx_colsum', ctypes.c_void_p)]
 
 
 class PosSegment(ctypes.Structure):

@@ -2,6 +2,7 @@
 //   LayerNorm forward/backward     clip_model.py:188-193 (eps 1e-5, fp32 math), dalle_bert.py:414-425 heads
 //   GroupNorm(32, eps 1e-6)+swish  taming/modules/diffusionmodules/model.py:38-42, 33-35 (NHWC here)
 // One wave per row for LayerNorm (E <= 64*4*MAXV lanes*float4), 16-B accesses.
+#include "../../include/mmvid_hip.h"
 #include "common.h"
 
 namespace {
@@ -222,6 +223,44 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_reduce_kernel(const float*
 #pragma unroll
         for (int i = 0; i < 32; ++i) t += sh[i][lane];
         out[col] += t;
+    }
+}
+
+// the same second stage for SEVERAL LayerNorm backwards in one launch (blockIdx.z = which one): the tower backward defers the
+// reductions of its 2 x layers LayerNorms to the end of the layer loop (24 launches of ~5 us, each a dependent step of the chain,
+// become one); the entries travel in the kernel arguments
+constexpr int LN_MULTI_MAX = 32;
+struct LnReduceTable {
+    mmvid_ln_reduce_t item[LN_MULTI_MAX];
+};
+__global__ __launch_bounds__(1024) void layernorm_bwd_reduce_multi_kernel(LnReduceTable t, int nblocks, int E) {
+    __shared__ float sh[32][33];
+    const int which = blockIdx.y;
+    const float* partial = t.item[blockIdx.z].partial;
+    float* out = which == 0 ? t.item[blockIdx.z].dw : (which == 1 ? t.item[blockIdx.z].db : t.item[blockIdx.z].dx_colsum);
+    if (!out) return;
+    const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + lane;
+    float a = 0.f;
+    if (col < E) {
+        const float* src = partial + (long)which * E + col;
+        int b = rg;
+        for (; b + 15 * 32 < nblocks; b += 16 * 32) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = src[(long)(b + i * 32) * 3 * E];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a += v[i];
+        }
+        for (; b < nblocks; b += 32) a += src[(long)b * 3 * E];
+    }
+    sh[rg][lane] = a;
+    __syncthreads();
+    if (rg == 0 && col < E) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s += sh[i][lane];
+        out[col] += s;
     }
 }
 
@@ -456,10 +495,11 @@ extern "C" int mmvid_layernorm_bwd_ws(const float* dy, int64_t lddy, const float
                                   workspace, workspace_floats, stream);
 }
 
-extern "C" int mmvid_layernorm_bwd_ex(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
-                                      const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
-                                      int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
-                                      float* workspace, int64_t workspace_floats, void* stream) {
+// stage 1 (+ stage 2 unless blocks_out is given: then the caller reduces the partial rows later, mmvid_layernorm_bwd_reduce_multi)
+static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                              const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx, int add_into_dx,
+                              void* dx_bf16, float* dw, float* db, float* dx_colsum, float* workspace, int64_t workspace_floats,
+                              int* blocks_out, void* stream) {
     MMVID_REQUIRE(dy && x && mean && rstd && w && dx, "layernorm_bwd: null pointer");
     MMVID_REQUIRE(E % 4 == 0 && E <= 64 * 4 * LN_MAXV && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0,
                   "layernorm_bwd: bad E/strides");
@@ -490,10 +530,56 @@ extern "C" int mmvid_layernorm_bwd_ex(const void* dy, int dy_is_bf16, int64_t ld
                            (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16,
                            partial ? (dw ? dw : workspace) : dw, partial ? (db ? db : workspace) : db,
                            partial ? (dx_colsum ? dx_colsum : nullptr) : dx_colsum, partial);
-    if (partial)
+    if (blocks_out) {
+        MMVID_REQUIRE(partial || !any_red, "layernorm_bwd_partial: needs a workspace of at least 64 * 3 * E floats");
+        *blocks_out = blocks;
+    } else if (partial) {
         hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(cdiv(E, 32), 3), dim3(1024), 0, (hipStream_t)stream, partial, blocks, E,
                            dw, db, dx_colsum);
+    }
     MMVID_LAUNCH_CHECK("layernorm_bwd");
+    return MMVID_OK;
+}
+
+extern "C" int mmvid_layernorm_bwd_ex(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                      const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
+                                      int add_into_dx, void* dx_bf16, float* dw, float* db, float* dx_colsum,
+                                      float* workspace, int64_t workspace_floats, void* stream) {
+    return layernorm_bwd_impl(dy, dy_is_bf16, lddy, x, ldx, mean, rstd, w, rows, E, dx, lddx, add_into_dx, dx_bf16, dw, db, dx_colsum,
+                              workspace, workspace_floats, nullptr, stream);
+}
+
+// Stage 1 only: dx (and dx_bf16) are final; the weight / bias / column-sum gradients stay as `*blocks_out` partial rows
+// [blocks][3][E] in `workspace` (which must therefore be this call's own).  want_dw / want_db / want_colsum say which of the three
+// the later reduction will take (the kernel skips the others).
+extern "C" int mmvid_layernorm_bwd_partial(const void* dy, int dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                           const float* rstd, const float* w, int64_t rows, int E, float* dx, int64_t lddx,
+                                           int add_into_dx, void* dx_bf16, int want_dw, int want_db, int want_colsum,
+                                           float* workspace, int64_t workspace_floats, int* blocks_out, void* stream) {
+    MMVID_REQUIRE(workspace && blocks_out, "layernorm_bwd_partial: null workspace / blocks_out");
+    // (non-null markers: in two-stage mode the kernel only tests these pointers, everything goes to the partial rows)
+    return layernorm_bwd_impl(dy, dy_is_bf16, lddy, x, ldx, mean, rstd, w, rows, E, dx, lddx, add_into_dx, dx_bf16,
+                              want_dw ? workspace : nullptr, want_db ? workspace : nullptr, want_colsum ? workspace : nullptr, workspace,
+                              workspace_floats, blocks_out, stream);
+}
+
+// out[e] += sum over the partial rows, for n LayerNorm backwards in one launch (fixed order: the arithmetic of the single reduction)
+extern "C" int mmvid_layernorm_bwd_reduce_multi(int n, const mmvid_ln_reduce_t* items, int blocks, int E, void* stream) {
+    MMVID_REQUIRE(n >= 0 && (n == 0 || items) && blocks > 0 && E > 0, "layernorm_bwd_reduce_multi: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += LN_MULTI_MAX) {
+        const int m = n - i0 < LN_MULTI_MAX ? n - i0 : LN_MULTI_MAX;
+        LnReduceTable t;
+        for (int i = 0; i < LN_MULTI_MAX; ++i) {
+            if (i < m) {
+                MMVID_REQUIRE(items[i0 + i].partial, "layernorm_bwd_reduce_multi: entry %d has no partial rows", i0 + i);
+                t.item[i] = items[i0 + i];
+            } else {
+                t.item[i].partial = nullptr, t.item[i].dw = t.item[i].db = t.item[i].dx_colsum = nullptr;
+            }
+        }
+        hipLaunchKernelGGL(layernorm_bwd_reduce_multi_kernel, dim3(cdiv(E, 32), 3, m), dim3(1024), 0, (hipStream_t)stream, t, blocks, E);
+    }
+    MMVID_LAUNCH_CHECK("layernorm_bwd_reduce_multi");
     return MMVID_OK;
 }
 

@@ -32,7 +32,7 @@ Dims dims_of(const mmvid_tower_cfg_t& c) {
 // the 12-layer training step -- in the layer's slice of the saved arena (which exists only for a forward that will be
 // differentiated), so that the weight gradients of ALL layers of a kind go out as one launch after the layer loop.
 struct SavedLayer {  // byte offsets inside one layer's slice of the saved arena
-    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1, qkv, o, lse2, h2, pre, act, k_gpj, k_dpre, k_gout, k_dqkv, total;
+    int64_t x_in, x_mid, mean1, rstd1, mean2, rstd2, h1, qkv, o, lse2, h2, pre, act, k_gpj, k_dpre, k_gout, k_dqkv, k_ln1, k_ln2, total;
 };
 SavedLayer saved_layout(const Dims& d) {
     SavedLayer s;
@@ -55,6 +55,8 @@ SavedLayer saved_layout(const Dims& d) {
     const int64_t keep = mmvid_option(MMVID_OPT_DW_GROUPED) ? 1 : 0;  // (written by the backward only)
     s.k_gpj = take(keep * d.M * d.E * 2), s.k_dpre = take(keep * d.M * d.F * 2);
     s.k_gout = take(keep * d.M * d.E * 2), s.k_dqkv = take(keep * d.M * 3 * d.E * 2);
+    // ... and the partial rows of its two LayerNorm backwards (weight / bias / column-sum gradients), reduced for all layers at once
+    s.k_ln1 = take(keep * (int64_t)kLnBwdBlocks * 3 * d.E * 4), s.k_ln2 = take(keep * (int64_t)kLnBwdBlocks * 3 * d.E * 4);
     s.total = off;
     return s;
 }
@@ -264,8 +266,17 @@ static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_towe
     const bool fuse_fc_bias = mmvid_option(MMVID_OPT_FUSE_COLSUM) != 0;
     void* d_h = scr + sc.d_h;
     float* ws = (float*)(scr + sc.splitk_ws);
-    float* ln_ws = (float*)(scr + sc.ln_ws);
     const int64_t ln_ws_floats = (int64_t)kLnBwdBlocks * 3 * d.E;
+    std::vector<mmvid_ln_reduce_t> ln_items;
+    int ln_blocks = 0;
+    const bool ln_now = mmvid_option(MMVID_OPT_DW_GROUPED) == 3;  // measurement: every LayerNorm backward reduces its own rows at once
+    auto ln_flush = [&]() -> int {
+        if (ln_now && !ln_items.empty()) {
+            TRY(mmvid_layernorm_bwd_reduce_multi((int)ln_items.size(), ln_items.data(), ln_blocks, d.E, stream));
+            ln_items.clear();
+        }
+        return MMVID_OK;
+    };
     for (int i = d.layers - 1; i >= 0; --i) {
         const mmvid_tower_layer_t& ly = layers[i];
         const char* sv = (const char*)saved + (int64_t)i * sl.total;
@@ -278,19 +289,33 @@ static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         TRY(linear_dx(d.M, d.E, d.F, g_pj, ly.pj_w, sv + sl.pre, nullptr, kp + kl.d_pre, stream, fuse_fc_bias ? ly.g_fc_b : nullptr));
         if (!fuse_fc_bias && ly.g_fc_b) TRY(mmvid_colsum_bf16(kp + kl.d_pre, d.F, d.M, d.F, ly.g_fc_b, stream));
         TRY(linear_dx(d.M, d.F, d.E, kp + kl.d_pre, ly.fc_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
-        TRY(mmvid_layernorm_bwd_ex(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
-                                   (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, kp + kl.g_out, ly.g_ln2_w, ly.g_ln2_b,
-                                   ly.g_out_b, ln_ws, ln_ws_floats, stream));
+        {
+            mmvid_ln_reduce_t r = {(const float*)(kp + sl.k_ln2), ly.g_ln2_w, ly.g_ln2_b, ly.g_out_b};
+            int nb = 0;
+            TRY(mmvid_layernorm_bwd_partial(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
+                                            (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, kp + kl.g_out, r.dw != nullptr,
+                                            r.db != nullptr, r.dx_colsum != nullptr, (float*)(kp + sl.k_ln2), ln_ws_floats, &nb, stream));
+            if (r.dw || r.db || r.dx_colsum) ln_items.push_back(r), ln_blocks = nb;
+            TRY(ln_flush());
+        }
         TRY(linear_dx(d.M, d.E, d.E, kp + kl.g_out, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
         TRY(mmvid_attention_bwd_bias(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
                                      (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
                                      cfg->r1, cfg->c1, kp + kl.dqkv, 3 * d.E, ly.g_in_b, stream));
         TRY(linear_dx(d.M, 3 * d.E, d.E, kp + kl.dqkv, ly.in_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
-        TRY(mmvid_layernorm_bwd_ex(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
-                                   (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1,
-                                   i > 0 ? (void*)(keep + (int64_t)(i - 1) * kl.total + kl.g_pj) : nullptr, ly.g_ln1_w, ly.g_ln1_b,
-                                   i > 0 ? layers[i - 1].g_pj_b : nullptr, ln_ws, ln_ws_floats, stream));
+        {
+            mmvid_ln_reduce_t r = {(const float*)(kp + sl.k_ln1), ly.g_ln1_w, ly.g_ln1_b, i > 0 ? layers[i - 1].g_pj_b : nullptr};
+            int nb = 0;
+            TRY(mmvid_layernorm_bwd_partial(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
+                                            (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1,
+                                            i > 0 ? (void*)(keep + (int64_t)(i - 1) * kl.total + kl.g_pj) : nullptr, r.dw != nullptr,
+                                            r.db != nullptr, r.dx_colsum != nullptr, (float*)(kp + sl.k_ln1), ln_ws_floats, &nb, stream));
+            if (r.dw || r.db || r.dx_colsum) ln_items.push_back(r), ln_blocks = nb;
+            TRY(ln_flush());
+        }
     }
+    // ---- LayerNorm weight / bias gradients and the column sums that are the biases' gradients: one reduction for all layers
+    if (!ln_items.empty()) TRY(mmvid_layernorm_bwd_reduce_multi((int)ln_items.size(), ln_items.data(), ln_blocks, d.E, stream));
     // ---- the weight gradients: dW[N][K] += dY^T X per kind
     struct Kind {
         int N, K;

@@ -187,6 +187,27 @@ def layernorm_bwd(dy, x, mean, rstd, w, dx=None, add=False, dw=None, db=None, dx
     return dx
 
 
+def layernorm_bwd_partial(dy, x, mean, rstd, w, workspace, dx=None, add=False, dx_bf16=None, want=(True, True, True)):
+    """Stage 1 of the LayerNorm backward: dx (added into `dx` when add) and the partial rows of dw / db / colsum(dx) in `workspace`
+    (fp32, this call's own, >= 64 * 3 * E floats).  dy fp32 or bf16.  Returns (dx, blocks)."""
+    _chk(x, f32, 'x'), _chk(workspace, f32, 'workspace')
+    rows, E = x.numel() // x.shape[-1], x.shape[-1]
+    if dx is None:
+        dx, add = torch.empty_like(x), False
+    nb = ctypes.c_int()
+    call('mmvid_layernorm_bwd_partial', _p(dy), int(dy.dtype == bf16), E, _p(x), E, _p(mean), _p(rstd), _p(w), rows, E, _p(dx), E, int(add),
+         _p(dx_bf16), int(want[0]), int(want[1]), int(want[2]), _p(workspace), workspace.numel(), ctypes.byref(nb), _stream())
+    return dx, nb.value
+
+
+def layernorm_bwd_reduce_multi(items, blocks, E):
+    """items: [(workspace, dw or None, db or None, dx_colsum or None)] -> targets += column sums of each workspace's partial rows."""
+    arr = (_lib.LnReduce * len(items))()
+    for a, (ws, dw, db, cs) in zip(arr, items):
+        a.partial, a.dw, a.db, a.dx_colsum = ws.data_ptr(), _p(dw), _p(db), _p(cs)
+    call('mmvid_layernorm_bwd_reduce_multi', len(items), arr, blocks, E, _stream())
+
+
 def gn_stats_buffer(N, hw, C, device):
     """fp32 scratch of mmvid_groupnorm_swish_nhwc: [N][C][2] affine, then partial sums [N][blocks][32][2] (blocks of 128
     pixels, or of 64 for the strip convolution: sized for the finer one)."""

@@ -861,3 +861,41 @@ def test_tower_backward_grouped_weight_gradients(chunked):
         worst = max(worst, e)
         assert e < 5e-5, (k, e)  # (bias gradients are atomically accumulated column sums: not bit-stable run to run either way)
     print('worst relative difference of a parameter gradient, grouped vs per-layer split-K:', worst)
+
+
+def test_layernorm_backward_deferred_reduction():
+    """mmvid_layernorm_bwd_partial + mmvid_layernorm_bwd_reduce_multi (what the tower backward does for its 2 x layers LayerNorms)
+    against the single-call two-stage backward: dx identical, parameter / column-sum gradients bit-identical (same partial rows, same
+    fixed-order reduction), null targets left alone, more entries than one launch holds."""
+    from mmvid_amd import ops
+    torch.manual_seed(2)
+    rows, E, n = 3001, 768, 35
+    items, want = [], []
+    for i in range(n):
+        x = torch.randn(rows, E, device=DEV)
+        dy = torch.randn(rows, E, device=DEV)
+        if i % 2:
+            dy = dy.to(torch.bfloat16)
+        w = torch.randn(E, device=DEV)
+        mean, var = x.mean(1), x.var(1, unbiased=False)
+        rstd = (var + 1e-5).rsqrt()
+        g0 = torch.randn(rows, E, device=DEV)
+        targets = [torch.randn(E, device=DEV) for _ in range(3)]
+        use = [(i % 3) != 1, True, (i % 4) != 2]  # some entries without dw / colsum targets
+        ref_t = [t.clone() for t in targets]
+        ws_ref = torch.empty(512 * 3 * E, device=DEV)
+        dx_ref = g0.clone()
+        from mmvid_amd import _lib
+        _lib.call('mmvid_layernorm_bwd_ex', ops._p(dy), int(dy.dtype == torch.bfloat16), E, ops._p(x), E, ops._p(mean), ops._p(rstd), ops._p(w),
+                  rows, E, ops._p(dx_ref), E, 1, None, ops._p(ref_t[0]) if use[0] else None, ops._p(ref_t[1]), ops._p(ref_t[2]) if use[2] else None,
+                  ops._p(ws_ref), ws_ref.numel(), ops._stream())
+        ws = torch.empty(512 * 3 * E, device=DEV)
+        dx = g0.clone()
+        _, nb = ops.layernorm_bwd_partial(dy, x, mean, rstd, w, ws, dx=dx, add=True, want=use)
+        assert torch.equal(dx, dx_ref)
+        items.append((ws, targets[0] if use[0] else None, targets[1], targets[2] if use[2] else None))
+        want.append((ref_t, targets, use))
+    ops.layernorm_bwd_reduce_multi(items, nb, E)
+    for ref_t, targets, use in want:
+        for k in range(3):
+            assert torch.equal(targets[k], ref_t[k]), 'deferred reduction differs from the single-call reduction'
