@@ -150,6 +150,12 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   gemm_fused_reduce MMVID_GEMM_FUSED_REDUCE 0 (default) = split-K slabs of the weight-gradient GEMM added by splitk_reduce_kernel; 1 = by the last
 //                                       block of each output tile inside the GEMM (bit-identical; measured +5 ms per step: the device-scope
 //                                       release writes back the XCD's whole L2)
+//   dw_grouped     MMVID_DW_GROUPED     1 (default) = the tower backward keeps every layer's dY tensors in the saved arena and computes the weight
+//                                       gradients of all layers and all four Linear shapes in ONE launch after the layer loop, and
+//                                       the LayerNorm parameter-gradient reductions in one launch (tower.hip; captured step 16.36 ->
+//                                       15.4 ms); 0 = per-layer split-K launches + reduces (rounds 1-2); measurement only: 2 = one
+//                                       launch per shape (+0.14 ms), 3 = grouped weights, per-LayerNorm reductions (+0.09 ms).
+//                                       Must not change between a forward and its backward (the arena's slice size follows it)
 enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_ATTN_RES = 15, MMVID_OPT_GEMM_FUSED_REDUCE = 16, MMVID_OPT_DW_GROUPED = 17, MMVID_OPT_COUNT = 18 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }
