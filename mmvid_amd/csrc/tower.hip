@@ -136,7 +136,7 @@ static int tower_forward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower
                                  float* x_out, void* saved, void* scratch, void* stream, void* kv_cache = nullptr,
                                  int kv_lmax = 0);
 static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
-                                  const void* saved, void* scratch, void* stream);
+                                  void* saved, void* scratch, void* stream);
 
 static uint64_t tower_key(uint64_t seed, const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const void* a,
                           const void* b, const void* c, const void* d, const void* stream) {
@@ -204,7 +204,7 @@ static int tower_forward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower
 }
 
 extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
-                                    const void* saved, void* scratch, void* stream) {
+                                    void* saved, void* scratch, void* stream) {
     TRY(check_cfg(cfg));
     MMVID_REQUIRE(layers && g && saved && scratch, "tower_backward: null pointer");
     const uint64_t key = tower_key(3, cfg, layers, g, saved, scratch, nullptr, stream);
@@ -253,7 +253,7 @@ static SideStream& side_stream() {
 // over all tokens (no split-K slabs, no reduce launches).  A kind whose group would leave the chip mostly idle (few layers per
 // call: the chunked backward of the multi-GPU engine) keeps the per-layer split-K launches, run after the loop on the same data.
 // Same arithmetic per element up to the fp32 summation order of the token reduction (one chain instead of split-K slabs).
-static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g, const void* saved,
+static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g, void* saved,
                                   void* scratch, void* stream) {
     const Dims d = dims_of(*cfg);
     const SavedLayer sl = saved_layout(d);
@@ -356,7 +356,7 @@ static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_towe
 }
 
 static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
-                                  const void* saved, void* scratch, void* stream) {
+                                  void* saved, void* scratch, void* stream) {
     const Dims d = dims_of(*cfg);
     const SavedLayer sl = saved_layout(d);
     const Scratch sc = scratch_layout(d);
