@@ -4,6 +4,7 @@ native tower of csrc/tower.hip.  Same constructor meaning, same state_dict keys
 mlp.c_proj.*, ln_2.*}`), same forward contract ([B, L, E] fp32 in/out).  The attention mask is kept as the
 predicate the reference's build_attention_mask (561-578) encodes, not as an L x L tensor."""
 import ctypes
+import os
 import math
 
 import torch
@@ -145,7 +146,7 @@ class OpenAICLIPTransformer(nn.Module):
         self._shadow_key = None
         self._scratch = None
         self._scratch_retired = []
-        self.backward_chunk_layers = 3  # the backward returns to the host every N layers ...
+        self.backward_chunk_layers = int(os.environ.get('MMVID_BWD_CHUNK', 3))  # the backward returns to the host every N layers ...
         self.on_layers_done = None      # ... and calls this (first_layer) so gradient exchange can overlap
 
     # ---- reference API -----------------------------------------------------------------------------
