@@ -101,8 +101,9 @@ def tower_fwd(sd, cfg, tokens, stable=False):
 
 
 def forward_losses(sd, cfg, text, target_tok, mask1, warp_tok=None, visual_tok=None, rel=True, vid=True,
-                   rel_no_fully_masked=True, not_fully_masked=None, stable=False):
-    """dalle_bert.py:1030-1127 given the injected mask / warped tokens.  Returns dict."""
+                   rel_no_fully_masked=True, not_fully_masked=None, stable=False, text_neg=None):
+    """dalle_bert.py:1030-1127 given the injected mask / warped tokens.  Returns dict.  `text_neg` = the negvc branch without
+    visuals (909-910, 927-935, 974-975, 1047-1054): the REL negative's control sequence is [REL] + text_neg + [VID] [SEP]."""
     B = text.shape[0]
     ctrl = control_embedding(sd, cfg, text, visual_tok)
     tpos = target_pos(sd, cfg)
@@ -119,8 +120,13 @@ def forward_losses(sd, cfg, text, target_tok, mask1, warp_tok=None, visual_tok=N
     nfm = not_fully_masked
     if rel:
         half = B // 2
-        ctrl_swap = torch.cat([ctrl[half:], ctrl[:half]], 0)  # swap(): chunk(2)[::-1], 110-114
+        if text_neg is not None:
+            assert cfg.num_visuals == 0
+            ctrl_swap = control_embedding(sd, cfg, text_neg)
+        else:
+            ctrl_swap = torch.cat([ctrl[half:], ctrl[:half]], 0)  # swap(): chunk(2)[::-1], 110-114
         out_neg = tower_fwd(sd, cfg, torch.cat([ctrl_swap, temb], 1), stable)
+        res['tokens_rel'] = torch.cat([ctrl_swap, temb], 1)
         lp = head(sd, 'to_logits_rel', out[:, 0]).squeeze()
         ln = head(sd, 'to_logits_rel', out_neg[:, 0]).squeeze()
         if rel_no_fully_masked:

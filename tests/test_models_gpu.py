@@ -159,6 +159,32 @@ def test_bert_training_forward_backward_vs_reference(golden, name, nv, cvae):
         close(G['visual_emb.weight'][::3, ::5], g['g_visual_emb'], 5e-2, 'g visual_emb')
 
 
+def test_bert_negvc_text_only_vs_reference(golden):
+    """negvc=True, num_visuals=0 (dalle_bert.py:927-935, 1047-1054): `text_neg` reaches mmvid_bert_build_ids; losses and
+    gradients against the reference's run of the same branch (tests/golden/bert_negvc.npz)."""
+    g, m = _bert_case(golden, 'bert_negvc', 0, False)
+    text, text_neg, frames = g['text'].to(DEV), g['text_neg'].to(DEV), g['frames'].to(DEV)
+
+    def run():
+        return m(text, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True, negvc=True, text_neg=text_neg,
+                 _mask1=g['mask1'], _target_warp=g['warped_frames'])
+    lm, lr, lv = _with_tokens(m, g, run)
+    losses = torch.stack([lm, lr, lv]).detach().cpu()
+    print('losses', losses.tolist(), 'ref', g['losses'].tolist())
+    assert torch.allclose(losses, g['losses'], rtol=2e-2, atol=2e-2)
+    (7 * lm + 0.5 * lr + 0.5 * lv).backward()
+    G = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    close(G['special_emb.weight'], g['g_special_emb'], 5e-2, 'g special_emb')
+    close(G['text_pos_emb.weight'][:, ::5], g['g_text_pos'], 5e-2, 'g text_pos')
+    close(G['to_logits_rel.1.weight'], g['g_relw'], 5e-2, 'g relw')
+    close(G['text_emb.weight'][g['g_text_emb_row_ids'].to(DEV)][:, ::11], g['g_text_emb_rows'], 5e-2, 'g text_emb rows')
+    tn = torch.sqrt(sum((v.double()**2).sum() for v in G.values())).item()
+    assert abs(tn / g['g_total_norm'].item() - 1) < 3e-2
+    # the negative's text rows are logged for the row-wise gradient exchange too
+    rows = m.sparse_grad_rows().get('text_emb.weight')
+    assert rows is not None and set(g['g_text_emb_row_ids'].tolist()) <= set(rows.cpu().tolist())
+
+
 def _with_tokens(m, g, fn):
     """Run fn with the VAEs answering the reference's token indices for the golden frames (isolates the
     transformer path from bf16 index flips in the encoder)."""

@@ -137,6 +137,33 @@ def test_bert_losses_and_grads(golden, name, nv):
     assert abs(tn.item() / g['g_total_norm'].item() - 1) < 1e-5
 
 
+def test_bert_negvc_text_only(golden):
+    """negvc=True without visuals: the reference's own run (tools/make_golden.py::case_bert_negvc) against the restatement."""
+    g = golden('bert_negvc')
+    sd = synth_model_sd(g, 17)
+    for k in sd:
+        sd[k].requires_grad_(not k.startswith(('vae.', 'cvae.')))
+    cfg = bert.Cfg(sd, 16, 0, 2, 64)
+    with torch.no_grad():
+        tt = bert.get_image_tokens(sd, cfg, g['frames'])
+        wt = bert.get_image_tokens(sd, cfg, g['warped_frames'])
+    assert torch.equal(tt, g['target_tok']) and torch.equal(wt, g['warp_tok'])
+    r = bert.forward_losses(sd, cfg, g['text'], tt, g['mask1'], wt, None, text_neg=g['text_neg'])
+    assert relerr(r['tokens_rel'][:, :19], g['tokens_rel_ctrl']) <= TOL
+    assert relerr(r['out_msm'][:, ::3, ::7], g['out_msm_s']) <= TOL
+    assert relerr(r['out_rel'][:, ::3, ::7], g['out_rel_s']) <= TOL
+    losses = torch.stack([r['loss_msm'], r['loss_rel'], r['loss_vid']])
+    assert torch.allclose(losses, g['losses'], rtol=1e-5)
+    (7 * r['loss_msm'] + .5 * r['loss_rel'] + .5 * r['loss_vid']).backward()
+    G = {k: v.grad for k, v in sd.items() if v.grad is not None}
+    assert relerr(G['special_emb.weight'], g['g_special_emb']) <= TOL
+    assert relerr(G['text_pos_emb.weight'][:, ::5], g['g_text_pos']) <= TOL
+    assert relerr(G['to_logits_rel.1.weight'], g['g_relw']) <= TOL
+    assert relerr(G['text_emb.weight'][g['g_text_emb_row_ids']][:, ::11], g['g_text_emb_rows']) <= TOL
+    tn = torch.sqrt(sum((v.double()**2).sum() for v in G.values()))
+    assert abs(tn.item() / g['g_total_norm'].item() - 1) < 1e-5
+
+
 @pytest.mark.parametrize('name', ['bert_flm', 'bert_flm_bottleneck'])
 def test_bert_fixed_language_model(golden, name):
     """dalle_bert.py:307-322, 924-925: the text is one mapped sentence feature (single Linear / LayerNorm-Linear bottleneck)."""
