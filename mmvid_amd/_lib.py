@@ -146,6 +146,7 @@ class PosSegment(ctypes.Structure):
                 ('naxes', ctypes.c_int32), ('src0', ctypes.c_int32), ('d', ctypes.c_int32 * 3), ('pad', ctypes.c_int32)]
 
 
+ABI_VERSION = 2  # include/mmvid_hip.h: mmvid_abi_version()
 _lib = None
 
 
@@ -171,6 +172,9 @@ def load():
         for name, (args, res) in OTHER.items():
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = args, res
+        if lib.mmvid_abi_version() != ABI_VERSION:
+            raise MMVIDError(f'{LIB_PATH} has ABI version {lib.mmvid_abi_version()}, this package needs {ABI_VERSION}: '
+                             'rebuild with `python -m mmvid_amd.build --force`')
         _lib = lib
     return _lib
 

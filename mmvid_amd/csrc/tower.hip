@@ -301,7 +301,9 @@ static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         TRY(linear_dx(d.M, d.E, d.E, kp + kl.g_out, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
         TRY(mmvid_attention_bwd_bias(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
                                      (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
-                                     cfg->r1, cfg->c1, kp + kl.dqkv, 3 * d.E, ly.g_in_b, stream));
+                                     cfg->r1, cfg->c1, kp + kl.dqkv, 3 * d.E, fuse_fc_bias ? ly.g_in_b : nullptr, stream));
+        // (option fuse_colsum 0: the bias gradient as column sums of the bf16-rounded dqkv -- the values the weight gradient uses)
+        if (!fuse_fc_bias && ly.g_in_b) TRY(mmvid_colsum_bf16(kp + kl.dqkv, 3 * d.E, d.M, 3 * d.E, ly.g_in_b, stream));
         TRY(linear_dx(d.M, 3 * d.E, d.E, kp + kl.dqkv, ly.in_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
         {
             mmvid_ln_reduce_t r = {(const float*)(kp + sl.k_ln1), ly.g_ln1_w, ly.g_ln1_b, i > 0 ? layers[i - 1].g_pj_b : nullptr};
@@ -425,7 +427,8 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         // the in-projection's bias gradient (column sums of dqkv) comes out of the attention backward's registers
         TRY(mmvid_attention_bwd_bias(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
                                      (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
-                                     cfg->r1, cfg->c1, scr + sc.dqkv, 3 * d.E, ly.g_in_b, stream));
+                                     cfg->r1, cfg->c1, scr + sc.dqkv, 3 * d.E, fuse_fc_bias ? ly.g_in_b : nullptr, stream));
+        if (!fuse_fc_bias && ly.g_in_b) TRY(mmvid_colsum_bf16(scr + sc.dqkv, 3 * d.E, d.M, 3 * d.E, ly.g_in_b, stream));
         fork();
         TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, nullptr, ws, wst));
         ev_in = mark();

@@ -204,6 +204,12 @@ class TextVideoDataset(torch.utils.data.Dataset):
                                                 align_corners=False, antialias=True)
         return x[0]
 
+    def skip_sample(self, index):
+        """loader.py:478-489: a random sample when the set is shuffled, else the next one (wrapping)."""
+        if getattr(self, 'shuffle', False):
+            return self[self._rand(len(self))]
+        return self[0 if index >= len(self) - 1 else index + 1]
+
     def __getitem__(self, index):
         """-> (tokenized_text, frames [T,3,S,S], visual [3,S,S]) as loader.py:500-562 (`text, frames, visuals = batch`).
         video_only: the text is the reference's 'dummy text' placeholder."""
@@ -215,8 +221,10 @@ class TextVideoDataset(torch.utils.data.Dataset):
         else:
             with open(self.texts[key]) as fh:
                 lines = [t for t in fh.read().split('\n') if len(t) > 0]  # loader.py:518-519: empty lines dropped
-            if not lines:
-                raise IndexError(f'{self.texts[key]} holds no caption')
+            if not lines:  # loader.py:533-536: a caption file without captions is skipped, not fatal
+                print(f"An exception occurred trying to load file {self.texts[key]}.")
+                print(f"Skipping index {index}")
+                return self.skip_sample(index)
             caption = lines[0] if self.deterministic else lines[self._rand(len(lines))]  # loader.py:521-524
         tokens = self.tokenizer.tokenize(caption, self.text_len, truncate_text=self.truncate_captions).squeeze(0)
         return tokens, frames, visual

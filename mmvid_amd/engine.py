@@ -267,6 +267,13 @@ class FlatTrainer:
     # ---------------------------------------------------------------------------------------------
     def zero_grad(self):
         z = self._lazy
+        if z is not None and not getattr(self, '_stepped_since_zero', True):
+            # a backward may have run since the last zero_grad() without a step() (e.g. a step skipped on a non-finite loss): its
+            # table rows were never recorded as dirty -- clear the whole table rather than leave stale rows behind unflagged rows
+            ids = self.model.sparse_grad_rows().get(z['name']) if hasattr(self.model, 'sparse_grad_rows') else None
+            if ids is None or ids.numel() > 0:
+                z['all_dirty'] = True
+        self._stepped_since_zero = False
         if z is None or z['all_dirty']:
             self.G.zero_()
         else:  # everything but the lazy table, and of the table only the rows the last step left a gradient in
@@ -399,7 +406,12 @@ class FlatTrainer:
         self._check_bindings()
         self.allreduce_grads()
         if self._lazy is not None:
-            self._lazy_mark(self.model.sparse_grad_rows().get(self._lazy['name']))
+            ids = self.model.sparse_grad_rows().get(self._lazy['name'])
+            # a multi-rank step whose table went through the DENSE all-reduce (sparse_tables off) carries the other ranks' rows
+            # too, and this rank's id log does not know them: every row counts from now on
+            dense_exchange = (self.world > 1 or self.force_exchange) and self.exchange_enabled and not self.sparse_tables
+            self._lazy_mark(None if dense_exchange else ids)
+        self._stepped_since_zero = True
         self.step_count += 1
         gscale = 1.0 / self.world
         # the update itself is the HIP kernel; on a host tensor ops.adam_step raises (there is no CPU path)

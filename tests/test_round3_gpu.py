@@ -899,3 +899,116 @@ def test_layernorm_backward_deferred_reduction():
     for ref_t, targets, use in want:
         for k in range(3):
             assert torch.equal(targets[k], ref_t[k]), 'deferred reduction differs from the single-call reduction'
+
+
+@pytest.mark.parametrize('case', ['vqgan_tiny', 'vqgan_full', 'bert_tiny', 'bert_tiny_visual'])
+def test_split_index_safety_margin(golden, case):
+    """How far the exact-index mode (`vae.strict = 'split'`) is from flipping an index, on every golden frame.  Only distance
+    DIFFERENCES decide an argmin (|z|^2 is common to all codes), so per token: gap = d(z_ref, c2) - d(z_ref, c1) for the reference's
+    best code c1 and its runner-up c2, err = |gap(z_split) - gap(z_ref)| (both in fp64 from the fp32 z: the encoder's error alone).
+    The indices must be equal, and the gap must exceed SAFETY x err on every token; the histogram of gap / err is printed."""
+    from mmvid_amd.vae import VQGanVAE1024
+    from oracle import vqgan as ov
+    from oracle.synth import synth_input
+    from test_host_logic import tiny_vae
+    SAFETY = 8.0
+    g = golden(case)
+    sets = []  # (vae module, frames [N,3,S,S], reference z [N*hw, C] or None (-> oracle), reference indices)
+    if case.startswith('vqgan'):
+        s = g.meta['image_size']
+        vae = tiny_vae() if case == 'vqgan_tiny' else VQGanVAE1024(None, 128)
+        vae.image_size = s
+        load_synth(vae, g, 11)
+        img = synth_input('img', (g.meta['n'], 3, s, s), 11, 'uniform')
+        zr = g['z_e'].permute(0, 2, 3, 1).reshape(-1, g['z_e'].shape[1])
+        sets.append((vae, img, zr, g['indices'].reshape(-1)))
+    else:
+        nv = 1 if case.endswith('visual') else 0
+        m = load_synth(tiny_bert(nv, nv > 0), g, 17)
+        for fr, tok in ((g['frames'], g['target_tok']), (g['warped_frames'], g['warp_tok'])):
+            sets.append((m.vae, fr.reshape(-1, *fr.shape[2:]), None, tok.reshape(-1)))
+        if nv:
+            sets.append((m.cvae, g['visual'].reshape(-1, *g['visual'].shape[2:]), None, g['visual_tok'].reshape(-1)))
+    ratios, worst = [], None
+    for vae, img, zr, idx_ref in sets:
+        e = vae.model.quantize.embedding.weight.detach().double().cpu()
+        if zr is None:  # the oracle's fp32 encoder (pinned to the reference: tests/test_oracle_golden.py)
+            sd = {'model.' + k: v.detach().float().cpu() for k, v in vae.model.state_dict().items()}
+            z4 = ov.encode_z(sd, img, vae.image_size)
+            zr = z4.permute(0, 2, 3, 1).reshape(-1, z4.shape[1])
+        vae.strict = 'split'
+        zs = vae.encode_z(img.to(DEV)).reshape(-1, zr.shape[1]).double().cpu()
+        idx = vae.get_codebook_indices(img.to(DEV)).reshape(-1).cpu()
+        vae.strict = False
+        assert torch.equal(idx, idx_ref)
+        zr = zr.double()
+
+        def dist(z):  # without |z|^2 (common to every code)
+            return (e * e).sum(1)[None, :] - 2.0 * z @ e.t()
+        Dr, Ds = dist(zr), dist(zs)
+        rows = torch.arange(zr.shape[0])
+        d1 = Dr[rows, idx_ref]
+        Dm = Dr.clone()
+        Dm[rows, idx_ref] = float('inf')
+        c2 = Dm.argmin(1)
+        gap_r = Dr[rows, c2] - d1
+        gap_s = Ds[rows, c2] - Ds[rows, idx_ref]
+        err = (gap_s - gap_r).abs().clamp_min(1e-30)
+        r = gap_r / err
+        ratios.append(r)
+        k = int(r.argmin())
+        if worst is None or r[k] < worst[0]:
+            worst = (r[k].item(), gap_r[k].item(), err[k].item())
+    r = torch.cat(ratios)
+    edges = [0, 1, 8, 64, 512, 4096, 1e30]
+    hist = np.histogram(r.numpy(), edges)[0].tolist()
+    print(f'{case}: {r.numel()} tokens; reference top-2 gap / split-mode error of that gap: min {r.min().item():.1f} '
+          f'(gap {worst[1]:.3e}, err {worst[2]:.3e}), median {r.median().item():.0f}; histogram (edges {edges[:-1]}): {hist}')
+    assert r.min().item() > SAFETY
+
+
+def test_lazy_rows_with_dense_table_exchange_and_skipped_step(golden):
+    """(1) world > 1 with sparse_tables off -- the text-embedding gradient goes through the DENSE all-reduce, so rows
+    only OTHER ranks touched carry a gradient here: the lazy-row flags must all be raised (Adam / grad-norm may skip nothing) and
+    zero_grad() must clear the whole table.  World 2 is simulated on one device by a fake all-reduce that adds a peer's gradient.
+    (2) a backward followed by zero_grad() WITHOUT step() must not leave its table rows behind."""
+    from mmvid_amd.engine import FlatTrainer, backward_order
+    g = golden('bert_tiny')
+    text, frames = g['text'].to(DEV), g['frames'].to(DEV)
+
+    def fwd_bwd(m):
+        lm, lr, lv = m(text, target=frames, return_loss=True, rel=True, vid=True)
+        (7 * lm + 0.5 * lr + 0.5 * lv).backward()
+
+    # (1)
+    m = load_synth(tiny_bert(), g, 17).train()
+    tr = FlatTrainer(m, order=backward_order, sparse_tables=False)
+    assert tr._lazy is not None
+    W = m.text_emb.weight
+    peer_rows = torch.tensor([3, 77, 40000], device=DEV)
+    assert not bool(tr._lazy['flags'][peer_rows].any())
+    tr.zero_grad()
+    fwd_bwd(m)
+    tr.world = 2
+
+    def fake_send(lo, hi, tr=tr):  # the dense all-reduce of a 2-rank group: the peer's rows land in G
+        if lo <= tr._lazy['lo'] < hi:
+            W.grad[peer_rows] += 0.5
+    tr._send, tr._exchange_sparse = fake_send, (lambda: None)
+    before = W.detach()[peer_rows].clone()
+    tr.step()
+    assert bool(tr._lazy['flags'].all()), 'rows touched only by other ranks must count'
+    assert not torch.equal(W.detach()[peer_rows], before), "Adam skipped a row that carried another rank's gradient"
+    tr.zero_grad()
+    assert float(W.grad.abs().sum()) == 0.0
+    # (2)
+    m2 = load_synth(tiny_bert(), g, 17).train()
+    tr2 = FlatTrainer(m2, order=backward_order)
+    tr2.zero_grad()
+    fwd_bwd(m2)
+    tr2.step()
+    tr2.zero_grad()
+    fwd_bwd(m2)  # e.g. a non-finite loss: the caller drops this step
+    assert float(m2.text_emb.weight.grad.abs().sum()) > 0
+    tr2.zero_grad()
+    assert float(m2.text_emb.weight.grad.abs().sum()) == 0.0, 'zero_grad() after a skipped step left table rows behind'
