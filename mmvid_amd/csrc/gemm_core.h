@@ -16,6 +16,8 @@
 //
 // Out-of-range chunks (row >= rows, k >= K) are zero-filled by the buffer range check (OperandStage below).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace mmvid_core {
@@ -52,6 +54,7 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 // beyond num_records, or the explicit OOB marker) write ZEROS to LDS -- verified on hardware by
 // tools/gpu_probe_buffer.py -- which pads ragged M / N / K edges without a zero page or per-lane pointer selects.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef __attribute__((ext_vector_type(4))) unsigned core_u32x4_t;
 constexpr uint32_t OOB = 0x80000000u;  // with num_records <= 0x7fffffff: always out of range
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);  // raw, stride 0
@@ -427,14 +430,48 @@ __device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, in
 // instruction inside the K loop; loader waves request the 48 one-KiB pieces of a K tile (a third after each of the first three
 // barriers of the tile, so that a refilled stage is never touched before both wave groups have passed their last read of it),
 // wait for their own requests with counted vmcnt and publish them through the barriers all waves of the block share.
-template <bool KM>
+template <bool KM, int NL = 4>
 struct LoaderStage {
+    static constexpr int PG = 16 / NL;  // this loader wave's pieces of a 16-piece (128-row) sub-tile
     rsrc_t rsrc;
     long ld;
     int rows, r0;
+    // Per-lane byte offsets of this loader wave's pieces (PG w .. PG w + PG - 1 of each 128-row sub-tile), computed ONCE per output tile: in
+    // the K loop a piece is then `s_mov m0` + the load with an SGPR K offset.  Measured (tools/gemm_kloop_anatomy.py): the loop is paced
+    // by the loader waves' instruction stream -- a dozen extra VALU/SALU per piece there cost the whole block 20 % of its K loop.
+    uint32_t voff[2][PG];
+    uint32_t kstep;  // bytes per unit of k
     __device__ __forceinline__ void init(const bf16_t* base, long ld_, int rows_, int K, int r0_) {
         ld = ld_, rows = rows_, r0 = r0_;
         rsrc = KM ? make_rsrc(base, (uint32_t)(((long)(K - 1) * ld + rows) * 2)) : make_rsrc(base, (uint32_t)(((long)(rows - 1) * ld + K) * 2));
+    }
+    __device__ __forceinline__ void init_offsets(int nsub, int w, int lane) {
+        kstep = KM ? (uint32_t)(ld * 2) : 2u;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int jj = 0; jj < PG; ++jj) {
+                const int j = w * PG + jj;
+                uint32_t v = OOB;
+                if (sub < nsub) {
+                    if constexpr (KM) {
+                        const int kr = j * 4 + (lane >> 4);
+                        const int c = (lane & 15) ^ ((kr & 3) << 2);
+                        const int r = r0 + sub * 128 + c * 8;
+                        if (r < rows) v = (uint32_t)(((long)kr * ld + r) * 2);
+                    } else {
+                        const int row = j * 8 + (lane >> 3);
+                        const int c = (lane & 7) ^ ((row >> 1) & 7);
+                        const int gr = r0 + sub * 128 + row;
+                        if (gr < rows) v = (uint32_t)(((long)gr * ld + c * 8) * 2);
+                    }
+                }
+                voff[sub][jj] = v;
+            }
+    }
+    // piece PG w + jj of sub-tile `sub` of a K tile that lies entirely below K (row-major) / any K tile (k-major: rows k >= K fall to the range check)
+    __device__ __forceinline__ void piece_fast(int k0, char* tile, int sub, int jj, int w) const {
+        blds16(rsrc, voff[sub][jj], (uint32_t)k0 * kstep, tile + (w * PG + jj) * 1024);
     }
     // piece j (0..15) of 128-row sub-tile `sub` of K tile [k0, k0 + 64) -> tile + j KiB
     __device__ __forceinline__ void piece(int k0, int K, char* tile, int sub, int j, int lane) const {
@@ -459,35 +496,52 @@ struct LoaderStage {
 // with a single loader against 0.9 us with every wave loading).  NLOAD = 4 loader waves, one per SIMD: loader w requests pieces
 // 4 w .. 4 w + 3 of each 16-piece group (A sub-tile 0, A sub-tile 1, B), i.e. 12 of the 48 pieces of a K tile, and waits for them.
 constexpr int NLOAD = 4;
-template <bool AKM, bool BKM>
-__device__ __forceinline__ void loader_issue_group(const LoaderStage<AKM>& sa, const LoaderStage<BKM>& sb, int k0, int K, char* stage, int g,
+template <bool AKM, bool BKM, int NL>
+__device__ __forceinline__ void loader_issue_group(const LoaderStage<AKM, NL>& sa, const LoaderStage<BKM, NL>& sb, int k0, int K, char* stage, int g,
                                                    int w, int lane) {
+    constexpr int PG = 16 / NL;
     if (g < 2) {
+        if (AKM || k0 + BK <= K) {
 #pragma unroll
-        for (int jj = 0; jj < 16 / NLOAD; ++jj) sa.piece(k0, K, stage + g * TILE_BYTES, g, w * (16 / NLOAD) + jj, lane);
+            for (int jj = 0; jj < PG; ++jj) sa.piece_fast(k0, stage + g * TILE_BYTES, g, jj, w);
+        } else {  // the K tail of a row-major operand: per-lane column check
+            asm volatile("; K-tail tile" ::: "memory");
+#pragma unroll
+            for (int jj = 0; jj < PG; ++jj) sa.piece(k0, K, stage + g * TILE_BYTES, g, w * PG + jj, lane);
+        }
     } else {
+        if (BKM || k0 + BK <= K) {
 #pragma unroll
-        for (int jj = 0; jj < 16 / NLOAD; ++jj) sb.piece(k0, K, stage + 2 * TILE_BYTES, 0, w * (16 / NLOAD) + jj, lane);
+            for (int jj = 0; jj < PG; ++jj) sb.piece_fast(k0, stage + 2 * TILE_BYTES, 0, jj, w);
+        } else {
+            asm volatile("; K-tail tile" ::: "memory");
+#pragma unroll
+            for (int jj = 0; jj < PG; ++jj) sb.piece(k0, K, stage + 2 * TILE_BYTES, 0, w * PG + jj, lane);
+        }
     }
 }
-template <bool AKM, bool BKM>
-__device__ __forceinline__ void loader_prologue(const LoaderStage<AKM>& sa, const LoaderStage<BKM>& sb, char* smem, int kt0, int nt, int K,
+template <bool AKM, bool BKM, int NL>
+__device__ __forceinline__ void loader_prologue(const LoaderStage<AKM, NL>& sa, const LoaderStage<BKM, NL>& sb, char* smem, int kt0, int nt, int K,
                                                 int w, int lane) {
     using S = BlockShape<4>;
     if (nt <= 0) return;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) loader_issue_group<AKM, BKM>(sa, sb, kt0 * BK, K, smem, g, w, lane);
+    for (int g = 0; g < 3; ++g) loader_issue_group<AKM, BKM, NL>(sa, sb, kt0 * BK, K, smem, g, w, lane);
     if (nt > 1) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) loader_issue_group<AKM, BKM>(sa, sb, (kt0 + 1) * BK, K, smem + S::STAGE_BYTES, g, w, lane);
+        for (int g = 0; g < 3; ++g) loader_issue_group<AKM, BKM, NL>(sa, sb, (kt0 + 1) * BK, K, smem + S::STAGE_BYTES, g, w, lane);
     }
 }
-// a loader wave's K loop: the prologue (its pieces of K tiles 0 and 1) has been requested
-template <bool AKM, bool BKM>
-__device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM>& sa, const LoaderStage<BKM>& sb, char* smem, int kt0, int nt, int K,
-                                              int w, int lane, bool half_barriers = false, bool skip_half_dma = false) {
+// a loader wave's K loop: the prologue (its pieces of K tiles 0 and 1) has been requested.  DBG: the timing experiments of
+// tools/gemm_kloop_anatomy.py (gemm_debug 4, 6, 7, 9, 10) are compiled into their own instance -- the shipped loop carries none of their
+// tests (the loop is paced by this instruction stream: a dozen extra SALU / VALU per piece here cost the block 20 % of its K loop)
+template <bool AKM, bool BKM, int NL, bool DBG = false>
+__device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM, NL>& sa, const LoaderStage<BKM, NL>& sb, char* smem, int kt0, int nt, int K,
+                                              int w, int lane, int debug = 0) {
     using S = BlockShape<4>;
-    constexpr int PER_TILE = 48 / NLOAD;  // this wave's pieces of a K tile
+    constexpr int PER_TILE = 48 / NL;  // this wave's pieces of a K tile
+    const bool half_barriers = DBG && debug == 4, skip_half_dma = DBG && debug == 6, no_dma = DBG && (debug == 7 || debug == 9),
+               k_fixed = DBG && debug == 10;
     char* b0 = smem;
     char* b1 = smem + S::STAGE_BYTES;
     char* b2 = smem + 2 * S::STAGE_BYTES;
@@ -498,17 +552,17 @@ __device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM>& sa, const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile 0 is visible to everyone
     for (int t = 0; t < nt; ++t) {
-        const bool more = t + 2 < nt;
-        const int k0 = (kt0 + t + 2) * BK;
+        const bool more = t + 2 < nt && !no_dma;
+        const int k0 = k_fixed ? kt0 * BK : (kt0 + t + 2) * BK;
         if (!half_barriers) __builtin_amdgcn_s_barrier();  // 1: the trailing group has finished its last read of tile t-1 (whose stage b2 is refilled)
-        if (more) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 0, w, lane);
+        if (more) loader_issue_group<AKM, BKM, NL>(sa, sb, k0, K, b2, 0, w, lane);
         __builtin_amdgcn_s_barrier();  // 2
-        if (more && !skip_half_dma) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 1, w, lane);
+        if (more && !skip_half_dma) loader_issue_group<AKM, BKM, NL>(sa, sb, k0, K, b2, 1, w, lane);
         if (!half_barriers) __builtin_amdgcn_s_barrier();  // 3
-        if (more) loader_issue_group<AKM, BKM>(sa, sb, k0, K, b2, 2, w, lane);
+        if (more) loader_issue_group<AKM, BKM, NL>(sa, sb, k0, K, b2, 2, w, lane);
         if (t + 1 < nt) {  // tile t+1 has landed before the barrier after which the leading group reads it
             if (more && skip_half_dma)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE - 16 / NLOAD) : "memory");  // (gemm_debug 6: timing experiment)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE - 16 / NL) : "memory");
             else if (more)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
             else
@@ -523,7 +577,7 @@ __device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM>& sa, const 
 // the MFMA waves' K loop: the schedule of k_loop_pingpong without any vector-memory instruction or vmcnt wait
 template <bool AKM, bool BKM>
 __device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, int lane, int wm, int wn, f32x16 (&acc)[2][2],
-                                                unsigned long long* stamp = nullptr, bool half_barriers = false) {
+                                                unsigned long long* stamp = nullptr, bool half_barriers = false, bool no_reads = false) {
     using S = BlockShape<4>;
     char* b0 = smem;
     char* b1 = smem + S::STAGE_BYTES;
@@ -532,6 +586,23 @@ __device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, in
     __builtin_amdgcn_s_barrier();                 // tile 0 is visible to everyone
     if (stamp) stamp[1] = wall_clock64();
     if (wave >= 4) __builtin_amdgcn_s_barrier();  // the trailing group starts one barrier late
+    if (no_reads) {  // gemm_debug 8 / 9 (timing experiment, results are wrong): the barrier + MFMA skeleton of the loop without its fragment reads
+        bf16x8_t a[2][2], b[2][2];
+        const uint32_t k0[2] = {lds_addr(b0), lds_addr(b0)};
+        pp_load_half<AKM, BKM, 0>(b0 + (wm >> 1) * TILE_BYTES, b0 + S::NSUB * TILE_BYTES, k0, k0, wm & 1, wn, lane, a, b);
+        for (int t = 0; t < nt; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                pp_compute_half<AKM, BKM>(a, b, acc, []() {});
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (wave < 4) __builtin_amdgcn_s_barrier();
+        return;
+    }
     for (int t = 0; t < nt; ++t) {
         const char* At = b0 + (wm >> 1) * TILE_BYTES;
         const char* Bt = b0 + S::NSUB * TILE_BYTES;
