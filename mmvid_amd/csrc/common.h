@@ -156,11 +156,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //                                       15.4 ms); 0 = per-layer split-K launches + reduces (rounds 1-2); measurement only: 2 = one
 //                                       launch per shape (+0.14 ms), 3 = grouped weights, per-LayerNorm reductions (+0.09 ms).
 //                                       Must not change between a forward and its backward (the arena's slice size follows it)
-//   gemm_sw        MMVID_GEMM_SW        1 (default) = persistent 256x128 GEMM blocks with packed bf16 outputs hand the finished tile to four STORER
-//                                       waves through LDS and start the next tile's K loop at once (gemm_bf16_sw_kernel); 0 = the MFMA waves
-//                                       store their own tile (round 3)
-//   gemm_stage     MMVID_GEMM_STAGE     operand staging of the loader-wave GEMM blocks: 0 = LDS-DMA (buffer_load ... lds), 1 = through the loader
-//                                       waves' registers (buffer_load_dwordx4 two K tiles ahead + ds_write_b128)
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_ATTN_RES = 15, MMVID_OPT_GEMM_FUSED_REDUCE = 16, MMVID_OPT_DW_GROUPED = 17, MMVID_OPT_GEMM_SW = 18, MMVID_OPT_GEMM_STAGE = 19, MMVID_OPT_COUNT = 20 };
+//   gemm_loaders   MMVID_GEMM_LOADERS   loader waves of the loader-wave GEMM block: 4 (default), 8 = sixteen-wave blocks (bf16-output form only)
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_ATTN_RES = 15, MMVID_OPT_GEMM_FUSED_REDUCE = 16, MMVID_OPT_DW_GROUPED = 17, MMVID_OPT_GEMM_LOADERS = 18, MMVID_OPT_COUNT = 19 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

@@ -63,7 +63,6 @@ struct GemmParams {
     int debug;       // option gemm_debug (measurement only): 1 = no global stores, 2 = no K loop
     int tiles_n, tiles_m;  // > 0: persistent blocks walk this tile grid (option gemm_persist); 0: one block per tile
     int group_n;     // persistent blocks: tiles are walked column-GROUP-major (groups of group_n column tiles), see launch_shape
-    int stage_regs;  // loader-wave blocks: operands staged through the loaders' registers instead of LDS-DMA (option gemm_stage)
     int defer;       // EPI >= 2: issue a tile's stores from inside the next tile's K loop (persistent blocks)
     unsigned long long* trace;  // measurement only (mmvid_gemm_trace): per block, wave group and tile 8 time stamps (100 MHz)
     // split-K slabs reduced inside the GEMM (option gemm_fused_reduce): the block that finishes a tile LAST adds the tile's slabs in
@@ -683,7 +682,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
 // k_loop_loader / k_loop_consumer), register-direct epilogues only (EPI 1: general, 2 / 3: packed bf16 with one / two outputs).
 // The loader requests the next output tile's first two K tiles while the MFMA waves are in their epilogue, so a persistent block
 // streams operands continuously; the MFMA waves never wait on vmcnt (their epilogue stores drain on their own).
-template <bool AKM, bool BKM, int EPI, bool GROUPED>
+template <bool AKM, bool BKM, int EPI, bool GROUPED, int NL = mmvid_core::NLOAD>
 __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt) {
     using S = BlockShape<4>;
     int multi_bm0 = 0, multi_bn0 = 0;
@@ -723,7 +722,7 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
     float* bias_lds = nullptr;
     if (p.bias) {
         bias_lds = reinterpret_cast<float*>(smem + S::LDS_BYTES);
-        for (int e = tid; e < p.N; e += 512 + 64 * NLOAD) bias_lds[e] = p.bias[e];
+        for (int e = tid; e < p.N; e += 512 + 64 * NL) bias_lds[e] = p.bias[e];
         __syncthreads();
     }
     auto tile_origin = [&](int tile, int& bm0, int& bn0) {
@@ -745,44 +744,27 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
     const int first = p.tiles_n > 0 ? (int)blockIdx.x : 0;
     if (wave >= 8) {  // ---------------------------------------------------------------- the loader waves
         const int w = wave - 8;
-        LoaderStage<AKM> sa;
-        LoaderStage<BKM> sb;
+        LoaderStage<AKM, NL> sa;
+        LoaderStage<BKM, NL> sb;
         bool have = false;
-        if (p.stage_regs) {  // option gemm_stage 1: operands through registers (buffer_load_dwordx4 + ds_write_b128) instead of LDS-DMA
-            LoaderRegs R;
-            for (int tile = first; tile < ntiles; tile += tile_step) {
-                int bm0, bn0;
-                if (!have) {
-                    tile_origin(tile, bm0, bn0);
-                    sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0), sa.init_offsets(2, w, lane), sb.init_offsets(1, w, lane);
-                    loader_regs_prologue<AKM, BKM>(sa, sb, R, smem, kt0, nt, p.K, w, lane);
-                }
-                k_loop_loader_regs<AKM, BKM>(sa, sb, R, smem, kt0, nt, p.K, w, lane);
-                have = false;
-                if (tile + tile_step < ntiles) {
-                    tile_origin(tile + tile_step, bm0, bn0);
-                    sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0), sa.init_offsets(2, w, lane), sb.init_offsets(1, w, lane);
-                    loader_regs_prologue<AKM, BKM>(sa, sb, R, smem, kt0, nt, p.K, w, lane);
-                    have = true;
-                }
-            }
-            return;
-        }
         for (int tile = first; tile < ntiles; tile += tile_step) {
             int bm0, bn0;
             if (!have) {
                 tile_origin(tile, bm0, bn0);
                 if (p.debug == 11) bm0 = bn0 = 0;  // (timing experiment: every block streams the same operand tiles)
                 sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0), sa.init_offsets(2, w, lane), sb.init_offsets(1, w, lane);
-                loader_prologue<AKM, BKM>(sa, sb, smem, kt0, nt, p.K, w, lane);
+                loader_prologue<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
             }
-            k_loop_loader<AKM, BKM>(sa, sb, smem, kt0, nt, p.K, w, lane, p.debug == 4, p.debug == 6, p.debug == 7 || p.debug == 9, p.debug == 10);
+            if (p.debug > 2)
+                k_loop_loader<AKM, BKM, NL, true>(sa, sb, smem, kt0, nt, p.K, w, lane, p.debug);
+            else
+                k_loop_loader<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
             have = false;
             if (tile + tile_step < ntiles) {  // every stage is free: stream the next output tile's first K tiles during the epilogue
                 tile_origin(tile + tile_step, bm0, bn0);
                 if (p.debug == 11) bm0 = bn0 = 0;
                 sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0), sa.init_offsets(2, w, lane), sb.init_offsets(1, w, lane);
-                loader_prologue<AKM, BKM>(sa, sb, smem, kt0, nt, p.K, w, lane);
+                loader_prologue<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
                 have = true;
             }
         }
@@ -811,7 +793,10 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
         [[maybe_unused]] PreRegs pre_in;
         if constexpr (EPI == 4) pre_load(p, de, bm0, bn0, wm, wn, lane, pre_in);
         if (stamp) stamp[5] = __builtin_readcyclecounter();  // shader clock (s_memtime), against the 100-MHz stamps: the actual frequency
-        k_loop_consumer<AKM, BKM>(smem, nt, wave, lane, wm, wn, acc, stamp, p.debug == 4, p.debug == 8 || p.debug == 9);
+        if (p.debug || p.trace)
+            k_loop_consumer<AKM, BKM, true>(smem, nt, wave, lane, wm, wn, acc, stamp, p.debug);
+        else
+            k_loop_consumer<AKM, BKM>(smem, nt, wave, lane, wm, wn, acc);
         if (stamp) stamp[2] = wall_clock64(), stamp[6] = __builtin_readcyclecounter(), stamp[7] = wall_clock64();
         if constexpr (EPI == 4) {
             if (stamp) stamp[3] = wall_clock64();
@@ -867,252 +852,13 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
     }
 }
 
-template <bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_kernel(GemmParams p) {
-    gemm_lw_body<AKM, BKM, EPI, false>(p, nullptr);
+template <bool AKM, bool BKM, int EPI, int NL = mmvid_core::NLOAD>
+__global__ __launch_bounds__(512 + 64 * NL, 1) void gemm_bf16_lw_kernel(GemmParams p) {
+    gemm_lw_body<AKM, BKM, EPI, false, NL>(p, nullptr);
 }
 // the grouped weight-gradient launch: both operands k-major, general register-direct epilogue (fp32 += result)
 __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_grouped_kernel(GemmParams p, GroupTable gt) {
     gemm_lw_body<true, true, 1, true>(p, &gt);
-}
-
-// ================================================================================================================
-// Storer-wave form of the 256x128 block (option gemm_sw, default 1; persistent blocks with packed bf16 outputs): 8 MFMA waves +
-// NLOAD loader waves + NSTORE storer waves = 16 waves, one per SIMD of each kind, 128 registers each.
-//
-// Why (profiles/r03_gemm_timeline_loader_and_dma_experiments.log): with the loader-wave block above a tile round of the qkv GEMM is
-// 15.2 us of which the K loop is 10.4-11.2: the MFMA waves spend the rest in their own epilogue (convert, 8-16 vector stores per wave
-// that all 256 CUs issue at the same moment) and in waiting for the next tile's first K tile behind it.  Stores issued by the MFMA
-// waves INSIDE the next K loop were measured negative (a vector-memory instruction stalls its wave for 60-185 cycles and the phase
-// barrier with it, gemm_epi 2).  Here the MFMA waves never issue a store: they convert the finished tile to bf16, drop it into LDS
-// (the 64 KiB that are free between two K loops: stage 2 + the former bias slab), pass ONE barrier and start the next tile's K loop,
-// whose first two K tiles the loaders requested meanwhile.  The storer waves pull the tile out of LDS into registers (64 per lane)
-// before the loaders refill stage 2, and trickle its 16 (EPI 3: 32) 1-KiB row-contiguous stores over the barriers of that K loop --
-// a storer stalled on a store arrives at the next barrier long before the MFMA waves do.  Every wave of the block executes the
-// same number of s_barrier (4 nt + 3 per tile); roles differ in what they do between them.
-//
-//   bias:   folded into the accumulators' initial value (no LDS copy, no registers held through the K loop)
-//   EPI 2:  out_bf16 = acc (+ bias)
-//   EPI 3:  save_pre = bf16(acc + bias), out_bf16 = QuickGELU(save_pre): the activation is computed BY THE STORERS from the rounded
-//           pre-activation -- exactly the value the backward differentiates at
-//   EPI 4:  out_bf16 = bf16(acc) * QuickGELU'(dact_pre) and column sums of it (the d_pre GEMM): the storers load the saved
-//           pre-activation piece by piece in their own output layout and reduce the column sums over their rows
-//   slab:   [256 rows][128 columns] bf16, 256 B per row, 16-B chunk c of row r at position c ^ (r & 15): conflict-free for the MFMA
-//           waves' ds_write_b128 (8 consecutive rows, one chunk column) and for the storers' ds_read_b128 (4 rows x 16 chunks)
-constexpr int NSTORE = 4;
-constexpr int SW_THREADS = 512 + 64 * (NLOAD + NSTORE);
-__device__ __forceinline__ uint32_t sw_slab_off(int r, int c) { return (uint32_t)(r * 256 + ((c ^ (r & 15)) << 4)); }
-
-template <int EPI>
-struct StorerTile {
-    u32x4_t v[16];  // piece t = rows 4 (16 w + t) + (lane >> 4), columns 8 (lane & 15) .. + 7 of the tile
-    u32x4_t pq[2];  // EPI 4: the saved pre-activation of pieces t, t + 1 (requested two pieces ahead: a storer must never sit on an HBM latency
-                    // in front of a barrier the MFMA waves are waiting at)
-    int bm0, bn0;
-    int left;       // pieces not yet stored (counts down from 16)
-};
-template <int EPI>
-__device__ __forceinline__ u32x4_t storer_pre_load(const GemmParams& p, const DirectEpi& d, const StorerTile<EPI>& st, int t, int w, int lane) {
-    const int row = st.bm0 + (w * 16 + t) * 4 + (lane >> 4), col = st.bn0 + (lane & 15) * 8;
-    return __builtin_amdgcn_raw_buffer_load_b128(d.r_pre_in, (t < 16 && row < p.M) ? (uint32_t)(((long)row * p.ldp + col) * 2) : OOB, 0, 0);
-}
-// QuickGELU of 8 packed bf16 -> 8 packed bf16
-__device__ __forceinline__ u32x4_t gelu_packed(u32x4_t x) {
-    u32x4_t y;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = pack_bf2(quick_gelu(bf_lo(x[e])), quick_gelu(bf_hi(x[e])));
-    return y;
-}
-template <int EPI, int T>
-__device__ __forceinline__ void storer_piece(const GemmParams& p, const DirectEpi& d, StorerTile<EPI>& st, int w, int lane, float (&cs)[8]) {
-    constexpr int t = T;
-    const u32x4_t val = st.v[T];
-    const int row = st.bm0 + (w * 16 + t) * 4 + (lane >> 4), col = st.bn0 + (lane & 15) * 8;
-    const bool ok = row < p.M && p.debug != 1;
-    const uint32_t off = ok ? (uint32_t)(((long)row * p.ldc + col) * 2) : OOB;
-    if constexpr (EPI == 3) {
-        __builtin_amdgcn_raw_buffer_store_b128(val, d.r_pre_out, ok ? (uint32_t)(((long)row * p.ldp + col) * 2) : OOB, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(gelu_packed(val), d.r_bf16, off, 0, 0);
-    } else if constexpr (EPI == 4) {
-        const u32x4_t pre = st.pq[T & 1];
-        st.pq[T & 1] = storer_pre_load<EPI>(p, d, st, T + 2, w, lane);
-        u32x4_t y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float a = bf_lo(val[e]) * quick_gelu_grad(bf_lo(pre[e])), b = bf_hi(val[e]) * quick_gelu_grad(bf_hi(pre[e]));
-            y[e] = pack_bf2(a, b);
-            if (ok) cs[2 * e] += a, cs[2 * e + 1] += b;
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(y, d.r_bf16, off, 0, 0);
-    } else {
-        __builtin_amdgcn_raw_buffer_store_b128(val, d.r_bf16, off, 0, 0);
-    }
-}
-// store piece 16 - left (a uniform switch: the register operand must be static)
-template <int EPI>
-__device__ __forceinline__ void storer_next(const GemmParams& p, const DirectEpi& d, StorerTile<EPI>& st, int w, int lane, float (&cs)[8]) {
-    const int t = 16 - st.left;
-#define MMVID_SP(T) case T: storer_piece<EPI, T>(p, d, st, w, lane, cs); break;
-    switch (t) {
-        MMVID_SP(0) MMVID_SP(1) MMVID_SP(2) MMVID_SP(3) MMVID_SP(4) MMVID_SP(5) MMVID_SP(6) MMVID_SP(7)
-        MMVID_SP(8) MMVID_SP(9) MMVID_SP(10) MMVID_SP(11) MMVID_SP(12) MMVID_SP(13) MMVID_SP(14)
-        default: storer_piece<EPI, 15>(p, d, st, w, lane, cs); break;
-    }
-#undef MMVID_SP
-    st.left -= 1;
-}
-// EPI 4: this lane's 8 column sums over its rows of the tile -> one atomic per column and wave (lanes l, l + 16, l + 32, l + 48 share columns)
-__device__ __forceinline__ void storer_colsum_flush(const GemmParams& p, int bn0, int lane, float (&cs)[8]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = cs[e];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lane < 16 && p.colsum) unsafeAtomicAdd(p.colsum + bn0 + lane * 8 + e, v);
-        cs[e] = 0.f;
-    }
-}
-
-template <bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(SW_THREADS) void gemm_bf16_sw_kernel(GemmParams p) {
-    using S = BlockShape<4>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // three stages + 16 KiB; the hand-off slab is [2 stages, end)
-    char* const slab = smem + 2 * S::STAGE_BYTES;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = p.tiles_n * p.tiles_m;  // (persistent blocks only)
-    const int tile_step = (int)gridDim.x;
-    const int ktiles_total = (p.K + BK - 1) / BK;
-    const int nt = p.debug == 2 ? 0 : ktiles_total;
-    const bf16_t* A = p.A;
-    const bf16_t* B = p.B;
-    auto tile_origin = [&](int tile, int& bm0, int& bn0) {
-        const int wg = xcd_remap(tile, ntiles);
-        int tn = wg % p.tiles_n, tm = wg / p.tiles_n;
-        if (p.group_n > 0) {  // column-group-major (launch_shape)
-            const int per_group = p.tiles_m * p.group_n;
-            const int g = wg / per_group, rem = wg - g * per_group;
-            const int c0 = g * p.group_n;
-            const int width = p.tiles_n - c0 < p.group_n ? p.tiles_n - c0 : p.group_n;
-            tm = rem / width, tn = c0 + rem - tm * width;
-        }
-        bn0 = tn * BN, bm0 = tm * S::ROWS;
-    };
-    const int first = (int)blockIdx.x;
-    if (wave >= 8 + NLOAD) {  // ------------------------------------------------------------- the storer waves
-        const int w = wave - 8 - NLOAD;
-        DirectEpi de;
-        de.init(p, 0);
-        StorerTile<EPI> st;
-        st.left = 0, st.bm0 = st.bn0 = 0;
-        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int nev = 4 * nt + 2;  // barrier events of a tile before its hand-off barrier
-        const int E0 = (EPI == 4 && nev > 8) ? 4 : 1;  // first event after which pieces are stored (EPI 4: its first loads get a K tile of time)
-        for (int tile = first; tile < ntiles; tile += tile_step) {
-            // the previous tile (in st) is stored while this one is multiplied: piece quota after event e = 16 e / (nev - 1)
-            for (int e = 0; e < nev; ++e) {
-                if (e == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab has been read: after event 1 the loaders refill stage 2
-                __builtin_amdgcn_s_barrier();
-                if (e >= E0 && st.left > 0) {  // quota rises linearly from event E0 - 1 to 16 at the last event
-                    const int quota = nev - E0 > 0 ? (16 * (e - E0 + 1) + nev - E0 - 1) / (nev - E0) : 16;
-                    while (16 - st.left < quota) storer_next<EPI>(p, de, st, w, lane, cs);
-                }
-            }
-            while (st.left > 0) storer_next<EPI>(p, de, st, w, lane, cs);  // (nt = 0: nothing was scheduled)
-            if constexpr (EPI == 4) {
-                if (tile != first) storer_colsum_flush(p, st.bn0, lane, cs);
-            }
-            __builtin_amdgcn_s_barrier();  // hand-off: the MFMA waves have written this tile into the slab
-            tile_origin(tile, st.bm0, st.bn0);
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-                st.v[t] = *reinterpret_cast<const u32x4_t*>(slab + sw_slab_off((w * 16 + t) * 4 + (lane >> 4), lane & 15));
-            st.left = 16;
-            if constexpr (EPI == 4) st.pq[0] = storer_pre_load<EPI>(p, de, st, 0, w, lane), st.pq[1] = storer_pre_load<EPI>(p, de, st, 1, w, lane);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        while (st.left > 0) storer_next<EPI>(p, de, st, w, lane, cs);
-        if constexpr (EPI == 4) {
-            if (first < ntiles) storer_colsum_flush(p, st.bn0, lane, cs);
-        }
-        return;
-    }
-    if (wave >= 8) {  // ---------------------------------------------------------------------- the loader waves
-        const int w = wave - 8;
-        LoaderStage<AKM> sa;
-        LoaderStage<BKM> sb;
-        int bm0, bn0;
-        if (first < ntiles) {
-            tile_origin(first, bm0, bn0);
-            sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0), sa.init_offsets(2, w, lane), sb.init_offsets(1, w, lane);
-            loader_prologue<AKM, BKM>(sa, sb, smem, 0, nt, p.K, w, lane);
-        }
-        for (int tile = first; tile < ntiles; tile += tile_step) {
-            k_loop_loader<AKM, BKM>(sa, sb, smem, 0, nt, p.K, w, lane);
-            if (nt <= 0) __builtin_amdgcn_s_barrier(), __builtin_amdgcn_s_barrier();  // (gemm_debug 2: keep the barrier count)
-            if (tile + tile_step < ntiles) {  // every stage is free; stages 0 and 1 take the next tile's first K tiles (stage 2 = slab)
-                tile_origin(tile + tile_step, bm0, bn0);
-                sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0), sa.init_offsets(2, w, lane), sb.init_offsets(1, w, lane);
-                loader_prologue<AKM, BKM>(sa, sb, smem, 0, nt, p.K, w, lane);
-            }
-            __builtin_amdgcn_s_barrier();  // hand-off
-        }
-        return;
-    }
-    // ------------------------------------------------------------------------------------- the eight MFMA waves
-    const int wm = wave >> 1, wn = wave & 1;
-    const int frow = lane & 31, fh = lane >> 5;
-    int tile_no = 0;
-    for (int tile = first; tile < ntiles; tile += tile_step, ++tile_no) {
-        unsigned long long* stamp = nullptr;
-        if (p.trace && lane == 0 && (wave & 3) == 0 && tile_no < TRACE_TILES)
-            stamp = p.trace + (((long)blockIdx.x * 2 + (wave >> 2)) * TRACE_TILES + tile_no) * 8;
-        if (stamp) stamp[0] = wall_clock64();
-        int bm0, bn0;
-        tile_origin(tile, bm0, bn0);
-        f32x16 acc[2][2];
-        if (p.bias) {  // the accumulators start from the bias
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + bn0 + wn * 64 + j * 32 + 8 * q + 4 * fh);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) acc[i][j][4 * q] = b4.x, acc[i][j][4 * q + 1] = b4.y, acc[i][j][4 * q + 2] = b4.z, acc[i][j][4 * q + 3] = b4.w;
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        }
-        if (stamp) stamp[5] = __builtin_readcyclecounter();
-        k_loop_consumer<AKM, BKM>(smem, nt, wave, lane, wm, wn, acc, stamp);
-        if (nt <= 0) __builtin_amdgcn_s_barrier(), __builtin_amdgcn_s_barrier();
-        if (stamp) stamp[2] = wall_clock64(), stamp[6] = __builtin_readcyclecounter(), stamp[7] = wall_clock64();
-        // every wave is past its last fragment read (the loop's closing barrier): the tile goes into the slab as packed bf16
-#pragma unroll
-        for (int i = 0; i < 2; ++i) mfma_settle(acc[i][0]), mfma_settle(acc[i][1]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = wm * 64 + i * 32 + frow;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                u32x2_t pk[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pk[q] = u32x2_t{pack_bf2(acc[i][j][4 * q], acc[i][j][4 * q + 1]), pack_bf2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3])};
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    *reinterpret_cast<u32x4_t*>(slab + sw_slab_off(r, wn * 8 + j * 4 + k * 2 + fh)) = widen_pair(pk[2 * k], pk[2 * k + 1]);
-            }
-        }
-        if (stamp) stamp[3] = wall_clock64();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // hand-off
-        if (stamp) stamp[4] = wall_clock64();
-    }
 }
 
 // ================================================================================================================
@@ -1317,7 +1063,6 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     GemmParams q = p;
     q.tiles_n = q.tiles_m = 0;
     q.defer = 0, q.group_n = 0;
-    q.stage_regs = mmvid_option(MMVID_OPT_GEMM_STAGE);
     q.red_out = nullptr, q.counters = nullptr;  // (set below when the split-K slabs are reduced inside the kernel)
     if (WM == 4 && mmvid_option(MMVID_OPT_GEMM_PERSIST) && (long)grid.x * grid.y > 256) {  // more than one tile per CU
         q.tiles_n = (int)grid.x, q.tiles_m = (int)grid.y;
@@ -1370,24 +1115,6 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
             const bool packed = p.out_bf16 && !p.out_f32 && !p.residual && !p.dact_pre && !p.accumulate && p.N % 128 == 0 && batch == 1;
             const int epi = dact_packed ? 4 : (packed ? (p.save_pre ? 3 : 2) : 1);
             const size_t lds = S::LDS_BYTES + BIAS_LDS_BYTES;
-            if (epi >= 2 && q.tiles_n > 0 && p.alpha == 1.0f && grid.z == 1 && mmvid_option(MMVID_OPT_GEMM_SW)) {
-                // storer-wave form: the finished tile is handed to four storer waves through LDS (gemm_bf16_sw_kernel)
-                static bool attr_sw[5] = {false, false, false, false, false};
-                auto go_sw = [&](auto kern) {
-                    if (!attr_sw[epi]) {
-                        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                        attr_sw[epi] = true;
-                    }
-                    hipLaunchKernelGGL(kern, grid, dim3(SW_THREADS), lds, stream, q);
-                };
-                if (epi == 4)
-                    go_sw(gemm_bf16_sw_kernel<AKM, BKM, 4>);
-                else if (epi == 3)
-                    go_sw(gemm_bf16_sw_kernel<AKM, BKM, 3>);
-                else
-                    go_sw(gemm_bf16_sw_kernel<AKM, BKM, 2>);
-                return;
-            }
             static bool attr[5] = {false, false, false, false, false};
             auto go = [&](auto kern) {
                 if (!attr[epi]) {
@@ -1396,6 +1123,15 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
                 }
                 hipLaunchKernelGGL(kern, grid, dim3(512 + 64 * NLOAD), lds, stream, q);
             };
+            if (epi == 2 && mmvid_option(MMVID_OPT_GEMM_LOADERS) == 8) {  // sixteen waves: 8 MFMA + 8 loaders, 128 registers each
+                static bool attr8 = false;
+                if (!attr8) {
+                    (void)hipFuncSetAttribute((const void*)gemm_bf16_lw_kernel<AKM, BKM, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    attr8 = true;
+                }
+                hipLaunchKernelGGL((gemm_bf16_lw_kernel<AKM, BKM, 2, 8>), grid, dim3(512 + 64 * 8), lds, stream, q);
+                return;
+            }
             if (epi == 4)
                 go(gemm_bf16_lw_kernel<AKM, BKM, 4>);
             else if (epi == 3)
@@ -1653,7 +1389,6 @@ extern "C" int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_ki
         p.partial = nullptr, p.colsum = nullptr;
         p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
         p.tiles_n = p.tiles_m = 0, p.group_n = 0, p.defer = 0;
-        p.stage_regs = mmvid_option(MMVID_OPT_GEMM_STAGE);
         p.trace = nullptr;
         p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
         MmvidProfScope prof(PROF_GEMM_TN, flops, (hipStream_t)stream);

@@ -574,19 +574,21 @@ __device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM, NL>& sa, co
     }
     __builtin_amdgcn_s_barrier();  // the closing barrier of the leading group
 }
-// the MFMA waves' K loop: the schedule of k_loop_pingpong without any vector-memory instruction or vmcnt wait
-template <bool AKM, bool BKM>
+// the MFMA waves' K loop: the schedule of k_loop_pingpong without any vector-memory instruction or vmcnt wait.  DBG = the instance that
+// carries the timing experiments (gemm_debug 4: half the barriers, 8 / 9: no fragment reads; results are wrong) and the time stamps.
+template <bool AKM, bool BKM, bool DBG = false>
 __device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, int lane, int wm, int wn, f32x16 (&acc)[2][2],
-                                                unsigned long long* stamp = nullptr, bool half_barriers = false, bool no_reads = false) {
+                                                unsigned long long* stamp = nullptr, int debug = 0) {
     using S = BlockShape<4>;
+    const bool half_barriers = DBG && debug == 4, no_reads = DBG && (debug == 8 || debug == 9);
     char* b0 = smem;
     char* b1 = smem + S::STAGE_BYTES;
     char* b2 = smem + 2 * S::STAGE_BYTES;
     if (nt <= 0) return;
     __builtin_amdgcn_s_barrier();                 // tile 0 is visible to everyone
-    if (stamp) stamp[1] = wall_clock64();
+    if (DBG && stamp) stamp[1] = wall_clock64();
     if (wave >= 4) __builtin_amdgcn_s_barrier();  // the trailing group starts one barrier late
-    if (no_reads) {  // gemm_debug 8 / 9 (timing experiment, results are wrong): the barrier + MFMA skeleton of the loop without its fragment reads
+    if (no_reads) {  // the barrier + MFMA skeleton of the loop without its fragment reads
         bf16x8_t a[2][2], b[2][2];
         const uint32_t k0[2] = {lds_addr(b0), lds_addr(b0)};
         pp_load_half<AKM, BKM, 0>(b0 + (wm >> 1) * TILE_BYTES, b0 + S::NSUB * TILE_BYTES, k0, k0, wm & 1, wn, lane, a, b);
@@ -616,7 +618,7 @@ __device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, in
         bf16x8_t a[2][2], b[2][2];
         pp_load_half<AKM, BKM, 0>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
         __builtin_amdgcn_sched_barrier(0);
-        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 1   (half_barriers: gemm_debug 4, a timing experiment -- results are wrong)
+        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 1
         pp_compute_half<AKM, BKM>(a, b, acc, []() {});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 2

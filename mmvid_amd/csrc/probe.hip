@@ -135,10 +135,52 @@ __global__ __launch_bounds__(1024) void probe_lds_pattern_kernel(const int* __re
     if (lane == 0 && wave < 4) out[wave] = t1 - t0;
     if (acc.x == 0x12345678u) out[4] = acc.x;
 }
+// which = 5: the matrix pipe's SUSTAINED ceiling (tools/power_probe.py).  Register-only v_mfma_f32_32x32x16_bf16 chains (4 accumulators, a
+// pool of 8 operand fragments cycled so that consecutive MFMAs see different bits), 8 waves per block, no memory traffic at all.
+// in (HOST int32[3]) = {iterations of 32 MFMAs per wave, blocks, operand mode: 0 zeros, 1 random bits with bf16 exponents near 1.0}.
+__global__ __launch_bounds__(512) void probe_mfma_kernel(int iters, int mode, float* __restrict__ out) {
+    const unsigned tid = threadIdx.x + blockIdx.x * 512u;
+    bf16x8_t f[8];
+    unsigned h = tid * 2654435761u + 12345u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h = h * 1664525u + 1013904223u;
+            // two bf16 per word: random sign + mantissa, exponent 0x3f (|x| in [0.5, 2)) -- the bit statistics of normalised activations
+            w[e] = mode ? ((h & 0x80ff80ffu) | 0x3f003f00u) : 0u;
+        }
+        f[i] = __builtin_bit_cast(bf16x8_t, uint4{w[0], w[1], w[2], w[3]});
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[(u + a) & 7], f[(u + 2 * a + 3) & 7], acc[a], 0, 0, 0);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[a][r];
+    if (sum == 1.2345e-30f) out[0] = sum;
+}
 }  // namespace
 
 extern "C" int mmvid_probe(int which, const void* in, void* out, void* stream) {
-    MMVID_REQUIRE((which >= 0 && which <= 4) && in && out, "probe: bad arguments");
+    MMVID_REQUIRE((which >= 0 && which <= 5) && in && out, "probe: bad arguments");
+    if (which == 5) {  // in = HOST int32[3]: iterations, blocks, operand mode
+        const int* a = (const int*)in;
+        hipLaunchKernelGGL(probe_mfma_kernel, dim3(a[1]), dim3(512), 0, (hipStream_t)stream, a[0], a[2], (float*)out);
+        MMVID_LAUNCH_CHECK("probe");
+        return MMVID_OK;
+    }
     if (which == 4) {
         hipLaunchKernelGGL(probe_lds_pattern_kernel, dim3(1), dim3(((const int*)in == nullptr) ? 256 : 1024), 0, (hipStream_t)stream, (const int*)in, (unsigned long long*)out);
         MMVID_LAUNCH_CHECK("probe");

@@ -13,7 +13,7 @@ from test_host_logic import tiny_bert
 from test_models_gpu import DEV, close, load_synth
 
 pytestmark = pytest.mark.gpu
-GEMM_STAGE_DEFAULT = 0  # option gemm_stage as the library ships it (tests that flip it restore this)
+GEMM_LOADERS_DEFAULT = 4  # option gemm_loaders as the library ships it (tests that flip it restore this)
 
 
 # ---------------------------------------------------------------------------------- H6 / N2: front-end vs the reference
@@ -395,12 +395,12 @@ def test_gemm_block_forms_are_bit_identical(M, N, K):
     Wk = (torch.randn(K, N, device=DEV) * 0.05).to(bf)
     bias = torch.randn(N, device=DEV) * 0.1
     pre_in = torch.randn(M, N, device=DEV).to(bf)
-    forms = {'lds': (0, 0, 0, 0), 'direct': (1, 0, 0, 0), 'loader': (1, 1, 0, 0), 'loader+groups': (1, 1, 1, 0),
-             'loader+groups, register-staged operands (round 4)': (1, 1, 1, 1)}
+    forms = {'lds': (0, 0, 0, 4), 'direct': (1, 0, 0, 4), 'loader': (1, 1, 0, 4), 'loader+groups': (1, 1, 1, 4),
+             'loader+groups, eight loader waves (round 4)': (1, 1, 1, 8)}
     outs = {}
     try:
-        for name, (epi, loader, groups, stage) in forms.items():
-            _lib.call('mmvid_set_option', b'gemm_stage', stage)
+        for name, (epi, loader, groups, nload) in forms.items():
+            _lib.call('mmvid_set_option', b'gemm_loaders', nload)
             _lib.call('mmvid_set_option', b'gemm_epi', epi)
             _lib.call('mmvid_set_option', b'gemm_loader', loader)
             _lib.call('mmvid_set_option', b'gemm_groupn', groups)
@@ -412,7 +412,7 @@ def test_gemm_block_forms_are_bit_identical(M, N, K):
                           ops.gemm(A, W, bias=bias, act=1, save_pre=save), save,          # c_fc-like: two bf16 results
                           ops.gemm(A, Wk, b_kmajor=True, dact_pre=pre_in, colsum=cs) if N % 8 == 0 else None, cs)
     finally:
-        for k, v in ((b'gemm_epi', 1), (b'gemm_loader', 1), (b'gemm_groupn', 1), (b'gemm_tile', 0), (b'gemm_stage', GEMM_STAGE_DEFAULT)):
+        for k, v in ((b'gemm_epi', 1), (b'gemm_loader', 1), (b'gemm_groupn', 1), (b'gemm_tile', 0), (b'gemm_loaders', GEMM_LOADERS_DEFAULT)):
             _lib.call('mmvid_set_option', k, v)
     ref = outs['lds']
     want = (A.float() @ W.float().t() + bias)

@@ -19,8 +19,8 @@ for name, N, K, kmajor in (('qkv fwd NT', 2304, 768, False), ('d_h dX NN', 768, 
     out = torch.empty(M, N, device=dev, dtype=bf)
     run = (lambda: ops.gemm(X, W, b_kmajor=kmajor, out=out))
     nt = (K + 63) // 64
-    for stage, dbg in ((0, 0), (0, 7)) if not os.environ.get('ANATOMY') else ((0, 0), (0, 6), (0, 7), (0, 8), (0, 9), (0, 10), (0, 11)):
-        _lib.call('mmvid_set_option', b'gemm_stage', stage)
+    for stage, dbg in ((4, 0), (8, 0), (8, 7)) if not os.environ.get('ANATOMY') else ((4, 0), (4, 6), (4, 7), (4, 8), (4, 9), (4, 10), (4, 11)):
+        _lib.call('mmvid_set_option', b'gemm_loaders', stage)
         _lib.call('mmvid_set_option', b'gemm_debug', dbg)
         for _ in range(3):
             run()
@@ -41,6 +41,6 @@ for name, N, K, kmajor in (('qkv fwd NT', 2304, 768, False), ('d_h dX NN', 768, 
             kl = (st[ok][:, 2] - st[ok][:, 1]) / 100.0
             mhz = (100.0 * (st[ok][:, 6] - st[ok][:, 5]) / (st[ok][:, 7] - st[ok][:, 0])).mean()
             rows.append(f'{kl.mean():6.2f} us = {kl.mean() * mhz / nt:6.0f} clk/K-tile @ {mhz:5.0f} MHz')
-        print(f'{name:12s} {M}x{N}x{K} gemm_stage {stage} gemm_debug {dbg}: K loop per tile: ' + ' | '.join(rows))
+        print(f'{name:12s} {M}x{N}x{K} gemm_loaders {stage} gemm_debug {dbg}: K loop per tile: ' + ' | '.join(rows))
 _lib.call('mmvid_set_option', b'gemm_debug', 0)
-_lib.call('mmvid_set_option', b'gemm_stage', 0)
+_lib.call('mmvid_set_option', b'gemm_loaders', 4)
