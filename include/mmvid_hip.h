@@ -484,7 +484,8 @@ int mmvid_vqgan_run(const mmvid_vqgan_op_t* ops, int nops, void* arena, void* st
 
 /* hardware probe (tools/gpu_probe.py): which = 0 -> ds_read_b64_tr_b16 lane layout | 1 -> LDS-DMA through a buffer descriptor |
  * 2 -> store-pattern bandwidth | 3 -> the DPP / permlane wave reductions (in float[64] -> out float[3][64]) | 4 -> LDS read patterns |
- * 5 -> register-only MFMA chains: the matrix pipe's sustained (power-limited) ceiling, in = HOST int32[3] {iterations, blocks, operand mode}. */
+ * 5 -> register-only MFMA chains: the matrix pipe's sustained (power-limited) ceiling, in = HOST int32[3] {iterations, blocks, operand mode} |
+ * 6 -> a read stream of known size (LDS-DMA or global_load) for calibrating FETCH_SIZE, in = HOST int64[2] {bytes, mode}, out = the buffer. */
 int mmvid_probe(int which, const void* in, void* out, void* stream);
 
 /* ---- optional HIP-event timing of the MFMA kernel families on their launch stream (bench.py roofline line).

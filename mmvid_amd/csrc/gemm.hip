@@ -36,6 +36,8 @@ struct GroupKind {             // one shape of a multi-shape grouped launch: `gr
     int M, N, tiles_n, tiles_m;
     int first;  // first tile (in the launch's linear tile order) of this kind
     int out0;   // its outputs are out_list[out0 + g]
+    int colmajor;  // walk a group's tiles column-major (rows fastest): set when the B operand (X) is the wider one, so that the tiles
+                   // sharing one of ITS panels are neighbours in the XCD's stretch and the big operand is streamed once
 };
 
 struct GemmParams {
@@ -696,7 +698,11 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
         const int g = rem / per, t = rem - g * per;
         float* const out = gt->out_list[kd.out0 + g];
         if (out == nullptr) return;  // (block-uniform, before any barrier)
-        const int tm = t / kd.tiles_n, tn = t - tm * kd.tiles_n;
+        int tm, tn;
+        if (kd.colmajor)
+            tn = t / kd.tiles_m, tm = t - tn * kd.tiles_m;
+        else
+            tm = t / kd.tiles_n, tn = t - tm * kd.tiles_n;
         multi_bm0 = tm * S::ROWS, multi_bn0 = tn * BN;
         p.A = kd.A + (long)g * kd.strideA, p.B = kd.B + (long)g * kd.strideB;
         p.strideA = p.strideB = p.strideC = 0;
@@ -1372,6 +1378,10 @@ extern "C" int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_ki
             o.strideA = kd.strideY, o.strideB = kd.strideX, o.lda = kd.ldy, o.ldb = kd.ldx;
             o.M = kd.N, o.N = kd.K, o.tiles_n = cdiv(kd.K, BN), o.tiles_m = cdiv(kd.N, S::ROWS);
             o.first = tiles, o.out0 = k * n;
+            // PMC (profiles/r03_pmc_fetch_size.csv, FETCH_SIZE doubled per the gfx950 rule, calibrated in r04_pmc_fetch_calibration.txt):
+            // the round-3 launch fetched 6.6 GB for 3.1 GB of operands -- row-major tile order re-reads the 64-MB activation of the
+            // c_proj weight gradient (a 768 x 3072 output: 3 tile rows x 24 tile columns) once per tile row
+            o.colmajor = (mmvid_option(MMVID_OPT_DW_ORDER) && kd.K > kd.N) ? 1 : 0;
             tiles += o.tiles_n * o.tiles_m * n;
             for (int g = 0; g < n; ++g) {
                 gt.out_list[o.out0 + g] = kd.dW_list[g0 + g];

@@ -1,6 +1,7 @@
 // Hardware probes (lane layouts of gfx950 instructions whose semantics the kernels rely on).  Not on the
 // product path; used by tools/gpu_probe.py to confirm assumptions before a kernel is built on them.
 #include "common.h"
+#include "gemm_core.h"
 
 namespace {
 // which = 0: ds_read_b64_tr_b16.  in: int32[64] per-lane LDS byte offsets.  LDS is filled with u16 value == its
@@ -171,10 +172,41 @@ __global__ __launch_bounds__(512) void probe_mfma_kernel(int iters, int mode, fl
         for (int r = 0; r < 16; ++r) sum += acc[a][r];
     if (sum == 1.2345e-30f) out[0] = sum;
 }
+// which = 6: an LDS-DMA read stream with a known byte count, for calibrating rocprofv3's FETCH_SIZE on this access path (the guide says
+// FETCH_SIZE reports HALF the bytes of a wide coalesced read on gfx950, `global_load` and `buffer_load ... lds` alike: profiles/
+// r04_pmc_fetch_calibration.txt).  in (HOST int64[2]) = {bytes (multiple of 64 KiB), mode: 0 = buffer_load_dwordx4 ... lds, 1 = global_load_dwordx4
+// into registers}; `out` is the buffer that is read (every byte exactly once, 1 KiB per wave-instruction, 256 threads per block).
+__global__ __launch_bounds__(256) void probe_stream_kernel(const char* __restrict__ buf, long bytes, int mode, float* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) char lds[4][1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long per_block = 65536;
+    const char* base = buf + (long)blockIdx.x * per_block;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    if (mode == 0) {
+        const mmvid_core::rsrc_t r = mmvid_core::make_rsrc(base, (uint32_t)per_block);
+        for (int i = wave; i < 64; i += 4) mmvid_core::blds16(r, (uint32_t)(i * 1024 + lane * 16), 0, lds[wave]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc = *reinterpret_cast<const uint4*>(lds[wave] + lane * 16);
+    } else {
+        for (int i = wave; i < 64; i += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(base + i * 1024 + lane * 16);
+            acc.x ^= v.x, acc.y ^= v.y, acc.z ^= v.z, acc.w ^= v.w;
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345679u) sink[0] = 1.f;
+    (void)bytes;
+}
 }  // namespace
 
 extern "C" int mmvid_probe(int which, const void* in, void* out, void* stream) {
-    MMVID_REQUIRE((which >= 0 && which <= 5) && in && out, "probe: bad arguments");
+    MMVID_REQUIRE((which >= 0 && which <= 6) && in && out, "probe: bad arguments");
+    if (which == 6) {  // in = HOST int64[2]: bytes, mode; out = the device buffer that is streamed (its first float is the sink)
+        const long long* a = (const long long*)in;
+        hipLaunchKernelGGL(probe_stream_kernel, dim3((unsigned)(a[0] / 65536)), dim3(256), 0, (hipStream_t)stream, (const char*)out, (long)a[0],
+                           (int)a[1], (float*)out);
+        MMVID_LAUNCH_CHECK("probe");
+        return MMVID_OK;
+    }
     if (which == 5) {  // in = HOST int32[3]: iterations, blocks, operand mode
         const int* a = (const int*)in;
         hipLaunchKernelGGL(probe_mfma_kernel, dim3(a[1]), dim3(512), 0, (hipStream_t)stream, a[0], a[2], (float*)out);

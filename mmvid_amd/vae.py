@@ -518,10 +518,10 @@ class VQGanVAE1024(nn.Module):
         return prep['ee']
 
     # ---- planning: the op sequence of one encode / decode for a given batch shape ------------------------------
-    def _plan(self, kind, n, size_or_hw):
+    def _plan(self, kind, n, size_or_hw, slot=0):
         prep = self._prepared()
         mode = 'split' if self.strict == 'split' else bool(self.strict)
-        key = ('plan', kind, n, size_or_hw, mode)
+        key = ('plan', kind, n, size_or_hw, mode, slot)  # (slot: plans that run concurrently need arenas of their own)
         if key not in prep:
             pl = _Planner(self, strict=mode)
             if kind == 'enc':
@@ -622,8 +622,8 @@ class VQGanVAE1024(nn.Module):
         img = ops._chk(img.contiguous().float(), f32, 'img')
         n, c, s, s2 = img.shape
         assert c == 3 and s == s2
-        plan = self._plan('enc', n, s)
         idx = torch.empty(n, (s // 16)**2, device=img.device, dtype=torch.int64)
+        plan = self._plan('enc', n, s)
         plan.run(ext_in={'img': img}, ext_out={'idx': idx})
         return idx, plan
 

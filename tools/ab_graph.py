@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of a library tuning knob on the whole training step.
 
-    python tools/ab_graph.py <option> <value> <value> [...]      e.g.  tower_streams 1 2   |   gemm_tile 0 128 256
+    python tools/ab_graph.py <option> <value> <value> [...]      e.g.  tower_streams 1 2   |   gemm_tile 0 128 256   |   py:vae.streams 1 2
 
 The step is captured once per value (engine.GraphedStep; the knob is baked into the capture) and the graphs are
 replayed alternately in groups of 5: GPU-bound timing, stable to ~0.2 %, and box-to-box / run-to-run drift cancels
@@ -31,7 +31,13 @@ def main():
         bench.eager_step(tr, fn, inputs)
     steps = {}
     for v in values:
-        _lib.call('mmvid_set_option', opt.encode(), v)
+        if opt.startswith('py:'):  # a Python attribute of the model instead of a library option, e.g. py:vae.streams 1 2
+            obj, path = model, opt[3:].split('.')
+            for name in path[:-1]:
+                obj = getattr(obj, name)
+            setattr(obj, path[-1], v)
+        else:
+            _lib.call('mmvid_set_option', opt.encode(), v)
         steps[v] = GraphedStep(tr, fn, inputs, warmup=1)
     res = {v: [] for v in values}
     for rep in range(8):
