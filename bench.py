@@ -131,7 +131,7 @@ def pmc_traffic(family):
     instance per GEMM layout)."""
     import csv
     prefixes = PMC_KERNELS.get(family, (family.split('<')[0].split(' ')[0], ))
-    for rnd in ('r03', 'r02', 'r01'):
+    for rnd in ('r04', 'r03', 'r02', 'r01'):
         tot, disp = 0.0, {}
         try:
             for name, mult in (('fetch', 2.0), ('write', 1.0)):
@@ -145,6 +145,30 @@ def pmc_traffic(family):
         except OSError:
             continue
     return None
+
+
+def matrix_pipe_sustained_tflops(dev, seconds=0.7):
+    """TFLOP/s of register-only bf16 MFMA chains on random operand bits, sustained for `seconds` (mmvid_probe 5): the ceiling the
+    power-managed chip grants the matrix pipe, next to which `roofline.frac` (against the 2.5 PFLOP/s data-sheet peak) is to be read."""
+    from mmvid_amd import _lib
+    try:
+        sink = torch.zeros(16, device=dev)
+        arr = (ctypes.c_int32 * 3)(2000, 512, 1)
+        flops = 2.0 * 32 * 32 * 16 * 32 * 2000 * 8 * 512
+        call = lambda: _lib.call('mmvid_probe', 5, arr, sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        call()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = max(4, int(seconds / 4.8e-3))
+        a.record()
+        for _ in range(n):
+            call()
+        b.record()
+        torch.cuda.synchronize()
+        return flops * n / (a.elapsed_time(b) * 1e-3) / 1e12
+    except Exception as e:  # measurement only
+        print(f'[bench] matrix-pipe ceiling probe failed: {e}', file=sys.stderr)
+        return None
 
 
 def host_cores():
@@ -565,6 +589,7 @@ def main():
                                 'tflops': fl[i] / (ms[i] * 1e-3) / 1e12})
         dom = max(kernels, key=lambda k: k['ms_per_step']) if kernels else None
         roofline = None
+        sustained = matrix_pipe_sustained_tflops(dev) if rank == 0 else None
         if dom:
             roofline = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS,
@@ -572,6 +597,10 @@ def main():
                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC passes committed under profiles/)',
                         'avg_launch_ms': dom['avg_ms'], 'launches_per_step': dom['launches_per_step'],
                         'timed_steps': n_timed_steps,
+                        # what the matrix pipe sustains on THIS box with nothing but MFMAs in flight (register-only
+                        # v_mfma_f32_32x32x16_bf16 chains on random operand bits, ~0.7 s; csrc/probe.hip): the chip clocks down to its
+                        # power limit (1.8-1.9 GHz, ~1.8 PFLOP/s; 2.46 PFLOP/s on all-zero operands, profiles/r04_power_probe_*.log)
+                        'sustained_mfma_ceiling': sustained, 'frac_of_sustained_ceiling': (dom['tflops'] / sustained) if sustained else None,
                         'measured_in': 'HIP events around every launch of %d eagerly launched step(s) of the same workload, run right '
                                        'after the timed region (events cannot be recorded inside a hipGraph replay)' % n_timed_steps}
         L = model.total_seq_len
