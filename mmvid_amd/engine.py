@@ -50,8 +50,15 @@ class WarmupLR:
 class FlatTrainer:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
                  process_group=None, bucket_mb=64, order=None, lr_schedule=None, force_exchange=False, sparse_tables=True,
-                 lazy_rows=True):
+                 lazy_rows=True, exchange=None):
         self.model = model
+        # how a dense gradient message is summed over the ranks: 'allreduce' (one RCCL all-reduce: a ring, bound by ONE xGMI link
+        # per hop) or 'direct' (every rank sends shard j of the message straight to rank j -- all_to_all over the 7
+        # point-to-point links at once --, sums the shards it received in rank order, and the summed shards are all-gathered).
+        # Same sums up to fp32 summation order; MMVID_EXCHANGE overrides.
+        self.exchange = os.environ.get('MMVID_EXCHANGE', exchange or 'allreduce')
+        assert self.exchange in ('allreduce', 'direct'), self.exchange
+        self._direct_buf = None
         # row-wise exchange of the tables model.sparse_grad_rows() names (MMVID_SPARSE_TABLES=0 forces the dense all-reduce)
         self.sparse_tables = bool(sparse_tables) and os.environ.get('MMVID_SPARSE_TABLES', '1') != '0'
         self.lr_schedule = lr_schedule
@@ -322,9 +329,37 @@ class FlatTrainer:
                 e = min(s + self.bucket_elems, phi)
                 if self._comm_stream is not None:
                     with torch.cuda.stream(self._comm_stream):
-                        self._works.append(dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                        self._reduce_message(s, e)
                 else:
-                    self._works.append(dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                    self._reduce_message(s, e)
+
+    def _reduce_message(self, s, e):
+        """G[s:e] <- sum over ranks (on the current stream)."""
+        if self.exchange == 'allreduce' or (e - s) % self.world != 0:
+            self._works.append(dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            return
+        # direct reduce-scatter + all-gather: fixed buffers (capturable), every peer link busy at once
+        n, w = e - s, self.world
+        if self._direct_buf is None or self._direct_buf.numel() < n + n // w:
+            self._direct_buf = torch.empty(self.bucket_elems + self.bucket_elems // w + w, device=self.G.device, dtype=torch.float32)
+        recv = self._direct_buf[:n].view(w, n // w)
+        shard = self._direct_buf[n:n + n // w]
+        msg = self.G[s:e]
+        nccl = dist.get_backend(self.pg) == 'nccl'
+        if nccl:
+            dist.all_to_all_single(recv.view(-1), msg, group=self.pg)
+        else:  # gloo (CPU tests) has no all_to_all: the same exchange as point-to-point sends
+            me, parts = self._rank(), msg.view(w, n // w)
+            recv[me].copy_(parts[me])
+            reqs = [dist.P2POp(dist.isend, parts[j].contiguous(), j, self.pg) for j in range(w) if j != me] + \
+                   [dist.P2POp(dist.irecv, recv[j], j, self.pg) for j in range(w) if j != me]
+            for r in dist.batch_isend_irecv(reqs):
+                r.wait()
+        torch.sum(recv, dim=0, out=shard)  # rank order: the same bits on every rank
+        if nccl:
+            dist.all_gather_into_tensor(msg, shard, group=self.pg)
+        else:
+            dist.all_gather(list(msg.view(w, n // w).unbind(0)), shard, group=self.pg)
 
     def _gather(self, t):
         """[n, ...] on every rank -> [world * n, ...] (rank-major)."""

@@ -40,7 +40,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange='allreduce'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -51,8 +51,8 @@ def _worker(rank, world, port, q):
             p.data.normal_()
         broadcast_parameters(m)
         ref = [p.detach().clone() for p in m.parameters()]
-        tr = FlatTrainer(m, order=backward_order, bucket_mb=0.001)  # tiny buckets: several messages per range
-        assert tr.world == world
+        tr = FlatTrainer(m, order=backward_order, bucket_mb=0.001, exchange=exchange)  # tiny buckets: several messages per range
+        assert tr.world == world and tr.exchange == exchange
         # flat order: tables first, then layers ascending, then heads
         kinds = [0 if not n.startswith(('transformer.', 'to_logits')) else (2 if n.startswith('to_logits') else 1) for n in tr.names]
         assert kinds == sorted(kinds)
@@ -298,11 +298,14 @@ def test_flat_trainer_real_model_callbacks_world2():
 
 
 @pytest.mark.timeout(300)
-def test_flat_trainer_exchange_world2():
+@pytest.mark.parametrize('exchange', ['allreduce', 'direct'])
+def test_flat_trainer_exchange_world2(exchange):
+    """Both forms of the dense gradient exchange: one all-reduce per message, and the direct form (all_to_all of shards, rank-ordered
+    local sum, all-gather: every point-to-point link busy at once) -- the same sums on every rank."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
