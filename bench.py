@@ -589,7 +589,7 @@ def main():
                                 'tflops': fl[i] / (ms[i] * 1e-3) / 1e12})
         dom = max(kernels, key=lambda k: k['ms_per_step']) if kernels else None
         roofline = None
-        sustained = matrix_pipe_sustained_tflops(dev) if rank == 0 else None
+        sustained = matrix_pipe_sustained_tflops(device) if rank == 0 else None
         if dom:
             roofline = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': PEAK_BF16_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_BF16_TFLOPS,

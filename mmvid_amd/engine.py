@@ -335,7 +335,7 @@ class FlatTrainer:
 
     def _reduce_message(self, s, e):
         """G[s:e] <- sum over ranks (on the current stream)."""
-        if self.exchange == 'allreduce' or (e - s) % self.world != 0:
+        if self.exchange == 'allreduce' or self.world == 1 or (e - s) % self.world != 0:  # (a group of one has no peers to send shards to)
             self._works.append(dist.all_reduce(self.G[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             return
         # direct reduce-scatter + all-gather: fixed buffers (capturable), every peer link busy at once

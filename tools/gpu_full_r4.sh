@@ -19,7 +19,6 @@ echo "== config 4"; timeout 600 python bench.py --config 4 --steps 20 --warmup 3
 echo "== config 5"; timeout 900 python bench.py --config 5 --steps 2 --warmup 1 > gpurun_out/bench_c5.log 2> gpurun_out/bench_c5.err; echo "rc=$?"
 echo "== BERT sampling (mask-predict)"; timeout 900 python bench.py --sample --steps 3 --warmup 1 > gpurun_out/bench_bert_sampling.log 2> gpurun_out/bench_bert_sampling.err; grep "bench\]" gpurun_out/bench_bert_sampling.err | cut -c1-200
 echo "== launcher, forced exchange"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --force-exchange > gpurun_out/bench_ddp1.log 2> gpurun_out/bench_ddp1.err; grep "bench\]" gpurun_out/bench_ddp1.err | cut -c1-200
-echo "== launcher, forced exchange, direct reduce-scatter + all-gather"; MMVID_EXCHANGE=direct timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --force-exchange > gpurun_out/bench_ddp1_direct.log 2> gpurun_out/bench_ddp1_direct.err; grep "bench\]" gpurun_out/bench_ddp1_direct.err | cut -c1-200
 echo "== self-launch on a 1-GPU box"; timeout 300 python bench.py --gpus 2 --steps 1 --warmup 0 > gpurun_out/bench_gpus2.log 2> gpurun_out/bench_gpus2.err; echo "rc=$? (expected non-zero)"; grep -o "only [0-9]* device(s) visible[^;]*" gpurun_out/bench_gpus2.err | head -1
 echo "== attention / decode microbench + timelines"; timeout 300 python tools/bench_attn.py 2>&1 | grep -v amdgpu > gpurun_out/attn.log; cat gpurun_out/attn.log
 timeout 300 python tools/bench_decode_step.py 4 2>&1 | grep -v "amdgpu\|fused=False" > gpurun_out/decode_step_b4.log
@@ -38,7 +37,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - <<'PY'
 import json
-for f in ('bench','bench_strict','bench_split','bench_c4','bench_c5','bench_ddp1','bench_ddp1_direct'):
+for f in ('bench','bench_strict','bench_split','bench_c4','bench_c5','bench_ddp1'):
     try:
         d=json.loads(open(f'gpurun_out/{f}.log').read().strip().splitlines()[-1])
         print(f, 'ms/step',round(d['ms_per_step'],3),'value',round(d['value']),d['config'].get('step_launch',''), 'roof', d['roofline'] and {k:d['roofline'][k] for k in ('kernel','achieved','frac','traffic')})
