@@ -12,7 +12,7 @@
 // LDS-DMA (no VGPR staging, no ds_write), double-buffered.  Operands whose MFMA rows are positions are read
 // with ds_read_b128; operands whose REDUCTION index is the position (V^T, K^T, Q^T, dO^T) are read from the
 // same row-major tile with the hardware transpose read ds_read_b64_tr_b16 -- there are no transposed copies
-// in HBM.  One 16-B-chunk XOR swizzle (chunk ^= (row>>1)&7, applied on the DMA source address) serves both.
+// in HBM.  One 16-B-chunk XOR swizzle (chunk ^= swz(row), applied on the DMA source address) serves both, conflict-free for both.
 // The inner loops are written for instruction count: packed fp32 fma/add, hardware bf16 pack, v_permlane32_swap for
 // the cross-half max, and a LAZY softmax rescale (the running max is only raised when a tile exceeds it by 2^8;
 // P <= 256 is exact enough in bf16).  What bounds them, measured with time stamps from inside (tools/attn_timeline.py,
@@ -52,7 +52,16 @@ constexpr int TILE = 64 * 128;       // [64 pos][64 d] bf16, 16-B chunks swizzle
 constexpr int ROWS_PER_BLOCK = 128;  // 4 waves x 32
 constexpr float RESCALE_THR = 8.0f;  // log2 domain
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// 16-B chunk swizzle of a [64 pos][64 d] tile: chunk ^= swz(row), swz = row bits (1, 3, 2) -> chunk bits (2, 1, 0).  Any bijection of
+// (row >> 1) & 7 keeps the ds_read_b128 lane groups of row_frag() conflict-free (8 even / 8 odd rows of a group need 8 distinct values);
+// sending row bit 1 to the 64-B-half bit (chunk bit 2) is what the transpose reads need: a half-wave of ds_read_b64_tr_b16 reads 4 rows x
+// 64 B, and with the round-3 swizzle ((row >> 1) & 7: row bit 1 -> chunk bit 0) rows r and r + 2 landed on the same 16 banks -- two extra
+// LDS cycles per transpose read (PMC round 4: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33 / 0.25 / 0.25 in fwd / dQ / dK,dV).
+__device__ __forceinline__ int swz(int row) {
+    const int x = (row >> 1) & 7;
+    return ((x & 1) << 2) | (x >> 1);
+}
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ swz(row)) << 4); }
 
 // LDS-DMA of positions [p0, p0+64) x 64 d of one (batch, head) slice of a token-major matrix: 8 pieces of 1 KiB, 2 per
 // wave, through a buffer descriptor that ends at row L-1 -- positions >= L are zero-filled by the range check.
@@ -66,7 +75,7 @@ struct TileStage {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int row = (wave * 2 + jj) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const int chunk = (lane & 7) ^ swz(row);
             voff[jj] = (uint32_t)(((long)row * ld + chunk * 8) * 2);
         }
     }
@@ -80,35 +89,46 @@ struct TileStage {
 __device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int s, int h) {
     return *reinterpret_cast<const bf16x8_t*>(tile + lds_off(row, 2 * s + h));
 }
-// Per-lane part of the transpose-read address (see tr_frag).
-__device__ __forceinline__ int tr_lane_off(int lane) {
+// Per-lane parts of the transpose-read address (see tr_frag): lane (G = lane >> 4, si = lane & 15) reads position rowl = 4 (G >> 1) +
+// (si >> 2) of an 8-row group, 16-B chunk cl = 2 (G & 1) + ((si & 3) >> 1) of a 32-d half dt, 8-B half si & 1.  With chunk = 4 dt + cl and
+// swz(row) = 4 x0 + 2 x2 + x1 (x0 = rowl bit 1, x1 = rowl bit 2, x2 = row bit 3 = which 8-row group of a 16-position reduction step):
+//   chunk ^ swz = 4 (dt ^ x0) + (cl ^ x1 ^ 2 x2)  ->  one lane offset per (dt, x2): four registers.
+struct TrLane {
+    uint32_t o[2][2];  // [dt][x2], byte offsets inside a tile
+};
+__device__ __forceinline__ TrLane tr_lane_offs(int lane) {
     const int G = lane >> 4, si = lane & 15;
-    const int rowl = 4 * (G >> 1) + (si >> 2);         // 0..7 : position inside the 8-row group, 4 h + j
-    const int cl = 2 * (G & 1) + ((si & 3) >> 1);      // 16-B chunk inside the 32-d half
-    return rowl * 128 + ((cl ^ (rowl >> 1)) << 4) + 8 * (si & 1);
+    const int rowl = 4 * (G >> 1) + (si >> 2);
+    const int cl = 2 * (G & 1) + ((si & 3) >> 1);
+    const int x0 = (rowl >> 1) & 1, x1 = (rowl >> 2) & 1;
+    TrLane t;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int x2 = 0; x2 < 2; ++x2) t.o[dt][x2] = (uint32_t)(rowl * 128 + ((4 * (dt ^ x0) + (cl ^ x1 ^ (2 * x2))) << 4) + 8 * (si & 1));
+    return t;
 }
 // MFMA operand whose rows are d (= 32 dt + lane&31) and whose reduction index is the position: reduction step
 // m (16 positions) of sub-tile ss (32 positions); element e of half h <-> position 32 ss + 16 m + 4 h + (e&3) +
-// 8 (e>>2), the order in which pack_half() lays out accumulator rows.  Two transpose reads, 8 positions apart
-// (the swizzle of rows r and r+8 differs in bit 2 of the chunk: dt ^ 1 on the second read).
+// 8 (e>>2), the order in which pack_half() lays out accumulator rows.  Two transpose reads, 8 positions apart (x2 = 0, 1).
 // Issued as inline asm (see gemm_core.h: the builtin would drain the LDS-DMA prefetch); await with lgkm_wait_tied.
 template <int DT, int SS, int M>
-__device__ __forceinline__ bf16x8_t tr_frag(uint32_t lane_addr) {
-    const bf16x4_t lo = ds_read_tr16<(32 * SS + 16 * M) * 128 + DT * 64>(lane_addr);
-    const bf16x4_t hi = ds_read_tr16<(32 * SS + 16 * M + 8) * 128 + (DT ^ 1) * 64>(lane_addr);
+__device__ __forceinline__ bf16x8_t tr_frag(uint32_t base, const TrLane& tl) {
+    const bf16x4_t lo = ds_read_tr16<(32 * SS + 16 * M) * 128>(base + tl.o[DT][0]);
+    const bf16x4_t hi = ds_read_tr16<(32 * SS + 16 * M + 8) * 128>(base + tl.o[DT][1]);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // the four fragments of sub-tile SS in MFMA order: (dt 0, m 0), (dt 1, m 0), (dt 0, m 1), (dt 1, m 1)
 template <int SS>
-__device__ __forceinline__ void tr_frags4(uint32_t lane_addr, bf16x8_t (&f)[4]) {
-    f[0] = tr_frag<0, SS, 0>(lane_addr), f[1] = tr_frag<1, SS, 0>(lane_addr);
-    f[2] = tr_frag<0, SS, 1>(lane_addr), f[3] = tr_frag<1, SS, 1>(lane_addr);
+__device__ __forceinline__ void tr_frags4(uint32_t base, const TrLane& tl, bf16x8_t (&f)[4]) {
+    f[0] = tr_frag<0, SS, 0>(base, tl), f[1] = tr_frag<1, SS, 0>(base, tl);
+    f[2] = tr_frag<0, SS, 1>(base, tl), f[3] = tr_frag<1, SS, 1>(base, tl);
 }
-__device__ __forceinline__ void tr_frags4(int ss, uint32_t lane_addr, bf16x8_t (&f)[4]) {
+__device__ __forceinline__ void tr_frags4(int ss, uint32_t base, const TrLane& tl, bf16x8_t (&f)[4]) {
     if (ss == 0)
-        tr_frags4<0>(lane_addr, f);
+        tr_frags4<0>(base, tl, f);
     else
-        tr_frags4<1>(lane_addr, f);
+        tr_frags4<1>(base, tl, f);
 }
 // The matching B operand: accumulator registers 8m..8m+7 of a 32x32 tile whose ROW index is the reduction
 // position: row(r, h) = (r&3) + 8 (r>>2) + 4 h.
@@ -284,7 +304,7 @@ __device__ __forceinline__ bool res_stage(const bf16_t* A, long lda, const bf16_
         const int p = 8 * t + wave;  // wave-uniform
         if (p >= npieces) break;
         const int row = p * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int chunk = (lane & 7) ^ swz(row);
         blds16(ra, (uint32_t)(((long)row * lda + chunk * 8) * 2), 0, resA + p * 1024);
         blds16(rb, (uint32_t)(((long)row * ldb + chunk * 8) * 2), 0, resB + p * 1024);
         last = t == ntiles - 1;
@@ -316,7 +336,7 @@ __global__ __launch_bounds__(RES ? W * 64 : 256, RES ? 1 : MINB) void attn_fwd_k
         block_coords(nrt, H, qt, hd, b);
     const bf16_t* Kbase = qkv + (long)b * L * ld + E + hd * 64;
     const bf16_t* Vbase = Kbase + E;
-    const int trl = tr_lane_off(lane);
+    const TrLane trl = tr_lane_offs(lane);
     const int rows = ((L + 31) >> 5) * 32, ntiles_all = (L + 63) >> 6;
     // measurement only (mmvid_attention_trace): blocks 100 and gridDim.x - 8 (a first-round and a tail-round block) stamp the
     // 100-MHz wall clock at 7 points of every tile, per wave: [2 blocks][4 waves][16 tiles][8]
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(RES ? W * 64 : 256, RES ? 1 : MINB) void attn_fwd_k
             f32x16& s = sv[ss];
             mfma_settle(s);
             bf16x8_t vt[4];  // V^T fragments: requested now, consumed after the softmax arithmetic
-            tr_frags4(ss, lds_addr(Vt) + trl, vt);
+            tr_frags4(ss, lds_addr(Vt), trl, vt);
             // mask needed?  padding keys, the causal diagonal band, or (wave-constant) a restricted query row in this wave
             if (key0 + 32 > L || (mask.mode == 1 && key0 + 31 > q_wave0) || key0 < row_kmax) {
 #pragma unroll
@@ -528,7 +548,7 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
         block_coords(nrt, H, qt, hd, b);
     const bf16_t* Kbase = qkv + (long)b * L * ld + E + hd * 64;
     const bf16_t* Vbase = Kbase + E;
-    const int trl = tr_lane_off(lane);
+    const TrLane trl = tr_lane_offs(lane);
     const int rows = ((L + 31) >> 5) * 32, ntiles_all = (L + 63) >> 6;
     const char* Kres = rsm;
     const char* Vres = rsm + rows * 128;
@@ -614,7 +634,7 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
             }
             mfma_settle(s), mfma_settle(dp);
             bf16x8_t kt4[4];  // K^T fragments
-            tr_frags4(ss, lds_addr(Kt) + trl, kt4);
+            tr_frags4(ss, lds_addr(Kt), trl, kt4);
             if (key0 + 32 > L || (mask.mode == 1 && key0 + 31 > q_wave0) || key0 < row_kmax) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = is_masked(mask, q, key0 + acc_row(r, h), L) ? -INFINITY : s[r];
@@ -663,7 +683,7 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
     const float* lse_b = lse2 + ((long)b * H + hd) * L;
     const float* del_b = delta + ((long)b * H + hd) * L;
     const int nq_tiles = (L + 63) >> 6;
-    const int trl = tr_lane_off(lane);
+    const TrLane trl = tr_lane_offs(lane);
     const int rows = ((L + 31) >> 5) * 32;
     const char* Qres = rsm;
     const char* dOres = rsm + rows * 128;
@@ -770,8 +790,8 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
                 }
                 mfma_settle(s), mfma_settle(dp);
                 bf16x8_t dot4[4], qt4[4];  // dO^T and Q^T fragments, in consumption order
-                tr_frags4(ss, lds_addr(dOt) + trl, dot4);
-                tr_frags4(ss, lds_addr(Qt) + trl, qt4);
+                tr_frags4(ss, lds_addr(dOt), trl, dot4);
+                tr_frags4(ss, lds_addr(Qt), trl, qt4);
                 // mask needed?  (wave-uniform) key padding, causal diagonal region, or a restricted query row in range
                 // (all wave-uniform: the wave's keys are key_wave0 .. key_wave0 + 31)
                 bool nm = key_wave0 + 32 > L;
