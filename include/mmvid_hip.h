@@ -168,6 +168,13 @@ int mmvid_pos_table_bwd(const mmvid_pos_segment_t* segs, int nseg, int E, const 
  * absent), and its backward ga / gb / gc = w * g[0]. */
 int mmvid_lincomb3(const float* a, const float* b, const float* c, float wa, float wb, float wc, float* out, void* stream);
 int mmvid_scale3(const float* g, float wa, float wb, float wc, float* ga, float* gb, float* gc, void* stream);
+/* ---- row-wise exchange of a sparse table gradient under data parallelism (the reference all-reduces every gradient densely,
+ * train.py:28-35; the text-embedding table's gradient has at most B * text_seq_len non-zero rows per rank).  rows_pack: ids [n <= 4096]
+ * -> uid [n] ascending, repeats blanked to -1, rows [n][E] = W[uid] (zeros where blanked): one rank's fixed-shape message.
+ * rows_merge: W[ids[i]] += rows[i] for ids[i] >= 0; ids unique within a message (no atomics): call once per peer, in rank order. */
+int mmvid_rows_pack(const float* W, int64_t V, int E, const int64_t* ids, int n, int64_t* uid, float* rows, void* stream);
+int mmvid_rows_merge(float* W, int64_t V, int E, const int64_t* ids, const float* rows, int n, void* stream);
+
 /* Kernels never fault on a bad index: an embedding id outside its table reads row 0, a cross-entropy target outside [0, V)
  * counts as class 0 -- and both are COUNTED on the device (the reference's nn.Embedding / F.cross_entropy raise a device-side
  * assert instead).  counts[0] = bad embedding ids, counts[1] = bad CE targets, [2..3] reserved; reset != 0 clears them.

@@ -125,6 +125,8 @@ SIGNATURES = {
     'mmvid_lincomb3': [P, P, P, F, F, F, P, P],
     'mmvid_scale3': [P, F, F, F, P, P, P, P],
     'mmvid_prof_end': [P, P, P, P, I],
+    'mmvid_rows_pack': [P, I64, I, P, I, P, P, P],
+    'mmvid_rows_merge': [P, I64, I, P, P, I, P],
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I),
          'mmvid_warp_params_bytes': ([], I), 'mmvid_gemm_dw_multi_fill': ([I, P, I], ctypes.c_double)}

@@ -491,6 +491,68 @@ extern "C" int mmvid_scale3(const float* g, float wa, float wb, float wc, float*
     return MMVID_OK;
 }
 
+// ---- row-wise exchange of a sparse table gradient (engine.FlatTrainer._exchange_sparse; train.py:28-35 all-reduces the whole table).
+// pack: ids [n] (any order, repeats allowed; the text ids of this rank's batch) -> uid [n] ascending with repeats blanked to -1, and
+// rows [n][E] = the table-gradient row of every kept id (zeros where blanked): one rank's fixed-shape message.  One block sorts the
+// ids in LDS (bitonic, n <= 4096), a second launch gathers the rows.  merge: W[ids[i]] += rows[i] for ids[i] >= 0 -- ids are unique within
+// one rank's message, so there are no atomics; the host calls it once per peer in rank order (a fixed summation order on every rank).
+namespace {
+constexpr int PACK_MAX = 4096;
+__global__ __launch_bounds__(1024) void rows_pack_ids_kernel(const long long* __restrict__ ids, int n, int np2, long long* __restrict__ uid) {
+    __shared__ long long key[PACK_MAX];
+    for (int i = threadIdx.x; i < np2; i += 1024) key[i] = i < n ? ids[i] : 0x7fffffffffffffffll;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const long long a = key[i], b = key[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) key[i] = b, key[p] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 1024) uid[i] = (i > 0 && key[i] == key[i - 1]) ? -1ll : key[i];
+}
+__global__ __launch_bounds__(256) void rows_pack_gather_kernel(const float* __restrict__ W, long long V, int E, const long long* __restrict__ uid,
+                                                               float* __restrict__ rows) {
+    const long long id = uid[blockIdx.x];
+    const bool ok = id >= 0 && id < V;
+    for (int c = threadIdx.x; c < (E >> 2); c += 256)
+        reinterpret_cast<float4*>(rows + (long)blockIdx.x * E)[c] =
+            ok ? reinterpret_cast<const float4*>(W + id * E)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ __launch_bounds__(256) void rows_merge_kernel(float* __restrict__ W, long long V, int E, const long long* __restrict__ ids,
+                                                         const float* __restrict__ rows) {
+    const long long id = ids[blockIdx.x];
+    if (id < 0 || id >= V) return;
+    for (int c = threadIdx.x; c < (E >> 2); c += 256) {
+        float4 a = reinterpret_cast<float4*>(W + id * E)[c];
+        const float4 b = reinterpret_cast<const float4*>(rows + (long)blockIdx.x * E)[c];
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        reinterpret_cast<float4*>(W + id * E)[c] = a;
+    }
+}
+}  // namespace
+
+extern "C" int mmvid_rows_pack(const float* W, int64_t V, int E, const int64_t* ids, int n, int64_t* uid, float* rows, void* stream) {
+    MMVID_REQUIRE(W && ids && uid && rows && n > 0 && n <= PACK_MAX && E % 4 == 0, "rows_pack: bad arguments (n <= %d, E %% 4 == 0)", PACK_MAX);
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    hipLaunchKernelGGL(rows_pack_ids_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long long*)ids, n, np2, (long long*)uid);
+    hipLaunchKernelGGL(rows_pack_gather_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, W, (long long)V, E, (const long long*)uid, rows);
+    MMVID_LAUNCH_CHECK("rows_pack");
+    return MMVID_OK;
+}
+extern "C" int mmvid_rows_merge(float* W, int64_t V, int E, const int64_t* ids, const float* rows, int n, void* stream) {
+    MMVID_REQUIRE(W && ids && rows && n > 0 && E % 4 == 0, "rows_merge: bad arguments");
+    hipLaunchKernelGGL(rows_merge_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, W, (long long)V, E, (const long long*)ids, rows);
+    MMVID_LAUNCH_CHECK("rows_merge");
+    return MMVID_OK;
+}
+
 // counts[4] <- the device fault counters (see g_faults); reset != 0 clears them.  Waits for the device.
 extern "C" int mmvid_device_faults(int64_t* counts, int reset) {
     MMVID_REQUIRE(counts, "device_faults: null pointer");

@@ -16,7 +16,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 
 ALIGN = 128  # elements: keeps every slice 16-B aligned for the vector kernels (fp32 and bf16)
 
@@ -396,7 +396,14 @@ class FlatTrainer:
     @staticmethod
     def pack_rows(W, ids):
         """This rank's message: (ids sorted, repeats blanked to -1) and the matching gradient rows (zero where blanked)."""
-        srt, _ = torch.sort(ids.reshape(-1))
+        ids = ids.reshape(-1)
+        if W.is_cuda and ids.numel() <= 4096 and W.dtype == torch.float32 and W.is_contiguous():  # two launches, no allocator traffic beyond the outputs
+            uid = torch.empty_like(ids)
+            rows = torch.empty(ids.numel(), W.shape[1], device=W.device, dtype=W.dtype)
+            _lib.call('mmvid_rows_pack', ops._p(W), W.shape[0], W.shape[1], ops._p(ids.contiguous()), ids.numel(), ops._p(uid), ops._p(rows),
+                      ops._stream())
+            return uid, rows
+        srt, _ = torch.sort(ids)
         first = torch.ones_like(srt, dtype=torch.bool)
         first[1:] = srt[1:] != srt[:-1]
         uid = torch.where(first, srt, torch.full_like(srt, -1))
@@ -406,6 +413,12 @@ class FlatTrainer:
     @staticmethod
     def merge_rows(W, all_ids, all_rows, rank, n):
         """Add every OTHER rank's rows (rank-major gathered messages of n rows each) to this rank's table gradient."""
+        if W.is_cuda and W.dtype == torch.float32 and W.is_contiguous():  # one launch per peer, in rank order: a fixed summation order
+            for r in range(all_ids.shape[0] // n):
+                if r != rank:
+                    _lib.call('mmvid_rows_merge', ops._p(W), W.shape[0], W.shape[1], ops._p(all_ids[r * n:(r + 1) * n]),
+                              ops._p(all_rows[r * n:(r + 1) * n]), n, ops._stream())
+            return
         own = torch.zeros(all_ids.shape[0], dtype=torch.bool, device=all_ids.device)
         own[rank * n:(rank + 1) * n] = True
         valid = (all_ids >= 0) & ~own

@@ -1,9 +1,114 @@
-"""Round 4: the storer-wave GEMM block (csrc/gemm.hip::gemm_bf16_sw_kernel) and what else the round changed, on the GPU."""
+"""Round 4 on the GPU: the grouped weight-gradient launch's tile order, the loader-wave GEMM forms, the hardware probes behind the
+round's measurements (matrix-pipe ceiling, FETCH_SIZE calibration streams)."""
+import ctypes
+
 import pytest
 import torch
 
-from test_models_gpu import DEV, close
+from test_models_gpu import DEV
 
 pytestmark = pytest.mark.gpu
 
 
+def test_grouped_weight_gradients_do_not_depend_on_the_tile_order():
+    """Option dw_order (default 1): an output whose X operand is the wider one (c_proj: 768 x 3072) is walked column-major so that
+    operand is streamed once.  Every tile still runs the same token reduction: the results are bit-identical to the row-major walk,
+    for the tower's four shapes over 12 layers, with frozen entries."""
+    from mmvid_amd import _lib, ops
+    torch.manual_seed(4)
+    G, M = 12, 579
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    kinds, bases = [], []
+    for ki, (N, K) in enumerate(shapes):
+        dY = (torch.randn(G, M, N, device=DEV) * 0.1).to(torch.bfloat16)
+        X = (torch.randn(G, M, K, device=DEV) * 0.1).to(torch.bfloat16)
+        base = torch.randn(G, N, K, device=DEV)
+        kinds.append((dY, X, [None if (g == 5 and ki == 0) else base[g].clone() for g in range(G)]))
+        bases.append(base)
+    res = {}
+    try:
+        for order in (0, 1):
+            _lib.call('mmvid_set_option', b'dw_order', order)
+            for (dY, X, outs), base in zip(kinds, bases):
+                for g, o in enumerate(outs):
+                    if o is not None:
+                        o.copy_(base[g])
+            ops.gemm_dw_multi(kinds, accumulate=True)
+            torch.cuda.synchronize()
+            res[order] = [[o.clone() if o is not None else None for o in outs] for _, _, outs in kinds]
+    finally:
+        _lib.call('mmvid_set_option', b'dw_order', 1)
+    for a, b in zip(res[0], res[1]):
+        assert all(x is None and y is None or torch.equal(x, y) for x, y in zip(a, b))
+    dY, X, outs = kinds[0]
+    want = torch.einsum('mn,mk->nk', dY[0].double(), X[0].double()) + bases[0][0].double()
+    assert ((outs[0].double() - want).abs().max() / want.abs().max()).item() < 2e-5
+
+
+def test_matrix_pipe_and_stream_probes_run():
+    """mmvid_probe 5 (register-only MFMA chains: the sustained matrix-pipe ceiling bench.py reports) and 6 (read streams of known size for
+    the FETCH_SIZE calibration) launch, finish and leave the streamed buffer untouched."""
+    from mmvid_amd import _lib, ops
+    sink = torch.zeros(16, device=DEV)
+    for mode in (0, 1):
+        _lib.call('mmvid_probe', 5, (ctypes.c_int32 * 3)(50, 256, mode), ops._p(sink), ops._stream())
+    buf = torch.arange(1 << 20, device=DEV, dtype=torch.int32)
+    ref = buf.clone()
+    for mode in (0, 1):
+        _lib.call('mmvid_probe', 6, (ctypes.c_int64 * 2)(buf.numel() * 4, mode), ops._p(buf), ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(buf, ref) and float(sink.abs().sum()) == 0.0
+
+
+def test_attention_outputs_are_batch_order_independent_after_the_swizzle_change():
+    """The round-4 LDS swizzle (csrc/attn.hip::swz) changes where a tile's chunks sit in LDS, not what is computed: forward and backward of
+    one (sequence, head) do not depend on which other sequences share the launch (bit-identical), with the restricted rows of the BERT mask."""
+    from mmvid_amd import _lib, ops
+    B, L, H, E = 5, 579, 12, 768
+    torch.manual_seed(9)
+    qkv = (torch.randn(B * L, 3 * E, device=DEV) * 0.5).bfloat16()
+    dO = (torch.randn(B * L, E, device=DEV) * 0.1).bfloat16()
+
+    def run(qkv_, dO_, b):
+        out = torch.empty(b * L, E, device=DEV, dtype=torch.bfloat16)
+        lse, delta = torch.empty(b * H * L, device=DEV), torch.empty(b * H * L, device=DEV)
+        dqkv = torch.empty(b * L, 3 * E, device=DEV, dtype=torch.bfloat16)
+        _lib.call('mmvid_attention_fwd', ops._p(qkv_), 3 * E, b, L, H, E, 0.125, 2, 65, 65, 66, 66, ops._p(out), E, ops._p(lse), ops._stream())
+        _lib.call('mmvid_attention_bwd', ops._p(qkv_), 3 * E, ops._p(out), E, ops._p(dO_), E, ops._p(lse), ops._p(delta), b, L, H, E, 0.125, 2, 65,
+                  65, 66, 66, ops._p(dqkv), 3 * E, ops._stream())
+        return out, dqkv
+
+    o_all, g_all = run(qkv, dO, B)
+    o_one, g_one = run(qkv[2 * L:3 * L].contiguous(), dO[2 * L:3 * L].contiguous(), 1)
+    assert torch.equal(o_all[2 * L:3 * L], o_one) and torch.equal(g_all[2 * L:3 * L], g_one)
+
+
+def test_sparse_exchange_pack_and_merge_kernels():
+    """mmvid_rows_pack / mmvid_rows_merge (what FlatTrainer._exchange_sparse runs on the device instead of torch sort / index_select /
+    index_add_): the message of a rank -- ids ascending, repeats blanked, rows zeroed where blanked -- equals the torch formulation bit
+    for bit, and merging three peers' messages in rank order equals the dense sum."""
+    from mmvid_amd.engine import FlatTrainer
+    torch.manual_seed(3)
+    V, E, n = 49472, 768, 1152
+    W = torch.randn(V, E, device=DEV)
+    ids = torch.randint(0, V, (n, ), device=DEV)
+    ids[100:400] = ids[:300].clone()  # repeats
+    uid, rows = FlatTrainer.pack_rows(W, ids)
+    srt, _ = torch.sort(ids)
+    first = torch.ones_like(srt, dtype=torch.bool)
+    first[1:] = srt[1:] != srt[:-1]
+    assert torch.equal(uid, torch.where(first, srt, torch.full_like(srt, -1)))
+    assert torch.equal(rows, W.index_select(0, srt) * first.unsqueeze(1).to(W.dtype))
+    # merge: this rank is 1 of 4; peers 0, 2, 3 bring their own messages (overlapping ids)
+    peers = []
+    for r in range(4):
+        pid = torch.randint(0, 2000, (n, ), device=DEV)  # dense in a small range: many rows get several contributions
+        Wp = torch.zeros(V, E, device=DEV)
+        Wp[pid.unique()] = torch.randn(pid.unique().numel(), E, device=DEV)
+        peers.append((Wp, ) + FlatTrainer.pack_rows(Wp, pid))
+    mine = peers[1][0].clone()
+    all_ids = torch.cat([p[1] for p in peers])
+    all_rows = torch.cat([p[2] for p in peers])
+    FlatTrainer.merge_rows(mine, all_ids, all_rows, 1, n)
+    want = peers[1][0] + peers[0][0] + peers[2][0] + peers[3][0]  # rank order 0, 2, 3 added to rank 1's own
+    assert torch.equal(mine, want)
