@@ -146,7 +146,7 @@ class OpenAICLIPTransformer(nn.Module):
         self._shadow_key = None
         self._scratch = None
         self._scratch_retired = []
-        self.backward_chunk_layers = int(os.environ.get('MMVID_BWD_CHUNK', 3))  # the backward returns to the host every N layers ...
+        self.backward_chunk_layers = int(os.environ.get('MMVID_BWD_CHUNK', 0))  # the backward returns to the host every N layers (0: planned, see backward_chunks) ...
         self.on_layers_done = None      # ... and calls this (first_layer) so gradient exchange can overlap
 
     # ---- reference API -----------------------------------------------------------------------------
@@ -320,13 +320,36 @@ class OpenAICLIPTransformer(nn.Module):
     def backward_chunks(self):
         """[(first_layer, end_layer)] in the order the backward walks them: the native layer loop returns to the host after
         each chunk so that the finished layers' gradients can go on the wire (engine.FlatTrainer.layers_done)."""
-        step = self.backward_chunk_layers if self.on_layers_done is not None else self.layers
+        if self.on_layers_done is None:
+            return [(0, self.layers)]
+        if self.backward_chunk_layers <= 0:
+            return self._planned_chunks()
+        step = self.backward_chunk_layers
         out, hi = [], self.layers
         while hi > 0:
             lo = max(0, hi - step)
             out.append((lo, hi))
             hi = lo
         return out
+
+    def _planned_chunks(self):
+        """Two backward calls whose grouped weight-gradient launches waste the fewest CU rounds.  A call over n layers launches
+        n * t output tiles of 256 x 128 (t = 216 for width 768 / 3072) on 256 CUs; what is lost is the unfilled part of the last round.
+        Three-layer calls (rounds 1-3) lost 1.9 rounds per backward (0.34 ms of the +0.42 ms a forced exchange cost); 7 + 5 layers lose
+        0.87 -- what the single launch of the exchange-free step loses (0.875) -- and the first call's 58 % of the gradients go on the
+        wire while five layers are still being differentiated."""
+        if getattr(self, '_chunk_plan', None) is None or self._chunk_plan[0] != self.layers:
+            E = self.width
+            F = 4 * E
+            t = sum(-(-n // 256) * -(-k // 128) for n, k in ((3 * E, E), (E, E), (F, E), (E, F)))
+            waste = lambda n: (-(-n * t // 256)) - n * t / 256.0
+            best, plan = None, [(0, self.layers)]
+            for a in range(3, self.layers - 2):  # a = layers of the FIRST call (the top of the tower); both calls >= 3 layers
+                w = waste(a) + waste(self.layers - a) + 0.02 * abs(a - 0.6 * self.layers)  # (ties: the first call a little larger)
+                if best is None or w < best:
+                    best, plan = w, [(self.layers - a, self.layers), (0, self.layers - a)]
+            self._chunk_plan = (self.layers, plan)
+        return self._chunk_plan[1]
 
     def _run_backward(self, g, saved, shape):
         if saved is None:
