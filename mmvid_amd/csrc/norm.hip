@@ -379,7 +379,9 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float v = f[e] * av[e] + bv[e];
-        if (swish) v = v * sigmoidf_(v);
+        // swish on the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 right after): the IEEE division of sigmoidf_ is ~10
+        // VALU per element, and with 16-B loads the bf16-input pass was VALU-bound (4.46 TB/s against 5.86 for the fp32-input pass)
+        if (swish) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
         o[e] = v;
     }
     if (y_bf16)
@@ -389,6 +391,83 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
         float4* d = reinterpret_cast<float4*>(y_f32 + pix * C + cc * 8);
         d[0] = make_float4(o[0], o[1], o[2], o[3]);
         d[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// Small maps (hw <= 256 pixels: the 8x8 and 16x16 levels of the VQGAN, one statistics block per image): statistics, finalisation and the
+// apply pass of ONE image in ONE block -- the three launches of the general path were 15 us per GroupNorm for 4 us of work, ten times
+// per encode.  The arithmetic is the general path's, operation for operation (groupnorm_stats_kernel's fixed-order sums with one block,
+// groupnorm_finalize_kernel's formulas, groupnorm_apply_kernel's element math): bit-identical outputs.
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_small_fused_kernel(const T* __restrict__ x, long hw, int C, float cnt, float eps,
+                                                                    const float* __restrict__ w, const float* __restrict__ b, int swish,
+                                                                    bf16_t* __restrict__ y_bf16, float* __restrict__ y_f32) {
+    __shared__ float red[2][2048];
+    __shared__ float sh[2][512];
+    __shared__ float ab[512][2];
+    const int n = blockIdx.x;
+    const int cchunks = C >> 3;
+    const int cc = threadIdx.x % cchunks, prow = threadIdx.x / cchunks, pstep = 256 / cchunks;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    const T* base = x + ((long)n * hw) * C + cc * 8;
+    for (long p = prow; p < hw; p += pstep) {
+        float f[8];
+        load8<T>(base + p * C, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += f[e], q[e] += f[e] * f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[0][prow * C + cc * 8 + e] = s[e];
+        red[1][prow * C + cc * 8 + e] = q[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const int which = c / C, ch = c - which * C;
+        float a = 0.f;
+        for (int r = 0; r < pstep; ++r) a += red[which][r * C + ch];
+        sh[which][ch] = a;
+    }
+    __syncthreads();
+    const int cpg = C / 32;
+    if (threadIdx.x < 32) {  // one lane per group: the sums of groupnorm_stats_kernel, the formulas of groupnorm_finalize_kernel
+        const int grp = threadIdx.x;
+        float sm = 0.f, sq = 0.f;
+        for (int e = 0; e < cpg; ++e) sm += sh[0][grp * cpg + e];
+        for (int e = 0; e < cpg; ++e) sq += sh[1][grp * cpg + e];
+        const float mu = sm / cnt;
+        float var = sq / cnt - mu * mu;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + eps);
+        for (int e = 0; e < cpg; ++e) {
+            const int ch = grp * cpg + e;
+            const float a = rstd * w[ch];
+            ab[ch][0] = a, ab[ch][1] = b[ch] - mu * a;
+        }
+    }
+    __syncthreads();
+    float av[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) av[e] = ab[cc * 8 + e][0], bv[e] = ab[cc * 8 + e][1];
+    for (long p = prow; p < hw; p += pstep) {
+        float f[8], o[8];
+        load8<T>(base + p * C, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = f[e] * av[e] + bv[e];
+            if (swish) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+            o[e] = v;
+        }
+        const long at = ((long)n * hw + p) * C + cc * 8;
+        if (y_bf16)
+            *reinterpret_cast<uint4*>(y_bf16 + at) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+        if (y_f32) {
+            float4* d = reinterpret_cast<float4*>(y_f32 + at);
+            d[0] = make_float4(o[0], o[1], o[2], o[3]);
+            d[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
     }
 }
 
@@ -599,6 +678,16 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
     float* ab = stats_scratch;                         // [N][C][2]
     float* partial = stats_scratch + (long)N * C * 2;  // [N][nblk][32][2]
     const long chunks = (long)N * hw * (C / 8);
+    if (partial_blocks == 0 && hw <= pix_per_block && mmvid_option(MMVID_OPT_GN_FUSED)) {  // one block per image does all three steps
+        if (x_is_bf16)
+            hipLaunchKernelGGL(groupnorm_small_fused_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, (long)hw, C,
+                               (float)hw * (float)(C / 32), eps, w, b, swish, (bf16_t*)y_bf16, y_f32);
+        else
+            hipLaunchKernelGGL(groupnorm_small_fused_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)x, (long)hw, C,
+                               (float)hw * (float)(C / 32), eps, w, b, swish, (bf16_t*)y_bf16, y_f32);
+        MMVID_LAUNCH_CHECK("groupnorm");
+        return MMVID_OK;
+    }
     if (partial_blocks == 0) {
         nblk = cdiv(hw, pix_per_block);
         dim3 g1(nblk, N);

@@ -112,3 +112,31 @@ def test_sparse_exchange_pack_and_merge_kernels():
     FlatTrainer.merge_rows(mine, all_ids, all_rows, 1, n)
     want = peers[1][0] + peers[0][0] + peers[2][0] + peers[3][0]  # rank order 0, 2, 3 added to rank 1's own
     assert torch.equal(mine, want)
+
+
+@pytest.mark.parametrize('n,h,c,dt,swish,out', [(54, 8, 512, torch.float32, True, torch.bfloat16), (7, 8, 512, torch.bfloat16, True, torch.bfloat16),
+                                                (3, 16, 256, torch.float32, False, torch.float32), (5, 4, 128, torch.float32, True, torch.bfloat16),
+                                                (2, 16, 32, torch.bfloat16, True, torch.bfloat16)])
+def test_small_map_groupnorm_single_launch_is_bit_identical(n, h, c, dt, swish, out):
+    """GroupNorm of a map of <= 256 pixels without fused statistics (the VQGAN's 8x8 / 16x16 levels): one launch (option gn_fused, one
+    block per image: statistics, finalisation, apply) against the three launches of the general path -- the same arithmetic in the same
+    order, so the outputs must be bit-identical -- and against torch."""
+    import torch.nn.functional as F
+    from mmvid_amd import _lib, ops
+    torch.manual_seed(n + h + c)
+    x = (torch.randn(n, h, h, c, device=DEV) * 2 + 0.5).to(dt)
+    w, b = torch.randn(c, device=DEV), torch.randn(c, device=DEV)
+    res = {}
+    try:
+        for fused in (1, 0):
+            _lib.call('mmvid_set_option', b'gn_fused', fused)
+            res[fused] = ops.groupnorm_swish(x, w, b, swish=swish, out_dtype=out)
+    finally:
+        _lib.call('mmvid_set_option', b'gn_fused', 1)
+    assert torch.equal(res[1], res[0])
+    ref = F.group_norm(x.float().permute(0, 3, 1, 2), 32, w, b, 1e-6)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    err = ((res[1].float() - ref).abs().max() / ref.abs().max()).item()
+    assert err < (1e-2 if out == torch.bfloat16 else 1e-5), err
