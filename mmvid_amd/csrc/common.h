@@ -111,7 +111,9 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   gemm_sched     MMVID_GEMM_SCHED     K loop of the 256x128 block: 0 = one barrier per tile; 1 = two-group ping-pong with
 //                                       the DMA requests in the load parts (-2 % step time); 2 = ping-pong with the DMA
 //                                       requests inside the MFMA clusters (default; a further -0.5 %, tools/ab_graph.py)
-//   fuse_colsum    MMVID_FUSE_COLSUM    1 = c_fc's bias gradient from the epilogue of the GEMM that produces d_pre (default)
+//   fuse_colsum    MMVID_FUSE_COLSUM    1 (default) = c_fc's bias gradient from the epilogue of the GEMM that produces d_pre, the in-projection's from the
+//                                       registers of the attention backward (unrounded fp32 sums); 0 = both as column sums of the bf16 tensors the
+//                                       weight gradients are computed from (mmvid_colsum_bf16)
 //   ln_bwd_blocks  MMVID_LN_BWD_BLOCKS  grid cap of the LayerNorm backward (default 512: its dw/db atomics scale with the
 //                                       grid -- measured on the whole step 2048: +0.6 ms, 1024: +0.11 ms, 256: +0.25 ms)
 //   strip_sched    MMVID_STRIP_SCHED    strip convolution: 0 = LDS-DMA requests right after the tile barrier, 1 = spread over the
