@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 r=r04; g=gpurun_out; p=profiles
 cp $g/bench.log $p/${r}_bench_n1.json; cp $g/bench.err $p/${r}_bench_n1.stderr.log
 cp $g/bench_strict.log $p/${r}_bench_strict.json; cp $g/bench_split.log $p/${r}_bench_strict_split.json
-cp $g/bench_c4.log $p/${r}_bench_config4.json; cp $g/bench_c5.log $p/${r}_bench_config5.json
+cp $g/bench_c4.log $p/${r}_bench_config4.json; cp $g/bench_c4_b20.log $p/${r}_bench_config4_batch20.json; cp $g/bench_c5.log $p/${r}_bench_config5.json
 cp $g/bench_ddp1.log $p/${r}_bench_launcher_forced_exchange.json
 cp $g/power_probe.log $p/${r}_power_probe_mfma_ceiling.log; cp $g/kloop_anatomy_final.log $p/${r}_gemm_kloop_anatomy.log; cp $g/gemm_microbench.log $p/${r}_gemm_microbench.log
 cp $g/bench_bert_sampling.log $p/${r}_bench_bert_sampling.json

@@ -16,6 +16,7 @@ echo "== gpu tests"; timeout 1500 python -m pytest tests -m gpu -v -s --timeout 
 echo "== strict"; timeout 600 python bench.py --strict --steps 20 --no-cpu-baseline > gpurun_out/bench_strict.log 2> gpurun_out/bench_strict.err; grep "bench\]" gpurun_out/bench_strict.err | cut -c1-200
 echo "== strict split"; timeout 600 python bench.py --strict split --steps 20 --no-cpu-baseline --no-exact > gpurun_out/bench_split.log 2> gpurun_out/bench_split.err; grep "bench\]" gpurun_out/bench_split.err | cut -c1-200
 echo "== config 4"; timeout 600 python bench.py --config 4 --steps 20 --warmup 3 > gpurun_out/bench_c4.log 2> gpurun_out/bench_c4.err; grep "bench\]" gpurun_out/bench_c4.err | cut -c1-200
+echo "== config 4, the recipe batch on one GPU"; timeout 600 python bench.py --config 4 --batch 20 --steps 10 --warmup 3 --no-cpu-baseline --no-exact > gpurun_out/bench_c4_b20.log 2> gpurun_out/bench_c4_b20.err; grep "bench\]" gpurun_out/bench_c4_b20.err | cut -c1-200
 echo "== config 5"; timeout 900 python bench.py --config 5 --steps 2 --warmup 1 > gpurun_out/bench_c5.log 2> gpurun_out/bench_c5.err; echo "rc=$?"
 echo "== BERT sampling (mask-predict)"; timeout 900 python bench.py --sample --steps 3 --warmup 1 > gpurun_out/bench_bert_sampling.log 2> gpurun_out/bench_bert_sampling.err; grep "bench\]" gpurun_out/bench_bert_sampling.err | cut -c1-200
 echo "== launcher, forced exchange"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --force-exchange > gpurun_out/bench_ddp1.log 2> gpurun_out/bench_ddp1.err; grep "bench\]" gpurun_out/bench_ddp1.err | cut -c1-200
