@@ -298,6 +298,21 @@ def test_flat_trainer_real_model_callbacks_world2():
 
 
 @pytest.mark.timeout(300)
+def test_flat_trainer_direct_exchange_world4():
+    """The direct exchange with four ranks (shards of a quarter; every rank receives three peers' shards and sums them in rank order)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, q, 'direct')) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == 'ok' for r in res), res
+
+
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize('exchange', ['allreduce', 'direct'])
 def test_flat_trainer_exchange_world2(exchange):
     """Both forms of the dense gradient exchange: one all-reduce per message, and the direct form (all_to_all of shards, rank-ordered
