@@ -138,6 +138,15 @@ int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, int64_t ldo,
 int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                              const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode, int r0,
                              int c0, int r1, int c1, void* dqkv, int64_t ldg, float* dbias, void* stream);
+/* The same with a caller-provided device workspace of mmvid_attention_bwd_workspace_bytes(B, L, H) bytes (contents undefined on entry and
+ * exit; nullptr / 0 = mmvid_attention_bwd_bias).  With it the dK/dV pass cuts the blocks of its last, partly filled round of resident
+ * blocks into parts over disjoint query ranges and adds the parts in a fixed order: results stay bit-reproducible run to run, and differ
+ * from the workspace-free call only by fp32 summation order in those blocks.  (Not used under the causal mask.) */
+int mmvid_attention_bwd_ws(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
+                           const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode, int r0,
+                           int c0, int r1, int c1, void* dqkv, int64_t ldg, float* dbias, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+int64_t mmvid_attention_bwd_workspace_bytes(int B, int L, int H);
 
 /* ---- sequence assembly + losses: dalle_bert.py:899-973,1030-1040; dalle_artv.py:441-491,526-539. */
 int mmvid_assemble_sequence(const float* const* tables, const int64_t* table_rows, int ntables, const int64_t* ids,

@@ -53,6 +53,7 @@ SIGNATURES = {
     'mmvid_attention_fwd': [P, I64, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
     'mmvid_attention_bwd': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P],
     'mmvid_attention_bwd_bias': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
+    'mmvid_attention_bwd_ws': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P, P, I64, P],
     'mmvid_assemble_sequence': [POINTER(P), POINTER(I64), I, P, P, P, I64, I, I, P, P],
     'mmvid_assemble_sequence_bwd': [POINTER(P), POINTER(I64), I, P, P, P, I64, I, I, P, I, P],
     'mmvid_cross_entropy_fwd': [P, I64, P, P, I64, I, P, P, P],
@@ -129,7 +130,8 @@ SIGNATURES = {
     'mmvid_rows_merge': [P, I64, I, P, P, I, P],
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I),
-         'mmvid_warp_params_bytes': ([], I), 'mmvid_gemm_dw_multi_fill': ([I, P, I], ctypes.c_double)}
+         'mmvid_warp_params_bytes': ([], I), 'mmvid_gemm_dw_multi_fill': ([I, P, I], ctypes.c_double),
+         'mmvid_attention_bwd_workspace_bytes': ([I, I, I], I64)}
 
 class DwKind(ctypes.Structure):
     """mmvid_dw_kind_t (include/mmvid_hip.h)."""

@@ -257,6 +257,23 @@ __device__ __forceinline__ bool tile_needs_mask(const MaskSpec& m, int q_lane, i
 }
 
 // blocks of one (batch, head) are consecutive AND on one XCD: they share K/V (or Q/dO) through that XCD's L2
+// ---- tail split.  The grids of these kernels do not divide into the resident block slots (L = 579, 18 sequences: 1,080 blocks against
+// 1,024 / 768 / 512), and a block lasts 25-30 us whatever shares its CU: the 56 blocks of the last, 5-%-full round cost a whole round.
+// With a workspace the launcher cuts exactly those blocks -- the last `tail` in dispatch order -- into `parts` blocks over disjoint ranges
+// of the streamed dimension (query tiles in dK/dV); they write their fp32 accumulators to the workspace and a small second launch adds
+// the parts in order (a fixed summation order: still bit-reproducible) and runs the normal epilogue.  The last round then lasts a
+// quarter as long.  nfull = blocks that run whole; dispatch ids >= nfull are (tail block j, part p) = ((id - nfull) / parts, % parts).
+struct TailSplit {
+    int nfull, parts, nlogical;
+    float* ws;  // [tail][parts][4 waves][64 accumulator registers][64 lanes] fp32
+};
+__device__ __forceinline__ void block_coords_of(int dispatch_id, int nblocks, int nrt, int H, int& rt, int& hd, int& b) {
+    const int id = xcd_remap(dispatch_id, nblocks);
+    rt = id % nrt;
+    const int bh = id / nrt;
+    hd = bh % H;
+    b = bh / H;
+}
 __device__ __forceinline__ void block_coords(int nrt, int H, int& rt, int& hd, int& b) {
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     rt = id % nrt;
@@ -668,15 +685,20 @@ template <int MINB, bool RES, bool TRACE = false>
 __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, long ld, const bf16_t* __restrict__ dO, long lddo, const float* __restrict__ lse2,
     const float* __restrict__ delta, int L, int H, int E, int nrt, float scale, float scale_log2, MaskSpec mask,
-    bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias, unsigned long long* trace) {
+    bf16_t* __restrict__ dqkv, long ldg, float* __restrict__ dbias, unsigned long long* trace, TailSplit ts) {
     if (TRACE && trace && threadIdx.x == 0) trace[1024 + 8192 + 2 * blockIdx.x] = wall_clock64();
     __shared__ __attribute__((aligned(16))) char dsm[RES ? 16 : 2 * DKV_BUF];
     extern __shared__ __attribute__((aligned(16))) char rsm[];  // resident: Q rows, dO rows, -lse2[rows], delta[rows]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
     int kt = 0, hd, b;
+    int part = -1, tail_j = 0;  // tail split: this block covers query tiles [part * nq / parts, (part + 1) * nq / parts) of tail block tail_j
     if constexpr (RES)
         hd = blockIdx.x % H, b = blockIdx.x / H;
-    else
+    else if (ts.parts > 1) {
+        int did = blockIdx.x;
+        if (did >= ts.nfull) tail_j = (did - ts.nfull) / ts.parts, part = (did - ts.nfull) % ts.parts, did = ts.nfull + tail_j;
+        block_coords_of(did, ts.nlogical, nrt, H, kt, hd, b);
+    } else
         block_coords(nrt, H, kt, hd, b);
     const bf16_t* Qbase = qkv + (long)b * L * ld + hd * 64;
     const bf16_t* dObase = dO + (long)b * L * lddo + hd * 64;
@@ -739,7 +761,8 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
         if (ui + 1 < RES_UNITS && unit_k0(ui + 1) < L) load_kv(unit_k0(ui + 1) + l32, kn, vn);  // flies under this unit's work
     }
     const int t0 = (mask.mode == 1) ? key_wave0 >> 6 : 0;  // causal: only queries >= keys contribute
-    const int t_begin = RES ? (ui == 0 ? 0 : t0) : ((mask.mode == 1) ? (kt * ROWS_PER_BLOCK) >> 6 : 0);
+    const int t_begin = RES ? (ui == 0 ? 0 : t0) : (part >= 0 ? part * nq_tiles / ts.parts : ((mask.mode == 1) ? (kt * ROWS_PER_BLOCK) >> 6 : 0));
+    const int t_end = (!RES && part >= 0) ? (part + 1) * nq_tiles / ts.parts : nq_tiles;
 
     TileStage sq, sdo;
     float stat = 0.f;
@@ -751,14 +774,14 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
     }
 
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-    for (int t = t_begin; t < nq_tiles; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         const int bi = (t - t_begin) & 1;
         const char* Qt = RES ? Qres + t * TILE : dsm + bi * DKV_BUF;
         const char* dOt = RES ? dOres + t * TILE : Qt + TILE;
         const float* st_nlse = RES ? nlse_res + t * 64 : reinterpret_cast<const float*>(Qt + 2 * TILE);
         const float* st_del = RES ? del_res + t * 64 : st_nlse + 64;
         char* nx = dsm + (RES ? 0 : (bi ^ 1) * DKV_BUF);
-        const bool more = t + 1 < nq_tiles;
+        const bool more = t + 1 < t_end;
         if constexpr (RES) {
             if (ui == 0) res_wait_tile(t, nq_tiles, issued_last);
             if (t < t0) continue;
@@ -840,6 +863,14 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
         if constexpr (RES) continue; else return;
     }
     mfma_settle(dk[0]), mfma_settle(dk[1]), mfma_settle(dv[0]), mfma_settle(dv[1]);
+    if (!RES && part >= 0) {  // a part of a tail block: raw accumulators to the workspace, [register][lane] so that a store is 256 contiguous bytes
+        float* w = ts.ws + ((long)(tail_j * ts.parts + part) * 4 + wave) * 64 * 64 + lane;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[(16 * dt + r) * 64] = dk[dt][r], w[(32 + 16 * dt + r) * 64] = dv[dt][r];
+        return;
+    }
     if (key < L) {
         bf16_t* kp = dqkv + ((long)b * L + key) * ldg + E + hd * 64;
         store_row64(kp, dk, scale, h);
@@ -853,10 +884,53 @@ __global__ __launch_bounds__(RES ? RES_WAVES * 64 : 256, RES ? 1 : MINB) void at
     }  // unit
 }
 
+// second launch of a tail-split dK/dV pass: one block per tail block; a wave adds the parts of its 32 keys in part order and runs the
+// epilogue of attn_bwd_dkv_kernel (bf16 rows of dK, dV and their share of the in-projection's bias gradient)
+__global__ __launch_bounds__(256) void attn_dkv_combine_kernel(int L, int H, int E, int nrt, float scale, bf16_t* __restrict__ dqkv, long ldg,
+                                                               float* __restrict__ dbias, TailSplit ts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
+    int kt, hd, b;
+    block_coords_of(ts.nfull + blockIdx.x, ts.nlogical, nrt, H, kt, hd, b);
+    const int key_wave0 = kt * ROWS_PER_BLOCK + wave * 32, key = key_wave0 + l32;
+    if (key_wave0 >= L) return;
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    for (int p = 0; p < ts.parts; ++p) {
+        const float* w = ts.ws + ((long)(blockIdx.x * ts.parts + p) * 4 + wave) * 64 * 64 + lane;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dk[dt][r] += w[(16 * dt + r) * 64], dv[dt][r] += w[(32 + 16 * dt + r) * 64];
+    }
+    if (key < L) {
+        bf16_t* kp = dqkv + ((long)b * L + key) * ldg + E + hd * 64;
+        store_row64(kp, dk, scale, h);
+        store_row64(kp + E, dv, 1.0f, h);
+    }
+    if (dbias) {
+        colsum_rows64(dk, scale, key < L, dbias + E + hd * 64, lane);
+        colsum_rows64(dv, 1.0f, key < L, dbias + 2 * E + hd * 64, lane);
+    }
+}
+
 // the resident kernels hold 2 x ceil32(L) x 128 B in LDS (+ 8 B per row of statistics in dK/dV): L <= 608.  Geometry only.
 static bool attn_resident(int L) { return L <= RES_MAX_L && mmvid_option(MMVID_OPT_ATTN_RES) != 0; }  // (default 0: measured slower)
 
 unsigned long long* g_attn_trace = nullptr;
+
+// resident 256-thread blocks of a kernel on the whole device (occupancy query x CU count; cached per kernel)
+static int attn_block_slots(const void* kernel) {
+    static const void* k_cached = nullptr;
+    static int slots_cached = 0;
+    if (kernel != k_cached) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return 0;
+        k_cached = kernel, slots_cached = per_cu * prop.multiProcessorCount;
+    }
+    return slots_cached;
+}
 
 static MaskSpec make_mask(int mode, int r0, int c0, int r1, int c1) {
     MaskSpec m;
@@ -935,7 +1009,16 @@ extern "C" int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void*
                                         const float* lse2, float* delta, int B, int L, int H, int E, float scale,
                                         int mask_mode, int r0, int c0, int r1, int c1, void* dqkv, int64_t ldg,
                                         float* dbias, void* stream) {
+    return mmvid_attention_bwd_ws(qkv, ld, O, ldo, dO, lddo, lse2, delta, B, L, H, E, scale, mask_mode, r0, c0, r1, c1, dqkv, ldg, dbias,
+                                  nullptr, 0, stream);
+}
+
+extern "C" int mmvid_attention_bwd_ws(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
+                                      const float* lse2, float* delta, int B, int L, int H, int E, float scale,
+                                      int mask_mode, int r0, int c0, int r1, int c1, void* dqkv, int64_t ldg,
+                                      float* dbias, void* workspace, int64_t workspace_bytes, void* stream) {
     MMVID_REQUIRE(qkv && O && dO && lse2 && delta && dqkv, "attention_bwd: null pointer");
+    const TailSplit no_split = {0, 1, 0, nullptr};
     ATTN_COMMON_CHECKS("attention_bwd");
     MMVID_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldg % 8 == 0 && ((uintptr_t)dqkv & 15) == 0,
                   "attention_bwd: leading dims must be multiples of 8, dqkv 16-byte aligned");
@@ -974,16 +1057,35 @@ extern "C" int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void*
         }
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, true>), dim3(H * B), dim3(RES_WAVES * 64), (size_t)cdiv(L, 32) * 32 * 264, s,
                            (const bf16_t*)qkv, (long)ld, (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m,
-                           (bf16_t*)dqkv, (long)ldg, dbias, nullptr);
+                           (bf16_t*)dqkv, (long)ldg, dbias, nullptr, no_split);
     } else if (mmvid_option(MMVID_OPT_ATTN_OCC) & 4)
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<3, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, nullptr);
+                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, nullptr, no_split);
     else if (g_attn_trace)
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, false, true>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, g_attn_trace);
-    else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, false>), dim3(nrt * H * B), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
-                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, nullptr);
+                       (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, g_attn_trace, no_split);
+    else {
+        // tail split (see TailSplit): needs the caller's workspace; not for the causal mask (its query range depends on the keys)
+        const int nblocks = nrt * H * B, slots = attn_block_slots((const void*)attn_bwd_dkv_kernel<2, false>);
+        const int nq = (L + 63) >> 6, parts = nq >= 8 ? 4 : (nq >= 4 ? 2 : 1);
+        const int tail = slots > 0 ? nblocks % slots : 0;
+        TailSplit ts = no_split;
+        if (workspace && mask_mode != 1 && parts > 1 && nblocks > slots && tail > 0 && tail * parts <= slots / 2 &&
+            (int64_t)tail * parts * 4 * 64 * 64 * 4 <= workspace_bytes && mmvid_option(MMVID_OPT_ATTN_TAIL)) {
+            ts.nfull = nblocks - tail, ts.parts = parts, ts.nlogical = nblocks, ts.ws = (float*)workspace;
+        }
+        const int grid = ts.parts > 1 ? ts.nfull + tail * ts.parts : nblocks;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, false>), dim3(grid), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld,
+                           (const bf16_t*)dO, (long)lddo, lse2, delta, L, H, E, nrt, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, nullptr, ts);
+        if (ts.parts > 1)
+            hipLaunchKernelGGL(attn_dkv_combine_kernel, dim3(tail), dim3(256), 0, s, L, H, E, nrt, scale, (bf16_t*)dqkv, (long)ldg, dbias, ts);
+    }
     MMVID_LAUNCH_CHECK("attention_bwd");
     return MMVID_OK;
+}
+
+// bytes of workspace with which mmvid_attention_bwd_ws can split the blocks of its last, partly filled round (0: nothing to split)
+extern "C" int64_t mmvid_attention_bwd_workspace_bytes(int B, int L, int H) {
+    const int nrt = cdiv(L, ROWS_PER_BLOCK);
+    return (int64_t)nrt * H * B > 0 ? (int64_t)256 * 4 * 4 * 64 * 64 * 4 : 0;  // at most slots / 2 = 256 part blocks of 64 KiB
 }

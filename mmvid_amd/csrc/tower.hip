@@ -62,7 +62,7 @@ SavedLayer saved_layout(const Dims& d) {
 }
 
 struct Scratch {  // byte offsets inside the scratch arena
-    int64_t delta, dqkv, d_h, d_o, d_pre, g_bf16, splitk_ws, ln_ws, infer, total;
+    int64_t delta, attn_ws, attn_ws_bytes, dqkv, d_h, d_o, d_pre, g_bf16, splitk_ws, ln_ws, infer, total;
 };
 Scratch scratch_layout(const Dims& d) {
     Scratch s;
@@ -73,6 +73,8 @@ Scratch scratch_layout(const Dims& d) {
         return o;
     };
     s.delta = take((int64_t)d.B * d.H * d.L * 4);
+    s.attn_ws_bytes = mmvid_attention_bwd_workspace_bytes(d.B, d.L, d.H);
+    s.attn_ws = take(s.attn_ws_bytes);
     s.dqkv = take(d.M * 3 * d.E * 2);
     s.d_h = take(d.M * d.E * 4);  // (bf16 by default: half of it is used)
     s.d_o = take(d.M * d.E * 2);
@@ -299,9 +301,9 @@ static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_towe
             TRY(ln_flush());
         }
         TRY(linear_dx(d.M, d.E, d.E, kp + kl.g_out, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
-        TRY(mmvid_attention_bwd_bias(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
+        TRY(mmvid_attention_bwd_ws(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
                                      (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
-                                     cfg->r1, cfg->c1, kp + kl.dqkv, 3 * d.E, fuse_fc_bias ? ly.g_in_b : nullptr, stream));
+                                     cfg->r1, cfg->c1, kp + kl.dqkv, 3 * d.E, fuse_fc_bias ? ly.g_in_b : nullptr, scr + sc.attn_ws, sc.attn_ws_bytes, stream));
         // (option fuse_colsum 0: the bias gradient as column sums of the bf16-rounded dqkv -- the values the weight gradient uses)
         if (!fuse_fc_bias && ly.g_in_b) TRY(mmvid_colsum_bf16(kp + kl.dqkv, 3 * d.E, d.M, 3 * d.E, ly.g_in_b, stream));
         TRY(linear_dx(d.M, 3 * d.E, d.E, kp + kl.dqkv, ly.in_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
@@ -425,9 +427,9 @@ static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         TRY(linear_dx(d.M, d.E, d.E, gb, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
         wait(ev_in);  // the previous layer's in_proj dW still reads dqkv
         // the in-projection's bias gradient (column sums of dqkv) comes out of the attention backward's registers
-        TRY(mmvid_attention_bwd_bias(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
+        TRY(mmvid_attention_bwd_ws(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
                                      (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
-                                     cfg->r1, cfg->c1, scr + sc.dqkv, 3 * d.E, fuse_fc_bias ? ly.g_in_b : nullptr, stream));
+                                     cfg->r1, cfg->c1, scr + sc.dqkv, 3 * d.E, fuse_fc_bias ? ly.g_in_b : nullptr, scr + sc.attn_ws, sc.attn_ws_bytes, stream));
         if (!fuse_fc_bias && ly.g_in_b) TRY(mmvid_colsum_bf16(scr + sc.dqkv, 3 * d.E, d.M, 3 * d.E, ly.g_in_b, stream));
         fork();
         TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, nullptr, ws, wst));

@@ -83,6 +83,39 @@ def test_attention_outputs_are_batch_order_independent_after_the_swizzle_change(
     assert torch.equal(o_all[2 * L:3 * L], o_one) and torch.equal(g_all[2 * L:3 * L], g_one)
 
 
+def test_attention_backward_tail_split_matches_whole_blocks_and_is_reproducible():
+    """mmvid_attention_bwd_ws at the training step's shape (18 sequences x 12 heads x L = 579: 1,080 dK/dV blocks, 56 of them in a third,
+    5-%-full round): the last round's blocks are cut into query-range parts whose fp32 accumulators are added in a fixed order.  dQ is
+    untouched (bit-identical to the workspace-free call); dK / dV differ by summation order only (within one bf16 ulp, almost everywhere
+    equal); two runs are bit-identical; the fused in-projection bias gradient stays the column sum of dqkv."""
+    from mmvid_amd import _lib, ops
+    B, L, H, E = 18, 579, 12, 768
+    torch.manual_seed(11)
+    qkv = (torch.randn(B * L, 3 * E, device=DEV) * 0.5).bfloat16()
+    dO = (torch.randn(B * L, E, device=DEV) * 0.1).bfloat16()
+    spec = ('rows', [(65, 65), (66, 66)])
+    out, lse2 = ops.attention_fwd(qkv, B, L, H, spec)
+    db0, db1 = torch.zeros(3 * E, device=DEV), torch.zeros(3 * E, device=DEV)
+    whole = ops.attention_bwd(qkv, out, dO, lse2, B, L, H, spec, dbias=db0, workspace=False)
+    split = ops.attention_bwd(qkv, out, dO, lse2, B, L, H, spec, dbias=db1, workspace=True)
+    again = ops.attention_bwd(qkv, out, dO, lse2, B, L, H, spec, workspace=True)
+    assert torch.equal(split, again)
+    assert torch.equal(split[:, :E], whole[:, :E])
+    w, s_ = whole[:, E:].float(), split[:, E:].float()
+    diff = (w - s_).abs()
+    assert float((diff > 0).float().mean()) < 0.02  # only the 56 split blocks can differ, and there mostly not
+    # <= one bf16 ulp, or (elements that cancel to ~0) the fp32 summation-order error of the terms
+    assert bool((diff <= 2.0**-7 * w.abs() + 1e-5 * w.abs().max()).all())
+    assert float((db1 - db0).abs().max()) <= 2e-3 * float(db0.abs().max())
+    # the option switches it off: then the call with a workspace IS the workspace-free call
+    _lib.call('mmvid_set_option', b'attn_tail', 0)
+    try:
+        off = ops.attention_bwd(qkv, out, dO, lse2, B, L, H, spec, workspace=True)
+    finally:
+        _lib.call('mmvid_set_option', b'attn_tail', 1)
+    assert torch.equal(off, whole)
+
+
 def test_sparse_exchange_pack_and_merge_kernels():
     """mmvid_rows_pack / mmvid_rows_merge (what FlatTrainer._exchange_sparse runs on the device instead of torch sort / index_select /
     index_add_): the message of a rank -- ids ascending, repeats blanked, rows zeroed where blanked -- equals the torch formulation bit

@@ -30,8 +30,18 @@ def bwd():
               65, 66, 66, ops._p(dqkv), 3 * E, st())
 
 
+nws = _lib.load().mmvid_attention_bwd_workspace_bytes(B, L, H)
+ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+
+
+def bwd_ws():  # the tower's call: with the workspace that lets the last round's blocks be split (option attn_tail)
+    _lib.call('mmvid_attention_bwd_ws', ops._p(qkv), 3 * E, ops._p(out), E, ops._p(dO), E, ops._p(lse), ops._p(delta), B, L, H, E, 0.125, 2, 65,
+              65, 66, 66, ops._p(dqkv), 3 * E, None, ops._p(ws), nws, st())
+
+
 fwd()
-tf, tb = timeit(fwd, 30), timeit(bwd, 30)
+tf, tb, tw = timeit(fwd, 30), timeit(bwd, 30), timeit(bwd_ws, 30)
+print(f'bwd with the tail-split workspace {tw*1e3:6.1f} us (without {tb*1e3:6.1f})')
 fl = 4.0 * B * H * L * L * 64
 print(f'attention fwd {tf*1e3:6.1f} us {fl/tf/1e9:6.1f} TF | bwd (dQ + dK/dV) {tb*1e3:6.1f} us {2.5*fl/tb/1e9:6.1f} TF')
 # reference check against torch (fp32 math on the bf16 inputs)
@@ -45,6 +55,9 @@ o2 = o.transpose(1, 2).reshape(B * L, E)
 o2.backward(dO.float())
 err = lambda a, b: ((a.float() - b).abs().max() / b.abs().max()).item()
 g = torch.cat([t.grad.transpose(1, 2).reshape(B * L, E) for t in (q, k, v)], 1)
+bwd_ws()
+print(f'rel err with the tail split: dqkv {err(dqkv, g):.2e}')
+assert err(dqkv, g) < 3e-2
 bwd()
 db = torch.zeros(3 * E, device=dev)
 _lib.call('mmvid_attention_bwd_bias', ops._p(qkv), 3 * E, ops._p(out), E, ops._p(dO), E, ops._p(lse), ops._p(delta), B, L, H, E, 0.125, 2, 65,
