@@ -52,6 +52,8 @@ int mmvid_gemm_trace(void* dev_buf);
 int mmvid_attention_trace(void* dev_buf);
 /* and for the decode gemv (csrc/decode.hip): [512 blocks][8] stamps of the next mmvid_gemv_rows launches (tools/bench_decode_step.py). */
 int mmvid_decode_trace(void* dev_buf);
+/* and for the persistent decode step (csrc/decode_persistent.hip): [4 blocks][12 layers][16] stamps (tools/decode_persistent_timeline.py). */
+int mmvid_decode_persistent_trace(void* dev_buf);
 
 /* Weight gradient dW[N][K] (+)= dY^T X over M tokens (autograd of nn.Linear); split-K through `workspace`
  * ([splitk][N][K] fp32) with a fixed-order reduction: deterministic. */
@@ -323,6 +325,15 @@ int mmvid_tower_decode(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* 
 int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                              float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
                              void* stream);
+/* The same step as ONE launch: 256 co-resident blocks walk the 60 phases and hand values to each other as tagged 8-byte words that
+ * the consumers poll (csrc/decode_persistent.hip) -- no launch boundary, no barrier.  _supported: the 768 / 3072 / 12-head causal tower,
+ * <= 12 layers, B <= 2, Lmax <= 4096, a device with >= 256 CUs and nothing else running beside the step.
+ * workspace: _workspace_bytes(B) bytes, ZERO before the first call, then owned by the session (it carries the step counter the tags are
+ * made from; word 1 becomes non-zero if a poll ever timed out, i.e. the blocks were not resident together). */
+int mmvid_tower_decode_persistent_supported(const mmvid_tower_cfg_t* cfg, int Lmax);
+int64_t mmvid_tower_decode_persistent_workspace_bytes(int B);
+int mmvid_tower_decode_persistent(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in, float* x_out,
+                                  void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* workspace, void* stream);
 int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const float* ln_w, const float* ln_b, float eps, const void* W,
                     const float* bias, int N, int act, const float* residual, int64_t ldr, int round_in, int round_out,
                     float* out, int64_t ldo, void* stream);

@@ -68,6 +68,7 @@ SIGNATURES = {
     'mmvid_tower_prefill': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, P],
     'mmvid_tower_decode': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, I, P, P],
     'mmvid_tower_decode_fused': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, I, P, P],
+    'mmvid_tower_decode_persistent': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, I, P, P],
     'mmvid_gemv_rows': [P, I64, I, I, P, P, F, P, P, I, I, P, I64, I, I, P, I64, P],
     'mmvid_decode_embed': [P, P, I64, P, P, I, I, I, P, P],
     'mmvid_kv_store': [P, I64, I, I, I, P, I, I, P, P],
@@ -87,6 +88,7 @@ SIGNATURES = {
     'mmvid_groupnorm_swish_nhwc_split': [P, I, I64, I, P, P, F, I, P, I, P, P],
     'mmvid_attention_trace': [P],
     'mmvid_decode_trace': [P],
+    'mmvid_decode_persistent_trace': [P],
     'mmvid_vqgan_run': [POINTER(VqganOp), I, P, P],
     'mmvid_sample_race': [P, I64, P, P, F, F, I64, I, I64, P, P, P],
     'mmvid_mp_select_keep': [P, P, P, I, I, I, I, P, P],
@@ -131,7 +133,9 @@ SIGNATURES = {
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I),
          'mmvid_warp_params_bytes': ([], I), 'mmvid_gemm_dw_multi_fill': ([I, P, I], ctypes.c_double),
-         'mmvid_attention_bwd_workspace_bytes': ([I, I, I], I64)}
+         'mmvid_attention_bwd_workspace_bytes': ([I, I, I], I64),
+         'mmvid_tower_decode_persistent_supported': ([POINTER(TowerCfg), I], I),
+         'mmvid_tower_decode_persistent_workspace_bytes': ([I], I64)}
 
 class DwKind(ctypes.Structure):
     """mmvid_dw_kind_t (include/mmvid_hip.h)."""

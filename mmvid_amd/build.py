@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(HERE, 'libmmvid_hip.so')
-SOURCES = ['errors', 'graphs', 'vq', 'gemm', 'norm', 'attn', 'embed', 'optim', 'tower', 'decode', 'conv', 'conv_strip', 'strict', 'sample', 'frontend', 'vqgan', 'probe']
+SOURCES = ['errors', 'graphs', 'vq', 'gemm', 'norm', 'attn', 'embed', 'optim', 'tower', 'decode', 'decode_persistent', 'conv', 'conv_strip', 'strict', 'sample', 'frontend', 'vqgan', 'probe']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
 

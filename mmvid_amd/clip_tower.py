@@ -94,12 +94,23 @@ class DecodeSession:
         self.y = torch.zeros_like(self.x)
         self.pos = torch.tensor([first_pos], dtype=torch.int32, device=dev)
         self.graph, self.want_graph, self.calls = None, graph, 0
+        # the whole step as one launch of 256 co-resident blocks (csrc/decode_persistent.hip) where the tower / batch / device allow it;
+        # MMVID_DECODE_PERSISTENT=0 (or fused='launches') keeps the five-launches-per-layer form
+        lib = _lib.load()
+        self.persistent = bool(fused is True and os.environ.get('MMVID_DECODE_PERSISTENT', '1') != '0'
+                               and lib.mmvid_tower_decode_persistent_supported(ctypes.byref(self.cfg), kv_cache.shape[2]))
+        self.ws = torch.zeros(lib.mmvid_tower_decode_persistent_workspace_bytes(B) // 8, dtype=torch.int64, device=dev) if self.persistent else None
 
     def _enqueue(self):
         # batches of up to 8 sequences take the matrix-vector path (five launches per layer, csrc/decode.hip); larger
         # ones the M = B corner of the MFMA GEMM
         # the fused small-batch kernels stage the whole [B, K] input block: B <= 8, B * 3072 <= 24576, B * 768 <= 6144 (csrc/decode.hip)
         B, E = self.x.shape[0], self.x.shape[-1]
+        if self.persistent:
+            _lib.call('mmvid_tower_decode_persistent', ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
+                      ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.ws), ops._stream())
+            self.pos.add_(1)
+            return
         fn = 'mmvid_tower_decode_fused' if (self.fused and B <= 8 and B * 4 * E <= 24576 and B * E <= 6144) else 'mmvid_tower_decode'
         _lib.call(fn, ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
                   ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())

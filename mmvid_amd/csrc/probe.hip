@@ -196,10 +196,77 @@ __global__ __launch_bounds__(256) void probe_stream_kernel(const char* __restric
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345679u) sink[0] = 1.f;
     (void)bytes;
 }
+// which = 7: the dependency chain of a persistent decode kernel.  `blocks` co-resident blocks run `phases` phases; in a phase every block
+// POLLS a row of K tagged words written by the other blocks in the previous phase (8 bytes = fp32 payload | 32-bit phase tag, agent-scope
+// relaxed atomics: the tag makes the data its own flag, no separate barrier), sums it, and writes its own share of the next row.
+// mode 1: a counter barrier (atomic add + poll) followed by plain agent-scope loads of the row instead.  Time / phases = the floor of one
+// phase of a megakernel decode step.  in = HOST int32[4]: phases, blocks, K, mode; out = device uint64[2 * K + 64] zeroed by the caller.
+// Spins are bounded (a lost block ends the kernel with out[2K + 1] = 1 instead of hanging the device).
+__global__ __launch_bounds__(256) void probe_chain_kernel(int phases, int K, int mode, unsigned long long* buf) {
+    unsigned long long* rows[2] = {buf, buf + K};
+    unsigned int* counter = reinterpret_cast<unsigned int*>(buf + 2 * K);
+    unsigned long long* fail = buf + 2 * K + 1;
+    __shared__ float red[4];
+    const int tid = threadIdx.x, nb = gridDim.x;
+    const int per = (K + nb - 1) / nb;  // words a block writes per phase
+    float carry = 1.0f;
+    for (int p = 1; p <= phases; ++p) {
+        unsigned long long* dst = rows[p & 1];
+        const unsigned long long* src = rows[(p + 1) & 1];
+        // write this block's share (phase 1 needs no input)
+        if (tid < per && blockIdx.x * per + tid < K) {
+            const unsigned long long word = ((unsigned long long)(unsigned)p << 32) | __float_as_uint(carry * 0.5f + (float)tid);
+            __hip_atomic_store(dst + blockIdx.x * per + tid, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (mode == 1) {
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p * nb)) {
+                    if (++spins > (1 << 22)) {
+                        *fail = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float s = 0.f;
+        for (int k = tid; k < K; k += 256) {
+            unsigned long long w = __hip_atomic_load(dst + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mode == 0) {
+                int spins = 0;
+                while ((unsigned)(w >> 32) != (unsigned)p) {
+                    if (++spins > (1 << 22)) {
+                        *fail = 1;
+                        break;
+                    }
+                    w = __hip_atomic_load(dst + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            s += __uint_as_float((unsigned)w);
+        }
+        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        carry = ((red[0] + red[1]) + (red[2] + red[3])) * 1e-6f;
+        __syncthreads();
+        (void)src;
+    }
+    if (carry == 1.2345e-30f) buf[2 * K + 2] = 1;
+}
 }  // namespace
 
 extern "C" int mmvid_probe(int which, const void* in, void* out, void* stream) {
-    MMVID_REQUIRE((which >= 0 && which <= 6) && in && out, "probe: bad arguments");
+    MMVID_REQUIRE((which >= 0 && which <= 7) && in && out, "probe: bad arguments");
+    if (which == 7) {  // in = HOST int32[4]: phases, blocks, K, mode
+        const int* a = (const int*)in;
+        MMVID_REQUIRE(a[1] > 0 && a[1] <= 256 && a[2] > 0, "probe 7: at most 256 (co-resident) blocks");
+        hipLaunchKernelGGL(probe_chain_kernel, dim3(a[1]), dim3(256), 0, (hipStream_t)stream, a[0], a[2], a[3], (unsigned long long*)out);
+        MMVID_LAUNCH_CHECK("probe");
+        return MMVID_OK;
+    }
     if (which == 6) {  // in = HOST int64[2]: bytes, mode; out = the device buffer that is streamed (its first float is the sink)
         const long long* a = (const long long*)in;
         hipLaunchKernelGGL(probe_stream_kernel, dim3((unsigned)(a[0] / 65536)), dim3(256), 0, (hipStream_t)stream, (const char*)out, (long)a[0],

@@ -173,3 +173,31 @@ def test_small_map_groupnorm_single_launch_is_bit_identical(n, h, c, dt, swish, 
     ref = ref.permute(0, 2, 3, 1)
     err = ((res[1].float() - ref).abs().max() / ref.abs().max()).item()
     assert err < (1e-2 if out == torch.bfloat16 else 1e-5), err
+
+
+@pytest.mark.parametrize('B,P', [(1, 2), (1, 250), (2, 250), (2, 7)])
+def test_persistent_decode_step_matches_the_five_launch_form(B, P):
+    """mmvid_tower_decode_persistent (csrc/decode_persistent.hip): one launch of 256 co-resident blocks per token, values handed between
+    blocks as tagged words.  Same rounding points as the five-launches-per-layer step: hidden states and the key/value cache agree to
+    fp32-summation-order / one-bf16-ulp level over 24 positions (eager, then captured and replayed), attention ranges of 0 (prompt of 2 positions: an empty
+    range at batch 1) .. 68 keys per range, every supported batch size; no poll ever timed out (workspace word 1)."""
+    from mmvid_amd.clip_tower import OpenAICLIPTransformer
+    from test_models_gpu import close
+    torch.manual_seed(B)
+    L, steps = 320, 24
+    tw = OpenAICLIPTransformer(seq_len=L, which_model='openai_clip_visual', causal=True, layers=3).to(DEV).eval()
+    x = torch.randn(B, P + steps, 768, device=DEV) * 0.5
+    with torch.no_grad():
+        caches = [tw.new_kv_cache(B, L, DEV) for _ in range(2)]
+        for c in caches:
+            tw.prefill(x[:, :P].contiguous(), c)
+        ref = tw.decode_session(caches[0], P, fused='launches')
+        per = tw.decode_session(caches[1], P, graph=True)
+        assert per.persistent and not ref.persistent
+        for k in range(steps):
+            hr = ref.step(x[:, P + k].contiguous()).clone()
+            hp = per.step(x[:, P + k].contiguous()).clone()
+            close(hp, hr, 1e-2, f'B={B}: persistent vs five-launch decode step at position {P + k}')
+        assert per.graph is not None
+        close(caches[1][:, :, :P + steps], caches[0][:, :, :P + steps], 1e-2, 'key/value cache')
+        assert int(per.ws[1]) == 0 and int(per.ws[0]) == steps
