@@ -325,6 +325,11 @@ int mmvid_tower_decode(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* 
 int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                              float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
                              void* stream);
+/* ... for cfg->B consecutive sequences of a cache of cache_batch sequences (kv_cache = the first of them in layer 0; x_in / x_out = their
+ * rows): how batches above 8 run, as slices of 8. */
+int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
+                                   float* x_out, void* kv_cache, int Lmax, int cache_batch, const int32_t* pos_dev, int pos,
+                                   void* scratch, void* stream);
 /* The same step as ONE launch: 256 co-resident blocks walk the 60 phases and hand values to each other as tagged 8-byte words that
  * the consumers poll (csrc/decode_persistent.hip) -- no launch boundary, no barrier.  _supported: the 768 / 3072 / 12-head causal tower,
  * <= 12 layers, B <= 2, Lmax <= 4096, a device with >= 256 CUs and nothing else running beside the step.

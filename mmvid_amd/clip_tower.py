@@ -94,6 +94,7 @@ class DecodeSession:
         self.y = torch.zeros_like(self.x)
         self.pos = torch.tensor([first_pos], dtype=torch.int32, device=dev)
         self.graph, self.want_graph, self.calls = None, graph, 0
+        self._slice_cfgs = {}
         # the whole step as one launch of 256 co-resident blocks (csrc/decode_persistent.hip) where the tower / batch / device allow it;
         # MMVID_DECODE_PERSISTENT=0 (or fused='launches') keeps the five-launches-per-layer form
         lib = _lib.load()
@@ -109,6 +110,16 @@ class DecodeSession:
         if self.persistent:
             _lib.call('mmvid_tower_decode_persistent', ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
                       ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.ws), ops._stream())
+            self.pos.add_(1)
+            return
+        if self.fused and B > 8 and E <= 768:
+            # slices of 8 sequences through the matrix-vector kernels (the M = B corner of the training GEMM: 2.2 ms per token at batch 16)
+            Lmax = self.cache.shape[2]
+            for b0 in range(0, B, 8):
+                nb = min(8, B - b0)
+                cfg = self._slice_cfgs.setdefault(nb, self.tower._cfg(nb, Lmax))
+                _lib.call('mmvid_tower_decode_fused_slice', ctypes.byref(cfg), self.layers, self.x[b0:].data_ptr(), self.y[b0:].data_ptr(),
+                          self.cache[0, b0].data_ptr(), Lmax, B, ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
             self.pos.add_(1)
             return
         fn = 'mmvid_tower_decode_fused' if (self.fused and B <= 8 and B * 4 * E <= 24576 and B * E <= 6144) else 'mmvid_tower_decode'

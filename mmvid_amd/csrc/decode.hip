@@ -7,6 +7,7 @@
 // the twelve layers' GEMMs at M = B.
 #include "../../include/mmvid_hip.h"
 #include "common.h"
+#include "wave_reduce.h"
 #include <type_traits>
 
 namespace {
@@ -147,62 +148,6 @@ struct GemvArgs {
 // KIT = ceil(K / 512): 16-byte weight loads per lane and output feature.  The kernel is latency-bound (a decode step is a
 // chain of ~60 of these), so the two global round trips it needs are overlapped: every weight load of the wave is issued
 // FIRST, into registers, and the input rows are fetched / normalised / staged in LDS while those are in flight.
-// ---- reduce-scatter of a short list of per-lane partial sums over the 64 lanes of a wave.  A gemv wave ends with 2 * NB partial dot
-// products per lane (2 output features x NB rows); summing each with a full butterfly costs 6 cross-lane steps per value.  Here the
-// list is HALVED per lane bit instead: at bit 5 (v_permlane32_swap) a lane hands one half of its list to its partner and keeps the
-// sum of the other half, then bit 4 (v_permlane16_swap), bit 3 (row_mirror), bit 2 (row_half_mirror) -- N - 1 exchanges for N values
-// -- and the remaining lane bits are a butterfly on the ONE value left.  Value j of the list ends, complete, in lanes
-// [j << (6 - LOGN), (j + 1) << (6 - LOGN)).
-template <int BIT>
-__device__ __forceinline__ float xchg_add(float x, float y, int lane) {  // lanes with BIT clear: x over the pair; set: y over the pair
-    if constexpr (BIT == 5) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    } else if constexpr (BIT == 4) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    } else {
-        const bool up = (lane >> BIT) & 1;
-        const float keep = up ? y : x, send = up ? x : y;
-        return keep + dpp_mov<BIT == 3 ? 0x140 : (BIT == 2 ? 0x141 : (BIT == 1 ? 0x4E : 0xB1))>(send);
-    }
-}
-template <int BIT>
-__device__ __forceinline__ float bfly_add(float v) {  // all-reduce step over lane bit BIT
-    if constexpr (BIT == 5) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    } else if constexpr (BIT == 4) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    } else {
-        return v + dpp_mov<BIT == 3 ? 0x140 : (BIT == 2 ? 0x141 : (BIT == 1 ? 0x4E : 0xB1))>(v);
-    }
-}
-template <int LOGN>
-__device__ __forceinline__ float reduce_scatter(float (&v)[1 << LOGN], int lane) {
-    if constexpr (LOGN >= 1) {
-#pragma unroll
-        for (int i = 0; i < (1 << LOGN) / 2; ++i) v[i] = xchg_add<5>(v[i], v[i + (1 << LOGN) / 2], lane);
-    }
-    if constexpr (LOGN >= 2) {
-#pragma unroll
-        for (int i = 0; i < (1 << LOGN) / 4; ++i) v[i] = xchg_add<4>(v[i], v[i + (1 << LOGN) / 4], lane);
-    }
-    if constexpr (LOGN >= 3) {
-#pragma unroll
-        for (int i = 0; i < (1 << LOGN) / 8; ++i) v[i] = xchg_add<3>(v[i], v[i + (1 << LOGN) / 8], lane);
-    }
-    if constexpr (LOGN >= 4) v[0] = xchg_add<2>(v[0], v[1], lane);
-    float r = v[0];
-    if constexpr (LOGN < 1) r = bfly_add<5>(r);
-    if constexpr (LOGN < 2) r = bfly_add<4>(r);
-    if constexpr (LOGN < 3) r = bfly_add<3>(r);
-    if constexpr (LOGN < 4) r = bfly_add<2>(r);
-    r = bfly_add<1>(r);
-    return bfly_add<0>(r);
-}
-
 unsigned long long* g_decode_trace = nullptr;  // measurement only (mmvid_decode_trace): [blocks][8] wall-clock stamps of the next gemv
 
 // BF: the staged rows are bf16-exact (round_in) -> LDS holds them as bf16 (half the LDS traffic, 16-byte conflict-free reads) and the
@@ -577,7 +522,18 @@ extern "C" int mmvid_decode_embed(const int64_t* tok, const float* table, int64_
 extern "C" int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                                         float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
                                         void* stream) {
+    MMVID_REQUIRE(cfg, "tower_decode_fused: null pointer");
+    return mmvid_tower_decode_fused_slice(cfg, layers, x_in, x_out, kv_cache, Lmax, cfg->B, pos_dev, pos, scratch, stream);
+}
+
+// The same for cfg->B consecutive sequences of a cache that holds cache_batch >= cfg->B of them: kv_cache points at the first of these
+// sequences in layer 0, a layer is cache_batch * Lmax * 2E elements further.  (Batches above 8 run as slices of 8: the M = B corner of the
+// training GEMM takes 2.2 ms per token at batch 16.)
+extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
+                                              float* x_out, void* kv_cache, int Lmax, int cache_batch, const int32_t* pos_dev, int pos,
+                                              void* scratch, void* stream) {
     MMVID_REQUIRE(cfg && layers && x_in && x_out && kv_cache && scratch, "tower_decode_fused: null pointer");
+    MMVID_REQUIRE(cache_batch >= cfg->B, "tower_decode_fused: cache_batch %d < batch %d", cache_batch, cfg->B);
     MMVID_REQUIRE(cfg->mask_mode == 1 && cfg->E == cfg->H * 64 && cfg->B <= GV_MAXB && Lmax <= DEC_MAXL,
                   "tower_decode_fused: causal tower, head_dim 64, batch <= %d, Lmax <= %d", GV_MAXB, DEC_MAXL);
     const int B = cfg->B, E = cfg->E, F = cfg->F, H = cfg->H;
@@ -597,7 +553,7 @@ extern "C" int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvi
     const float* x = x_in;
     for (int i = 0; i < cfg->layers; ++i) {
         const mmvid_tower_layer_t& ly = layers[i];
-        bf16_t* cache = (bf16_t*)kv_cache + (long)i * B * Lmax * 2 * E;
+        bf16_t* cache = (bf16_t*)kv_cache + (long)i * cache_batch * Lmax * 2 * E;
         float* xnext = (i == cfg->layers - 1) ? x_out : ((i & 1) ? xb : xa);
         GemvArgs g = {};
         g.NB = B, g.eps = cfg->ln_eps;

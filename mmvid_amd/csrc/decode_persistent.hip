@@ -9,11 +9,11 @@
 //     atomics (single-copy atomic: whoever sees the tag sees the payload).  The tag names (decode step, layer, phase); a consumer polls
 //     the words it needs until they carry the tag it expects: the data is its own flag.  tools/chain_probe.py: 2.4 us per hop over 256
 //     blocks (store -> memory side -> load; a counter barrier with release / acquire costs 8.7 us, a launch boundary 4.4).
-//   * weights do not depend on anything: a wave requests the rows of its next phase's output features (16 B per lane, straight into
-//     registers: 1 wave per SIMD, 512 VGPRs) as soon as its current inputs have arrived, so they stream under the compute, the stores and
-//     the next poll.
+//   * weights do not depend on anything: a wave requests the rows of its next phases' output features (16 B per lane, straight into
+//     registers: 1 wave per SIMD, 512 VGPRs) right BEFORE a poll -- the poll is a memory round trip anyway, and they arrive under it.
 //   * the attention over the cache is split over S key ranges per (sequence, head) (S = 4: 48 blocks per sequence instead of 12 stream the
-//     cache), each writing (o[64], max, sum); the out-projection's loader merges them.
+//     cache; the first 256 keys / values of a range are requested before q exists), each writing (o[64], max, sum); the out-projection's
+//     loader merges them.  fc activations travel as bf16 pairs (half the lines to poll); residual rows stay in LDS.
 //
 //   phase 1  q,k,v = LN1(x) W_in^T + b        9 output features per block; K|V appended to the cache (plain stores: for later steps)
 //   phase 2  partial attention                 block u < B * 12 * S: (sequence, head, key range); the new position's K|V come from phase 1's words
@@ -21,8 +21,9 @@
 //   phase 4  a = QuickGELU(LN2(x_mid) W_fc^T + b)   12 features per block
 //   phase 5  x' = x_mid + a W_proj^T + b       3 features per block (K = 3072)
 // Operands are rounded to bf16 where the full forward stores bf16 (LayerNorm output, q/k/v, o, the GELU output), as csrc/decode.hip
-// does: the two paths differ by fp32 summation order only.  HBM/latency-bound; shape: E = 768, F = 3072, 12 heads, <= 12 layers, B <= 2
-// (at B = 4 the five-launch form is faster: every block polls every row, and the rows no longer fit the registers of the pollers).
+// does: the two paths differ by fp32 summation order only.  What bounds it: five coherent round trips per layer.
+// HBM/latency-bound; shape: E = 768, F = 3072, 12 heads, <= 12 layers, B <= 2 (at B = 4 the five-launch form is faster: every block
+// polls every row, and the rows no longer fit the registers of the pollers).
 //
 // Safety: a poll gives up after PD_SPIN rounds (~0.3 s) and raises workspace word 1 instead of hanging the device -- it cannot happen
 // while all 256 blocks are resident, which the launcher checks (CU count) and which holds when nothing else shares the device.
@@ -234,7 +235,13 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
     u64* const ACT = XMID + (long)NBT * PD_E;
     const int pos = a.pos_dev ? *a.pos_dev : a.pos0;
     const int n = pos + 1;
-    const int f0 = blk + 256 * wave;  // this wave's output feature j is f0 + 1024 * j
+    // Output features are numbered so that a BLOCK's words of a row are contiguous: a 64-byte line whose eight words come from eight
+    // blocks on eight XCDs reaches its readers 0.8 us later than one with two or three writers (tools/chain_probe.py, "writers
+    // interleaved").  768-wide rows: feature 3 blk + wave (waves 0-2); q|k|v: 9 per block (wave 0: 3, waves 1-3: 2 each); fc pairs: 6 per
+    // block (waves 0, 1: 2 each, waves 2, 3: 1 each).
+    const int f0 = 3 * blk + wave;                                           // phases 3 and 5 (wave < 3)
+    const int n1 = wave == 0 ? 3 : 2, f1 = 9 * blk + (wave == 0 ? 0 : 1 + 2 * wave);   // phase 1: features f1 .. f1 + n1 - 1
+    const int n4 = wave < 2 ? 2 : 1, p4 = 6 * blk + (wave < 2 ? 2 * wave : 2 + wave);   // phase 4: pairs p4 .. p4 + n4 - 1
     const int tslot = blk == 0 ? 0 : (blk == 1 ? 1 : (blk == 128 ? 2 : (blk == 255 ? 3 : -1)));
     u64* const tr = (a.trace && tslot >= 0 && tid == 0) ? a.trace + (long)tslot * PD_LAYERS * 16 : nullptr;
 #define PD_STAMP(i) \
@@ -259,8 +266,8 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
     auto fetch1 = [&](const GLayer& L) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int f = f0 + 1024 * j;
-            const bool on = f < 3 * PD_E;
+            const int f = f1 + j;
+            const bool on = j < n1;
             w1[j] = load_w768(L.in_w + (long)(on ? f : 0) * PD_E, lane);
             b1[j] = L.in_b[(on ? f : 0) + vz];
         }
@@ -270,13 +277,13 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
         }
     };
     auto fetch45 = [&](const GLayer& L) {  // the fc rows of this wave, LN2, the c_proj row
-        // fc features come in adjacent PAIRS (pair p = f0 + 1024 j < 1536: features 2p, 2p + 1) so that the two bf16-exact activations
+        // fc features come in adjacent PAIRS (pair p: features 2p, 2p + 1) so that the two bf16-exact activations
         // travel in one tagged word: phase 5 polls half the lines
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int pr = f0 + 1024 * j, f = pr < PD_F / 2 ? 2 * pr + e : 0;
+                const int pr = p4 + j, f = j < n4 ? 2 * pr + e : 0;
                 w4[2 * j + e] = load_w768(L.fc_w + (long)f * PD_E, lane), b4[2 * j + e] = L.fc_b[f + vz];
             }
         if (wave < 3) {
@@ -343,8 +350,8 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int f = f0 + 1024 * j;
-                if (f >= 3 * PD_E) break;  // wave-uniform
+                const int f = f1 + j;
+                if (j >= n1) break;  // wave-uniform
 #pragma unroll
                 for (int b = 0; b < NBT; ++b) {
                     if (b >= NB) break;
@@ -550,8 +557,8 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int pr = f0 + 1024 * j;
-                if (pr >= PD_F / 2) break;  // wave-uniform
+                const int pr = p4 + j;
+                if (j >= n4) break;  // wave-uniform
 #pragma unroll
                 for (int b = 0; b < NBT; ++b) {
                     if (b >= NB) break;

@@ -214,11 +214,14 @@ __global__ __launch_bounds__(256) void probe_chain_kernel(int phases, int K, int
         unsigned long long* dst = rows[p & 1];
         const unsigned long long* src = rows[(p + 1) & 1];
         // write this block's share (phase 1 needs no input)
-        if (tid < per && blockIdx.x * per + tid < K) {
+        // mode bit 1 (value 2): the words of a block are INTERLEAVED with the other blocks' (word = tid * blocks + block: every 64-byte
+        // line has eight writers on eight XCDs) instead of contiguous
+        const int widx = (mode & 2) ? tid * nb + (int)blockIdx.x : (int)blockIdx.x * per + tid;
+        if (tid < per && widx < K) {
             const unsigned long long word = ((unsigned long long)(unsigned)p << 32) | __float_as_uint(carry * 0.5f + (float)tid);
-            __hip_atomic_store(dst + blockIdx.x * per + tid, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + widx, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (mode == 1) {
+        if (mode & 1) {
             __syncthreads();
             if (tid == 0) {
                 __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -233,9 +236,29 @@ __global__ __launch_bounds__(256) void probe_chain_kernel(int phases, int K, int
             __syncthreads();
         }
         float s = 0.f;
+        if (mode & 4) {  // mode bit 2 (value 4): ONE wave polls the row, 12 words per lane, all requested before any is examined
+            if (tid < 64) {
+                unsigned long long w[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) w[i] = (i * 64 + tid < K) ? __hip_atomic_load(dst + i * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)(unsigned)p << 32);
+                for (int spins = 0;; ++spins) {
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i)
+                        if ((unsigned)(w[i] >> 32) != (unsigned)p) ok = false, w[i] = __hip_atomic_load(dst + i * 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ok) break;
+                    if (spins > (1 << 20)) {
+                        *fail = 1;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) s += __uint_as_float((unsigned)w[i]);
+            }
+        } else
         for (int k = tid; k < K; k += 256) {
             unsigned long long w = __hip_atomic_load(dst + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (mode == 0) {
+            if (!(mode & 1)) {
                 int spins = 0;
                 while ((unsigned)(w >> 32) != (unsigned)p) {
                     if (++spins > (1 << 22)) {

@@ -12,9 +12,13 @@ import torch
 from mmvid_amd import _lib, ops
 
 dev = 'cuda'
+MODES = {0: 'tagged words', 1: 'counter barrier + loads', 2: 'tagged words, writers interleaved', 4: 'tagged words, one wave polls 12 words / lane',
+         6: 'tagged words, interleaved writers, one wave polls'}
 for blocks in (256, 128):
     for K in (768, 3072):
-        for mode in (0, 1):
+        for mode in (0, 1, 2, 4, 6):
+            if K != 768 and mode >= 4:
+                continue
             res = []
             for phases in (200, 1000):
                 buf = torch.zeros(2 * K + 64, device=dev, dtype=torch.int64)
@@ -35,5 +39,5 @@ for blocks in (256, 128):
                 assert int(buf[2 * K + 1]) == 0, 'a spin ran out'
                 res.append(min(ts))
             per = (res[1] - res[0]) / 800
-            print(f'blocks {blocks} K {K} mode {"tagged words" if mode == 0 else "counter barrier + loads"}: {per:6.2f} us per phase '
+            print(f'blocks {blocks} K {K} mode {MODES[mode]}: {per:6.2f} us per phase '
                   f'(200 phases {res[0]:8.1f} us, 1000 phases {res[1]:8.1f} us)')
