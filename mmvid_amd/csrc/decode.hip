@@ -350,87 +350,109 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned lon
 }
 
 // One block per (head, batch): q fp32 [B][ldq] (already bf16-rounded), K|V rows from the cache (position `pos` included).
-__global__ __launch_bounds__(256) void attn_decode2_kernel(const float* __restrict__ q, long ldq, const bf16_t* __restrict__ cache,
-                                                           int Lmax, int E, const int* __restrict__ pos_dev, int pos0,
-                                                           float scale_log2, float* __restrict__ out, long ldo) {
+// Thread (kg, dc) = (tid >> 3, tid & 7) holds dims [8 dc, 8 dc + 8) of q in registers and takes that 16-byte slice of the keys kg, kg + NG,
+// ... (NG = 8 NW key groups): a key's row is read by 8 adjacent lanes, its score is the sum over them (three DPP steps), 8 loads per
+// thread are in flight in both passes.  NW = 16 waves for long caches: the kernel is a chain of memory round trips (1,100 keys took
+// three for K and five for V with 256 threads: 16 us of a 48-us layer at batch 8), and one block is all a (head, sequence) gets.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __restrict__ q, long ldq, const bf16_t* __restrict__ cache,
+                                                               int Lmax, int E, const int* __restrict__ pos_dev, int pos0,
+                                                               float scale_log2, float* __restrict__ out, long ldo) {
     __shared__ float sc[DEC_MAXL];
-    __shared__ float qs[64];
-    __shared__ float red[32][64];
-    __shared__ float stat[8];
+    __shared__ float red[NW][64];
+    __shared__ float stat[2][NW];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = (pos_dev ? *pos_dev : pos0) + 1;
-    if (tid < 64) qs[tid] = q[(long)b * ldq + h * 64 + tid];
-    __syncthreads();
-    const bf16_t* kv = cache + (long)b * Lmax * 2 * E + h * 64;
-    float mx = -INFINITY;
-    for (int k0 = tid; k0 < n; k0 += 512) {  // two keys (16 loads) in flight per thread
-        uint4 ua[8], ub[8];
-        const int k1 = k0 + 256;
-        const uint4* ka = reinterpret_cast<const uint4*>(kv + (long)k0 * 2 * E);
-        const uint4* kb = reinterpret_cast<const uint4*>(kv + (long)(k1 < n ? k1 : k0) * 2 * E);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) ua[c] = ka[c], ub[c] = kb[c];
-        float da = 0.f, db = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float* qq = qs + 8 * c;
-            da += (bf_lo(ua[c].x) * qq[0] + bf_hi(ua[c].x) * qq[1]) + (bf_lo(ua[c].y) * qq[2] + bf_hi(ua[c].y) * qq[3]) +
-                  (bf_lo(ua[c].z) * qq[4] + bf_hi(ua[c].z) * qq[5]) + (bf_lo(ua[c].w) * qq[6] + bf_hi(ua[c].w) * qq[7]);
-            db += (bf_lo(ub[c].x) * qq[0] + bf_hi(ub[c].x) * qq[1]) + (bf_lo(ub[c].y) * qq[2] + bf_hi(ub[c].y) * qq[3]) +
-                  (bf_lo(ub[c].z) * qq[4] + bf_hi(ub[c].z) * qq[5]) + (bf_lo(ub[c].w) * qq[6] + bf_hi(ub[c].w) * qq[7]);
-        }
-        da *= scale_log2, db *= scale_log2;
-        sc[k0] = da;
-        mx = fmaxf(mx, da);
-        if (k1 < n) sc[k1] = db, mx = fmaxf(mx, db);
-    }
-    // the values do not depend on the scores: request the first batch of V rows now, under the softmax statistics
-    // o[d] = sum_k p[k] V[k][d]: thread (kg = tid>>3, dc = tid&7) owns 8 dims of every 32nd key: 16-B loads, 8 accumulators
     const int kg = tid >> 3, dc = tid & 7;
+    const int n = (pos_dev ? *pos_dev : pos0) + 1;
+    // a short cache is one round trip for four waves already: the others leave (the block size is fixed when the step is captured,
+    // the position is not; 16 waves at position 129 cost the step 12 us)
+    const int nw = (NW > 4 && n <= 512) ? 4 : NW;
+    if (wave >= nw) return;
+    const int NT = nw * 64, NG = nw * 8;
+    const bf16_t* kv = cache + (long)b * Lmax * 2 * E + h * 64 + dc * 8;
+    // the first batch of keys does not depend on q: requested before it
     uint4 u[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int k = kg + 32 * j;
-        u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E + dc * 8) : make_uint4(0u, 0u, 0u, 0u);
+        const int k = kg + NG * j;
+        u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float qv[8];
+    {
+        const float4 q0 = *reinterpret_cast<const float4*>(q + (long)b * ldq + h * 64 + dc * 8);
+        const float4 q1 = *reinterpret_cast<const float4*>(q + (long)b * ldq + h * 64 + dc * 8 + 4);
+        qv[0] = q0.x, qv[1] = q0.y, qv[2] = q0.z, qv[3] = q0.w, qv[4] = q1.x, qv[5] = q1.y, qv[6] = q1.z, qv[7] = q1.w;
+    }
+    float mx = -INFINITY;
+    for (int k0 = kg; k0 < n; k0 += NG * 8) {
+        if (k0 != kg) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + NG * j;
+                u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + NG * j;
+            float d = (bf_lo(u[j].x) * qv[0] + bf_hi(u[j].x) * qv[1]) + (bf_lo(u[j].y) * qv[2] + bf_hi(u[j].y) * qv[3]) +
+                      (bf_lo(u[j].z) * qv[4] + bf_hi(u[j].z) * qv[5]) + (bf_lo(u[j].w) * qv[6] + bf_hi(u[j].w) * qv[7]);
+            d = group8_sum(d) * scale_log2;
+            if (k < n) {
+                if (dc == 0) sc[k] = d;
+                mx = fmaxf(mx, d);
+            }
+        }
+    }
+    // the values do not depend on the scores: request the first batch of V rows now, under the softmax statistics
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kg + NG * j;
+        u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E) : make_uint4(0u, 0u, 0u, 0u);
     }
     mx = wave_max_fast(mx);
-    if (lane == 0) stat[wave] = mx;
+    if (lane == 0) stat[0][wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(stat[0], stat[1]), fmaxf(stat[2], stat[3]));
+    mx = stat[0][0];
+    for (int w = 1; w < nw; ++w) mx = fmaxf(mx, stat[0][w]);
     float sum = 0.f;
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += NT) {
         const float p = __builtin_amdgcn_exp2f(sc[k] - mx);
         sc[k] = p;
         sum += p;
     }
     sum = wave_sum_fast(sum);
-    if (lane == 0) stat[4 + wave] = sum;
+    if (lane == 0) stat[1][wave] = sum;
     __syncthreads();
-    sum = (stat[4] + stat[5]) + (stat[6] + stat[7]);
+    sum = 0.f;
+    for (int w = 0; w < nw; ++w) sum += stat[1][w];
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kg; k0 < n; k0 += 32 * 8) {  // 8 independent 16-byte loads per round trip (the first batch is already here)
+    for (int k0 = kg; k0 < n; k0 += NG * 8) {  // 8 independent 16-byte loads per round trip (the first batch is already here)
         if (k0 != kg) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k = k0 + 32 * j;
-                u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E + dc * 8) : make_uint4(0u, 0u, 0u, 0u);
+                const int k = k0 + NG * j;
+                u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E) : make_uint4(0u, 0u, 0u, 0u);
             }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = k0 + 32 * j;
+            const int k = k0 + NG * j;
             const float p = k < n ? sc[k] : 0.f;
             acc[0] += p * bf_lo(u[j].x), acc[1] += p * bf_hi(u[j].x), acc[2] += p * bf_lo(u[j].y), acc[3] += p * bf_hi(u[j].y);
             acc[4] += p * bf_lo(u[j].z), acc[5] += p * bf_hi(u[j].z), acc[6] += p * bf_lo(u[j].w), acc[7] += p * bf_hi(u[j].w);
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[kg][dc * 8 + e] = acc[e];
+    for (int e = 0; e < 8; ++e) acc[e] = over_groups_sum(acc[e]);  // the wave's 8 key groups
+    if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave][dc * 8 + e] = acc[e];
+    }
     __syncthreads();
     if (tid < 64) {
         float s = 0.f;
-#pragma unroll
-        for (int g = 0; g < 32; ++g) s += red[g][tid];
+        for (int w = 0; w < nw; ++w) s += red[w][tid];
         out[(long)b * ldo + h * 64 + tid] = round_bf16(s / sum);  // the full forward stores the attention output in bf16
     }
 }
@@ -563,8 +585,12 @@ extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, cons
         g.pos_dev = pos_dev, g.pos0 = pos;
         int rc = gemv_launch(g, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(attn_decode2_kernel, dim3(H, B), dim3(256), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
-                           0.125f * 1.4426950408889634f, o, (long)E);
+        if (Lmax > 512)
+            hipLaunchKernelGGL(attn_decode2_kernel<16>, dim3(H, B), dim3(1024), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
+                               0.125f * 1.4426950408889634f, o, (long)E);
+        else
+            hipLaunchKernelGGL(attn_decode2_kernel<4>, dim3(H, B), dim3(256), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
+                               0.125f * 1.4426950408889634f, o, (long)E);
         GemvArgs g2 = {};
         g2.NB = B, g2.x = o, g2.ldx = E, g2.W = (const bf16_t*)ly.out_w, g2.bias = ly.out_b, g2.N = E, g2.K = E, g2.residual = x,
         g2.ldr = E, g2.out = xmid, g2.ldo = E, g2.round_in = 1;  // (o is bf16-exact already: rounding is a no-op, LDS holds bf16)

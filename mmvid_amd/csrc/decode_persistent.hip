@@ -29,6 +29,7 @@
 // while all 256 blocks are resident, which the launcher checks (CU count) and which holds when nothing else shares the device.
 #include "../../include/mmvid_hip.h"
 #include "common.h"
+#include "wave_reduce.h"
 
 namespace {
 
@@ -101,23 +102,6 @@ __device__ __forceinline__ void poll_fn(F at, uint32_t tag, float (&v)[N], u64* 
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = __uint_as_float((uint32_t)w[i]);
 }
-// sum over the 8 lanes of a group (lane bits 0-2), result in all of them
-__device__ __forceinline__ float group8_sum(float v) {
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    return v + dpp_mov<0x141>(v);
-}
-// sum over lane bits 3, 4, 5 (the lanes that share bits 0-2), result in all of them
-__device__ __forceinline__ float over_groups_sum(float v) {
-    v += dpp_mov<0x128>(v);  // row_ror:8
-    const uint32_t u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    const uint32_t w = __float_as_uint(v);
-    const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
-
 // the same over a [NR][NC] block of words (row stride rs, column stride cs)
 template <int NR, int NC>
 __device__ __forceinline__ void poll_words2(const u64* p, long rs, long cs, uint32_t tag, float (&v)[NR * NC], u64* fail) {

@@ -57,3 +57,20 @@ __device__ __forceinline__ float reduce_scatter(float (&v)[1 << LOGN], int lane)
     r = bfly_add<1>(r);
     return bfly_add<0>(r);
 }
+
+// sum over the 8 lanes of a group (lane bits 0-2), result in all of them
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    return v + dpp_mov<0x141>(v);
+}
+// sum over lane bits 3, 4, 5 (the lanes that share bits 0-2), result in all of them
+__device__ __forceinline__ float over_groups_sum(float v) {
+    v += dpp_mov<0x128>(v);  // row_ror:8
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const uint32_t w = __float_as_uint(v);
+    const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
