@@ -319,14 +319,14 @@ int mmvid_tower_prefill(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t*
 int mmvid_tower_decode(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in, float* x_out,
                        void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch, void* stream);
 /* The same step as five matrix-vector launches per layer (weights streamed once, rows in LDS, 256 CUs busy) instead of
- * the M = B corner of the training GEMM: ~10x less time per token.  B <= 8.  scratch: B * (7E + F) floats.
+ * the M = B corner of the training GEMM: ~10x less time per token.  B <= 16 (9-16: a wide instance of the gemv).  scratch: B * (7E + F) floats.
  * mmvid_gemv_rows is the building block (y = act(LN?(x) W^T + b) (+ residual), x / y fp32 [NB, *], W bf16 [N, K]);
  * mmvid_decode_embed writes the embedding row of the token just sampled (table[tok] + pos_rows[*pos_dev + pos_off]). */
 int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                              float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
                              void* stream);
 /* ... for cfg->B consecutive sequences of a cache of cache_batch sequences (kv_cache = the first of them in layer 0; x_in / x_out = their
- * rows): how batches above 8 run, as slices of 8. */
+ * rows): how batches above 16 run, as slices of 16. */
 int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                                    float* x_out, void* kv_cache, int Lmax, int cache_batch, const int32_t* pos_dev, int pos,
                                    void* scratch, void* stream);

@@ -122,7 +122,7 @@ extern "C" int mmvid_attention_decode(const void* qkv, int64_t ldq, const void* 
 // output), so cached and recomputed logits differ only by fp32 summation order.  HBM/latency-bound.
 namespace {
 
-constexpr int GV_MAXB = 8;    // sequences per decode batch
+constexpr int GV_MAXB = 16;   // sequences per decode batch (9-16: the WIDE instance, rows staged as bf16 only)
 constexpr int GV_COLS = 8;    // output features per block (2 per wave)
 __device__ __forceinline__ float round_bf16(float v) { return bf2f(f2bf(v)); }
 
@@ -152,7 +152,7 @@ unsigned long long* g_decode_trace = nullptr;  // measurement only (mmvid_decode
 
 // BF: the staged rows are bf16-exact (round_in) -> LDS holds them as bf16 (half the LDS traffic, 16-byte conflict-free reads) and the
 // products go through v_dot2c_f32_bf16 (two multiply-adds per instruction, fp32 accumulate)
-template <int KIT, bool TRACE = false, int FPW = 2, bool BF = false>  // FPW: output features per wave (1 for the narrow outputs: twice the blocks)
+template <int KIT, bool TRACE = false, int FPW = 2, bool BF = false, bool WIDE = false>  // FPW: output features per wave (1 for the narrow outputs: twice the blocks); WIDE: 9-16 rows
 __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned long long* trace = nullptr) {
 #define GV_STAMP(i) \
     if constexpr (TRACE)  \
@@ -185,15 +185,28 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned lon
     const float ebias = (elane && a.bias) ? a.bias[en] : 0.f;
     const float eres = (elane && a.residual) ? a.residual[eb * a.ldr + en] : 0.f;
     const int epos = a.kv_cache ? (a.pos_dev ? *a.pos_dev : a.pos0) : 0;
+    // WIDE: one reduce-scatter of 16 rows per feature -- row b of a feature ends in lanes [4 b, 4 b + 4)
+    const int wb = lane >> 2;
+    const bool wlane = WIDE && (lane & 3) == 0 && wb < NB;
+    float wbias[2] = {0.f, 0.f}, wres[2] = {0.f, 0.f};
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int c = 0; c < FPW; ++c) {
+            const bool on = wlane && n0 + c < a.N;
+            wbias[c] = (on && a.bias) ? a.bias[n0 + c] : 0.f;
+            wres[c] = (on && a.residual) ? a.residual[wb * a.ldr + n0 + c] : 0.f;
+        }
+    }
     GV_STAMP(1)
     // ---- 2. input rows: wave w owns rows w and w + 4 (NB <= 8) -- a row is K/256 coalesced 16-byte loads per lane, its LayerNorm
     // statistics are two in-wave reductions (no cross-wave step, no barrier), and the normalised row goes to LDS.  (The first form
     // spread the rows' float4 over all 256 threads: per-row partial sums through eight-way selects, a cross-wave LDS reduction and
     // four barriers -- 3.8 us of an 11-us kernel at batch 4, tools/decode_gemv_timeline.py.)
     constexpr int XR = 2 * KIT;  // float4 per lane and row: K <= 512 * KIT
-    float4 xr[2][XR];
+    constexpr int RW = WIDE ? 4 : 2;  // rows per wave (WIDE: one wave per SIMD, the register file is this block's)
+    float4 xr[RW][XR];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
+    for (int rr = 0; rr < RW; ++rr) {
         const int r = wave + 4 * rr;
 #pragma unroll
         for (int jj = 0; jj < XR; ++jj) {
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned lon
     }
     GV_STAMP(2)
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
+    for (int rr = 0; rr < RW; ++rr) {
         const int r = wave + 4 * rr;
         if (r >= NB) break;  // wave-uniform
         float mu = 0.f, rs = 1.f;
@@ -262,11 +275,12 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned lon
     }
     GV_STAMP(5)
     // ---- 3. dot products: weights from registers, rows from LDS
-    float acc[2][GV_MAXB];
+    constexpr int MAXB = WIDE ? 16 : 8;
+    float acc[2][MAXB];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int b = 0; b < GV_MAXB; ++b) acc[c][b] = 0.f;
+        for (int b = 0; b < MAXB; ++b) acc[c][b] = 0.f;
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
         const int k0 = (it * 64 + lane) * 8;
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned lon
         const float f0[8] = {bf_lo(u0.x), bf_hi(u0.x), bf_lo(u0.y), bf_hi(u0.y), bf_lo(u0.z), bf_hi(u0.z), bf_lo(u0.w), bf_hi(u0.w)};
         const float f1[8] = {bf_lo(u1.x), bf_hi(u1.x), bf_lo(u1.y), bf_hi(u1.y), bf_lo(u1.z), bf_hi(u1.z), bf_lo(u1.w), bf_hi(u1.w)};
 #pragma unroll
-        for (int b = 0; b < GV_MAXB; ++b) {
+        for (int b = 0; b < MAXB; ++b) {
             if constexpr (BF) {
                 if (b < NB) {
                     typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
@@ -300,6 +314,27 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned lon
                                  (f1[6] * xb.z + f1[7] * xb.w);
             }
         }
+    }
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int c = 0; c < FPW; ++c) {
+            float l16[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) l16[j] = acc[c][j];
+            float v = reduce_scatter<4>(l16, lane);
+            const int en = n0 + c;
+            if (wlane && en < a.N) {
+                v += wbias[c];
+                if (a.act == 1) v = v * sigmoidf_(1.702f * v);  // QuickGELU (clip_model.py:196-198)
+                v += wres[c];
+                if (a.round_out) v = round_bf16(v);
+                a.out[wb * a.ldo + en] = v;
+                if (a.kv_cache && en >= a.kv_lo && en < a.kv_lo + a.kv_width && epos < a.Lmax)
+                    a.kv_cache[((long)wb * a.Lmax + epos) * a.kv_width + (en - a.kv_lo)] = f2bf(v);
+            }
+        }
+        GV_STAMP(6)
+        return;
     }
     // 2 * NBP partial sums per lane -> the complete sum (c, b) in lane group c * NBP + b (see reduce_scatter above)
     float v;
@@ -469,8 +504,11 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const long long* __restr
 }
 
 int gemv_launch(GemvArgs a, hipStream_t s) {
-    if (a.NB > GV_MAXB || a.K % 8 != 0 || (long)a.NB * a.K > 24576 || a.K > 3072 || a.ldx % 4 != 0) {
-        mmvid_set_error("decode gemv: NB=%d (<= %d), K=%d (multiple of 8, <= 3072, NB*K <= 24576), ldx %% 4 == 0", a.NB, GV_MAXB, a.K);
+    const bool wide = a.NB > 8;  // 9-16 rows: bf16-exact staged rows only (96 KiB of LDS at 16 x 3,072)
+    if (a.NB > GV_MAXB || a.K % 8 != 0 || (long)a.NB * a.K * (a.round_in ? 2 : 4) > 24576 * 4 || (wide && !a.round_in) || a.K > 3072 ||
+        a.ldx % 4 != 0) {
+        mmvid_set_error("decode gemv: NB=%d (<= %d; > 8 needs round_in), K=%d (multiple of 8, <= 3072, staged rows <= 96 KiB), ldx %% 4 == 0", a.NB,
+                        GV_MAXB, a.K);
         return MMVID_ERR_ARG;
     }
     // 8 output features per block, or 4 (one per wave) for the narrow outputs (out-proj, c_proj: N = 768 would be 96 blocks on 256 CUs)
@@ -487,6 +525,24 @@ int gemv_launch(GemvArgs a, hipStream_t s) {
         attr = true;
     }
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, g_decode_trace); };
+    if (wide) {
+        static bool wattr = false;
+        if (!wattr) {
+            (void)hipFuncSetAttribute((const void*)(gemv_rows_kernel<2, false, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
+            (void)hipFuncSetAttribute((const void*)(gemv_rows_kernel<2, false, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
+            (void)hipFuncSetAttribute((const void*)(gemv_rows_kernel<6, false, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4);
+            wattr = true;
+        }
+        if (kit <= 2)
+            narrow ? go(gemv_rows_kernel<2, false, 1, true, true>) : go(gemv_rows_kernel<2, false, 2, true, true>);
+        else if (narrow)
+            go(gemv_rows_kernel<6, false, 1, true, true>);
+        else {
+            mmvid_set_error("decode gemv: NB=%d > 8 with K=%d > 1024 and N=%d > 1024 is not instantiated", a.NB, a.K, a.N);
+            return MMVID_ERR_ARG;
+        }
+        return MMVID_OK;
+    }
     const bool bf = a.round_in != 0;  // (the staged rows are then bf16-exact)
     auto pick = [&](auto kit_c) {
         constexpr int KITC = decltype(kit_c)::value;
@@ -549,8 +605,8 @@ extern "C" int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvi
 }
 
 // The same for cfg->B consecutive sequences of a cache that holds cache_batch >= cfg->B of them: kv_cache points at the first of these
-// sequences in layer 0, a layer is cache_batch * Lmax * 2E elements further.  (Batches above 8 run as slices of 8: the M = B corner of the
-// training GEMM takes 2.2 ms per token at batch 16.)
+// sequences in layer 0, a layer is cache_batch * Lmax * 2E elements further.  (Batches above 16 run as slices of 16: the M = B corner of
+// the training GEMM takes 2.2 ms per token at batch 16.)
 extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                                               float* x_out, void* kv_cache, int Lmax, int cache_batch, const int32_t* pos_dev, int pos,
                                               void* scratch, void* stream) {
