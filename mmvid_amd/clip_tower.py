@@ -127,6 +127,13 @@ class DecodeSession:
                   ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
         self.pos.add_(1)
 
+    def check(self):
+        """Raise if a poll of the persistent step ever timed out (its 256 blocks were not resident together: something else was running
+        on the device beside it) -- the hidden states of that and every later step are void.  One device read: call it after the loop."""
+        if self.persistent and int(self.ws[1]) != 0:
+            raise _lib.MMVIDError('persistent decode step: a poll timed out (the device was shared while it ran); results are invalid. '
+                                  'Set MMVID_DECODE_PERSISTENT=0 to use the five-launch step.')
+
     @torch.no_grad()
     def step(self, x_new):
         self.x.copy_(x_new)

@@ -52,7 +52,7 @@ struct PdArgs {
     const int* pos_dev;
     int pos0, layers, Lmax, NB;
     float eps, scale_log2;
-    int nowait;  // measurement only (MMVID_PD_NOWAIT=1): polls accept whatever they read -- the step without its dependency chain (results void)
+    int nowait;  // measurement only (MMVID_PD_NOWAIT bit 0: polls accept whatever they read -- the step without its dependency chain; bit 1: no weight loads; results void)
     u64* trace;  // measurement only (mmvid_decode_persistent_trace): [4 blocks][layers][16] wall-clock stamps of blocks 0, 1, 128, 255
 };
 u64* g_pd_trace = nullptr;
@@ -247,7 +247,9 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
     uint4 w5[6];
     float b1[3], b3, b4[4], b5;
     float g1[12], h1[12], g2[12], h2[12];
+    const bool noweights = (a.nowait & 2) != 0;  // measurement only: the step without its weight stream (operands are whatever the registers hold)
     auto fetch1 = [&](const GLayer& L) {
+        if (noweights) return;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int f = f1 + j;
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
         }
     };
     auto fetch45 = [&](const GLayer& L) {  // the fc rows of this wave, LN2, the c_proj row
+        if (noweights) return;
         // fc features come in adjacent PAIRS (pair p: features 2p, 2p + 1) so that the two bf16-exact activations
         // travel in one tagged word: phase 5 polls half the lines
 #pragma unroll
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
     for (int l = 0; l < a.layers; ++l) {
         const GLayer L = uniform_layer(lys[l]);
         const uint32_t tag = seq * 64u + (uint32_t)l * 5u;
-        const uint32_t pm = a.nowait ? 0u : 0xffffffffu;  // (nowait: the polls compare with tag 0 = accept anything)
+        const uint32_t pm = (a.nowait & 1) ? 0u : 0xffffffffu;  // (nowait: the polls compare with tag 0 = accept anything)
         bf16_t* const cache = a.cache + (long)l * NB * a.Lmax * 2 * PD_E;
         // the cached keys / values of the unit do not depend on this step's q: the first 256 keys of the range are requested now and are
         // in registers when q arrives (they used to be requested after it: 2.9 us of attention for 33 keys, tools/decode_persistent_timeline.py)
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
         PD_STAMP(0)
         // Requests for later phases go out right BEFORE a poll: the poll is a memory round trip anyway, the weights arrive under it, and
         // whatever conservative full wait the compiler places afterwards (it cannot count across this control flow) finds nothing pending.
-        if (wave < 3) w3 = load_w768(L.out_w + (long)f0 * PD_E, lane), b3 = L.out_b[f0 + vz];  // the out-projection row of this wave
+        if (wave < 3 && !noweights) w3 = load_w768(L.out_w + (long)f0 * PD_E, lane), b3 = L.out_b[f0 + vz];  // the out-projection row of this wave
         if (wave < NB) {
             float v[12];
             if (l == 0) {

@@ -351,6 +351,7 @@ class DALLE(nn.Module):
                 torch.cuda.current_stream().wait_stream(side)
         draw(steps - 1)
         out[:, steps - 1].copy_(tok)
+        sess.check()
         return [out[:, i:i + 1] for i in range(steps)]
 
     def sampling_probs(self, block_logits, filter_thres=0.5, temperature=1.0):

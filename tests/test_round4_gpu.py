@@ -181,6 +181,7 @@ def test_persistent_decode_step_matches_the_five_launch_form(B, P):
     blocks as tagged words.  Same rounding points as the five-launches-per-layer step: hidden states and the key/value cache agree to
     fp32-summation-order / one-bf16-ulp level over 24 positions (eager, then captured and replayed), attention ranges of 0 (prompt of 2 positions: an empty
     range at batch 1) .. 68 keys per range, every supported batch size; no poll ever timed out (workspace word 1)."""
+    from mmvid_amd import _lib
     from mmvid_amd.clip_tower import OpenAICLIPTransformer
     from test_models_gpu import close
     torch.manual_seed(B)
@@ -201,3 +202,9 @@ def test_persistent_decode_step_matches_the_five_launch_form(B, P):
         assert per.graph is not None
         close(caches[1][:, :, :P + steps], caches[0][:, :, :P + steps], 1e-2, 'key/value cache')
         assert int(per.ws[1]) == 0 and int(per.ws[0]) == steps
+        per.check()
+        # a raised failure flag (a poll that timed out) voids the session loudly, and the kernel returns at once from then on
+        per.ws[1] = 1
+        per.step(x[:, P].contiguous())
+        with pytest.raises(_lib.MMVIDError, match='timed out'):
+            per.check()
