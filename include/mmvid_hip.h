@@ -344,6 +344,10 @@ int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const float* ln_
                     float* out, int64_t ldo, void* stream);
 int mmvid_decode_embed(const int64_t* tok, const float* table, int64_t table_rows, const float* pos_rows,
                        const int32_t* pos_dev, int pos_off, int B, int E, float* x, void* stream);
+/* ... that also files the token: record[b][*pos_dev - record_pos0] = tok[b] (int64 [B][record_ld]; null = mmvid_decode_embed) */
+int mmvid_decode_embed_record(const int64_t* tok, const float* table, int64_t table_rows, const float* pos_rows,
+                              const int32_t* pos_dev, int pos_off, int B, int E, float* x, int64_t* record, int64_t record_ld,
+                              int record_pos0, void* stream);
 /* building blocks: append K|V rows of qkv [B*L, ldq] at positions pos..pos+L-1, and one-query attention over the
  * cached positions 0..pos (head_dim 64, Lmax <= 4096). */
 int mmvid_kv_store(const void* qkv, int64_t ldq, int B, int L, int E, const int32_t* pos_dev, int pos0, int Lmax,

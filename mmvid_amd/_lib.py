@@ -72,6 +72,7 @@ SIGNATURES = {
     'mmvid_tower_decode_fused_slice': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, I, P, I, P, P],
     'mmvid_gemv_rows': [P, I64, I, I, P, P, F, P, P, I, I, P, I64, I, I, P, I64, P],
     'mmvid_decode_embed': [P, P, I64, P, P, I, I, I, P, P],
+    'mmvid_decode_embed_record': [P, P, I64, P, P, I, I, I, P, P, I64, I, P],
     'mmvid_kv_store': [P, I64, I, I, I, P, I, I, P, P],
     'mmvid_attention_decode': [P, I64, P, I, I, I, I, P, I, F, P, I64, P],
     'mmvid_conv2d_nhwc': [I, P, I, I, I, I, P, P, I, P, P, I, P, P, P, P],

@@ -495,9 +495,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
 // x[b, :] = table[tok[b]] + pos_rows[*pos_dev + pos_off]: the embedding of the token just sampled (dalle_artv.py:484-491)
 __global__ __launch_bounds__(256) void dec_embed_kernel(const long long* __restrict__ tok, const float* __restrict__ table,
                                                         long table_rows, const float* __restrict__ pos_rows,
-                                                        const int* __restrict__ pos_dev, int pos_off, int E, float* __restrict__ x) {
+                                                        const int* __restrict__ pos_dev, int pos_off, int E, float* __restrict__ x,
+                                                        long long* __restrict__ record, long record_ld, int record_pos0) {
     const int b = blockIdx.x;
     long long id = tok[b];
+    // the sampler's output row: token number (*pos_dev - record_pos0) of sequence b (a scatter_ and a counter update per token otherwise)
+    if (record && threadIdx.x == 0 && *pos_dev >= record_pos0 && *pos_dev - record_pos0 < record_ld) record[b * record_ld + (*pos_dev - record_pos0)] = id;
     if (id < 0 || id >= table_rows) id = 0;
     const long p = (long)(*pos_dev) + pos_off;
     for (int e = threadIdx.x; e < E; e += 256) x[(long)b * E + e] = table[id * E + e] + pos_rows[p * E + e];
@@ -589,9 +592,16 @@ extern "C" int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const
 
 extern "C" int mmvid_decode_embed(const int64_t* tok, const float* table, int64_t table_rows, const float* pos_rows,
                                   const int32_t* pos_dev, int pos_off, int B, int E, float* x, void* stream) {
+    return mmvid_decode_embed_record(tok, table, table_rows, pos_rows, pos_dev, pos_off, B, E, x, nullptr, 0, 0, stream);
+}
+
+// ... and record[b][*pos_dev - record_pos0] = tok[b] (record: int64 [B][record_ld] or null): the sampler's list of drawn tokens
+extern "C" int mmvid_decode_embed_record(const int64_t* tok, const float* table, int64_t table_rows, const float* pos_rows,
+                                         const int32_t* pos_dev, int pos_off, int B, int E, float* x, int64_t* record, int64_t record_ld,
+                                         int record_pos0, void* stream) {
     MMVID_REQUIRE(tok && table && pos_rows && pos_dev && x && B > 0, "decode_embed: bad arguments");
     hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long*)tok, table, (long)table_rows,
-                       pos_rows, pos_dev, pos_off, E, x);
+                       pos_rows, pos_dev, pos_off, E, x, (long long*)record, (long)record_ld, record_pos0);
     MMVID_LAUNCH_CHECK("decode_embed");
     return MMVID_OK;
 }

@@ -307,10 +307,14 @@ class DALLE(nn.Module):
         hbuf, logits = h.clone(), torch.empty(B, V, device=dev)
         tok, E = torch.empty(B, dtype=torch.long, device=dev), torch.empty(B, V, device=dev)
 
+        hid = [hbuf]  # the hidden state the next draw reads: the prompt's last position, then the session's output buffer
+
         def draw(step):
+            src = hid[0]
             if self.stable:
-                hbuf.copy_(self.norm_by_max(hbuf))
-            ops.gemv_rows(hbuf, w_blk, b_blk, ln=(ln.weight, ln.bias, ln.eps), round_in=True, out=logits)  # LN + head block
+                hbuf.copy_(self.norm_by_max(src))
+                src = hbuf
+            ops.gemv_rows(src, w_blk, b_blk, ln=(ln.weight, ln.bias, ln.eps), round_in=True, out=logits)  # LN + head block
             lg = logits
             if k_keep < V:
                 val, ind = torch.topk(lg, k_keep)
@@ -319,13 +323,14 @@ class DALLE(nn.Module):
                 E.copy_(race(f'tok{step}', (B, V)))
             else:
                 E.exponential_()
-            t, _ = ops.sample_race(lg, E, None, 0.0, logit_div=temperature, want_y=False)
-            tok.copy_(t)
+            ops.sample_race(lg, E, None, 0.0, logit_div=temperature, want_y=False, tok_out=tok)
 
         def advance():
-            ops.decode_embed(tok, iemb, pos_rows, sess.pos, sess.x)
-            sess._enqueue()  # one position through the tower; advances sess.pos
-            hbuf.copy_(sess.y)
+            # the embedding row of the drawn token (which the same launch files in `out` at column pos - first_pos), then one position
+            # through the tower; advances sess.pos
+            ops.decode_embed(tok, iemb, pos_rows, sess.pos, sess.x, record=out, record_pos0=first_pos)
+            sess._enqueue()
+            hid[0] = sess.y
 
         graph = None
         use_graph = race is None and k_keep >= V and not self.stable and steps > 4
@@ -334,19 +339,15 @@ class DALLE(nn.Module):
                 graph.replay()
                 continue
             draw(step)
-            out[:, step].copy_(tok)
             advance()
             if use_graph and step == 1:
-                # two eager steps have warmed every kernel; capture [draw -> record -> advance] once and replay it
-                idx = torch.full((1, ), step + 1, dtype=torch.long, device=dev)  # the column of `out` the next token goes to
+                # two eager steps have warmed every kernel; capture [draw -> advance] once and replay it
                 graph = torch.cuda.CUDAGraph()
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     with torch.cuda.graph(graph, stream=side):
                         draw(-1)
-                        out.scatter_(1, idx.expand(B, 1), tok.view(B, 1))
-                        idx.add_(1)
                         advance()
                 torch.cuda.current_stream().wait_stream(side)
         draw(steps - 1)

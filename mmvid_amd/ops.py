@@ -482,13 +482,16 @@ def exponential_like(shape, device):
     return torch.empty(shape, device=device, dtype=f32).exponential_()
 
 
-def sample_race(logits, E, noise_u=None, temperature=0.0, logit_div=1.0, tok_offset=0, want_y=True):
-    """logits [R, V] f32 (row stride = logits.stride(0)), E [R, V] f32 Exp(1) variates -> (tok int64 [R], y f32 [R])."""
+def sample_race(logits, E, noise_u=None, temperature=0.0, logit_div=1.0, tok_offset=0, want_y=True, tok_out=None):
+    """logits [R, V] f32 (row stride = logits.stride(0)), E [R, V] f32 Exp(1) variates -> (tok int64 [R] (tok_out if given), y f32 [R])."""
     _chk(E, f32, 'E')
     assert logits.dtype == f32 and logits.is_cuda and logits.stride(1) == 1
     R, V = logits.shape
     assert E.shape == (R, V)
-    tok = torch.empty(R, device=logits.device, dtype=i64)
+    if tok_out is not None:
+        _chk(tok_out, i64, 'tok_out')
+        assert tok_out.shape == (R, )
+    tok = tok_out if tok_out is not None else torch.empty(R, device=logits.device, dtype=i64)
     y = torch.empty(R, device=logits.device, dtype=f32) if want_y else None
     if noise_u is not None:
         _chk(noise_u, f32, 'noise_u')
@@ -582,10 +585,14 @@ def gemv_rows(x, W, bias=None, ln=None, act=0, residual=None, round_in=False, ro
     return out
 
 
-def decode_embed(tok, table, pos_rows, pos_dev, out, pos_off=0):
-    """out[b] = table[tok[b]] + pos_rows[pos_dev + pos_off] (the embedding row of a freshly sampled token)."""
+def decode_embed(tok, table, pos_rows, pos_dev, out, pos_off=0, record=None, record_pos0=0):
+    """out[b] = table[tok[b]] + pos_rows[pos_dev + pos_off] (the embedding row of a freshly sampled token); record (int64 [B, n],
+    optional): record[b, pos_dev - record_pos0] = tok[b]."""
     _chk(tok, i64, 'tok'), _chk(table, f32, 'table'), _chk(pos_rows, f32, 'pos_rows')
     B, E = out.shape
-    call('mmvid_decode_embed', _p(tok), _p(table), table.shape[0], _p(pos_rows), _p(pos_dev), int(pos_off), B, E, _p(out),
-         _stream())
+    if record is not None:
+        _chk(record, i64, 'record')
+        assert record.shape[0] == B and record.stride(1) == 1
+    call('mmvid_decode_embed_record', _p(tok), _p(table), table.shape[0], _p(pos_rows), _p(pos_dev), int(pos_off), B, E, _p(out),
+         _p(record) if record is not None else None, record.stride(0) if record is not None else 0, int(record_pos0), _stream())
     return out
