@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
     __shared__ float stat[2][NW];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = tid >> 3, dc = tid & 7;
-    const int n = (pos_dev ? *pos_dev : pos0) + 1;
+    const int n = min((pos_dev ? *pos_dev : pos0) + 1, Lmax);  // (never beyond the cache)
     // a short cache is one round trip for four waves already: the others leave (the block size is fixed when the step is captured,
     // the position is not; 16 waves at position 129 cost the step 12 us)
     const int nw = (NW > 4 && n <= 512) ? 4 : NW;

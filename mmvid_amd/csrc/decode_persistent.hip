@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
     u64* const XMID = PART + (long)NBT * PD_H * S * PD_REC;
     u64* const ACT = XMID + (long)NBT * PD_E;
     const int pos = a.pos_dev ? *a.pos_dev : a.pos0;
-    const int n = pos + 1;
+    const int n = pos + 1 < a.Lmax ? pos + 1 : a.Lmax;  // (a position beyond the cache attends the cache and is not appended: never out of bounds)
     // Output features are numbered so that a BLOCK's words of a row are contiguous: a 64-byte line whose eight words come from eight
     // blocks on eight XCDs reaches its readers 0.8 us later than one with two or three writers (tools/chain_probe.py, "writers
     // interleaved").  768-wide rows: feature 3 blk + wave (waves 0-2); q|k|v: 9 per block (wave 0: 3, waves 1-3: 2 each); fc pairs: 6 per
