@@ -165,6 +165,8 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //                                       finalisation, apply: one block per image; bit-identical to the three launches); 0 = three launches
 //   attn_tail      MMVID_ATTN_TAIL      1 (default) = the attention backward cuts the blocks of its last, partly filled round into parts over disjoint
 //                                       query ranges (a workspace + a small combine launch; csrc/attn.hip TailSplit); 0 = whole blocks only
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_ATTN_RES = 15, MMVID_OPT_GEMM_FUSED_REDUCE = 16, MMVID_OPT_DW_GROUPED = 17, MMVID_OPT_GEMM_LOADERS = 18, MMVID_OPT_DW_ORDER = 19, MMVID_OPT_GN_FUSED = 20, MMVID_OPT_ATTN_TAIL = 21, MMVID_OPT_COUNT = 22 };
+//   gemm_fat       MMVID_GEMM_FAT       1 = the loader-wave GEMM block runs FOUR MFMA waves of 128 x 64 (0.75 KiB of LDS fragment reads per MFMA
+//                                       instead of 1: the K loop is bound by LDS bandwidth, csrc/gemm_core.h k_loop_consumer_fat); 0 (default) = eight of 64 x 64
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_ATTN_RES = 15, MMVID_OPT_GEMM_FUSED_REDUCE = 16, MMVID_OPT_DW_GROUPED = 17, MMVID_OPT_GEMM_LOADERS = 18, MMVID_OPT_DW_ORDER = 19, MMVID_OPT_GN_FUSED = 20, MMVID_OPT_ATTN_TAIL = 21, MMVID_OPT_GEMM_FAT = 22, MMVID_OPT_COUNT = 23 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

@@ -54,7 +54,8 @@ Opt g_opts[MMVID_OPT_COUNT] = {{"gemm_tile", "MMVID_GEMM_TILE", 0, 0, false},
                                {"gemm_loaders", "MMVID_GEMM_LOADERS", 4, 0, false},
                                {"dw_order", "MMVID_DW_ORDER", 1, 0, false},
                                {"gn_fused", "MMVID_GN_FUSED", 1, 0, false},
-                               {"attn_tail", "MMVID_ATTN_TAIL", 1, 0, false}};
+                               {"attn_tail", "MMVID_ATTN_TAIL", 1, 0, false},
+                               {"gemm_fat", "MMVID_GEMM_FAT", 0, 0, false}};
 }  // namespace
 
 int mmvid_option(int which) {
@@ -74,7 +75,7 @@ extern "C" int mmvid_set_option(const char* name, int value) {
             g_opts[i].value = value, g_opts[i].set = true;
             return MMVID_OK;
         }
-    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs, ln_bwd_blocks, gemm_sched, fuse_colsum, strip_sched, gemm_debug, gemm_wshape, attn_occ, gemm_persist, gemm_epi, dh_bf16, gemm_loader, gemm_groupn, attn_res, gemm_fused_reduce, dw_grouped, gemm_loaders, dw_order, gn_fused, attn_tail)", name);
+    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs, ln_bwd_blocks, gemm_sched, fuse_colsum, strip_sched, gemm_debug, gemm_wshape, attn_occ, gemm_persist, gemm_epi, dh_bf16, gemm_loader, gemm_groupn, attn_res, gemm_fused_reduce, dw_grouped, gemm_loaders, dw_order, gn_fused, attn_tail, gemm_fat)", name);
     return MMVID_ERR_ARG;
 }
 

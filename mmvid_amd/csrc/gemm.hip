@@ -684,9 +684,11 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
 // k_loop_loader / k_loop_consumer), register-direct epilogues only (EPI 1: general, 2 / 3: packed bf16 with one / two outputs).
 // The loader requests the next output tile's first two K tiles while the MFMA waves are in their epilogue, so a persistent block
 // streams operands continuously; the MFMA waves never wait on vmcnt (their epilogue stores drain on their own).
-template <bool AKM, bool BKM, int EPI, bool GROUPED, int NL = mmvid_core::NLOAD>
+// FAT (option gemm_fat): four MFMA waves of 128 x 64 instead of eight of 64 x 64 (gemm_core.h, k_loop_consumer_fat) + the NL loader waves
+template <bool AKM, bool BKM, int EPI, bool GROUPED, int NL = mmvid_core::NLOAD, bool FAT = false>
 __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt) {
     using S = BlockShape<4>;
+    constexpr int NMW = FAT ? 4 : 8;  // MFMA waves
     int multi_bm0 = 0, multi_bn0 = 0;
     if constexpr (GROUPED) {  // this block's (kind, group, tile): every XCD walks a contiguous stretch of the (kind, group, row, column) order
         const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -712,7 +714,7 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // three stages, then the bias vector
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave & 7) >> 1, wn = wave & 1;
+    const int wm = FAT ? (wave & 3) >> 1 : (wave & 7) >> 1, wn = wave & 1;  // (FAT: wm = the wave's 128-row half)
     const int ntiles = p.tiles_n > 0 ? p.tiles_n * p.tiles_m : 1;
     const int tile_step = p.tiles_n > 0 ? (int)gridDim.x : 1;
     // blockIdx.z = batch entry, or (split-K: batch 1) the K range whose partial product goes to slab z of the workspace
@@ -728,7 +730,7 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
     float* bias_lds = nullptr;
     if (p.bias) {
         bias_lds = reinterpret_cast<float*>(smem + S::LDS_BYTES);
-        for (int e = tid; e < p.N; e += 512 + 64 * NL) bias_lds[e] = p.bias[e];
+        for (int e = tid; e < p.N; e += 64 * NMW + 64 * NL) bias_lds[e] = p.bias[e];
         __syncthreads();
     }
     auto tile_origin = [&](int tile, int& bm0, int& bn0) {
@@ -748,8 +750,8 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
         bn0 = tn * BN, bm0 = tm * S::ROWS;
     };
     const int first = p.tiles_n > 0 ? (int)blockIdx.x : 0;
-    if (wave >= 8) {  // ---------------------------------------------------------------- the loader waves
-        const int w = wave - 8;
+    if (wave >= NMW) {  // ---------------------------------------------------------------- the loader waves
+        const int w = wave - NMW;
         LoaderStage<AKM, NL> sa;
         LoaderStage<BKM, NL> sb;
         bool have = false;
@@ -761,7 +763,9 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
                 sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0), sa.init_offsets(2, w, lane), sb.init_offsets(1, w, lane);
                 loader_prologue<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
             }
-            if (p.debug > 2)
+            if constexpr (FAT)
+                k_loop_loader_fat<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
+            else if (p.debug > 2)
                 k_loop_loader<AKM, BKM, NL, true>(sa, sb, smem, kt0, nt, p.K, w, lane, p.debug);
             else
                 k_loop_loader<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
@@ -776,11 +780,46 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
         }
         return;
     }
-    // ------------------------------------------------------------------------------------- the eight MFMA waves
     DirectEpi de;
     de.init(p, batch);
     constexpr int NOUT = EPI == 3 ? 2 : 1;
     [[maybe_unused]] Pending<NOUT> pend;
+    if constexpr (FAT) {  // ---------------------------------------------------------------- the four 128 x 64 MFMA waves
+        for (int tile = first; tile < ntiles; tile += tile_step) {
+            int bm0, bn0;
+            tile_origin(tile, bm0, bn0);
+            f32x16 acc[2][2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
+            [[maybe_unused]] PreRegs pre_in[2];
+            if constexpr (EPI == 4) pre_load(p, de, bm0, bn0, 2 * wm, wn, lane, pre_in[0]), pre_load(p, de, bm0, bn0, 2 * wm + 1, wn, lane, pre_in[1]);
+            k_loop_consumer_fat<AKM, BKM>(smem, nt, lane, wm, wn, acc);
+            // the epilogues of a 64 x 64 wave, once per 64-row half (acc[h] has that wave's layout at wave row 2 wm + h)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int wr = 2 * wm + h;
+                if constexpr (EPI == 4) {
+                    pending_fill_dact(p, pre_in[h], acc[h], pend, bm0, bn0, wr, wn, lane);
+                    pending_flush<1>(de, pend);
+                } else if constexpr (EPI >= 2) {
+                    BiasRegs br;
+                    bias_load(bias_lds, bn0, wn, lane, br);
+                    pending_fill<NOUT>(p, br, acc[h], pend, bm0, bn0, wr, wn, lane);
+                    pending_flush<NOUT>(de, pend);
+                } else {
+                    gemm_epilogue_direct(p, de, bias_lds, acc[h], bm0, bn0, wr, wn, lane);
+                }
+            }
+        }
+        return;  // (the fused split-K reduction below is an eight-wave form; the launcher does not combine it with gemm_fat)
+    }
+    // ------------------------------------------------------------------------------------- the eight MFMA waves
     int tile_no = 0;
     for (int tile = first; tile < ntiles; tile += tile_step, ++tile_no) {
         unsigned long long* stamp = nullptr;
@@ -861,6 +900,13 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
 template <bool AKM, bool BKM, int EPI, int NL = mmvid_core::NLOAD>
 __global__ __launch_bounds__(512 + 64 * NL, 1) void gemm_bf16_lw_kernel(GemmParams p) {
     gemm_lw_body<AKM, BKM, EPI, false, NL>(p, nullptr);
+}
+template <bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(256 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_fat_kernel(GemmParams p) {
+    gemm_lw_body<AKM, BKM, EPI, false, mmvid_core::NLOAD, true>(p, nullptr);
+}
+__global__ __launch_bounds__(256 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_fat_grouped_kernel(GemmParams p, GroupTable gt) {
+    gemm_lw_body<true, true, 1, true, mmvid_core::NLOAD, true>(p, &gt);
 }
 // the grouped weight-gradient launch: both operands k-major, general register-direct epilogue (fp32 += result)
 __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_grouped_kernel(GemmParams p, GroupTable gt) {
@@ -1138,6 +1184,25 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
                 hipLaunchKernelGGL((gemm_bf16_lw_kernel<AKM, BKM, 2, 8>), grid, dim3(512 + 64 * 8), lds, stream, q);
                 return;
             }
+            if (mmvid_option(MMVID_OPT_GEMM_FAT) && !q.red_out) {  // four 128 x 64 MFMA waves + the loader waves
+                static bool fattr[5] = {false, false, false, false, false};
+                auto gof = [&](auto kern) {
+                    if (!fattr[epi]) {
+                        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        fattr[epi] = true;
+                    }
+                    hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * NLOAD), lds, stream, q);
+                };
+                if (epi == 4)
+                    gof(gemm_bf16_fat_kernel<AKM, BKM, 4>);
+                else if (epi == 3)
+                    gof(gemm_bf16_fat_kernel<AKM, BKM, 3>);
+                else if (epi == 2)
+                    gof(gemm_bf16_fat_kernel<AKM, BKM, 2>);
+                else
+                    gof(gemm_bf16_fat_kernel<AKM, BKM, 1>);
+                return;
+            }
             if (epi == 4)
                 go(gemm_bf16_lw_kernel<AKM, BKM, 4>);
             else if (epi == 3)
@@ -1347,6 +1412,8 @@ extern "C" int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_ki
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_lw_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(S::LDS_BYTES + BIAS_LDS_BYTES));
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_fat_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(S::LDS_BYTES + BIAS_LDS_BYTES));
         attr = true;
     }
     for (int k = 0; k < nkinds; ++k) {
@@ -1402,7 +1469,11 @@ extern "C" int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_ki
         p.trace = nullptr;
         p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
         MmvidProfScope prof(PROF_GEMM_TN, flops, (hipStream_t)stream);
-        hipLaunchKernelGGL(gemm_bf16_lw_grouped_kernel, dim3(tiles), dim3(512 + 64 * NLOAD), S::LDS_BYTES + BIAS_LDS_BYTES,
+        if (mmvid_option(MMVID_OPT_GEMM_FAT))
+            hipLaunchKernelGGL(gemm_bf16_fat_grouped_kernel, dim3(tiles), dim3(256 + 64 * NLOAD), S::LDS_BYTES + BIAS_LDS_BYTES,
+                           (hipStream_t)stream, p, gt);
+        else
+            hipLaunchKernelGGL(gemm_bf16_lw_grouped_kernel, dim3(tiles), dim3(512 + 64 * NLOAD), S::LDS_BYTES + BIAS_LDS_BYTES,
                            (hipStream_t)stream, p, gt);
     }
     MMVID_LAUNCH_CHECK("gemm_bf16_dw_multi");

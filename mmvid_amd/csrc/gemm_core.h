@@ -634,6 +634,125 @@ __device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, in
     if (wave < 4) __builtin_amdgcn_s_barrier();  // the leading group waits for the trailing one
 }
 
+// the loader waves' K loop beside k_loop_consumer_fat: two barriers per K tile
+template <bool AKM, bool BKM, int NL>
+__device__ __forceinline__ void k_loop_loader_fat(const LoaderStage<AKM, NL>& sa, const LoaderStage<BKM, NL>& sb, char* smem, int kt0, int nt, int K,
+                                                  int w, int lane) {
+    using S = BlockShape<4>;
+    constexpr int PER_TILE = 48 / NL;
+    char* b0 = smem;
+    char* b1 = smem + S::STAGE_BYTES;
+    char* b2 = smem + 2 * S::STAGE_BYTES;
+    if (nt <= 0) return;
+    if (nt > 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile 0 is visible to everyone
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 2 < nt;
+        __builtin_amdgcn_s_barrier();  // 1: every MFMA wave has entered tile t, i.e. finished reading tile t-1 (stage b2)
+        if (more) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) loader_issue_group<AKM, BKM, NL>(sa, sb, (kt0 + t + 2) * BK, K, b2, g, w, lane);
+        }
+        if (t + 1 < nt) {
+            if (more)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // 2: tile t+1 has landed
+        char* tmp = b0;
+        b0 = b1, b1 = b2, b2 = tmp;
+    }
+    __builtin_amdgcn_s_barrier();  // the closing barrier
+}
+
+// ---- "fat wave" consumer (option gemm_fat): FOUR MFMA waves per 256x128 block, each 128 x 64 = 4 x 2 MFMA tiles, one per SIMD.
+// Why: a 64x64 wave reads 2 A + 2 B fragments (4 KiB) per 4 MFMAs = 1 KiB of LDS per MFMA, and eight such waves plus the 48-KiB DMA
+// write of the stage ask the LDS for 176 KiB per K tile = 1,375 clocks at 128 B/clk, against 1,024 clocks of MFMA: the K loop is bound
+// by LDS bandwidth (tools/power_probe.py: register-only MFMA chains sustain 1.87 PFLOP/s, with 1 KiB of fragment reads per MFMA 1.47 at a
+// HIGHER clock, with 0.75 KiB 1.62).  A 128x64 wave reads 4 A + 2 B fragments per 8 MFMAs = 0.75 KiB per MFMA: 144 KiB per K tile.
+// One wave per SIMD keeps the matrix pipe busy by itself: its eight accumulators are independent, and the fragment reads of k-step
+// s + 1 are issued between the MFMAs of step s.  Two barriers per K tile (k_loop_loader_fat): with a single wave group the stage of tile
+// t-1 is free as soon as every wave has entered tile t, so a loader wave requests all its pieces of tile t+2 at once -- the MFMA waves
+// meet the loaders at the tile boundaries only (a barrier inside the tile drains the matrix pipe when nobody shares the SIMD).
+template <bool AKM, bool BKM, int SS>
+__device__ __forceinline__ void fat_load(const char* At, const char* Bt, const uint32_t (&kl)[2], const uint32_t (&kh)[2], const uint32_t (&kb)[2],
+                                         int wn, int lane, bf16x8_t (&al)[2], bf16x8_t (&ah)[2], bf16x8_t (&b)[2]) {
+    load_frags<AKM, SS>(At, kl, 0, lane, al), load_frags<AKM, SS>(At, kh, 64, lane, ah), load_frags<BKM, SS>(Bt, kb, wn * 64, lane, b);
+}
+template <bool AKM, bool BKM, int N>
+__device__ __forceinline__ void fat_ready(bf16x8_t (&al)[2], bf16x8_t (&ah)[2], bf16x8_t (&b)[2]) {
+    if constexpr (AKM && BKM)
+        lgkm_wait_tied<N>(al[0], al[1], ah[0], ah[1], b[0], b[1]);
+    else if constexpr (AKM)
+        lgkm_wait_tied<N>(al[0], al[1], ah[0], ah[1]);
+    else if constexpr (BKM)
+        lgkm_wait_tied<N>(b[0], b[1]);
+}
+__device__ __forceinline__ void fat_mma(const bf16x8_t (&al)[2], const bf16x8_t (&ah)[2], const bf16x8_t (&b)[2], f32x16 (&acc)[2][2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], al[i], acc[0][i][j], 0, 0, 0);
+            acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], ah[i], acc[1][i][j], 0, 0, 0);
+        }
+}
+// acc[h]: rows 64 h .. 64 h + 63 of the wave's 128 (= rows 128 wm2 + 64 h of the block tile), the layout of a 64x64 wave's acc[2][2]
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void k_loop_consumer_fat(char* smem, int nt, int lane, int wm2, int wn, f32x16 (&acc)[2][2][2]) {
+    using S = BlockShape<4>;
+    constexpr int NASM = (AKM ? 8 : 0) + (BKM ? 4 : 0);  // asm (transpose) reads per k-step
+    char* b0 = smem;
+    char* b1 = smem + S::STAGE_BYTES;
+    char* b2 = smem + 2 * S::STAGE_BYTES;
+    if (nt <= 0) return;
+    __builtin_amdgcn_s_barrier();  // tile 0 is visible to everyone
+    const char* At = b0 + wm2 * TILE_BYTES;
+    const char* Bt = b0 + S::NSUB * TILE_BYTES;
+    uint32_t kl[2] = {0, 0}, kh[2] = {0, 0}, kb[2] = {0, 0};
+    auto set_tile = [&](const char* st) {
+        At = st + wm2 * TILE_BYTES, Bt = st + S::NSUB * TILE_BYTES;
+        if constexpr (AKM) {
+            kl[0] = lds_addr(At) + km_lane_off(0, lane), kl[1] = lds_addr(At) + km_lane_off(32, lane);
+            kh[0] = lds_addr(At) + km_lane_off(64, lane), kh[1] = lds_addr(At) + km_lane_off(96, lane);
+        }
+        if constexpr (BKM) kb[0] = lds_addr(Bt) + km_lane_off(wn * 64, lane), kb[1] = lds_addr(Bt) + km_lane_off(wn * 64 + 32, lane);
+    };
+    set_tile(b0);
+    __builtin_amdgcn_s_setprio(2);  // ahead of the loader wave that shares the SIMD
+    bf16x8_t al0[2], ah0[2], bb0[2], al1[2], ah1[2], bb1[2];
+    fat_load<AKM, BKM, 0>(At, Bt, kl, kh, kb, wn, lane, al0, ah0, bb0);
+    for (int t = 0; t < nt; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // 1: every wave is past its last read of tile t-1 (its stage is refilled from here on)
+        fat_load<AKM, BKM, 1>(At, Bt, kl, kh, kb, wn, lane, al1, ah1, bb1);
+        fat_ready<AKM, BKM, NASM>(al0, ah0, bb0);
+        fat_mma(al0, ah0, bb0, acc);
+        fat_load<AKM, BKM, 2>(At, Bt, kl, kh, kb, wn, lane, al0, ah0, bb0);
+        fat_ready<AKM, BKM, NASM>(al1, ah1, bb1);
+        fat_mma(al1, ah1, bb1, acc);
+        fat_load<AKM, BKM, 3>(At, Bt, kl, kh, kb, wn, lane, al1, ah1, bb1);
+        fat_ready<AKM, BKM, NASM>(al0, ah0, bb0);
+        fat_mma(al0, ah0, bb0, acc);
+        fat_ready<AKM, BKM, 0>(al1, ah1, bb1);  // (the last reads of this tile have completed before barrier 4)
+        fat_mma(al1, ah1, bb1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // 2: tile t+1 has landed
+        char* tmp = b0;
+        b0 = b1, b1 = b2, b2 = tmp;
+        if (t + 1 < nt) {
+            set_tile(b0);
+            fat_load<AKM, BKM, 0>(At, Bt, kl, kh, kb, wn, lane, al0, ah0, bb0);
+        }
+    }
+    __builtin_amdgcn_s_barrier();  // the closing barrier
+    __builtin_amdgcn_s_setprio(0);
+}
+
 // ---- epilogue staging: one 32-row slab of every wave's accumulators -> LDS [64][SLAB_PITCH] fp32, so that the
 // global reads/writes of the epilogue are row-contiguous (512 B per row) instead of 16-B pieces at a row stride.
 constexpr int SLAB_PITCH = 132;  // floats; +4 keeps the 8-lane ds_write_b128 groups on distinct banks

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(1024) void probe_lds_pattern_kernel(const int* __re
 // in (HOST int32[3]) = {iterations of 32 MFMAs per wave, blocks, operand mode: 0 zeros, 1 random bits with bf16 exponents near 1.0}.
 __global__ __launch_bounds__(512) void probe_mfma_kernel(int iters, int mode, float* __restrict__ out) {
     const unsigned tid = threadIdx.x + blockIdx.x * 512u;
+    if ((mode & 0x100) && threadIdx.x >= 256) return;  // mode bit 8: ONE wave per SIMD (four waves per block) -- can a single wave keep the pipe full?
     bf16x8_t f[8];
     unsigned h = tid * 2654435761u + 12345u;
 #pragma unroll
@@ -159,11 +160,34 @@ __global__ __launch_bounds__(512) void probe_mfma_kernel(int iters, int mode, fl
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    // mode bits 4-7 = R: R fragment reads (ds_read_b128, 1 KiB per wave) per group of 4 MFMAs, from 64 KiB of LDS filled with the same
+    // kind of bits -- what a GEMM wave does besides its MFMAs (R = 4: a 2 x 2 register tile, 1 KiB per MFMA; 3: a 4 x 2 tile; 2: 4 x 4).
+    // Is the energy of the operand reads a visible part of the power budget?  (tools/power_probe.py)
+    __shared__ __attribute__((aligned(16))) unsigned ldsbuf[16384];
+    const int R = (mode >> 4) & 15;
+    if (R) {
+        unsigned g = tid * 747796405u + 2891336453u;
+        for (int i = threadIdx.x; i < 16384; i += ((mode & 0x100) ? 256 : 512)) {
+            g = g * 1664525u + 1013904223u;
+            ldsbuf[i] = (mode & 1) ? ((g & 0x80ff80ffu) | 0x3f003f00u) : 0u;
+        }
+        __syncthreads();
+    }
+    const int lane16 = (threadIdx.x & 63) * 4;  // this lane's 16 bytes inside a 1-KiB fragment
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 8; ++u) {
+            if (R) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < R) {
+                        const int frag = (it * 29 + u * 4 + r) & 63;  // 64 fragments of 1 KiB
+                        f[(u * 4 + r) & 7] = *reinterpret_cast<const bf16x8_t*>(&ldsbuf[frag * 256 + lane16]);
+                    }
+            }
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[(u + a) & 7], f[(u + 2 * a + 3) & 7], acc[a], 0, 0, 0);
+        }
     }
     float sum = 0.f;
 #pragma unroll

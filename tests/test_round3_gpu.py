@@ -14,6 +14,7 @@ from test_models_gpu import DEV, close, load_synth
 
 pytestmark = pytest.mark.gpu
 GEMM_LOADERS_DEFAULT = 4  # option gemm_loaders as the library ships it (tests that flip it restore this)
+GEMM_FAT_DEFAULT = 0
 
 
 # ---------------------------------------------------------------------------------- H6 / N2: front-end vs the reference
@@ -396,10 +397,11 @@ def test_gemm_block_forms_are_bit_identical(M, N, K):
     bias = torch.randn(N, device=DEV) * 0.1
     pre_in = torch.randn(M, N, device=DEV).to(bf)
     forms = {'lds': (0, 0, 0, 4), 'direct': (1, 0, 0, 4), 'loader': (1, 1, 0, 4), 'loader+groups': (1, 1, 1, 4),
-             'loader+groups, eight loader waves (round 4)': (1, 1, 1, 8)}
+             'loader+groups, eight loader waves (round 4)': (1, 1, 1, 8), 'loader+groups, four 128x64 MFMA waves (round 4)': (1, 1, 1, 4, 1)}
     outs = {}
     try:
-        for name, (epi, loader, groups, nload) in forms.items():
+        for name, (epi, loader, groups, nload, *fat) in forms.items():
+            _lib.call('mmvid_set_option', b'gemm_fat', fat[0] if fat else 0)
             _lib.call('mmvid_set_option', b'gemm_loaders', nload)
             _lib.call('mmvid_set_option', b'gemm_epi', epi)
             _lib.call('mmvid_set_option', b'gemm_loader', loader)
@@ -412,7 +414,8 @@ def test_gemm_block_forms_are_bit_identical(M, N, K):
                           ops.gemm(A, W, bias=bias, act=1, save_pre=save), save,          # c_fc-like: two bf16 results
                           ops.gemm(A, Wk, b_kmajor=True, dact_pre=pre_in, colsum=cs) if N % 8 == 0 else None, cs)
     finally:
-        for k, v in ((b'gemm_epi', 1), (b'gemm_loader', 1), (b'gemm_groupn', 1), (b'gemm_tile', 0), (b'gemm_loaders', GEMM_LOADERS_DEFAULT)):
+        for k, v in ((b'gemm_epi', 1), (b'gemm_loader', 1), (b'gemm_groupn', 1), (b'gemm_tile', 0), (b'gemm_loaders', GEMM_LOADERS_DEFAULT),
+                     (b'gemm_fat', GEMM_FAT_DEFAULT)):
             _lib.call('mmvid_set_option', k, v)
     ref = outs['lds']
     want = (A.float() @ W.float().t() + bias)

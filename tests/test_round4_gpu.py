@@ -27,8 +27,9 @@ def test_grouped_weight_gradients_do_not_depend_on_the_tile_order():
         bases.append(base)
     res = {}
     try:
-        for order in (0, 1):
-            _lib.call('mmvid_set_option', b'dw_order', order)
+        for order in (0, 1, 2):  # 2 = the column-major walk with the four-wave (128 x 64) block form, option gemm_fat
+            _lib.call('mmvid_set_option', b'dw_order', min(order, 1))
+            _lib.call('mmvid_set_option', b'gemm_fat', 1 if order == 2 else 0)
             for (dY, X, outs), base in zip(kinds, bases):
                 for g, o in enumerate(outs):
                     if o is not None:
@@ -38,8 +39,10 @@ def test_grouped_weight_gradients_do_not_depend_on_the_tile_order():
             res[order] = [[o.clone() if o is not None else None for o in outs] for _, _, outs in kinds]
     finally:
         _lib.call('mmvid_set_option', b'dw_order', 1)
-    for a, b in zip(res[0], res[1]):
-        assert all(x is None and y is None or torch.equal(x, y) for x, y in zip(a, b))
+        _lib.call('mmvid_set_option', b'gemm_fat', 0)
+    for other in (1, 2):
+        for a, b in zip(res[0], res[other]):
+            assert all(x is None and y is None or torch.equal(x, y) for x, y in zip(a, b)), other
     dY, X, outs = kinds[0]
     want = torch.einsum('mn,mk->nk', dY[0].double(), X[0].double()) + bases[0][0].double()
     assert ((outs[0].double() - want).abs().max() / want.abs().max()).item() < 2e-5

@@ -90,6 +90,18 @@ for mode, label in ((1, 'random bits'), (0, 'zeros')):
         arr = (ctypes.c_int32 * 3)(2000, blocks, mode)
         fl_p = 2.0 * 32 * 32 * 16 * 32 * 2000 * 8 * blocks
         phase(f'register-only MFMA chains, {blocks} blocks x 8 waves, {label}', lambda arr=arr: _lib.call('mmvid_probe', 5, arr, ops._p(sink), ops._stream()), fl_p, 1.5)
+# the same chains with R operand-fragment reads from LDS per 4 MFMAs (mode bits 4-7): 4 = what a 2 x 2 register tile per wave reads (1 KiB
+# per MFMA), 3 = a 4 x 2 tile, 2 = a 4 x 4 tile -- how much of the power budget the operand reads take
+for R in (4, 3, 2):
+    arr = (ctypes.c_int32 * 3)(2000, 256, 1 | (R << 4))
+    fl_p = 2.0 * 32 * 32 * 16 * 32 * 2000 * 8 * 256
+    phase(f'MFMA chains + {R} LDS fragment reads per 4 MFMAs, random bits', lambda arr=arr: _lib.call('mmvid_probe', 5, arr, ops._p(sink), ops._stream()), fl_p, 1.5)
+for R in (0, 3):
+    arr = (ctypes.c_int32 * 3)(2000, 256, 1 | (R << 4) | 0x100)
+    fl_p = 2.0 * 32 * 32 * 16 * 32 * 2000 * 4 * 256
+    phase(f'ONE wave per SIMD: MFMA chains + {R} LDS fragment reads per 4 MFMAs, random bits', lambda arr=arr: _lib.call('mmvid_probe', 5, arr, ops._p(sink), ops._stream()), fl_p, 1.5)
+if os.environ.get('PROBE_ONLY'):
+    sys.exit(0)
 phase('idle (torch.cuda.synchronize only)', lambda: None, 0, 0.5)
 phase('GEMM 10422x3072x768 random operands', lambda: ops.gemm(X, W, out=out), fl)
 phase('GEMM 10422x3072x768 zero operands', lambda: ops.gemm(X0, W0, out=out), fl)
