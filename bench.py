@@ -303,6 +303,16 @@ def run_artv_sampling(args, device, rank, world):
         return
     per_call = dt / args.steps
     tokens = world * b * 1024
+    # which form of the per-token tower step the decode session picks at this batch (mmvid_amd/clip_tower.py::DecodeSession)
+    from mmvid_amd import _lib as _l
+    import ctypes as _ct
+    _cfg = model.transformer._cfg(b, 1152)
+    if os.environ.get('MMVID_DECODE_PERSISTENT', '1') != '0' and _l.load().mmvid_tower_decode_persistent_supported(_ct.byref(_cfg), 1152):
+        step_form = 'one persistent launch (256 co-resident blocks, tagged-word hand-over)'
+    elif b <= 16:
+        step_form = 'five launches per layer (matrix-vector kernels%s)' % (', wide instance' if b > 8 else '')
+    else:
+        step_form = 'five launches per layer, slices of 16 sequences'
     # a decode step streams every tower weight once: 12 layers x 7.08 M matrix params x 2 B (bf16) + the image block of the head
     stream_bytes = args.layers * (4 * 768 * 768 + 2 * 768 * 3072) * 2 + 1024 * 768 * 2
     step_s = per_call / 1024
@@ -313,7 +323,7 @@ def run_artv_sampling(args, device, rank, world):
                       'layers': args.layers, 'note': 'value counts SAMPLED tokens (inference), not training tokens'},
            'roofline': {'bound': 'hbm', 'kernel': 'decode step (weight streaming, batch %d)' % b, 'achieved': stream_bytes / step_s / 1e9,
                         'peak': 8000.0, 'unit': 'GB/s', 'frac': stream_bytes / step_s / 1e9 / 8000.0, 'traffic': None,
-                        'ms_per_token_step': step_s * 1e3, 'algorithmic_bytes_per_step': stream_bytes},
+                        'ms_per_token_step': step_s * 1e3, 'algorithmic_bytes_per_step': stream_bytes, 'tower_step': step_form},
            'artv_train_step': {'ms_per_step': train_ms, 'video_tokens_per_s': b * 1024 / (train_ms * 1e-3), 'per_gpu_batch': b,
                                'loss': float(loss.detach())},
            'image_checksum': float(images.float().mean())}

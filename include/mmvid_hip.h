@@ -399,6 +399,11 @@ int mmvid_spatial_attention_ld(const void* q, const void* k, const void* v, int6
  * Gumbel(noise_u) when noise_u != NULL, dalle_bert.py:527-538); y (optional) = softmax probability of the drawn token. */
 int mmvid_sample_race(const float* logits, int64_t ld, const float* E, const float* noise_u, float temperature,
                       float logit_div, int64_t R, int V, int64_t tok_offset, int64_t* tok, float* y, void* stream);
+/* ... with the variates of draw number (*step_dev - step0) of a pre-drawn block E [draws][R][V] (e_step_stride = R * V): the whole
+ * sampling loop's variates are drawn once, outside the captured per-token step.  step_dev needs y == NULL, noise_u == NULL, R <= 1024. */
+int mmvid_sample_race_at(const float* logits, int64_t ld, const float* E, const int32_t* step_dev, int step0, int64_t e_step_stride,
+                         const float* noise_u, float temperature, float logit_div, int64_t R, int V, int64_t tok_offset, int64_t* tok,
+                         float* y, void* stream);
 /* keep-mask of a refinement step (dalle_bert.py:646-668): of the positions with preserve == 0, the k with the smallest
  * E / Y stay visible (k outside [1, #non-zero weights] -> 1, the reference's except branch); preserved positions always
  * stay.  Y [b, TS], E [b, Bm, TS], mask1 out [b, Bm, TS] (1 = keep). */

@@ -93,6 +93,7 @@ SIGNATURES = {
     'mmvid_decode_persistent_trace': [P],
     'mmvid_vqgan_run': [POINTER(VqganOp), I, P, P],
     'mmvid_sample_race': [P, I64, P, P, F, F, I64, I, I64, P, P, P],
+    'mmvid_sample_race_at': [P, I64, P, P, I, I64, P, F, F, I64, I, I64, P, P, P],
     'mmvid_mp_select_keep': [P, P, P, I, I, I, I, P, P],
     'mmvid_mp_build_input': [P, P, I64, P, P, P, I, I, I, I, I, I64, P, P],
     'mmvid_mp_update': [P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P],

@@ -67,6 +67,62 @@ __global__ __launch_bounds__(256) void sample_race_kernel(const float* __restric
     }
 }
 
+// The token draw alone (y_out not wanted: the ART-V sampler), one BLOCK per row: a thread's elements are requested together (the wave-per-row
+// loop is a chain of 2 x V / 64 dependent round trips: 13 us per token at V = 1,024, a twentieth of a batch-1 decode step).  The same keys
+// E_c / expf(x_c - max) and the same (key, index) order: the token is the wave-per-row kernel's, bit for bit.  E is the row block of draw
+// number (*step_dev - step0) when step_dev is given (the variates of a whole sampling loop are drawn at once, outside the captured step).
+__global__ __launch_bounds__(256) void sample_race_row_kernel(const float* __restrict__ logits, long ld, const float* __restrict__ E,
+                                                              const int* __restrict__ step_dev, int step0, long e_step_stride,
+                                                              float inv_temp_div, int V, long long tok_offset,
+                                                              long long* __restrict__ tok_out) {
+    __shared__ float smx[4];
+    __shared__ Best sb[4];
+    const long r = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + r * ld;
+    const float* e = E + (step_dev ? (long)(*step_dev - step0) * e_step_stride : 0) + r * (long)V;
+    float mx = -INFINITY;
+    for (int c0 = tid; c0 < V; c0 += 256 * 8) {
+        float xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = c0 + 256 * i < V ? x[c0 + 256 * i] * inv_temp_div : -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx = fmaxf(mx, xv[i]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) smx[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    Best b = {INFINITY, 0x7fffffff};
+    for (int c0 = tid; c0 < V; c0 += 256 * 8) {
+        float xv[8], ev[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool on = c0 + 256 * i < V;
+            xv[i] = on ? x[c0 + 256 * i] * inv_temp_div : -INFINITY, ev[i] = on ? e[c0 + 256 * i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (c0 + 256 * i >= V) continue;
+            const float p = expf(xv[i] - mx);
+            b = better(b, Best{p > 0.f ? ev[i] / p : INFINITY, c0 + 256 * i});
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Best ob;
+        ob.key = __shfl_xor(b.key, o, 64);
+        ob.idx = __shfl_xor(b.idx, o, 64);
+        b = better(b, ob);
+    }
+    if (lane == 0) sb[wave] = b;
+    __syncthreads();
+    if (tid == 0) {
+        b = better(better(sb[0], sb[1]), better(sb[2], sb[3]));
+        tok_out[r] = (long long)(b.idx < V ? b.idx : 0) + tok_offset;
+    }
+}
+
 // grid (Bm, b); dynamic LDS: TS floats
 __global__ __launch_bounds__(256) void mp_select_keep_kernel(const float* __restrict__ Y, const float* __restrict__ E,
                                                              const unsigned char* __restrict__ preserve, int TS, int Bm,
@@ -412,11 +468,25 @@ __global__ __launch_bounds__(256) void count_u8_kernel(const unsigned char* __re
 extern "C" int mmvid_sample_race(const float* logits, int64_t ld, const float* E, const float* noise_u, float temperature,
                                  float logit_div, int64_t R, int V, int64_t tok_offset, int64_t* tok, float* y,
                                  void* stream) {
+    return mmvid_sample_race_at(logits, ld, E, nullptr, 0, 0, noise_u, temperature, logit_div, R, V, tok_offset, tok, y, stream);
+}
+
+// The same with the variates of draw number (*step_dev - step0) of a pre-drawn block E [draws][R][V] (e_step_stride = R * V elements);
+// step_dev == null: E is the [R][V] block itself.
+extern "C" int mmvid_sample_race_at(const float* logits, int64_t ld, const float* E, const int32_t* step_dev, int step0,
+                                    int64_t e_step_stride, const float* noise_u, float temperature, float logit_div, int64_t R, int V,
+                                    int64_t tok_offset, int64_t* tok, float* y, void* stream) {
     MMVID_REQUIRE(logits && E && tok && R >= 0 && V > 0, "sample_race: bad arguments");
     MMVID_REQUIRE(logit_div > 0.f, "sample_race: logit_div (the softmax temperature divisor) must be > 0");
     if (R == 0) return MMVID_OK;
-    hipLaunchKernelGGL(sample_race_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, E, noise_u,
-                       temperature, 1.0f / logit_div, (long)R, V, (long long)tok_offset, (long long*)tok, y);
+    if (!y && !noise_u && R <= 1024) {  // the ART-V draw: one block per row
+        hipLaunchKernelGGL(sample_race_row_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, E, step_dev, step0,
+                           (long)e_step_stride, 1.0f / logit_div, V, (long long)tok_offset, (long long*)tok);
+    } else {
+        MMVID_REQUIRE(!step_dev, "sample_race_at: a device-side draw index needs the token-only form (no y, no noise, R <= 1024)");
+        hipLaunchKernelGGL(sample_race_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, E, noise_u,
+                           temperature, 1.0f / logit_div, (long)R, V, (long long)tok_offset, (long long*)tok, y);
+    }
     MMVID_LAUNCH_CHECK("sample_race");
     return MMVID_OK;
 }

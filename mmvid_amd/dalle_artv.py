@@ -306,6 +306,9 @@ class DALLE(nn.Module):
         out = torch.empty(B, steps, dtype=torch.long, device=dev)
         hbuf, logits = h.clone(), torch.empty(B, V, device=dev)
         tok, E = torch.empty(B, dtype=torch.long, device=dev), torch.empty(B, V, device=dev)
+        # production: the race variates of the whole loop in one draw (an exponential_ inside the captured step costs its launch and two
+        # generator-state fills per replay: 12 us per token); the draw of token n reads block n = position - first_pos
+        E_all = torch.empty(steps, B, V, device=dev).exponential_() if (race is None and steps * B * V <= (1 << 28)) else None
 
         hid = [hbuf]  # the hidden state the next draw reads: the prompt's last position, then the session's output buffer
 
@@ -319,6 +322,9 @@ class DALLE(nn.Module):
             if k_keep < V:
                 val, ind = torch.topk(lg, k_keep)
                 lg = torch.full_like(lg, float('-inf')).scatter_(1, ind, val)
+            if E_all is not None:
+                ops.sample_race(lg, E_all, None, 0.0, logit_div=temperature, want_y=False, tok_out=tok, step_dev=sess.pos, step0=first_pos)
+                return
             if race is not None:
                 E.copy_(race(f'tok{step}', (B, V)))
             else:

@@ -482,12 +482,13 @@ def exponential_like(shape, device):
     return torch.empty(shape, device=device, dtype=f32).exponential_()
 
 
-def sample_race(logits, E, noise_u=None, temperature=0.0, logit_div=1.0, tok_offset=0, want_y=True, tok_out=None):
-    """logits [R, V] f32 (row stride = logits.stride(0)), E [R, V] f32 Exp(1) variates -> (tok int64 [R] (tok_out if given), y f32 [R])."""
+def sample_race(logits, E, noise_u=None, temperature=0.0, logit_div=1.0, tok_offset=0, want_y=True, tok_out=None, step_dev=None, step0=0):
+    """logits [R, V] f32 (row stride = logits.stride(0)), E [R, V] f32 Exp(1) variates -> (tok int64 [R] (tok_out if given), y f32 [R]).
+    step_dev (int32 device scalar): E is [draws, R, V] and draw number step_dev - step0 is used (token-only form: want_y False, no noise)."""
     _chk(E, f32, 'E')
     assert logits.dtype == f32 and logits.is_cuda and logits.stride(1) == 1
     R, V = logits.shape
-    assert E.shape == (R, V)
+    assert E.shape[-2:] == (R, V) and E.is_contiguous() and (E.dim() == 2 or (E.dim() == 3 and step_dev is not None))
     if tok_out is not None:
         _chk(tok_out, i64, 'tok_out')
         assert tok_out.shape == (R, )
@@ -495,8 +496,8 @@ def sample_race(logits, E, noise_u=None, temperature=0.0, logit_div=1.0, tok_off
     y = torch.empty(R, device=logits.device, dtype=f32) if want_y else None
     if noise_u is not None:
         _chk(noise_u, f32, 'noise_u')
-    call('mmvid_sample_race', _p(logits), logits.stride(0), _p(E), _p(noise_u), float(temperature), float(logit_div), R, V,
-         int(tok_offset), _p(tok), _p(y), _stream())
+    call('mmvid_sample_race_at', _p(logits), logits.stride(0), _p(E), _p(step_dev) if step_dev is not None else None, int(step0), R * V,
+         _p(noise_u), float(temperature), float(logit_div), R, V, int(tok_offset), _p(tok), _p(y), _stream())
     return tok, y
 
 

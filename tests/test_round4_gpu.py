@@ -211,3 +211,25 @@ def test_persistent_decode_step_matches_the_five_launch_form(B, P):
         per.step(x[:, P].contiguous())
         with pytest.raises(_lib.MMVIDError, match='timed out'):
             per.check()
+
+
+@pytest.mark.parametrize('R,V', [(1, 1024), (16, 1024), (3, 1000), (5, 4099)])
+def test_token_draw_one_block_per_row_equals_the_wave_per_row_kernel(R, V):
+    """mmvid_sample_race_at without y (the ART-V draw): one block per row, a thread's elements requested together.  Same keys E / expf(x - max),
+    same (key, index) order: the tokens are the wave-per-row kernel's (the form the oracle parity tests pin) bit for bit, with near-ties and
+    -inf logits in the rows; with a device-side draw index the variates are block (index - step0) of a pre-drawn [draws, R, V] tensor."""
+    from mmvid_amd import ops
+    torch.manual_seed(R * 7 + V)
+    logits = torch.randn(R, V, device=DEV) * 3
+    logits[:, ::7] = float('-inf')
+    logits[:, 5] = logits[:, 11]  # equal probabilities: the lower E wins, and equal keys the lower index
+    E3 = torch.empty(6, R, V, device=DEV).exponential_()
+    E3[:, :, 5] = E3[:, :, 11]
+    for d in (0, 4):
+        ref, _ = ops.sample_race(logits, E3[d].contiguous(), None, 0.0, logit_div=0.7, want_y=True)   # wave per row (with y)
+        tok, y = ops.sample_race(logits, E3[d].contiguous(), None, 0.0, logit_div=0.7, want_y=False)  # block per row
+        assert y is None and torch.equal(tok, ref)
+        pos = torch.tensor([100 + d], dtype=torch.int32, device=DEV)
+        out = torch.full((R, ), -1, dtype=torch.long, device=DEV)
+        ops.sample_race(logits, E3, None, 0.0, logit_div=0.7, want_y=False, tok_out=out, step_dev=pos, step0=100)
+        assert torch.equal(out, ref)
