@@ -334,11 +334,12 @@ int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, const mmvid_tow
  * the consumers poll (csrc/decode_persistent.hip) -- no launch boundary, no barrier.  _supported: the 768 / 3072 / 12-head causal tower,
  * <= 12 layers, B <= 2, Lmax <= 4096, a device with >= 256 CUs and nothing else running beside the step.
  * workspace: _workspace_bytes(B) bytes, ZERO before the first call, then owned by the session (it carries the step counter the tags are
- * made from; word 1 becomes non-zero if a poll ever timed out, i.e. the blocks were not resident together). */
+ * made from; word 1 becomes non-zero if a poll ever timed out, i.e. the blocks were not resident together).  advance_pos != 0: the
+ * step also increments *pos_dev when it is done (a launch less per token for the sampler). */
 int mmvid_tower_decode_persistent_supported(const mmvid_tower_cfg_t* cfg, int Lmax);
 int64_t mmvid_tower_decode_persistent_workspace_bytes(int B);
 int mmvid_tower_decode_persistent(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in, float* x_out,
-                                  void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* workspace, void* stream);
+                                  void* kv_cache, int Lmax, int32_t* pos_dev, int pos, int advance_pos, void* workspace, void* stream);
 int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const float* ln_w, const float* ln_b, float eps, const void* W,
                     const float* bias, int N, int act, const float* residual, int64_t ldr, int round_in, int round_out,
                     float* out, int64_t ldo, void* stream);

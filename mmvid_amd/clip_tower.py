@@ -109,8 +109,7 @@ class DecodeSession:
         B, E = self.x.shape[0], self.x.shape[-1]
         if self.persistent:
             _lib.call('mmvid_tower_decode_persistent', ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
-                      ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.ws), ops._stream())
-            self.pos.add_(1)
+                      ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, 1, ops._p(self.ws), ops._stream())  # (advances pos itself)
             return
         if self.fused and B > 16 and E <= 768:
             # slices of 16 sequences through the matrix-vector kernels (the M = B corner of the training GEMM: 2.2 ms per token at batch 16)

@@ -50,6 +50,7 @@ struct PdArgs {
     bf16_t* cache;  // [layers][B][Lmax][2E]
     u64* ws;        // [0] step counter, [1] failure flag, [8...] the tagged rows
     const int* pos_dev;
+    int* pos_advance;  // = pos_dev when the step itself advances the position (block 0, after its last phase), or null
     int pos0, layers, Lmax, NB;
     float eps, scale_log2;
     int nowait;  // measurement only (MMVID_PD_NOWAIT bit 0: polls accept whatever they read -- the step without its dependency chain; bit 1: no weight loads; results void)
@@ -609,7 +610,10 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
     }
 #undef PD_STAMP
     // every block has read the counter before it wrote anything this block waited for: block 0 may advance it now
-    if (blk == 0 && tid == 0) a.ws[0] = seq;
+    if (blk == 0 && tid == 0) {
+        a.ws[0] = seq;
+        if (a.pos_advance) *a.pos_advance = pos + 1;  // (every block read the position when it started)
+    }
 }
 
 int64_t workspace_words(int nbt) {
@@ -648,8 +652,8 @@ extern "C" int64_t mmvid_tower_decode_persistent_workspace_bytes(int B) {
 }
 
 extern "C" int mmvid_tower_decode_persistent(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
-                                             float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* workspace,
-                                             void* stream) {
+                                             float* x_out, void* kv_cache, int Lmax, int32_t* pos_dev, int pos, int advance_pos,
+                                             void* workspace, void* stream) {
     MMVID_REQUIRE(cfg && layers && x_in && x_out && kv_cache && workspace, "tower_decode_persistent: null pointer");
     MMVID_REQUIRE(mmvid_tower_decode_persistent_supported(cfg, Lmax),
                   "tower_decode_persistent: needs the causal 768 / 3072 / 12-head tower, <= 12 layers, batch <= 2, a device with >= 256 CUs");
@@ -663,6 +667,7 @@ extern "C" int mmvid_tower_decode_persistent(const mmvid_tower_cfg_t* cfg, const
     }
     for (int i = cfg->layers; i < PD_LAYERS; ++i) a.ly[i] = a.ly[0];
     a.x_in = x_in, a.x_out = x_out, a.cache = (bf16_t*)kv_cache, a.ws = (u64*)workspace, a.pos_dev = pos_dev, a.pos0 = pos;
+    a.pos_advance = (advance_pos && pos_dev) ? pos_dev : nullptr;
     a.layers = cfg->layers, a.Lmax = Lmax, a.NB = cfg->B, a.eps = cfg->ln_eps, a.scale_log2 = 0.125f * 1.4426950408889634f;
     a.trace = g_pd_trace;
     static const int nowait = getenv("MMVID_PD_NOWAIT") ? atoi(getenv("MMVID_PD_NOWAIT")) : 0;
