@@ -340,6 +340,31 @@ int mmvid_tower_decode_persistent_supported(const mmvid_tower_cfg_t* cfg, int Lm
 int64_t mmvid_tower_decode_persistent_workspace_bytes(int B);
 int mmvid_tower_decode_persistent(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in, float* x_out,
                                   void* kv_cache, int Lmax, int32_t* pos_dev, int pos, int advance_pos, void* workspace, void* stream);
+/* The sampler's whole token as ONE launch: embedding row of the token drawn last (table[tok] + pos_rows[*pos_dev + pos_off], dalle_artv.py:484-491)
+ * -> the persistent tower step -> LN + the image block of to_logits -> the draw of the next token (csrc/sample.hip's rule on the pre-drawn
+ * variates E [draws][B][V], draw number *pos_dev + 1 - e_pos0) -> *pos_dev += 1.  tok [B] is read at the start and overwritten at the end;
+ * record (optional) [B][record_ld]: record[b][*pos_dev - record_pos0] = the token embedded.  V = 1,024 or 2,048. */
+typedef struct {
+    int64_t* tok;
+    const float* table;
+    int64_t table_rows;
+    const float* pos_rows;
+    int32_t pos_off;
+    int32_t record_pos0;
+    int64_t* record;
+    int64_t record_ld;
+    const float *lnf_w, *lnf_b;
+    const void* head_w; /* bf16 [V][E] */
+    const float* head_b;
+    const float* E;
+    int64_t e_step_stride;
+    int64_t tok_offset;
+    float* logits_out; /* [B][V] or NULL */
+    int32_t V, e_pos0;
+    float lnf_eps, temperature;
+} mmvid_decode_token_t;
+int mmvid_artv_token_step_persistent(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const mmvid_decode_token_t* t,
+                                     float* x_out, void* kv_cache, int Lmax, int32_t* pos_dev, void* workspace, void* stream);
 int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const float* ln_w, const float* ln_b, float eps, const void* W,
                     const float* bias, int N, int act, const float* residual, int64_t ldr, int round_in, int round_out,
                     float* out, int64_t ldo, void* stream);

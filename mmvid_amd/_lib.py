@@ -26,6 +26,14 @@ class TowerCfg(Structure):
                 ('c0', I), ('r1', I), ('c1', I), ('ln_eps', F)]
 
 
+class DecodeToken(Structure):
+    """mmvid_decode_token_t (include/mmvid_hip.h)."""
+    _fields_ = [('tok', c_void_p), ('table', c_void_p), ('table_rows', c_int64), ('pos_rows', c_void_p), ('pos_off', c_int32),
+                ('record_pos0', c_int32), ('record', c_void_p), ('record_ld', c_int64), ('lnf_w', c_void_p), ('lnf_b', c_void_p),
+                ('head_w', c_void_p), ('head_b', c_void_p), ('E', c_void_p), ('e_step_stride', c_int64), ('tok_offset', c_int64),
+                ('logits_out', c_void_p), ('V', c_int32), ('e_pos0', c_int32), ('lnf_eps', c_float), ('temperature', c_float)]
+
+
 class VqganOp(Structure):
     _fields_ = [('op', c_int32), ('mode', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32), ('C', c_int32),
                 ('Cout', c_int32), ('flags', c_int32), ('in0', I64), ('in1', I64), ('in2', I64), ('out_bf16', I64),
@@ -69,6 +77,7 @@ SIGNATURES = {
     'mmvid_tower_decode': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, I, P, P],
     'mmvid_tower_decode_fused': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, I, P, P],
     'mmvid_tower_decode_persistent': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, I, I, P, P],
+    'mmvid_artv_token_step_persistent': [POINTER(TowerCfg), POINTER(TowerLayer), POINTER(DecodeToken), P, P, I, P, P, P],
     'mmvid_tower_decode_fused_slice': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, I, P, I, P, P],
     'mmvid_gemv_rows': [P, I64, I, I, P, P, F, P, P, I, I, P, I64, I, I, P, I64, P],
     'mmvid_decode_embed': [P, P, I64, P, P, I, I, I, P, P],

@@ -126,6 +126,13 @@ class DecodeSession:
                   ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
         self.pos.add_(1)
 
+    def token_step(self, tk):
+        """The sampler's whole token in one launch (csrc/decode_persistent.hip: embedding of the token drawn last -> tower step -> head ->
+        draw of the next token -> position + 1).  tk: a filled _lib.DecodeToken (the caller keeps its tensors alive).  Persistent sessions only."""
+        assert self.persistent
+        _lib.call('mmvid_artv_token_step_persistent', ctypes.byref(self.cfg), self.layers, ctypes.byref(tk), ops._p(self.y), ops._p(self.cache),
+                  self.cache.shape[2], ops._p(self.pos), ops._p(self.ws), ops._stream())
+
     def check(self):
         """Raise if a poll of the persistent step ever timed out (its 256 blocks were not resident together: something else was running
         on the device beside it) -- the hidden states of that and every later step are void.  One device read: call it after the loop."""

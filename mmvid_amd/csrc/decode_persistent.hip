@@ -37,6 +37,7 @@ constexpr int PD_BLOCKS = 256, PD_E = 768, PD_F = 3072, PD_H = 12, PD_LAYERS = 1
 constexpr int PD_REC = 72;         // words of one partial-attention record: o[64], max, sum, pad
 constexpr int PD_MAXKEYS = 1024;   // keys of one attention unit
 constexpr int PD_SPIN = 1 << 18;
+constexpr int PD_MAXV = 2048;  // classes of the token step's head (a multiple of 1,024)
 typedef unsigned long long u64;
 
 struct PdLayer {
@@ -53,6 +54,30 @@ struct PdArgs {
     int* pos_advance;  // = pos_dev when the step itself advances the position (block 0, after its last phase), or null
     int pos0, layers, Lmax, NB;
     float eps, scale_log2;
+    // The sampler's whole token in the same launch (mmvid_artv_token_step_persistent; tk.table == null: the tower step alone): the input
+    // row is the embedding of the token drawn last (table[tok] + pos_rows[pos + pos_off], dalle_artv.py:484-491), and after the last layer
+    // come the head (LN + the image block of to_logits) and the draw of the next token (exponential race, csrc/sample.hip).
+    struct Tok {
+        long long* tok;  // [B]: read when the step starts, overwritten by the draw when it ends
+        const float* table;
+        long table_rows;
+        const float* pos_rows;
+        int pos_off;
+        long long* record;  // [B][record_ld] or null: record[b][pos - record_pos0] = tok[b]
+        long record_ld;
+        int record_pos0;
+        const float *lnf_w, *lnf_b;
+        float lnf_eps;
+        const bf16_t* head_w;  // [V][E]
+        const float* head_b;
+        int V;
+        const float* E;  // [draws][B][V]: the draw made here is number (pos + 1 - e_pos0)
+        long e_step_stride;
+        int e_pos0;
+        float inv_temp;
+        long long tok_offset;
+        float* logits_out;  // [B][V] or null
+    } tk;
     int nowait;  // measurement only (MMVID_PD_NOWAIT bit 0: polls accept whatever they read -- the step without its dependency chain; bit 1: no weight loads; results void)
     u64* trace;  // measurement only (mmvid_decode_persistent_trace): [4 blocks][layers][16] wall-clock stamps of blocks 0, 1, 128, 255
 };
@@ -218,6 +243,7 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
     u64* const PART = QKV + (long)NBT * 3 * PD_E;
     u64* const XMID = PART + (long)NBT * PD_H * S * PD_REC;
     u64* const ACT = XMID + (long)NBT * PD_E;
+    u64* const LOGITS = ACT + (long)NBT * PD_F;  // (the token step's head output: up to 2,048 words per row)
     const int pos = a.pos_dev ? *a.pos_dev : a.pos0;
     const int n = pos + 1 < a.Lmax ? pos + 1 : a.Lmax;  // (a position beyond the cache attends the cache and is not appended: never out of bounds)
     // Output features are numbered so that a BLOCK's words of a row are contiguous: a 64-byte line whose eight words come from eight
@@ -317,7 +343,14 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
         if (wave < 3 && !noweights) w3 = load_w768(L.out_w + (long)f0 * PD_E, lane), b3 = L.out_b[f0 + vz];  // the out-projection row of this wave
         if (wave < NB) {
             float v[12];
-            if (l == 0) {
+            if (l == 0 && a.tk.table) {  // the embedding row of the token drawn last
+                long long id = a.tk.tok[wave];
+                if (id < 0 || id >= a.tk.table_rows) id = 0;
+                const float* tr_ = a.tk.table + id * PD_E;
+                const float* pr_ = a.tk.pos_rows + (long)(pos + a.tk.pos_off) * PD_E;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) v[i] = tr_[i * 64 + lane] + pr_[i * 64 + lane];
+            } else if (l == 0) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) v[i] = a.x_in[(long)wave * PD_E + i * 64 + lane];
             } else {
@@ -598,10 +631,8 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
                 const float r = wave_sum_fast(s);
                 if (lane == 0) {
                     const float out = r + b5 + xres[1][b][f0];
-                    if (final_layer)
-                        a.x_out[(long)b * PD_E + f0] = out;
-                    else
-                        st_word(X + (long)b * PD_E + f0, tag + 5, out);  // = the next layer's base tag
+                    if (final_layer && a.x_out) a.x_out[(long)b * PD_E + f0] = out;
+                    if (!final_layer || a.tk.table) st_word(X + (long)b * PD_E + f0, tag + 5, out);  // = the next layer's (the head's) base tag
                 }
             }
         }
@@ -609,6 +640,93 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
         __syncthreads();
     }
 #undef PD_STAMP
+    if (a.tk.table) {
+        const int V = a.tk.V, NFW = V >> 10;            // classes; head features per wave (V / 256 per block, contiguous)
+        const uint32_t tagH = seq * 64u + (uint32_t)a.layers * 5u;
+        const uint32_t pmh = (a.nowait & 1) ? 0u : 0xffffffffu;
+        if (blk == 0 && tid < NB && a.tk.record && pos >= a.tk.record_pos0 && pos - a.tk.record_pos0 < a.tk.record_ld)
+            a.tk.record[tid * a.tk.record_ld + (pos - a.tk.record_pos0)] = a.tk.tok[tid];  // (the token this step embedded)
+        // ---- head: LN_f(x) . W_head^T + b over the image block of the vocabulary
+        W768 wh[2];
+        float bh[2] = {0.f, 0.f};
+        const int fh0 = blk * (V >> 8) + wave * NFW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j < NFW) wh[j] = load_w768((gbf_p)a.tk.head_w + (long)(fh0 + j) * PD_E, lane), bh[j] = a.tk.head_b[fh0 + j + vz];
+        // the race variates of this block's row (a draw block only): requested before anything is waited for
+        float ev[8];
+        if (blk < NB) {
+            const float* e = a.tk.E + (long)(pos + 1 - a.tk.e_pos0) * a.tk.e_step_stride + (long)blk * V;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ev[i] = i * 256 + tid < V ? e[i * 256 + tid] : 0.f;
+        }
+        if (wave < NB) {
+            float gf[12], hf[12], v[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) gf[i] = a.tk.lnf_w[i * 64 + lane], hf[i] = a.tk.lnf_b[i * 64 + lane];
+            poll_words<12>(X + (long)wave * PD_E + lane, 64, tagH & pmh, v, fail);
+            ln_row_to_lds(v, gf, hf, a.tk.lnf_eps, xs[wave], nullptr, lane);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NBT; ++b) {
+            if (b >= NB) break;
+            const uint4 xa = *reinterpret_cast<const uint4*>(&xs[b][lane * 8]);
+            const uint2 xb = *reinterpret_cast<const uint2*>(&xs[b][512 + lane * 4]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j >= NFW) break;
+                const float r = wave_sum_fast(dot768(wh[j], xa, xb)) + bh[j];
+                if (lane == 0) {
+                    st_word(LOGITS + (long)b * PD_MAXV + fh0 + j, tagH + 1, r);
+                    if (a.tk.logits_out) a.tk.logits_out[(long)b * V + fh0 + j] = r;
+                }
+            }
+        }
+        // ---- draw: block b < B takes row b -- first argmin of E_c / expf(x_c / T - max), the rule of csrc/sample.hip
+        if (blk < NB) {
+            float xv[8];
+            poll_fn<8>([&](int i) { return LOGITS + (long)blk * PD_MAXV + (i * 256 + tid < V ? i * 256 + tid : tid); }, (tagH + 1) & pmh, xv, fail);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xv[i] = i * 256 + tid < V ? xv[i] * a.tk.inv_temp : -INFINITY;
+                mx = fmaxf(mx, xv[i]);
+            }
+            mx = wave_max_fast(mx);
+            __syncthreads();  // (stat: the last attention unit of this block is long done)
+            if (lane == 0) stat[wave] = mx;
+            __syncthreads();
+            mx = fmaxf(fmaxf(stat[0], stat[1]), fmaxf(stat[2], stat[3]));
+            float bkey = INFINITY;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i * 256 + tid >= V) continue;
+                const float p = expf(xv[i] - mx);
+                const float key = p > 0.f ? ev[i] / p : INFINITY;
+                if (key < bkey || (key == bkey && i * 256 + tid < bidx)) bkey = key, bidx = i * 256 + tid;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ok = __shfl_xor(bkey, o, 64);
+                const int oi = __shfl_xor(bidx, o, 64);
+                if (ok < bkey || (ok == bkey && oi < bidx)) bkey = ok, bidx = oi;
+            }
+            __syncthreads();
+            if (lane == 0) stat[wave] = bkey, stat[4 + wave] = __int_as_float(bidx);
+            __syncthreads();
+            if (tid == 0) {
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const float ok = stat[w];
+                    const int oi = __float_as_int(stat[4 + w]);
+                    if (ok < bkey || (ok == bkey && oi < bidx)) bkey = ok, bidx = oi;
+                }
+                a.tk.tok[blk] = (long long)(bidx < V ? bidx : 0) + a.tk.tok_offset;
+            }
+        }
+    }
     // every block has read the counter before it wrote anything this block waited for: block 0 may advance it now
     if (blk == 0 && tid == 0) {
         a.ws[0] = seq;
@@ -618,7 +736,7 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
 
 int64_t workspace_words(int nbt) {
     const int S = PD_S;
-    return 8 + (int64_t)nbt * (PD_E + 3 * PD_E + PD_H * S * PD_REC + PD_E + PD_F);
+    return 8 + (int64_t)nbt * (PD_E + 3 * PD_E + PD_H * S * PD_REC + PD_E + PD_F + PD_MAXV);
 }
 int template_batch(int B) { return B <= 1 ? 1 : 2; }
 
@@ -627,6 +745,31 @@ int template_batch(int B) { return B <= 1 ? 1 : 2; }
 // measurement only: dev_buf = u64 [4][12][16] that the next steps stamp (tools/decode_persistent_timeline.py), or null
 extern "C" int mmvid_decode_persistent_trace(void* dev_buf) {
     g_pd_trace = (u64*)dev_buf;
+    return MMVID_OK;
+}
+
+// the launch shared by the two entry points
+static int pd_launch(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, PdArgs& a, void* kv_cache, int Lmax, int32_t* pos_dev,
+                     int pos, int advance_pos, void* workspace, void* stream) {
+    for (int i = 0; i < cfg->layers; ++i) {
+        const mmvid_tower_layer_t& s = layers[i];
+        PdLayer& d = a.ly[i];
+        d.in_w = (const bf16_t*)s.in_w, d.out_w = (const bf16_t*)s.out_w, d.fc_w = (const bf16_t*)s.fc_w, d.pj_w = (const bf16_t*)s.pj_w;
+        d.in_b = s.in_b, d.out_b = s.out_b, d.fc_b = s.fc_b, d.pj_b = s.pj_b;
+        d.ln1_w = s.ln1_w, d.ln1_b = s.ln1_b, d.ln2_w = s.ln2_w, d.ln2_b = s.ln2_b;
+    }
+    for (int i = cfg->layers; i < PD_LAYERS; ++i) a.ly[i] = a.ly[0];
+    a.cache = (bf16_t*)kv_cache, a.ws = (u64*)workspace, a.pos_dev = pos_dev, a.pos0 = pos;
+    a.pos_advance = (advance_pos && pos_dev) ? pos_dev : nullptr;
+    a.layers = cfg->layers, a.Lmax = Lmax, a.NB = cfg->B, a.eps = cfg->ln_eps, a.scale_log2 = 0.125f * 1.4426950408889634f;
+    a.trace = g_pd_trace;
+    static const int nowait = getenv("MMVID_PD_NOWAIT") ? atoi(getenv("MMVID_PD_NOWAIT")) : 0;
+    a.nowait = nowait;
+    hipStream_t s = (hipStream_t)stream;
+    switch (template_batch(cfg->B)) {
+        case 1: hipLaunchKernelGGL(decode_persistent_kernel<1>, dim3(PD_BLOCKS), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(decode_persistent_kernel<2>, dim3(PD_BLOCKS), dim3(256), 0, s, a); break;
+    }
     return MMVID_OK;
 }
 
@@ -658,25 +801,31 @@ extern "C" int mmvid_tower_decode_persistent(const mmvid_tower_cfg_t* cfg, const
     MMVID_REQUIRE(mmvid_tower_decode_persistent_supported(cfg, Lmax),
                   "tower_decode_persistent: needs the causal 768 / 3072 / 12-head tower, <= 12 layers, batch <= 2, a device with >= 256 CUs");
     PdArgs a;
-    for (int i = 0; i < cfg->layers; ++i) {
-        const mmvid_tower_layer_t& s = layers[i];
-        PdLayer& d = a.ly[i];
-        d.in_w = (const bf16_t*)s.in_w, d.out_w = (const bf16_t*)s.out_w, d.fc_w = (const bf16_t*)s.fc_w, d.pj_w = (const bf16_t*)s.pj_w;
-        d.in_b = s.in_b, d.out_b = s.out_b, d.fc_b = s.fc_b, d.pj_b = s.pj_b;
-        d.ln1_w = s.ln1_w, d.ln1_b = s.ln1_b, d.ln2_w = s.ln2_w, d.ln2_b = s.ln2_b;
-    }
-    for (int i = cfg->layers; i < PD_LAYERS; ++i) a.ly[i] = a.ly[0];
-    a.x_in = x_in, a.x_out = x_out, a.cache = (bf16_t*)kv_cache, a.ws = (u64*)workspace, a.pos_dev = pos_dev, a.pos0 = pos;
-    a.pos_advance = (advance_pos && pos_dev) ? pos_dev : nullptr;
-    a.layers = cfg->layers, a.Lmax = Lmax, a.NB = cfg->B, a.eps = cfg->ln_eps, a.scale_log2 = 0.125f * 1.4426950408889634f;
-    a.trace = g_pd_trace;
-    static const int nowait = getenv("MMVID_PD_NOWAIT") ? atoi(getenv("MMVID_PD_NOWAIT")) : 0;
-    a.nowait = nowait;
-    hipStream_t s = (hipStream_t)stream;
-    switch (template_batch(cfg->B)) {
-        case 1: hipLaunchKernelGGL(decode_persistent_kernel<1>, dim3(PD_BLOCKS), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(decode_persistent_kernel<2>, dim3(PD_BLOCKS), dim3(256), 0, s, a); break;
-    }
+    a.tk = {};
+    a.x_in = x_in, a.x_out = x_out;
+    pd_launch(cfg, layers, a, kv_cache, Lmax, pos_dev, pos, advance_pos, workspace, stream);
     MMVID_LAUNCH_CHECK("tower_decode_persistent");
+    return MMVID_OK;
+}
+
+// The ART-V sampler's whole token as one launch (dalle_artv.py:252-293 over the key/value cache): embedding row of the token drawn last
+// -> the tower step above -> LN + the image block of to_logits -> the draw of the next token (exponential race on pre-drawn variates) ->
+// *pos_dev += 1.  t->tok is read at the start and overwritten at the end.  Needs V = 1,024 or 2,048 and what _supported needs.
+extern "C" int mmvid_artv_token_step_persistent(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const mmvid_decode_token_t* t,
+                                                float* x_out, void* kv_cache, int Lmax, int32_t* pos_dev, void* workspace, void* stream) {
+    MMVID_REQUIRE(cfg && layers && t && kv_cache && workspace && pos_dev, "artv_token_step_persistent: null pointer");
+    MMVID_REQUIRE(mmvid_tower_decode_persistent_supported(cfg, Lmax),
+                  "artv_token_step_persistent: needs the causal 768 / 3072 / 12-head tower, <= 12 layers, batch <= 2, a device with >= 256 CUs");
+    MMVID_REQUIRE(t->tok && t->table && t->pos_rows && t->lnf_w && t->lnf_b && t->head_w && t->head_b && t->E, "artv_token_step_persistent: null pointer in the token block");
+    MMVID_REQUIRE((t->V == 1024 || t->V == 2048) && t->temperature > 0.f, "artv_token_step_persistent: V = %d (1024 or 2048), temperature > 0", t->V);
+    PdArgs a;
+    a.x_in = nullptr, a.x_out = x_out;
+    a.tk.tok = (long long*)t->tok, a.tk.table = t->table, a.tk.table_rows = (long)t->table_rows, a.tk.pos_rows = t->pos_rows, a.tk.pos_off = t->pos_off;
+    a.tk.record = (long long*)t->record, a.tk.record_ld = (long)t->record_ld, a.tk.record_pos0 = t->record_pos0;
+    a.tk.lnf_w = t->lnf_w, a.tk.lnf_b = t->lnf_b, a.tk.lnf_eps = t->lnf_eps, a.tk.head_w = (const bf16_t*)t->head_w, a.tk.head_b = t->head_b, a.tk.V = t->V;
+    a.tk.E = t->E, a.tk.e_step_stride = (long)t->e_step_stride, a.tk.e_pos0 = t->e_pos0, a.tk.inv_temp = 1.0f / t->temperature;
+    a.tk.tok_offset = (long long)t->tok_offset, a.tk.logits_out = t->logits_out;
+    pd_launch(cfg, layers, a, kv_cache, Lmax, pos_dev, 0, 1, workspace, stream);
+    MMVID_LAUNCH_CHECK("artv_token_step_persistent");
     return MMVID_OK;
 }

@@ -9,11 +9,13 @@ materialised: each of the three position segments runs `to_logits` against ITS b
 MFMA GEMM + the fused cross-entropy kernels), which is the same loss with ~14x fewer head FLOPs and no [B, L, 51584]
 tensors.  Sampling keeps a per-layer key/value cache (the reference recomputes the whole prefix per token) and draws
 tokens with the device sampler of csrc/sample.hip."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 from .clip_tower import OpenAICLIPTransformer
 from .dalle_bert import DivideMax, eval_decorator, exists, set_requires_grad
 from .frontend import Frontend, face_choices
@@ -340,6 +342,33 @@ class DALLE(nn.Module):
 
         graph = None
         use_graph = race is None and k_keep >= V and not self.stable and steps > 4
+        # batch 1-2 in production: the whole token (embedding -> tower -> head -> draw) is ONE persistent launch (MMVID_DECODE_TOKEN=0: the
+        # launches below).  The first token is drawn from the prompt's hidden state the usual way; every launch then embeds the token drawn
+        # last, files it in `out`, and draws the next one.
+        if (use_graph and sess.persistent and E_all is not None and V in (1024, 2048) and os.environ.get('MMVID_DECODE_TOKEN', '1') != '0'):
+            tk = _lib.DecodeToken()
+            tk.tok, tk.table, tk.table_rows, tk.pos_rows, tk.pos_off = tok.data_ptr(), iemb.data_ptr(), iemb.shape[0], pos_rows.data_ptr(), 0
+            tk.record, tk.record_ld, tk.record_pos0 = out.data_ptr(), out.stride(0), first_pos
+            lnw, lnb = ln.weight.detach(), ln.bias.detach()
+            tk.lnf_w, tk.lnf_b, tk.lnf_eps, tk.head_w, tk.head_b, tk.V = lnw.data_ptr(), lnb.data_ptr(), ln.eps, w_blk.data_ptr(), b_blk.data_ptr(), V
+            tk.E, tk.e_step_stride, tk.e_pos0, tk.temperature, tk.tok_offset, tk.logits_out = E_all.data_ptr(), B * V, first_pos, temperature, 0, None
+            draw(0)
+            for step in range(steps - 1):
+                if graph is not None:
+                    graph.replay()
+                    continue
+                sess.token_step(tk)
+                if step == 1:
+                    graph = torch.cuda.CUDAGraph()
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        with torch.cuda.graph(graph, stream=side):
+                            sess.token_step(tk)
+                    torch.cuda.current_stream().wait_stream(side)
+            out[:, steps - 1].copy_(tok)
+            sess.check()
+            return [out[:, i:i + 1] for i in range(steps)]
         for step in range(steps - 1):  # every token but the last: draw it, then run it through the tower
             if graph is not None:
                 graph.replay()

@@ -233,3 +233,56 @@ def test_token_draw_one_block_per_row_equals_the_wave_per_row_kernel(R, V):
         out = torch.full((R, ), -1, dtype=torch.long, device=DEV)
         ops.sample_race(logits, E3, None, 0.0, logit_div=0.7, want_y=False, tok_out=out, step_dev=pos, step0=100)
         assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('B', [1, 2])
+def test_artv_token_step_in_one_launch(B):
+    """mmvid_artv_token_step_persistent: [embedding row of the token drawn last -> persistent tower step -> LN + head block -> draw of the
+    next token -> position + 1] as ONE launch.  Against the same chain as separate launches from the same state: the embedded token is
+    filed in the record, the hidden state and the head's logits agree to fp32-summation-order / bf16-ulp level, the token drawn IS the
+    draw kernel's on the logits the launch produced (same rule, bit for bit), the position has advanced; three consecutive steps."""
+    from mmvid_amd import _lib, ops
+    from mmvid_amd.clip_tower import OpenAICLIPTransformer
+    from test_models_gpu import close
+    torch.manual_seed(40 + B)
+    L, P, V, E_, steps = 320, 200, 1024, 768, 3
+    tw = OpenAICLIPTransformer(seq_len=L, which_model='openai_clip_visual', causal=True, layers=3).to(DEV).eval()
+    table = torch.randn(1500, E_, device=DEV) * 0.5
+    pos_rows = torch.randn(L + 4, E_, device=DEV) * 0.1
+    lnw, lnb = torch.rand(E_, device=DEV) + 0.5, torch.randn(E_, device=DEV) * 0.1
+    w_blk = (torch.randn(V, E_, device=DEV) * 0.05).bfloat16()
+    b_blk = torch.randn(V, device=DEV) * 0.1
+    Eall = torch.empty(8, B, V, device=DEV).exponential_()
+    tok0 = torch.randint(0, 1500, (B, ), device=DEV)
+    x = torch.randn(B, P, E_, device=DEV) * 0.5
+    with torch.no_grad():
+        caches = [tw.new_kv_cache(B, L, DEV) for _ in range(2)]
+        for c in caches:
+            tw.prefill(x, c)
+        ref = tw.decode_session(caches[0], P, graph=False, fused='launches')
+        one = tw.decode_session(caches[1], P, graph=False)
+        assert one.persistent
+        tok_r, tok_o = tok0.clone(), tok0.clone()
+        record = torch.full((B, 8), -1, dtype=torch.long, device=DEV)
+        logits_o = torch.empty(B, V, device=DEV)
+        tk = _lib.DecodeToken()
+        tk.tok, tk.table, tk.table_rows, tk.pos_rows, tk.pos_off = tok_o.data_ptr(), table.data_ptr(), 1500, pos_rows.data_ptr(), 2
+        tk.record, tk.record_ld, tk.record_pos0 = record.data_ptr(), 8, P
+        tk.lnf_w, tk.lnf_b, tk.lnf_eps, tk.head_w, tk.head_b, tk.V = lnw.data_ptr(), lnb.data_ptr(), 1e-5, w_blk.data_ptr(), b_blk.data_ptr(), V
+        tk.E, tk.e_step_stride, tk.e_pos0, tk.temperature, tk.tok_offset, tk.logits_out = Eall.data_ptr(), B * V, P - 1, 0.9, 0, logits_o.data_ptr()
+        for n in range(steps):
+            emb = torch.empty(B, E_, device=DEV)
+            ops.decode_embed(tok_r, table, pos_rows, ref.pos, emb, pos_off=2)
+            before = tok_o.clone()
+            h_r = ref.step(emb).clone()
+            logits_r = torch.empty(B, V, device=DEV)
+            ops.gemv_rows(h_r, w_blk, b_blk, ln=(lnw, lnb, 1e-5), round_in=True, out=logits_r)
+            one.token_step(tk)
+            torch.cuda.synchronize()
+            close(one.y, h_r, 1e-2, f'B={B} step {n}: hidden state')
+            close(logits_o, logits_r, 1e-2, f'B={B} step {n}: head logits')
+            assert torch.equal(record[:, n], before) and int(one.pos) == P + n + 1
+            want, _ = ops.sample_race(logits_o, Eall[n + 2].contiguous(), None, 0.0, logit_div=0.9, want_y=False)
+            assert torch.equal(tok_o, want), (n, tok_o, want)
+            tok_r.copy_(tok_o)  # keep the two chains on the same trajectory
+        one.check()
