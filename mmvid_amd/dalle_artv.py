@@ -353,12 +353,13 @@ class DALLE(nn.Module):
             tk.lnf_w, tk.lnf_b, tk.lnf_eps, tk.head_w, tk.head_b, tk.V = lnw.data_ptr(), lnb.data_ptr(), ln.eps, w_blk.data_ptr(), b_blk.data_ptr(), V
             tk.E, tk.e_step_stride, tk.e_pos0, tk.temperature, tk.tok_offset, tk.logits_out = E_all.data_ptr(), B * V, first_pos, temperature, 0, None
             draw(0)
+            direct = os.environ.get('MMVID_DECODE_TOKEN_GRAPH', '0') == '0'  # one kernel per token: launched directly (a one-node graph replay costs more)
             for step in range(steps - 1):
                 if graph is not None:
                     graph.replay()
                     continue
                 sess.token_step(tk)
-                if step == 1:
+                if step == 1 and not direct:
                     graph = torch.cuda.CUDAGraph()
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())
