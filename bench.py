@@ -449,16 +449,23 @@ def main():
     if args.dry_run:
         return dry_run(args, world, rank)
     ndev = torch.cuda.device_count()
-    if ndev < world or local >= ndev:
+    # MMVID_BENCH_SHARED_GPU=1 (a check of the world > 1 GPU path on a 1-GPU box, never a measurement): the ranks share the devices that
+    # exist and exchange through gloo -- RCCL refuses two ranks on one device; gloo collectives cannot be captured, so the step runs eagerly
+    shared = os.environ.get('MMVID_BENCH_SHARED_GPU', '0') == '1' and ndev >= 1
+    if (ndev < world or local >= ndev) and not shared:
         raise SystemExit(f'[bench] --gpus {args.gpus}: only {ndev} device(s) visible on this node (rank {rank}, local rank {local}); '
                          'one process per GPU needs as many devices as ranks')
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
+    dev_index = local % ndev if shared else local
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     under_launcher = 'RANK' in os.environ  # torch.distributed.run: join the group even when it has one member
     if world > 1 or under_launcher:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if shared and ndev < world:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from mmvid_amd import _lib
     from mmvid_amd.build import build
@@ -499,10 +506,16 @@ def main():
     # The step is replayed as ONE hipGraph at every world size (with torch.distributed the bucketed all-reduces are captured
     # inside it, between the backward chunks they overlap with).  The host only calls replay.
     use_graph = not args.eager
+    capture_note = None
+    if use_graph and dist.is_initialized():
+        from mmvid_amd.engine import collectives_capturable
+        if not collectives_capturable(device):  # asked on a throw-away group: a collective that fails inside the step's capture would
+            use_graph = False                   # take the eager fall-back down with it (mmvid_amd/engine.py)
+            capture_note = 'eager (the %s backend cannot capture a collective)' % dist.get_backend()
     graph_warm = min(2, args.warmup) if use_graph else 0
     for _ in range(args.warmup - graph_warm):
         eager_step(trainer, fn, batch)
-    graphed, step_launch = None, 'eager'
+    graphed, step_launch = None, capture_note or 'eager'
     if use_graph:
         graphed = GraphedStep(trainer, fn, batch, warmup=graph_warm)
         step_launch = 'hipGraph replay' if graphed.graph is not None else f'eager (capture failed: {graphed.capture_error})'
@@ -628,7 +641,7 @@ def main():
             'config': {'workload': WORKLOADS[args.config] + {None: '', 'fp32': ' [vae.strict: fp32 encoder]',
                                                              'split': " [vae.strict = 'split': bf16-pair encoder]"}[args.strict],
                        'config_id': args.config, 'per_gpu_batch': B, 'global_batch': world * B,
-                       'seq_len': L, 'parallelism': f'dp{world}', 'step_launch': step_launch, 'layers': args.layers},
+                       'seq_len': L, 'parallelism': f'dp{world}' + (' (ranks SHARE the visible GPUs, gloo exchange: a path check, not a measurement)' if os.environ.get('MMVID_BENCH_SHARED_GPU', '0') == '1' and torch.cuda.device_count() < world else ''), 'step_launch': step_launch, 'layers': args.layers},
             'loss': loss_value, 'roofline': roofline, 'kernels': kernels,
             'host_issue_ms_per_step': host_s / args.steps * 1e3, 'host_load_average': os.getloadavg()[0],
             'lr_device_scalar': float(trainer._lr_dev), 'optimizer_steps': trainer.step_count,

@@ -433,6 +433,15 @@ class FlatTrainer:
         self._send(lo, self._sent_from)
         self._sent_from = lo
 
+    def after_failed_capture(self):
+        """A step that was being captured raised (e.g. a collective the runtime cannot capture).  The communication stream joined that
+        capture through an event and HIP leaves it in capture mode when the origin's capture is torn down: every later launch on it fails
+        with 'operation not permitted when stream is capturing'.  Take a fresh stream and forget the half-finished exchange."""
+        if self._comm_stream is not None:
+            self._comm_stream = torch.cuda.Stream(device=self.G.device)
+        self._works = []
+        self._sent_from = self.numel
+
     def allreduce_grads(self):
         """Send whatever is still local (embedding tables, or everything when no callback fired) and wait."""
         if self.world > 1 or self.force_exchange:
@@ -524,7 +533,11 @@ class GraphedStep:
             self.graph = graph
         except Exception as e:  # e.g. a collective that cannot be captured: keep training, eagerly
             self.capture_error = f'{type(e).__name__}: {e}'.splitlines()[0][:200]
-            torch.cuda.synchronize()
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # (the failed capture's own error may surface once more here)
+                pass
+            trainer.after_failed_capture()
         # the capture pass enqueued nothing: it was not a step
         trainer.step_count = saved[0]
         trainer._step_dev.copy_(saved[1])
@@ -554,6 +567,41 @@ class GraphedStep:
         self.graph.replay()
         self.trainer.step_count += 1
         return self.loss
+
+
+def collectives_capturable(device):
+    """Can this runtime capture a collective of the current backend into a hipGraph?  Asked BEFORE the training step is captured, on a
+    throw-away process group: a collective that fails inside a capture leaves the group's internal streams in capture mode (HIP does not
+    release the streams that joined a capture that is torn down), and every later EAGER collective on that group fails with 'operation
+    not permitted when stream is capturing' -- the eager fall-back would be dead too.  gloo copies through the host: never capturable.
+    All ranks return the same answer."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    if dist.get_backend() != 'nccl':
+        return False
+    ok = True
+    try:
+        pg = dist.new_group(backend='nccl')
+        t = torch.zeros(64, device=device)
+        dist.all_reduce(t, group=pg)  # (the communicator is built by the first, eager, collective)
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                dist.all_reduce(t, group=pg)
+            g.replay()
+            torch.cuda.synchronize()
+        except Exception:
+            ok = False
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+    except Exception:
+        ok = False
+    flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # (the default group: untouched by the trial)
+    return bool(int(flag.item()))
 
 
 def backward_order(params):

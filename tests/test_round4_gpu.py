@@ -286,3 +286,30 @@ def test_artv_token_step_in_one_launch(B):
             assert torch.equal(tok_o, want), (n, tok_o, want)
             tok_r.copy_(tok_o)  # keep the two chains on the same trajectory
         one.check()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_sharing_this_gpu_run_the_world2_step():
+    """The world > 1 GPU path, end to end through bench.py on a 1-GPU box (MMVID_BENCH_SHARED_GPU=1: both ranks on the devices that
+    exist, exchange through gloo because RCCL refuses two ranks on one device; never a measurement): per-rank seeds, weight broadcast, the
+    backward split into chunks with the bucketed exchange between them, the row-wise table exchange with its pack / merge kernels, clip +
+    Adam on the averaged gradients, max-over-ranks timing, ONE JSON line.  gloo cannot be captured: `collectives_capturable` says so BEFORE
+    the step is captured (a collective failing inside a capture would leave the group's streams in capture mode and take the eager
+    fall-back down with it), and the step runs eagerly."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['MMVID_BENCH_SHARED_GPU'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29517', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline', '--layers', '2'], capture_output=True, text=True, timeout=540, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 12 and 'SHARE' in out['config']['parallelism']
+    assert out['config']['step_launch'].startswith('eager (the gloo backend cannot capture')
+    assert out['loss'] == out['loss'] and out['gradient_exchange']['row_wise_tables'] == ['text_emb.weight']
