@@ -14,7 +14,7 @@ from mmvid_amd import _lib, ops
 dev = 'cuda'
 MODES = {0: 'tagged words', 1: 'counter barrier + loads', 2: 'tagged words, writers interleaved', 4: 'tagged words, one wave polls 12 words / lane',
          6: 'tagged words, interleaved writers, one wave polls'}
-for blocks in (256, 128):
+for blocks in (256, 128, 64, 32):
     for K in (768, 3072):
         for mode in (0, 1, 2, 4, 6):
             if K != 768 and mode >= 4:
