@@ -48,8 +48,6 @@ int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void*
 
 /* Measurement only (tools/gemm_timeline.py): per-block time stamps of the next 256x128 GEMM launches; NULL switches it off. */
 int mmvid_gemm_trace(void* dev_buf);
-/* the same for the streaming attention forward kernel: [2 blocks][4 waves][16 tiles][8] stamps (tools/attn_timeline.py). */
-int mmvid_attention_trace(void* dev_buf);
 /* and for the decode gemv (csrc/decode.hip): [512 blocks][8] stamps of the next mmvid_gemv_rows launches (tools/bench_decode_step.py). */
 int mmvid_decode_trace(void* dev_buf);
 /* and for the persistent decode step (csrc/decode_persistent.hip): [4 blocks][12 layers][16] stamps (tools/decode_persistent_timeline.py). */
@@ -131,6 +129,13 @@ int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, 
  * lse2[b][h][q] = log2-domain log-sum-exp, consumed by the backward.  delta: fp32 [B,H,L] scratch. */
 int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, int H, int E, float scale, int mask_mode, int r0,
                         int c0, int r1, int c1, void* out, int64_t ldo, float* lse2, void* stream);
+/* The forward with a caller-provided device workspace of mmvid_attention_bwd_workspace_bytes(B, L, H) bytes (contents undefined on entry and
+ * exit; nullptr / 0 = mmvid_attention_fwd): the blocks of the launch's last, partly filled round of resident slots are cut into parts over
+ * disjoint key ranges whose (O, max, sum) records a second small launch merges in a fixed order -- bit-reproducible, but a row's rounding
+ * then depends on whether its block was in that round (i.e. on B): the workspace-free entry point is the batch-independent one. */
+int mmvid_attention_fwd_ws(const void* qkv, int64_t ld, int B, int L, int H, int E, float scale, int mask_mode, int r0,
+                           int c0, int r1, int c1, void* out, int64_t ldo, float* lse2, void* workspace, int64_t workspace_bytes,
+                           void* stream);
 int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                         const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode,
                         int r0, int c0, int r1, int c1, void* dqkv, int64_t ldg, void* stream);
@@ -141,9 +146,9 @@ int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void* O, int64_t
                              const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode, int r0,
                              int c0, int r1, int c1, void* dqkv, int64_t ldg, float* dbias, void* stream);
 /* The same with a caller-provided device workspace of mmvid_attention_bwd_workspace_bytes(B, L, H) bytes (contents undefined on entry and
- * exit; nullptr / 0 = mmvid_attention_bwd_bias).  With it the dK/dV pass cuts the blocks of its last, partly filled round of resident
- * blocks into parts over disjoint query ranges and adds the parts in a fixed order: results stay bit-reproducible run to run, and differ
- * from the workspace-free call only by fp32 summation order in those blocks.  (Not used under the causal mask.) */
+ * exit; nullptr / 0 = mmvid_attention_bwd_bias).  With it the dQ and the dK/dV pass cut the blocks of their last, partly filled round of
+ * resident blocks into parts over disjoint key / query ranges and add the parts in a fixed order: results stay bit-reproducible run to
+ * run, and differ from the workspace-free call only by fp32 summation order in those blocks.  (Not used under the causal mask.) */
 int mmvid_attention_bwd_ws(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                            const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode, int r0,
                            int c0, int r1, int c1, void* dqkv, int64_t ldg, float* dbias, void* workspace,

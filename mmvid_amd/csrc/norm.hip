@@ -4,6 +4,7 @@
 // One wave per row for LayerNorm (E <= 64*4*MAXV lanes*float4), 16-B accesses.
 #include "../../include/mmvid_hip.h"
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -180,6 +181,121 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DY* __restrict
             const int c = lane + 64 * i;
             if (c < nv) reinterpret_cast<float4*>(red[0][wave])[c] = pc[i];
         }
+        __syncthreads();
+        for (int e = threadIdx.x; e < E; e += 256) {
+            const float sc = (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]);
+            if (partial)
+                partial[((long)blockIdx.x * 3 + 2) * E + e] = sc;
+            else
+                unsafeAtomicAdd(dx_colsum + e, sc);
+        }
+    }
+}
+
+// Round 5: the same backward for E = 256 * NVI (768: the tower; 512: the text tower), software-pipelined.  The generic kernel's wave runs
+// load -> two wave reductions -> store per row with nothing in flight in between (2 waves per SIMD: 36 us for 128 MB, 3.6 TB/s); here
+// the NEXT row's operands are requested before this row is reduced and stored, the row loop is branch-free (no per-lane column guard:
+// every lane owns NVI float4 of the row) so the compiler's waits are counted (vmcnt(n) for the row in use, the prefetch stays in
+// flight), and the row index is wave-uniform (scalar loads of mean / rstd).  The arithmetic and its order are the generic kernel's:
+// bit-identical results.
+template <typename DY, int NVI>
+__global__ __launch_bounds__(256) void layernorm_bwd_fast_kernel(const DY* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                                 long ldx, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ w, long rows,
+                                                                 float* __restrict__ dx, long lddx, int add,
+                                                                 bf16_t* __restrict__ dx_bf16, float* __restrict__ dw,
+                                                                 float* __restrict__ db, float* __restrict__ dx_colsum,
+                                                                 float* __restrict__ partial) {
+    constexpr int E = 256 * NVI;
+    __shared__ float red[2][4][E];
+    typedef typename std::conditional<sizeof(DY) == 4, float4, uint2>::type dy_raw_t;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 pw[NVI], pb[NVI], pc[NVI], w4[NVI];
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+        pw[i] = pb[i] = pc[i] = make_float4(0, 0, 0, 0);
+        w4[i] = reinterpret_cast<const float4*>(w)[lane + 64 * i];
+    }
+    struct RowIn {
+        float4 prev[NVI], x4[NVI];
+        dy_raw_t d[NVI];
+        float mu, rs;
+    };
+    const long rstep = (long)gridDim.x * 4;
+    auto load_row = [&](RowIn& in, long r) {
+        in.mu = mean[r], in.rs = rstd[r];
+#pragma unroll
+        for (int i = 0; i < NVI; ++i) {
+            const int c = lane + 64 * i;
+            in.prev[i] = reinterpret_cast<const float4*>(dx + r * lddx)[c];
+            in.d[i] = reinterpret_cast<const dy_raw_t*>(dy + r * lddy)[c];
+            in.x4[i] = reinterpret_cast<const float4*>(x + r * ldx)[c];
+        }
+    };
+    RowIn cur, nxt;
+    long r = (long)blockIdx.x * 4 + wave;
+    if (r < rows) load_row(nxt, r);
+    for (; r < rows; r += rstep) {
+        cur = nxt;
+        load_row(nxt, r + rstep < rows ? r + rstep : r);  // (the last row of a wave re-requests itself: no branch around the loads)
+        const float mu = cur.mu, rs = cur.rs;
+        float4 g[NVI], xh[NVI];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVI; ++i) {
+            float4 d4;
+            if constexpr (sizeof(DY) == 4) {
+                d4 = cur.d[i];
+            } else {
+                const uint2 u = cur.d[i];
+                d4 = make_float4(bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y));
+            }
+            const float4 x4 = cur.x4[i];
+            xh[i] = make_float4((x4.x - mu) * rs, (x4.y - mu) * rs, (x4.z - mu) * rs, (x4.w - mu) * rs);
+            g[i] = make_float4(d4.x * w4[i].x, d4.y * w4[i].y, d4.z * w4[i].z, d4.w * w4[i].w);
+            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+            pw[i].x += d4.x * xh[i].x, pw[i].y += d4.y * xh[i].y, pw[i].z += d4.z * xh[i].z, pw[i].w += d4.w * xh[i].w;
+            pb[i].x += d4.x, pb[i].y += d4.y, pb[i].z += d4.z, pb[i].w += d4.w;
+        }
+        const float m1 = wave_sum_fast(s1) / (float)E, m2 = wave_sum_fast(s2) / (float)E;
+#pragma unroll
+        for (int i = 0; i < NVI; ++i) {
+            const int c = lane + 64 * i;
+            float4 o;
+            o.x = rs * (g[i].x - m1 - xh[i].x * m2);
+            o.y = rs * (g[i].y - m1 - xh[i].y * m2);
+            o.z = rs * (g[i].z - m1 - xh[i].z * m2);
+            o.w = rs * (g[i].w - m1 - xh[i].w * m2);
+            if (add) o.x += cur.prev[i].x, o.y += cur.prev[i].y, o.z += cur.prev[i].z, o.w += cur.prev[i].w;
+            reinterpret_cast<float4*>(dx + r * lddx)[c] = o;
+            pc[i].x += o.x, pc[i].y += o.y, pc[i].z += o.z, pc[i].w += o.w;
+            if (dx_bf16) reinterpret_cast<uint2*>(dx_bf16 + r * lddx)[c] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+        }
+    }
+    if (dw || db) {
+#pragma unroll
+        for (int i = 0; i < NVI; ++i) {
+            reinterpret_cast<float4*>(red[0][wave])[lane + 64 * i] = pw[i];
+            reinterpret_cast<float4*>(red[1][wave])[lane + 64 * i] = pb[i];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < E; e += 256) {
+            const float sw = (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]);
+            const float sb = (red[1][0][e] + red[1][1][e]) + (red[1][2][e] + red[1][3][e]);
+            if (partial) {
+                partial[((long)blockIdx.x * 3 + 0) * E + e] = sw;
+                partial[((long)blockIdx.x * 3 + 1) * E + e] = sb;
+            } else {
+                if (dw) unsafeAtomicAdd(dw + e, sw);
+                if (db) unsafeAtomicAdd(db + e, sb);
+            }
+        }
+    }
+    if (dx_colsum) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NVI; ++i) reinterpret_cast<float4*>(red[0][wave])[lane + 64 * i] = pc[i];
         __syncthreads();
         for (int e = threadIdx.x; e < E; e += 256) {
             const float sc = (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]);
@@ -394,6 +510,87 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
     }
 }
 
+// Round 5: finalisation + apply in ONE launch (the separate finalize launch was 18 launches of ~7 us per encode).  grid = (blocks per
+// image, N); a block first turns the partial sums of ITS image into the per-channel affine -- the arithmetic of groupnorm_finalize_kernel,
+// operation for operation (lanes stride over the partial blocks by 64, xor butterfly 32..1; the eight groups of a wave run their
+// butterflies side by side so the LDS-crossbar round trips pipeline) -- keeps the 8 + 8 coefficients of its channel chunk in registers,
+// and then streams its share of the image's pixels with four independent 16-B loads in flight per thread (the one-chunk-per-thread
+// form re-read 64 B of coefficients per 16 B of data).  Outputs are bit-identical to finalize + apply.
+template <typename T>
+__global__ __launch_bounds__(256) void groupnorm_apply_fused_kernel(const T* __restrict__ x, long hw, int C, const float* __restrict__ partial,
+                                                                    int nblk, float cnt, float eps, const float* __restrict__ w,
+                                                                    const float* __restrict__ b, int swish, int pix_per_block,
+                                                                    bf16_t* __restrict__ y_bf16, float* __restrict__ y_f32) {
+    __shared__ float ab[512][2];
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cpg = C >> 5;
+    {
+        float sm[8], sq[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            sm[g] = sq[g] = 0.f;
+            const int grp = wave * 8 + g;
+            for (int k = lane; k < nblk; k += 64) {
+                const float2 v = *reinterpret_cast<const float2*>(partial + (((long)n * nblk + k) * 32 + grp) * 2);
+                sm[g] += v.x, sq[g] += v.y;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) sm[g] += __shfl_xor(sm[g], o, 64), sq[g] += __shfl_xor(sq[g], o, 64);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int grp = wave * 8 + g;
+            const float mu = sm[g] / cnt;
+            float var = sq[g] / cnt - mu * mu;
+            var = var < 0.f ? 0.f : var;
+            const float rstd = rsqrtf(var + eps);
+            if (lane < cpg) {
+                const int ch = grp * cpg + lane;
+                const float a = rstd * w[ch];
+                ab[ch][0] = a, ab[ch][1] = b[ch] - mu * a;
+            }
+        }
+    }
+    __syncthreads();
+    const int cchunks = C >> 3;
+    const int cc = threadIdx.x % cchunks, prow = threadIdx.x / cchunks, pstep = 256 / cchunks;
+    float av[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) av[e] = ab[cc * 8 + e][0], bv[e] = ab[cc * 8 + e][1];
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    long p1 = p0 + pix_per_block;
+    if (p1 > hw) p1 = hw;
+    const long base = (long)n * hw * C + cc * 8;
+    for (long p = p0 + prow; p < p1; p += 4 * pstep) {
+        float f[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p + u * pstep < p1) load8<T>(x + base + (p + u * pstep) * C, f[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p + u * pstep >= p1) break;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = f[u][e] * av[e] + bv[e];
+                if (swish) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+                o[e] = v;
+            }
+            const long at = base + (p + u * pstep) * C;
+            if (y_bf16)
+                *reinterpret_cast<uint4*>(y_bf16 + at) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+            if (y_f32) {
+                float4* d = reinterpret_cast<float4*>(y_f32 + at);
+                d[0] = make_float4(o[0], o[1], o[2], o[3]);
+                d[1] = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+}
+
 // Small maps (hw <= 256 pixels: the 8x8 and 16x16 levels of the VQGAN, one statistics block per image): statistics, finalisation and the
 // apply pass of ONE image in ONE block -- the three launches of the general path were 15 us per GroupNorm for 4 us of work, ten times
 // per encode.  The arithmetic is the general path's, operation for operation (groupnorm_stats_kernel's fixed-order sums with one block,
@@ -599,7 +796,22 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, int64_t lddy, cons
         if (blocks > cap) blocks = cap;
     }
     // in two-stage mode the kernel needs non-null dw/db to take the reduction branch at all
-    if (dy_is_bf16)
+    float* const a_dw = partial ? (dw ? dw : workspace) : dw;
+    float* const a_db = partial ? (db ? db : workspace) : db;
+    float* const a_cs = partial ? (dx_colsum ? dx_colsum : nullptr) : dx_colsum;
+    // E = 512 / 768 (the towers): the software-pipelined instance (bit-identical); the prev row is always read, so `dx` must be readable
+    // memory even when it is only stored to (add_into_dx = 0) -- it is the output buffer: it is
+    if ((E == 768 || E == 512) && mmvid_option(MMVID_OPT_LN_FAST)) {
+#define MMVID_LN_FAST(DYT, NVI)                                                                                                            \
+    hipLaunchKernelGGL((layernorm_bwd_fast_kernel<DYT, NVI>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const DYT*)dy, (long)lddy, x, \
+                       (long)ldx, mean, rstd, w, (long)rows, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16, a_dw, a_db, a_cs, partial)
+        if (dy_is_bf16) {
+            if (E == 768) MMVID_LN_FAST(bf16_t, 3); else MMVID_LN_FAST(bf16_t, 2);
+        } else {
+            if (E == 768) MMVID_LN_FAST(float, 3); else MMVID_LN_FAST(float, 2);
+        }
+#undef MMVID_LN_FAST
+    } else if (dy_is_bf16)
         hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)lddy, x,
                            (long)ldx, mean, rstd, w, (long)rows, E, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16,
                            partial ? (dw ? dw : workspace) : dw, partial ? (db ? db : workspace) : db,
@@ -697,6 +909,19 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
         else
             hipLaunchKernelGGL(groupnorm_stats_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (long)hw, C,
                                pix_per_block, partial);
+    }
+    if (mmvid_option(MMVID_OPT_GN_FUSED)) {  // finalisation inside the apply launch (bit-identical to the two launches below)
+        long ppb = hw / 32;
+        ppb = ppb < 64 ? 64 : (ppb > 512 ? 512 : ppb);
+        const dim3 grid(cdiv(hw, ppb), N);
+        if (x_is_bf16)
+            hipLaunchKernelGGL(groupnorm_apply_fused_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)hw, C, partial, nblk,
+                               (float)hw * (float)(C / 32), eps, w, b, swish, (int)ppb, (bf16_t*)y_bf16, y_f32);
+        else
+            hipLaunchKernelGGL(groupnorm_apply_fused_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (long)hw, C, partial, nblk,
+                               (float)hw * (float)(C / 32), eps, w, b, swish, (int)ppb, (bf16_t*)y_bf16, y_f32);
+        MMVID_LAUNCH_CHECK("groupnorm");
+        return MMVID_OK;
     }
     hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv((long)N * 32, 4)), dim3(256), 0, s, partial, nblk, N, C,
                        (float)hw * (float)(C / 32), eps, w, b, ab);

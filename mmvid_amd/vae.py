@@ -175,11 +175,14 @@ class _Planner:
     STRICT = 16  # MMVID_VQFLAG_STRICT: the fp32-accurate operator (csrc/strict.hip); all planned tensors are fp32
     SPLIT = 64   # MMVID_VQFLAG_SPLIT: the bf16-pair operator; planned tensors are fp32 or pair planes [2][n,h,w,c] bf16
 
-    def __init__(self, vae, strict=False):
+    def __init__(self, vae, strict=False, stream16=False):
         self.vae, self.ops, self.free, self.top, self.recording = vae, [], [], 0, True
         self.patches, self.kept = [], {}
         self.split = strict == 'split'
         self.strict = bool(strict) and not self.split
+        # bf16 operator only: the residual stream between blocks is stored as bf16 as well (no fp32 activation leaves a conv except
+        # the VQ rows and the decoded image); the exact operators keep their fp32 streams
+        self.stream16 = bool(stream16) and not self.strict and not self.split
 
     # ---- split operator (vae.strict = 'split'): fp32 tensors between ops, every conv input a bf16 pair ----------------------
     def _planes(self, x):
@@ -264,12 +267,15 @@ class _Planner:
         self.patches.append((i, 'ext_in', 'img'))
         return out
 
-    def conv(self, x, holder, mode, residual=None, out32=False, clamp01=False, feeds_gn=False, also_bf16=False):
+    def conv(self, x, holder, mode, residual=None, out32=False, clamp01=False, feeds_gn=False, also_bf16=False, keep32=False):
         """feeds_gn: a GroupNorm reads this output next -> the epilogue also emits its partial statistics (when the
         shape allows), into a stats area that lives as long as the output buffer.
-        also_bf16 (with out32): the epilogue stores a bf16 copy too (`out.bf16`), instead of a later cast pass."""
+        also_bf16 (with out32): the epilogue stores a bf16 copy too (`out.bf16`), instead of a later cast pass.
+        keep32: fp32 output even with a bf16 residual stream (the VQ rows, the decoded image)."""
         if self.split:
             return self._conv_split(x, holder, mode, residual, clamp01, feeds_gn)
+        if self.stream16 and not keep32:
+            out32 = also_bf16 = False
         w, b, _ = self.vae._cw(holder, self.strict)
         n, h, wd, cin = x.shape
         assert x.dtype == (f32 if self.strict else bf16) and cin == w.shape[2], (x.shape, w.shape)
@@ -451,6 +457,11 @@ class VQGanVAE1024(nn.Module):
         # strict = 'split': the middle path -- bf16-pair convolutions on the bf16 matrix pipe (3 products per convolution,
         # fp32 accumulate; ~1e-5 of the fp32 result), fp32 residual stream / GroupNorm / attention
         self.strict = False
+        # default (bf16) operator only: 'bf16' = the ENCODER's residual stream between blocks is bf16 too (round 5: the fp32 stream
+        # cost 0.3 ms of the training step in stores / GroupNorm reads and bought nothing the default mode promises -- its indices
+        # are 97-100 % of the reference's either way); 'bf16_all' = the decoder's as well; 'f32' = fp32
+        # residual streams (rounds 1-4)
+        self.stream = os.environ.get('MMVID_VQGAN_STREAM', 'bf16')
         self._prep = {}
         self._prep_key = None
 
@@ -521,9 +532,11 @@ class VQGanVAE1024(nn.Module):
     def _plan(self, kind, n, size_or_hw, slot=0):
         prep = self._prepared()
         mode = 'split' if self.strict == 'split' else bool(self.strict)
-        key = ('plan', kind, n, size_or_hw, mode, slot)  # (slot: plans that run concurrently need arenas of their own)
+        # (the decoder keeps its fp32 stream unless 'bf16_all': it is off the training path and its pixel tolerance is pinned)
+        s16 = mode is False and (self.stream == 'bf16_all' or (self.stream == 'bf16' and kind == 'enc'))
+        key = ('plan', kind, n, size_or_hw, mode, slot, s16)  # (slot: plans that run concurrently need arenas of their own)
         if key not in prep:
-            pl = _Planner(self, strict=mode)
+            pl = _Planner(self, strict=mode, stream16=s16)
             if kind == 'enc':
                 self._plan_encode(pl, n, size_or_hw)
             elif kind == 'dec_z':
@@ -583,7 +596,7 @@ class VQGanVAE1024(nn.Module):
         h = self._plan_attn(pl, h, enc.mid.attn_1)
         h = self._plan_resblock(pl, h, enc.mid.block_2)
         h = pl.conv(pl.gn(h, enc.norm_out), enc.conv_out, 0)
-        z = pl.conv(h, self.model.quant_conv, 3, out32=True)  # [N, h, w, embed_dim] fp32 = VQ rows
+        z = pl.conv(h, self.model.quant_conv, 3, out32=True, keep32=True)  # [N, h, w, embed_dim] fp32 = VQ rows
         pl.keep('z', z)
         pl.vq_argmin(z)
 
@@ -606,7 +619,7 @@ class VQGanVAE1024(nn.Module):
             if hasattr(u, 'upsample'):
                 h = pl.conv(pl.cast(h), u.upsample.conv, 2, out32=True, feeds_gn=True)
         h = pl.gn(h, dec.norm_out)
-        img = pl.conv(h, dec.conv_out, 0, out32=True, clamp01=True)  # (clamp(x,-1,1)+1)/2 fused, vae.py:55
+        img = pl.conv(h, dec.conv_out, 0, out32=True, clamp01=True, keep32=True)  # (clamp(x,-1,1)+1)/2 fused, vae.py:55
         pl.to_nchw(img, 3)
 
     # ---- reference API ------------------------------------------------------------------------------

@@ -455,40 +455,6 @@ def test_attention_backward_with_fused_in_proj_bias_gradient():
     close(db, g.sum(0), 1e-2, 'fused in_proj bias gradient')
 
 
-@pytest.mark.parametrize('B,L,mode,rows', [(3, 579, 2, (65, 65, 66, 66)), (2, 51, 2, (17, 17, 18, 18)), (2, 200, 1, (0, 0, 0, 0)),
-                                           (2, 608, 0, (0, 0, 0, 0)), (1, 33, 1, (0, 0, 0, 0))])
-def test_resident_attention_kernels_bit_identical_to_streaming(B, L, mode, rows):
-    """The resident form of the three attention kernels (one 8-wave block per (batch, head), K/V or Q/dO staged into LDS once;
-    L <= 608) runs the streaming kernels' own per-row arithmetic in the same order: out, lse2, delta and dqkv must be
-    bit-identical, the fused bias gradient (fp32 atomics) equal to round-off.  All three mask shapes, ragged and full L."""
-    from mmvid_amd import _lib, ops
-    H, E = 12, 768
-    torch.manual_seed(L)
-    qkv = (torch.randn(B * L, 3 * E, device=DEV) * 0.5).bfloat16()
-    dO = (torch.randn(B * L, E, device=DEV) * 0.1).bfloat16()
-    st = ops._stream
-    res = {}
-    try:
-        for flag in (0, 1, 2):  # 2: the forward kernel with 16 waves (the backward kernels as 1)
-            _lib.call('mmvid_set_option', b'attn_res', flag)
-            out = torch.zeros(B * L, E, device=DEV, dtype=torch.bfloat16)
-            lse, delta = torch.zeros(B * H * L, device=DEV), torch.zeros(B * H * L, device=DEV)
-            dqkv = torch.zeros(B * L, 3 * E, device=DEV, dtype=torch.bfloat16)
-            db = torch.zeros(3 * E, device=DEV)
-            _lib.call('mmvid_attention_fwd', ops._p(qkv), 3 * E, B, L, H, E, 0.125, mode, *rows, ops._p(out), E, ops._p(lse), st())
-            _lib.call('mmvid_attention_bwd_bias', ops._p(qkv), 3 * E, ops._p(out), E, ops._p(dO), E, ops._p(lse), ops._p(delta), B, L, H, E,
-                      0.125, mode, *rows, ops._p(dqkv), 3 * E, ops._p(db), st())
-            torch.cuda.synchronize()
-            res[flag] = (out, lse, delta, dqkv, db)
-    finally:
-        _lib.call('mmvid_set_option', b'attn_res', 0)
-    for flag in (1, 2):
-        for name, a, b in zip(('out', 'lse2', 'delta', 'dqkv'), res[0], res[flag]):
-            assert torch.equal(a, b), f'{name}: resident ({flag}) differs from streaming in {(a != b).sum().item()} of {a.numel()} elements'
-        assert torch.isfinite(res[flag][3].float()).all()
-        close(res[flag][4], res[0][4], 1e-5, 'fused in_proj bias gradient, resident vs streaming')
-
-
 def test_tower_12_layers_at_training_length_vs_reference(golden):
     """The HIP tower at full depth and the training shape (12 layers, L = 579, restricted rows 65 / 66) against the reference's own
     forward + backward (tests/golden/tower12.npz): bf16 tolerances after 12 layers, norms within 2 %."""

@@ -87,10 +87,11 @@ def test_attention_outputs_are_batch_order_independent_after_the_swizzle_change(
 
 
 def test_attention_backward_tail_split_matches_whole_blocks_and_is_reproducible():
-    """mmvid_attention_bwd_ws at the training step's shape (18 sequences x 12 heads x L = 579: 1,080 dK/dV blocks, 56 of them in a third,
-    5-%-full round): the last round's blocks are cut into query-range parts whose fp32 accumulators are added in a fixed order.  dQ is
-    untouched (bit-identical to the workspace-free call); dK / dV differ by summation order only (within one bf16 ulp, almost everywhere
-    equal); two runs are bit-identical; the fused in-projection bias gradient stays the column sum of dqkv."""
+    """mmvid_attention_bwd_ws at the training step's shape (18 sequences x 12 heads x L = 579: 1,080 blocks per pass against 768 / 512
+    resident slots): the blocks of each pass's last, partly filled round are cut into parts over disjoint key (dQ) / query (dK, dV)
+    ranges whose fp32 accumulators are added in a fixed order.  The results differ from the workspace-free call by summation order only
+    (within one bf16 ulp, almost everywhere equal); two runs are bit-identical; the fused in-projection bias gradient stays the column
+    sum of dqkv."""
     from mmvid_amd import _lib, ops
     B, L, H, E = 18, 579, 12, 768
     torch.manual_seed(11)
@@ -103,12 +104,13 @@ def test_attention_backward_tail_split_matches_whole_blocks_and_is_reproducible(
     split = ops.attention_bwd(qkv, out, dO, lse2, B, L, H, spec, dbias=db1, workspace=True)
     again = ops.attention_bwd(qkv, out, dO, lse2, B, L, H, spec, workspace=True)
     assert torch.equal(split, again)
-    assert torch.equal(split[:, :E], whole[:, :E])
-    w, s_ = whole[:, E:].float(), split[:, E:].float()
-    diff = (w - s_).abs()
-    assert float((diff > 0).float().mean()) < 0.02  # only the 56 split blocks can differ, and there mostly not
-    # <= one bf16 ulp, or (elements that cancel to ~0) the fp32 summation-order error of the terms
-    assert bool((diff <= 2.0**-7 * w.abs() + 1e-5 * w.abs().max()).all())
+    for name, lo_, hi_, frac in (('dQ', 0, E, 0.12), ('dK, dV', E, 3 * E, 0.02)):
+        w, s_ = whole[:, lo_:hi_].float(), split[:, lo_:hi_].float()
+        diff = (w - s_).abs()
+        # only the split blocks can differ (312 of 1,080 in dQ, 56 in dK / dV), and there mostly not
+        assert float((diff > 0).float().mean()) < frac, name
+        # <= one bf16 ulp, or (elements that cancel to ~0) the fp32 summation-order error of the terms
+        assert bool((diff <= 2.0**-7 * w.abs() + 1e-5 * w.abs().max()).all()), name
     assert float((db1 - db0).abs().max()) <= 2e-3 * float(db0.abs().max())
     # the option switches it off: then the call with a workspace IS the workspace-free call
     _lib.call('mmvid_set_option', b'attn_tail', 0)

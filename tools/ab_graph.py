@@ -20,7 +20,8 @@ from mmvid_amd.engine import FlatTrainer, GraphedStep, backward_order
 
 
 def main():
-    opt, values = sys.argv[1], [int(v) for v in sys.argv[2:]]
+    opt = sys.argv[1]
+    values = [v if opt.startswith('py:') and not v.lstrip('-').isdigit() else int(v) for v in sys.argv[2:]]
     dev = torch.device('cuda', 0)
     torch.manual_seed(0), np.random.seed(0)
     model = bench.build_model(2, dev, 12).train()
