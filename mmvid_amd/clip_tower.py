@@ -93,6 +93,7 @@ class DecodeSession:
         self.x = torch.zeros(B, tower.width, device=dev, dtype=torch.float32)
         self.y = torch.zeros_like(self.x)
         self.pos = torch.tensor([first_pos], dtype=torch.int32, device=dev)
+        self._first_pos = int(first_pos)
         self.graph, self.want_graph, self.calls = None, graph, 0
         self._slice_cfgs = {}
         # the whole step as one launch of 256 co-resident blocks (csrc/decode_persistent.hip) where the tower / batch / device allow it;
@@ -133,15 +134,30 @@ class DecodeSession:
         _lib.call('mmvid_artv_token_step_persistent', ctypes.byref(self.cfg), self.layers, ctypes.byref(tk), ops._p(self.y), ops._p(self.cache),
                   self.cache.shape[2], ops._p(self.pos), ops._p(self.ws), ops._stream())
 
+    def failed(self):
+        """True when a poll of the persistent step has timed out on this session's workspace (its 256 blocks were not resident together:
+        something else held part of the device); every later launch on the workspace returns at once.  One device read (a sync)."""
+        return bool(self.persistent and int(self.ws[1]) != 0)
+
+    def fall_back(self, pos):
+        """Leave the persistent form for good: this session continues from position `pos` with the five-launch step (the key/value
+        entries at and beyond `pos` are rewritten by the steps that follow)."""
+        self.persistent, self.graph = False, None
+        self.fell_back = getattr(self, 'fell_back', 0) + 1
+        self.pos.fill_(int(pos))
+
     def check(self):
-        """Raise if a poll of the persistent step ever timed out (its 256 blocks were not resident together: something else was running
-        on the device beside it) -- the hidden states of that and every later step are void.  One device read: call it after the loop."""
-        if self.persistent and int(self.ws[1]) != 0:
+        """Raise if the persistent step failed and nobody recovered from it (`step(verify=True)` and the ART-V sampling loop do, by
+        repeating the affected positions with the five-launch step)."""
+        if self.failed():
             raise _lib.MMVIDError('persistent decode step: a poll timed out (the device was shared while it ran); results are invalid. '
                                   'Set MMVID_DECODE_PERSISTENT=0 to use the five-launch step.')
 
     @torch.no_grad()
-    def step(self, x_new):
+    def step(self, x_new, verify=True):
+        """One position.  verify (persistent sessions only; one device read per step): a step whose polls timed out is repeated with the
+        five-launch form and the session stays there -- the returned hidden state is always valid.  verify=False for loops that keep their
+        own restart point and call failed() / check() themselves."""
         self.x.copy_(x_new)
         self.calls += 1
         if self.want_graph and self.graph is None and self.calls == 2:
@@ -157,6 +173,9 @@ class DecodeSession:
         if self.graph is not None:
             self.graph.replay()
         else:
+            self._enqueue()
+        if verify and self.persistent and self.failed():
+            self.fall_back(self._first_pos + self.calls - 1)
             self._enqueue()
         return self.y
 

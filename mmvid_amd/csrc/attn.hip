@@ -664,7 +664,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
                 __builtin_amdgcn_sched_barrier(0);
                 sk.issue((t + 1) * 64, nxt, wave), sv.issue((t + 1) * 64, nxt + TILE, wave);
             }
-            if constexpr (!PLAIN) mfma_settle(s), mfma_settle(dp);  // (see the forward kernel)
+            // (see the forward kernel; the single-lane form reads s through asm statements, for which hipcc inserts no MFMA -> VALU
+            //  wait states at all: it keeps the settle in every body)
+            if constexpr (!PLAIN || !PK) mfma_settle(s), mfma_settle(dp);
             bf16x8_t kt4[4];  // K^T fragments
             tr_frags4<SS, KOFF>(trk, kt4);
             if constexpr (!PLAIN) {
@@ -960,7 +962,7 @@ static int attn_block_slots(const void* kernel) {
 static TailSplit plan_tail(int nblocks, int slots, int ntiles, int nreg, void* workspace, int64_t workspace_bytes, bool allowed, int* tail_out) {
     TailSplit ts = {0, 0, 0, nullptr};
     *tail_out = 0;
-    if (!allowed || !workspace || slots <= 0 || nblocks <= slots || !mmvid_option(MMVID_OPT_ATTN_TAIL)) return ts;
+    if (!allowed || !workspace || slots <= 0 || nblocks <= slots) return ts;
     const int tail = nblocks % slots;
     if (tail == 0) return ts;
     int pl = ntiles >= 8 ? 2 : (ntiles >= 4 ? 1 : 0);
@@ -1003,9 +1005,10 @@ extern "C" int mmvid_attention_fwd_ws(const void* qkv, int64_t ld, int B, int L,
     const MaskSpec m = make_mask(mask_mode, r0, c0, r1, c1);
     // tail split (see TailSplit): needs the caller's workspace; not for the causal mask (a block's key range depends on its rows)
     int tail = 0;
-    const bool pk = mmvid_option(MMVID_OPT_ATTN_PK) != 0;
+    const bool pk = (mmvid_option(MMVID_OPT_ATTN_PK) & 1) != 0;
     const void* kern = pk ? (const void*)attn_fwd_kernel<true> : (const void*)attn_fwd_kernel<false>;
-    const TailSplit ts = plan_tail(nblocks, attn_block_slots(kern), (L + 63) >> 6, FWD_NREG, workspace, workspace_bytes, mask_mode != 1, &tail);
+    const TailSplit ts = plan_tail(nblocks, attn_block_slots(kern), (L + 63) >> 6, FWD_NREG, workspace, workspace_bytes,
+                                   mask_mode != 1 && (mmvid_option(MMVID_OPT_ATTN_TAIL) & 1), &tail);
     const int grid = ts.parts_log2 > 0 ? ts.nfull + (tail << ts.parts_log2) : nblocks;
     if (pk)
         hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld, L, H, E, nrt_d, h_d,
@@ -1054,9 +1057,10 @@ extern "C" int mmvid_attention_bwd_ws(const void* qkv, int64_t ld, const void* O
     // tail splits (see TailSplit): need the caller's workspace (the two passes use it one after the other); not for the causal mask
     {
         int tail = 0;
-        const bool pk = mmvid_option(MMVID_OPT_ATTN_PK) != 0;
+        const bool pk = (mmvid_option(MMVID_OPT_ATTN_PK) & 2) != 0;
         const void* kern = pk ? (const void*)attn_bwd_dq_kernel<true> : (const void*)attn_bwd_dq_kernel<false>;
-        const TailSplit ts = plan_tail(nblocks, attn_block_slots(kern), ntiles, DQ_NREG, workspace, workspace_bytes, mask_mode != 1, &tail);
+        const TailSplit ts = plan_tail(nblocks, attn_block_slots(kern), ntiles, DQ_NREG, workspace, workspace_bytes,
+                                       mask_mode != 1 && (mmvid_option(MMVID_OPT_ATTN_TAIL) & 2), &tail);
         const int grid = ts.parts_log2 > 0 ? ts.nfull + (tail << ts.parts_log2) : nblocks;
         if (pk)
             hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(grid), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld, (const bf16_t*)O, (long)ldo,
@@ -1070,7 +1074,7 @@ extern "C" int mmvid_attention_bwd_ws(const void* qkv, int64_t ld, const void* O
     {
         int tail = 0;
         const TailSplit ts = plan_tail(nblocks, attn_block_slots((const void*)attn_bwd_dkv_kernel), ntiles, DKV_NREG, workspace, workspace_bytes,
-                                       mask_mode != 1, &tail);
+                                       mask_mode != 1 && (mmvid_option(MMVID_OPT_ATTN_TAIL) & 4), &tail);
         const int grid = ts.parts_log2 > 0 ? ts.nfull + (tail << ts.parts_log2) : nblocks;
         hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld, (const bf16_t*)dO, (long)lddo, lse2,
                            delta, L, H, E, nrt_d, h_d, scale, sl2, m, (bf16_t*)dqkv, (long)ldg, dbias, ts);

@@ -169,9 +169,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //                                       instead of 1: the K loop is bound by LDS bandwidth, csrc/gemm_core.h k_loop_consumer_fat); 0 (default) = eight of 64 x 64
 //   ln_fast        MMVID_LN_FAST        1 (default) = LayerNorm backward of E = 512 / 768 rows on the software-pipelined kernel (next row's operands in
 //                                       flight while a row is reduced; bit-identical); 0 = the generic kernel (rounds 1-4)
-//   gemm_stagger   MMVID_GEMM_STAGGER   persistent multi-round GEMMs: every other CU of an XCD starts this many 0.1-us ticks late (per K = 768 tile;
-//                                       scaled with K), so that one half's epilogue store burst drains under the other half's K loops; 0 = off
 //   attn_pk        MMVID_ATTN_PK        attention forward / dQ softmax arithmetic: 1 = packed fp32 fma / add (v_pk_*), 0 = single-lane instructions
-enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_ATTN_RES = 15, MMVID_OPT_GEMM_FUSED_REDUCE = 16, MMVID_OPT_DW_GROUPED = 17, MMVID_OPT_GEMM_LOADERS = 18, MMVID_OPT_DW_ORDER = 19, MMVID_OPT_GN_FUSED = 20, MMVID_OPT_ATTN_TAIL = 21, MMVID_OPT_GEMM_FAT = 22, MMVID_OPT_LN_FAST = 23, MMVID_OPT_GEMM_STAGGER = 24, MMVID_OPT_ATTN_PK = 25, MMVID_OPT_COUNT = 26 };
+enum { MMVID_OPT_GEMM_TILE = 0, MMVID_OPT_TOWER_STREAMS = 1, MMVID_OPT_GRAPHS = 2, MMVID_OPT_LN_BWD_BLOCKS = 3, MMVID_OPT_GEMM_SCHED = 4, MMVID_OPT_FUSE_COLSUM = 5, MMVID_OPT_STRIP_SCHED = 6, MMVID_OPT_GEMM_DEBUG = 7, MMVID_OPT_GEMM_WSHAPE = 8, MMVID_OPT_ATTN_OCC = 9, MMVID_OPT_GEMM_PERSIST = 10, MMVID_OPT_GEMM_EPI = 11, MMVID_OPT_DH_BF16 = 12, MMVID_OPT_GEMM_LOADER = 13, MMVID_OPT_GEMM_GROUPN = 14, MMVID_OPT_ATTN_RES = 15, MMVID_OPT_GEMM_FUSED_REDUCE = 16, MMVID_OPT_DW_GROUPED = 17, MMVID_OPT_GEMM_LOADERS = 18, MMVID_OPT_DW_ORDER = 19, MMVID_OPT_GN_FUSED = 20, MMVID_OPT_ATTN_TAIL = 21, MMVID_OPT_GEMM_FAT = 22, MMVID_OPT_LN_FAST = 23, MMVID_OPT_ATTN_PK = 24, MMVID_OPT_COUNT = 25 };
 int mmvid_option(int which);  // errors.hip
 static inline int mmvid_tile_override() { return mmvid_option(MMVID_OPT_GEMM_TILE); }

@@ -87,6 +87,21 @@ __device__ __forceinline__ u64 ld_word(const u64* p) { return __hip_atomic_load(
 __device__ __forceinline__ void st_word(u64* p, uint32_t tag, float v) {
     __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The failure flag (workspace word 1).  A poll that runs out of patience raises it (agent scope: the other XCDs see it) and goes on with
+// whatever it read; every OTHER poll looks at the flag every PD_FLAG_EVERY rounds and gives up at once when it is up -- one time-out
+// ends the launch within a fraction of a millisecond instead of costing ~0.3 s in each of the launch's 60 dependent phases.
+constexpr int PD_FLAG_EVERY = 1024;
+__device__ __forceinline__ void raise_fail(u64* fail) {
+    __hip_atomic_store(fail, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+__device__ __forceinline__ bool give_up(int spins, u64* fail) {
+    if (spins > PD_SPIN) {  // (every later launch on this workspace returns at once: the step is void)
+        raise_fail(fail);
+        return true;
+    }
+    return (spins & (PD_FLAG_EVERY - 1)) == PD_FLAG_EVERY - 1 && ld_word(fail) != 0;
+}
 // N words at p, p + stride, ...: all requested at once, then re-requested one by one until they carry `tag`
 template <int N>
 __device__ __forceinline__ void poll_words(const u64* p, long stride, uint32_t tag, float (&v)[N], u64* fail) {
@@ -99,10 +114,7 @@ __device__ __forceinline__ void poll_words(const u64* p, long stride, uint32_t t
         for (int i = 0; i < N; ++i)
             if (tag && (uint32_t)(w[i] >> 32) != tag) ok = false, w[i] = ld_word(p + i * stride);
         if (ok) break;
-        if (spins > PD_SPIN) {  // (every later launch on this workspace returns at once: the step is void)
-            *fail = 1;
-            break;
-        }
+        if (give_up(spins, fail)) break;
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = __uint_as_float((uint32_t)w[i]);
@@ -120,10 +132,7 @@ __device__ __forceinline__ void poll_fn(F at, uint32_t tag, float (&v)[N], u64* 
         for (int i = 0; i < N; ++i)
             if (tag && (uint32_t)(w[i] >> 32) != tag) ok = false, w[i] = ld_word(at(i));
         if (ok) break;
-        if (spins > PD_SPIN) {
-            *fail = 1;
-            break;
-        }
+        if (give_up(spins, fail)) break;
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = __uint_as_float((uint32_t)w[i]);
@@ -140,10 +149,7 @@ __device__ __forceinline__ void poll_words2(const u64* p, long rs, long cs, uint
         for (int i = 0; i < NR * NC; ++i)
             if (tag && (uint32_t)(w[i] >> 32) != tag) ok = false, w[i] = ld_word(p + (i / NC) * rs + (i % NC) * cs);
         if (ok) break;
-        if (spins > PD_SPIN) {
-            *fail = 1;
-            break;
-        }
+        if (give_up(spins, fail)) break;
     }
 #pragma unroll
     for (int i = 0; i < NR * NC; ++i) v[i] = __uint_as_float((uint32_t)w[i]);
@@ -780,13 +786,19 @@ extern "C" int mmvid_tower_decode_persistent_supported(const mmvid_tower_cfg_t* 
     if (cfg->B < 1 || cfg->B > PD_MAXB) return 0;
     const int S = PD_S;
     if (Lmax < 1 || (Lmax + S - 1) / S > PD_MAXKEYS) return 0;
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0;
+    // the 256 blocks must be resident together: one block per CU at the kernel's own register / LDS footprint, on THIS device
+    static int slots[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (slots[dev] < 0) {
         hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+        int p1 = 0, p2 = 0;
+        const bool ok = hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&p1, (const void*)decode_persistent_kernel<1>, 256, 0) == hipSuccess &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, (const void*)decode_persistent_kernel<2>, 256, 0) == hipSuccess;
+        slots[dev] = ok ? (p1 < p2 ? p1 : p2) * prop.multiProcessorCount : 0;
     }
-    return cus >= PD_BLOCKS ? 1 : 0;  // the 256 blocks must be resident together
+    return slots[dev] >= PD_BLOCKS ? 1 : 0;
 }
 
 // bytes of the workspace; it must be ZERO before its first use and is owned by the decode session from then on

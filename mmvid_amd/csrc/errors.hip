@@ -54,11 +54,10 @@ Opt g_opts[MMVID_OPT_COUNT] = {{"gemm_tile", "MMVID_GEMM_TILE", 0, 0, false},
                                {"gemm_loaders", "MMVID_GEMM_LOADERS", 4, 0, false},
                                {"dw_order", "MMVID_DW_ORDER", 1, 0, false},
                                {"gn_fused", "MMVID_GN_FUSED", 1, 0, false},
-                               {"attn_tail", "MMVID_ATTN_TAIL", 1, 0, false},
+                               {"attn_tail", "MMVID_ATTN_TAIL", 7, 0, false},
                                {"gemm_fat", "MMVID_GEMM_FAT", 0, 0, false},
                                {"ln_fast", "MMVID_LN_FAST", 1, 0, false},
-                               {"gemm_stagger", "MMVID_GEMM_STAGGER", 0, 0, false},
-                               {"attn_pk", "MMVID_ATTN_PK", 1, 0, false}};
+                               {"attn_pk", "MMVID_ATTN_PK", 3, 0, false}};
 }  // namespace
 
 int mmvid_option(int which) {

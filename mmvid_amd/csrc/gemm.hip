@@ -66,7 +66,6 @@ struct GemmParams {
     int tiles_n, tiles_m;  // > 0: persistent blocks walk this tile grid (option gemm_persist); 0: one block per tile
     int group_n;     // persistent blocks: tiles are walked column-GROUP-major (groups of group_n column tiles), see launch_shape
     int defer;       // EPI >= 2: issue a tile's stores from inside the next tile's K loop (persistent blocks)
-    int stagger;     // persistent loader-wave blocks: every other CU of an XCD starts this many 0.1-us ticks late (option gemm_stagger)
     unsigned long long* trace;  // measurement only (mmvid_gemm_trace): per block, wave group and tile 8 time stamps (100 MHz)
     // split-K slabs reduced inside the GEMM (option gemm_fused_reduce): the block that finishes a tile LAST adds the tile's slabs in
     // slab order (+ red_out when red_accumulate) into red_out [M][red_ld]; counters = one int per output tile, zero between launches
@@ -715,16 +714,6 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // three stages, then the bias vector
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Persistent blocks of a multi-round GEMM start together and stay in lock step: all 256 CUs reach their epilogue at once and the
-    // chip alternates between an HBM write burst with idle matrix pipes (16-33 MB per round: 3-7 us at 5 TB/s) and K loops with an
-    // idle write path.  Half of the CUs (every other one of each XCD) therefore start half a tile period late: one half's stores then
-    // drain under the other half's K loops.
-    if constexpr (!GROUPED) {
-        if (p.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
-            const unsigned long long t0 = wall_clock64(), dt = (unsigned long long)p.stagger * 10;  // 100-MHz counter
-            while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     const int wm = FAT ? (wave & 3) >> 1 : (wave & 7) >> 1, wn = wave & 1;  // (FAT: wm = the wave's 128-row half)
     const int ntiles = p.tiles_n > 0 ? p.tiles_n * p.tiles_m : 1;
     const int tile_step = p.tiles_n > 0 ? (int)gridDim.x : 1;
@@ -1125,14 +1114,10 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, S::ROWS), batch * p.splitk);
     GemmParams q = p;
     q.tiles_n = q.tiles_m = 0;
-    q.defer = 0, q.group_n = 0, q.stagger = 0;
+    q.defer = 0, q.group_n = 0;
     q.red_out = nullptr, q.counters = nullptr;  // (set below when the split-K slabs are reduced inside the kernel)
     if (WM == 4 && mmvid_option(MMVID_OPT_GEMM_PERSIST) && (long)grid.x * grid.y > 256) {  // more than one tile per CU
         q.tiles_n = (int)grid.x, q.tiles_m = (int)grid.y;
-        // two or more rounds: stagger the CUs by (about) half a tile period -- the option is that delay in 0.1-us ticks for a K = 768
-        // tile and scales with the K loop's length
-        if ((long)grid.x * grid.y > 400 && grid.z == 1) q.stagger = (int)((long)mmvid_option(MMVID_OPT_GEMM_STAGGER) * (p.K < 768 ? 768 : p.K) / 768);
-        grid = dim3(256, 1, grid.z);
         // Several rounds per CU: an XCD's 32 blocks then meet the same B (weight) column tiles again in every round, and with all
         // column tiles in play (qkv: 3.5 MB, c_fc: 4.7 MB of W next to the A panels) they do not survive in its 4-MB L2 -- PMC r02:
         // 34 % L2 misses, 2.4x the algorithmic reads.  Walking the tiles in column GROUPS keeps one group's B tiles resident:
@@ -1354,7 +1339,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.out_f32 = out_f32, p.out_bf16 = (bf16_t*)out_bf16, p.ldc = ldc;
     p.partial = nullptr, p.colsum = out_colsum;
     p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
-    p.tiles_n = p.tiles_m = 0, p.stagger = 0;
+    p.tiles_n = p.tiles_m = 0;
     p.trace = g_gemm_trace;
     p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
     hipStream_t s = (hipStream_t)stream;
@@ -1398,7 +1383,7 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     p.partial = splitk > 1 ? workspace : nullptr;
     p.colsum = nullptr;
     p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
-    p.tiles_n = p.tiles_m = 0, p.stagger = 0;
+    p.tiles_n = p.tiles_m = 0;
     p.trace = nullptr;
     // split-K: the slabs are added in slab order either by the last block of each output tile inside the GEMM (option
     // gemm_fused_reduce, the 256x128 loader-wave kernel) or by splitk_reduce_kernel -- the same additions in the same order
@@ -1479,7 +1464,7 @@ extern "C" int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_ki
         p.out_f32 = nullptr, p.out_bf16 = nullptr, p.ldc = gt.kinds[0].N;
         p.partial = nullptr, p.colsum = nullptr;
         p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
-        p.tiles_n = p.tiles_m = 0, p.group_n = 0, p.defer = 0, p.stagger = 0;
+        p.tiles_n = p.tiles_m = 0, p.group_n = 0, p.defer = 0;
         p.trace = nullptr;
         p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
         MmvidProfScope prof(PROF_GEMM_TN, flops, (hipStream_t)stream);

@@ -354,21 +354,45 @@ class DALLE(nn.Module):
             tk.E, tk.e_step_stride, tk.e_pos0, tk.temperature, tk.tok_offset, tk.logits_out = E_all.data_ptr(), B * V, first_pos, temperature, 0, None
             draw(0)
             direct = os.environ.get('MMVID_DECODE_TOKEN_GRAPH', '0') == '0'  # one kernel per token: launched directly (a one-node graph replay costs more)
-            for step in range(steps - 1):
+            # Restart point.  The launch needs its 256 blocks resident together; if the device is shared while it runs, a poll times
+            # out, the launch and all later ones on the session's workspace are void, and the failure flag says so.  Every CHECK tokens
+            # the flag is read (one sync per ~15 ms of work) and the token to embed next is kept; after a failure the loop goes back to
+            # the last verified token and finishes with the launches below (five per layer), which need no co-residency.
+            CHECK = 64
+            good_step, good_tok = 0, tok.clone()
+            step = 0
+            while step < steps - 1:
                 if graph is not None:
                     graph.replay()
-                    continue
-                sess.token_step(tk)
-                if step == 1 and not direct:
-                    graph = torch.cuda.CUDAGraph()
-                    side = torch.cuda.Stream()
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        with torch.cuda.graph(graph, stream=side):
-                            sess.token_step(tk)
-                    torch.cuda.current_stream().wait_stream(side)
+                else:
+                    sess.token_step(tk)
+                    if step == 1 and not direct:
+                        graph = torch.cuda.CUDAGraph()
+                        side = torch.cuda.Stream()
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):
+                            with torch.cuda.graph(graph, stream=side):
+                                sess.token_step(tk)
+                        torch.cuda.current_stream().wait_stream(side)
+                step += 1
+                if step % CHECK == 0 or step == steps - 1:
+                    if sess.failed():
+                        break
+                    good_step = step
+                    good_tok.copy_(tok)
+            else:
+                out[:, steps - 1].copy_(tok)
+                return [out[:, i:i + 1] for i in range(steps)]
+            # a persistent launch failed somewhere after token `good_step`: go on from there with the separate launches
+            tok.copy_(good_tok)
+            sess.fall_back(first_pos + good_step)
+            graph = None
+            for step in range(good_step, steps - 1):
+                if step > good_step:
+                    draw(step)
+                advance()
+            draw(steps - 1)
             out[:, steps - 1].copy_(tok)
-            sess.check()
             return [out[:, i:i + 1] for i in range(steps)]
         for step in range(steps - 1):  # every token but the last: draw it, then run it through the tower
             if graph is not None:

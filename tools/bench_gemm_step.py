@@ -3,8 +3,8 @@
 QuickGELU + saved pre-activation, fp32 residual in / out, QuickGELU' operand + fused column sums, bf16 dX outputs -- HIP-event timed,
 TFLOP/s.  (tools/bench_gemm.py times bare X W^T products; the round-4 review asked for like-with-like against the in-situ numbers.)
 
-    python tools/bench_gemm_step.py [stagger values ...]     e.g.  tools/bench_gemm_step.py 0 40 60 80 100
-With values: the sweep of option gemm_stagger (0.1-us ticks per K = 768 tile) on the calls that run more than one round of tiles."""
+    python tools/bench_gemm_step.py [option value ...]     e.g.  tools/bench_gemm_step.py gemm_groupn 0 1
+With an option: one column per value of that library option (mmvid_set_option)."""
 import os
 import sys
 
@@ -45,19 +45,20 @@ CALLS = [
 
 
 def main():
-    vals = [int(v) for v in sys.argv[1:]] or [int(os.environ.get('MMVID_GEMM_STAGGER', '0'))]
-    print(f'{"call":44s} ' + ' '.join(f'{"stagger " + str(v):>18s}' for v in vals))
+    opt = sys.argv[1] if len(sys.argv) > 2 else None
+    vals = [int(v) for v in sys.argv[2:]] if opt else [0]
+    print(f'{"call":44s} ' + ' '.join(f'{(opt or "default") + " " + str(v):>18s}' for v in vals))
     tot = [0.0] * len(vals)
     for name, N, K, fn in CALLS:
         fl = 2.0 * M * N * K
         row = f'{name:44s} '
         for i, v in enumerate(vals):
-            _lib.call('mmvid_set_option', b'gemm_stagger', v)
+            if opt:
+                _lib.call('mmvid_set_option', opt.encode(), v)
             t = timeit(fn, 30)
             tot[i] += t
             row += f'{t * 1e3:8.1f} us {fl / t / 1e9:6.0f} TF '
         print(row)
-    _lib.call('mmvid_set_option', b'gemm_stagger', 0)
     fl = 2.0 * M * (3 * E * E + E * E + 2 * E * F) * 2
     print(f'{"one layer, forward + dX":44s} ' + ' '.join(f'{t * 1e3:8.1f} us {fl / t / 1e9:6.0f} TF ' for t in tot))
 

@@ -40,14 +40,14 @@ def attention():
                   ops._p(dqkv), 3 * E, None, ops._p(ws) if w else None, nws if w else 0, st())
 
     fl = 4.0 * B * H * L * L * 64
-    for pk in (1, 0):
+    fwd(1)
+    for pk in (3, 0):  # bit 0: forward packed, bit 1: dQ packed
         opt('attn_pk', pk)
-        fwd(1)
-        for w in (0, 1):
-            tf, tb = timeit(lambda: fwd(w), 40), timeit(lambda: bwd(w), 40)
-            print(f'attention pk={pk} tail split={"on " if w else "off"}: fwd {tf*1e3:6.1f} us {fl/tf/1e9:6.1f} TF | bwd (dQ + dK/dV) {tb*1e3:6.1f} us '
-                  f'{2.5*fl/tb/1e9:6.1f} TF')
-    opt('attn_pk', 1)
+        for tail in (0, 1, 2, 4, 7):  # bit 0: forward split, bit 1: dQ, bit 2: dK / dV
+            opt('attn_tail', tail)
+            tf, tb = timeit(lambda: fwd(1), 40), timeit(lambda: bwd(1), 40)
+            print(f'attention pk={pk} tail bits={tail}: fwd {tf*1e3:6.1f} us {fl/tf/1e9:6.1f} TF | bwd (dQ + dK/dV) {tb*1e3:6.1f} us {2.5*fl/tb/1e9:6.1f} TF')
+    opt('attn_pk', 3), opt('attn_tail', 7)
 
 
 def layernorm():
