@@ -129,13 +129,6 @@ int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, int64_t hw, 
  * lse2[b][h][q] = log2-domain log-sum-exp, consumed by the backward.  delta: fp32 [B,H,L] scratch. */
 int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, int H, int E, float scale, int mask_mode, int r0,
                         int c0, int r1, int c1, void* out, int64_t ldo, float* lse2, void* stream);
-/* The forward with a caller-provided device workspace of mmvid_attention_bwd_workspace_bytes(B, L, H) bytes (contents undefined on entry and
- * exit; nullptr / 0 = mmvid_attention_fwd): the blocks of the launch's last, partly filled round of resident slots are cut into parts over
- * disjoint key ranges whose (O, max, sum) records a second small launch merges in a fixed order -- bit-reproducible, but a row's rounding
- * then depends on whether its block was in that round (i.e. on B): the workspace-free entry point is the batch-independent one. */
-int mmvid_attention_fwd_ws(const void* qkv, int64_t ld, int B, int L, int H, int E, float scale, int mask_mode, int r0,
-                           int c0, int r1, int c1, void* out, int64_t ldo, float* lse2, void* workspace, int64_t workspace_bytes,
-                           void* stream);
 int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                         const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode,
                         int r0, int c0, int r1, int c1, void* dqkv, int64_t ldg, void* stream);

@@ -59,7 +59,6 @@ SIGNATURES = {
     'mmvid_layernorm_bwd_ex': [P, I, I64, P, I64, P, P, P, I64, I, P, I64, I, P, P, P, P, P, I64, P],
     'mmvid_groupnorm_swish_nhwc': [P, I, I, I64, I, P, P, F, I, P, I, P, P, P],
     'mmvid_attention_fwd': [P, I64, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
-    'mmvid_attention_fwd_ws': [P, I64, I, I, I, I, F, I, I, I, I, I, P, I64, P, P, I64, P],
     'mmvid_attention_bwd': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P],
     'mmvid_attention_bwd_bias': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
     'mmvid_attention_bwd_ws': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P, P, I64, P],

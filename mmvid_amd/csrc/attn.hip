@@ -315,7 +315,7 @@ __device__ __forceinline__ void colsum_rows64(const f32x16 (&acc)[2], float scal
 // (blocks of one (batch, head) are consecutive AND on one XCD: they share K/V (or Q/dO) through that XCD's L2)
 struct TailSplit {
     int nfull, parts_log2, nlogical;
-    float* ws;  // [tail][parts][4 waves][NREG registers][64 lanes] fp32; NREG = 34 (forward), 32 (dQ), 64 (dK/dV)
+    float* ws;  // [tail][parts][4 waves][NREG registers][64 lanes] fp32; NREG = 32 (dQ), 64 (dK/dV)
 };
 struct BlockCoords {
     int rt, hd, b, part, tail_j;
@@ -358,15 +358,14 @@ template <int V>
 using ic = std::integral_constant<int, V>;
 
 // ------------------------------------------------------------------------------------------ forward
-constexpr int FWD_NREG = 34;  // workspace registers per lane of a part: O^T (32), running maximum, row sum
-
 template <bool PK>
 __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int L, int H, int E, FastDiv nrt_d,
                                                            FastDiv h_d, float scale_log2, MaskSpec mask, bf16_t* __restrict__ out,
-                                                           long ldo, float* __restrict__ lse2, TailSplit ts) {
+                                                           long ldo, float* __restrict__ lse2) {
     __shared__ __attribute__((aligned(16))) char smem[2][2 * TILE];  // K tile, V tile, two stages
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, h = lane >> 5;
-    const BlockCoords bc = block_coords(ts, nrt_d, h_d);
+    const TailSplit no_split = {0, 0, 0, nullptr};  // (a key-range split of the last round's blocks was built and measured: +2.5 us,
+    const BlockCoords bc = block_coords(no_split, nrt_d, h_d);  //  profiles/r05_micro_attention_pk_tail_ln_gn.log -- the part records and the merge launch cost more than the 56-block tail)
     const int qt = bc.rt, hd = bc.hd, b = bc.b;
     const bf16_t* Kbase = qkv + (long)b * L * ld + E + hd * 64;
     const bf16_t* Vbase = Kbase + E;
@@ -387,8 +386,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
         const int blk_end = (qt + 1) * ROWS_PER_BLOCK;  // causal: the last key any of these queries may see, + 1
         if (blk_end < L) kv_end = blk_end;
     }
-    int t_begin = 0, t_end = (kv_end + 63) >> 6;
-    if (bc.part >= 0) part_range(ts, bc.part, t_end, t_begin, t_end);  // (never with the causal mask: the launcher)
+    const int t_begin = 0, t_end = (kv_end + 63) >> 6;
 
     TileStage stK, stV;
     stK.init(Kbase, ld, L, wave, lane), stV.init(Vbase, ld, L, wave, lane);
@@ -526,48 +524,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     }
     lsum = half_sum(lsum);
     mfma_settle(oacc[0]), mfma_settle(oacc[1]);
-    if (bc.part >= 0) {  // a part of a tail block: raw accumulators to the workspace, [register][lane] so that a store is 256 contiguous bytes
-        float* w = ts.ws + ((long)(((bc.tail_j << ts.parts_log2) + bc.part) * 4 + wave) * FWD_NREG) * 64 + lane;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) w[(16 * dt + r) * 64] = oacc[dt][r];
-        w[32 * 64] = m_run, w[33 * 64] = lsum;
-        return;
-    }
     if (q < L) {  // (lanes l and l + 32 hold the same row: the half-wave exchange inside store_row64 pairs two active lanes)
         store_row64(out + ((long)b * L + q) * ldo + hd * 64, oacc, 1.0f / lsum, h);
         if (h == 0) lse2[((long)b * H + hd) * L + q] = m_run + log2f(lsum);
-    }
-}
-
-// second launch of a tail-split forward: one block per tail block; a wave merges the parts of its 32 queries in part order --
-// O = sum_p 2^(m_p - m) O_p, l = sum_p 2^(m_p - m) l_p with m = max_p m_p -- and runs the epilogue of attn_fwd_kernel
-__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(int L, int H, FastDiv nrt_d, FastDiv h_d, bf16_t* __restrict__ out, long ldo,
-                                                               float* __restrict__ lse2, TailSplit ts) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
-    const BlockCoords bc = tail_coords(ts, blockIdx.x, nrt_d, h_d);
-    const int q_wave0 = bc.rt * ROWS_PER_BLOCK + wave * 32, q = q_wave0 + l32;
-    if (q_wave0 >= L) return;
-    const int parts = 1 << ts.parts_log2;
-    const float* w0 = ts.ws + ((long)((blockIdx.x << ts.parts_log2) * 4 + wave) * FWD_NREG) * 64 + lane;
-    float m = -INFINITY;
-    for (int p = 0; p < parts; ++p) m = fmaxf(m, w0[((long)p * 4 * FWD_NREG + 32) * 64]);
-    f32x16 o[2] = {zero16(), zero16()};
-    float l = 0.f;
-    for (int p = 0; p < parts; ++p) {
-        const float* w = w0 + (long)p * 4 * FWD_NREG * 64;
-        const float mp = w[32 * 64];
-        const float f = (mp == -INFINITY) ? 0.f : fast_exp2(mp - m);  // (a part whose keys are all masked for this row: nothing)
-        l += f * w[33 * 64];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] += f * w[(16 * dt + r) * 64];
-    }
-    if (q < L) {
-        store_row64(out + ((long)bc.b * L + q) * ldo + bc.hd * 64, o, 1.0f / l, h);
-        if (h == 0) lse2[((long)bc.b * H + bc.hd) * L + q] = m + log2f(l);
     }
 }
 
@@ -988,12 +947,6 @@ static MaskSpec make_mask(int mode, int r0, int c0, int r1, int c1) {
 
 extern "C" int mmvid_attention_fwd(const void* qkv, int64_t ld, int B, int L, int H, int E, float scale, int mask_mode,
                                    int r0, int c0, int r1, int c1, void* out, int64_t ldo, float* lse2, void* stream) {
-    return mmvid_attention_fwd_ws(qkv, ld, B, L, H, E, scale, mask_mode, r0, c0, r1, c1, out, ldo, lse2, nullptr, 0, stream);
-}
-
-extern "C" int mmvid_attention_fwd_ws(const void* qkv, int64_t ld, int B, int L, int H, int E, float scale, int mask_mode,
-                                      int r0, int c0, int r1, int c1, void* out, int64_t ldo, float* lse2, void* workspace,
-                                      int64_t workspace_bytes, void* stream) {
     MMVID_REQUIRE(qkv && out && lse2, "attention_fwd: null pointer");
     ATTN_COMMON_CHECKS("attention_fwd");
     MMVID_REQUIRE(ld % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out & 15) == 0, "attention_fwd: leading dims must be multiples of 8, out 16-byte aligned");
@@ -1003,21 +956,12 @@ extern "C" int mmvid_attention_fwd_ws(const void* qkv, int64_t ld, int B, int L,
     const int nrt = cdiv(L, ROWS_PER_BLOCK), nblocks = nrt * H * B;
     const FastDiv nrt_d = make_fastdiv(nrt), h_d = make_fastdiv(H);
     const MaskSpec m = make_mask(mask_mode, r0, c0, r1, c1);
-    // tail split (see TailSplit): needs the caller's workspace; not for the causal mask (a block's key range depends on its rows)
-    int tail = 0;
-    const bool pk = (mmvid_option(MMVID_OPT_ATTN_PK) & 1) != 0;
-    const void* kern = pk ? (const void*)attn_fwd_kernel<true> : (const void*)attn_fwd_kernel<false>;
-    const TailSplit ts = plan_tail(nblocks, attn_block_slots(kern), (L + 63) >> 6, FWD_NREG, workspace, workspace_bytes,
-                                   mask_mode != 1 && (mmvid_option(MMVID_OPT_ATTN_TAIL) & 1), &tail);
-    const int grid = ts.parts_log2 > 0 ? ts.nfull + (tail << ts.parts_log2) : nblocks;
-    if (pk)
-        hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld, L, H, E, nrt_d, h_d,
-                           scale * 1.4426950408889634f, m, (bf16_t*)out, (long)ldo, lse2, ts);
+    if (mmvid_option(MMVID_OPT_ATTN_PK) & 1)
+        hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld, L, H, E, nrt_d, h_d,
+                           scale * 1.4426950408889634f, m, (bf16_t*)out, (long)ldo, lse2);
     else
-        hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld, L, H, E, nrt_d, h_d,
-                           scale * 1.4426950408889634f, m, (bf16_t*)out, (long)ldo, lse2, ts);
-    if (ts.parts_log2 > 0)
-        hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(tail), dim3(256), 0, s, L, H, nrt_d, h_d, (bf16_t*)out, (long)ldo, lse2, ts);
+        hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)qkv, (long)ld, L, H, E, nrt_d, h_d,
+                           scale * 1.4426950408889634f, m, (bf16_t*)out, (long)ldo, lse2);
     MMVID_LAUNCH_CHECK("attention_fwd");
     return MMVID_OK;
 }
@@ -1085,7 +1029,7 @@ extern "C" int mmvid_attention_bwd_ws(const void* qkv, int64_t ld, const void* O
     return MMVID_OK;
 }
 
-// bytes of workspace with which mmvid_attention_fwd_ws / mmvid_attention_bwd_ws can split the blocks of their last, partly filled round
+// bytes of workspace with which mmvid_attention_bwd_ws can split the blocks of a pass's last, partly filled round
 // (0: nothing to split).  A split is only planned when its part blocks fit the kernel's resident slots together (<= 4 blocks per CU x
 // 256 CUs); the largest part record is dK/dV's: 4 waves x 64 registers x 64 lanes x 4 B = 64 KiB.
 extern "C" int64_t mmvid_attention_bwd_workspace_bytes(int B, int L, int H) {

@@ -647,7 +647,9 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
     }
 #undef PD_STAMP
     if (a.tk.table) {
-        const int V = a.tk.V, NFW = V >> 10;            // classes; head features per wave (V / 256 per block, contiguous)
+        // classes; head features per block (contiguous: ceil(V / 256)) and per wave (ceil of a quarter of those: 1 or 2) -- V = 1,024 and
+        // 2,048 (the models' image vocabularies) fill every wave; smaller vocabularies (the tiny test models) leave waves / blocks idle
+        const int V = a.tk.V, FPB = (V + 255) >> 8, NFW = (FPB + 3) >> 2;
         const uint32_t tagH = seq * 64u + (uint32_t)a.layers * 5u;
         const uint32_t pmh = (a.nowait & 1) ? 0u : 0xffffffffu;
         if (blk == 0 && tid < NB && a.tk.record && pos >= a.tk.record_pos0 && pos - a.tk.record_pos0 < a.tk.record_ld)
@@ -655,10 +657,14 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
         // ---- head: LN_f(x) . W_head^T + b over the image block of the vocabulary
         W768 wh[2];
         float bh[2] = {0.f, 0.f};
-        const int fh0 = blk * (V >> 8) + wave * NFW;
+        const int fh0 = blk * FPB + wave * NFW;
+        bool fon[2];  // (wave-uniform) this wave computes feature fh0 + j
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (j < NFW) wh[j] = load_w768((gbf_p)a.tk.head_w + (long)(fh0 + j) * PD_E, lane), bh[j] = a.tk.head_b[fh0 + j + vz];
+        for (int j = 0; j < 2; ++j) {
+            fon[j] = j < NFW && wave * NFW + j < FPB && fh0 + j < V;
+            const int f = fon[j] ? fh0 + j : 0;
+            wh[j] = load_w768((gbf_p)a.tk.head_w + (long)f * PD_E, lane), bh[j] = a.tk.head_b[f + vz];
+        }
         // the race variates of this block's row (a draw block only): requested before anything is waited for
         float ev[8];
         if (blk < NB) {
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
             const uint2 xb = *reinterpret_cast<const uint2*>(&xs[b][512 + lane * 4]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (j >= NFW) break;
+                if (!fon[j]) continue;
                 const float r = wave_sum_fast(dot768(wh[j], xa, xb)) + bh[j];
                 if (lane == 0) {
                     st_word(LOGITS + (long)b * PD_MAXV + fh0 + j, tagH + 1, r);
@@ -692,7 +698,7 @@ __global__ __launch_bounds__(256) void decode_persistent_kernel(PdArgs a) {
         // ---- draw: block b < B takes row b -- first argmin of E_c / expf(x_c / T - max), the rule of csrc/sample.hip
         if (blk < NB) {
             float xv[8];
-            poll_fn<8>([&](int i) { return LOGITS + (long)blk * PD_MAXV + (i * 256 + tid < V ? i * 256 + tid : tid); }, (tagH + 1) & pmh, xv, fail);
+            poll_fn<8>([&](int i) { return LOGITS + (long)blk * PD_MAXV + (i * 256 + tid < V ? i * 256 + tid : 0); }, (tagH + 1) & pmh, xv, fail);  // (word 0 always arrives)
             float mx = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -829,7 +835,7 @@ extern "C" int mmvid_artv_token_step_persistent(const mmvid_tower_cfg_t* cfg, co
     MMVID_REQUIRE(mmvid_tower_decode_persistent_supported(cfg, Lmax),
                   "artv_token_step_persistent: needs the causal 768 / 3072 / 12-head tower, <= 12 layers, batch <= 2, a device with >= 256 CUs");
     MMVID_REQUIRE(t->tok && t->table && t->pos_rows && t->lnf_w && t->lnf_b && t->head_w && t->head_b && t->E, "artv_token_step_persistent: null pointer in the token block");
-    MMVID_REQUIRE((t->V == 1024 || t->V == 2048) && t->temperature > 0.f, "artv_token_step_persistent: V = %d (1024 or 2048), temperature > 0", t->V);
+    MMVID_REQUIRE(t->V >= 1 && t->V <= 2048 && t->temperature > 0.f, "artv_token_step_persistent: V = %d (1 .. 2048), temperature > 0", t->V);
     PdArgs a;
     a.x_in = nullptr, a.x_out = x_out;
     a.tk.tok = (long long*)t->tok, a.tk.table = t->table, a.tk.table_rows = (long)t->table_rows, a.tk.pos_rows = t->pos_rows, a.tk.pos_off = t->pos_off;

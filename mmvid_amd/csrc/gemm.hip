@@ -1118,6 +1118,7 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     q.red_out = nullptr, q.counters = nullptr;  // (set below when the split-K slabs are reduced inside the kernel)
     if (WM == 4 && mmvid_option(MMVID_OPT_GEMM_PERSIST) && (long)grid.x * grid.y > 256) {  // more than one tile per CU
         q.tiles_n = (int)grid.x, q.tiles_m = (int)grid.y;
+        grid = dim3(256, 1, grid.z);
         // Several rounds per CU: an XCD's 32 blocks then meet the same B (weight) column tiles again in every round, and with all
         // column tiles in play (qkv: 3.5 MB, c_fc: 4.7 MB of W next to the A panels) they do not survive in its 4-MB L2 -- PMC r02:
         // 34 % L2 misses, 2.4x the algorithmic reads.  Walking the tiles in column GROUPS keeps one group's B tiles resident:

@@ -510,139 +510,6 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
     }
 }
 
-struct float8_raw {
-    float4 a, b;
-};
-__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
-    f[0] = bf_lo(u.x), f[1] = bf_hi(u.x), f[2] = bf_lo(u.y), f[3] = bf_hi(u.y);
-    f[4] = bf_lo(u.z), f[5] = bf_hi(u.z), f[6] = bf_lo(u.w), f[7] = bf_hi(u.w);
-}
-__device__ __forceinline__ void unpack8(const float8_raw& r, float (&f)[8]) {
-    f[0] = r.a.x, f[1] = r.a.y, f[2] = r.a.z, f[3] = r.a.w, f[4] = r.b.x, f[5] = r.b.y, f[6] = r.b.z, f[7] = r.b.w;
-}
-
-// Round 5: finalisation + apply in ONE launch (the separate finalize launch was 18 launches of ~7 us per encode).  grid = (blocks per
-// image, N); a block first turns the partial sums of ITS image into the per-channel affine -- the arithmetic of groupnorm_finalize_kernel,
-// operation for operation (lanes stride over the partial blocks by 64, xor butterfly 32..1; the eight groups of a wave run their
-// butterflies side by side so the LDS-crossbar round trips pipeline) -- keeps the 8 + 8 coefficients of its channel chunk in registers,
-// and then streams its share of the image's pixels, four 16-B chunks per thread and iteration with the next four in flight (the
-// one-chunk-per-thread form re-read 64 B of coefficients per 16 B of data).  The grid is ONE round of resident blocks (~1,024: a first
-// version with 1,728 blocks of 512 pixels ran two rounds, the second a third full, and lost 45 % against the separate launches).
-// Outputs are bit-identical to finalize + apply.
-template <typename T>
-__global__ __launch_bounds__(256) void groupnorm_apply_fused_kernel(const T* __restrict__ x, long hw, int C, const float* __restrict__ partial,
-                                                                    int nblk, float cnt, float eps, const float* __restrict__ w,
-                                                                    const float* __restrict__ b, int swish, int pix_per_block,
-                                                                    bf16_t* __restrict__ y_bf16, float* __restrict__ y_f32) {
-    __shared__ float ab[512][2];
-    const int n = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cpg = C >> 5;
-    {
-        float sm[8], sq[8];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) sm[g] = sq[g] = 0.f;
-        // lane l adds partial blocks l, l + 64, ... of each of the wave's eight groups, in that order (finalize's order); the eight groups
-        // of one block are 64 contiguous bytes, and up to four blocks per lane are requested before any is added (left as one loop per
-        // group, hipcc waited for every 8-byte load on its own: ~20 dependent L2 round trips in front of every block's first pixel)
-        for (int k0 = 0; k0 < nblk; k0 += 256) {
-            float4 v[4][4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int k = k0 + kk * 64 + lane;
-                const float4* src = reinterpret_cast<const float4*>(partial + (((long)n * nblk + (k < nblk ? k : 0)) * 32 + wave * 8) * 2);
-                // (a factor instead of a select: hipcc sinks a load under the select's branch and waits for it there; x * 1 = x exactly)
-                const float on = k < nblk ? 1.f : 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 t = src[j];
-                    v[kk][j] = make_float4(t.x * on, t.y * on, t.z * on, t.w * on);
-                }
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    sm[2 * j] += v[kk][j].x, sq[2 * j] += v[kk][j].y;
-                    sm[2 * j + 1] += v[kk][j].z, sq[2 * j + 1] += v[kk][j].w;
-                }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int g = 0; g < 8; ++g) sm[g] += __shfl_xor(sm[g], o, 64), sq[g] += __shfl_xor(sq[g], o, 64);
-        float wv[8], bv0[8];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {  // (all sixteen requests before the first use)
-            const int ch = (wave * 8 + g) * cpg + (lane < cpg ? lane : 0);
-            wv[g] = w[ch], bv0[g] = b[ch];
-        }
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int grp = wave * 8 + g;
-            const float mu = sm[g] / cnt;
-            float var = sq[g] / cnt - mu * mu;
-            var = var < 0.f ? 0.f : var;
-            const float rstd = rsqrtf(var + eps);
-            const float a = rstd * wv[g];
-            if (lane < cpg) {
-                const int ch = grp * cpg + lane;
-                ab[ch][0] = a, ab[ch][1] = bv0[g] - mu * a;
-            }
-        }
-    }
-    __syncthreads();
-    const int cchunks = C >> 3;
-    const int cc = threadIdx.x % cchunks, prow = threadIdx.x / cchunks, pstep = 256 / cchunks;
-    float av[8], bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) av[e] = ab[cc * 8 + e][0], bv[e] = ab[cc * 8 + e][1];
-    const long p0 = (long)blockIdx.x * pix_per_block;
-    long p1 = p0 + pix_per_block;
-    if (p1 > hw) p1 = hw;
-    if (p0 >= p1) return;
-    const long base = (long)n * hw * C + cc * 8;
-    // four chunks per thread and iteration, the NEXT four requested before these are normalised and stored (no branch around a load:
-    // rows past the block's range re-read its last row, their stores are skipped)
-    typedef typename std::conditional<sizeof(T) == 2, uint4, float8_raw>::type raw_t;
-    auto fetch = [&](raw_t (&r)[4], long p) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            long q = p + u * pstep;
-            q = q < p1 ? q : p1 - 1;
-            r[u] = *reinterpret_cast<const raw_t*>(x + base + q * C);
-        }
-    };
-    raw_t cur[4], nxt[4];
-    fetch(nxt, p0 + prow);
-    for (long p = p0 + prow; p < p1; p += 4 * pstep) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
-        fetch(nxt, p + 4 * pstep);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float f[8], o[8];
-            unpack8(cur[u], f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = f[e] * av[e] + bv[e];
-                if (swish) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
-                o[e] = v;
-            }
-            if (p + u * pstep < p1) {
-                const long at = base + (p + u * pstep) * C;
-                if (y_bf16)
-                    *reinterpret_cast<uint4*>(y_bf16 + at) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
-                if (y_f32) {
-                    float4* d = reinterpret_cast<float4*>(y_f32 + at);
-                    d[0] = make_float4(o[0], o[1], o[2], o[3]);
-                    d[1] = make_float4(o[4], o[5], o[6], o[7]);
-                }
-            }
-        }
-    }
-}
-
 // Small maps (hw <= 256 pixels: the 8x8 and 16x16 levels of the VQGAN, one statistics block per image): statistics, finalisation and the
 // apply pass of ONE image in ONE block -- the three launches of the general path were 15 us per GroupNorm for 4 us of work, ten times
 // per encode.  The arithmetic is the general path's, operation for operation (groupnorm_stats_kernel's fixed-order sums with one block,
@@ -961,22 +828,6 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
         else
             hipLaunchKernelGGL(groupnorm_stats_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (long)hw, C,
                                pix_per_block, partial);
-    }
-    if (mmvid_option(MMVID_OPT_GN_FUSED)) {  // finalisation inside the apply launch (bit-identical to the two launches below)
-        // blocks per image so that the launch is one round of ~1,024 resident blocks (4 per CU at <= 128 registers); a block takes
-        // whole multiples of 64 pixels
-        long bpi = 1024 / N;
-        bpi = bpi < 1 ? 1 : bpi;
-        long ppb = (cdiv(hw, bpi) + 63) / 64 * 64;
-        const dim3 grid(cdiv(hw, ppb), N);
-        if (x_is_bf16)
-            hipLaunchKernelGGL(groupnorm_apply_fused_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)hw, C, partial, nblk,
-                               (float)hw * (float)(C / 32), eps, w, b, swish, (int)ppb, (bf16_t*)y_bf16, y_f32);
-        else
-            hipLaunchKernelGGL(groupnorm_apply_fused_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (long)hw, C, partial, nblk,
-                               (float)hw * (float)(C / 32), eps, w, b, swish, (int)ppb, (bf16_t*)y_bf16, y_f32);
-        MMVID_LAUNCH_CHECK("groupnorm");
-        return MMVID_OK;
     }
     hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv((long)N * 32, 4)), dim3(256), 0, s, partial, nblk, N, C,
                        (float)hw * (float)(C / 32), eps, w, b, ab);

@@ -192,11 +192,8 @@ static int tower_forward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower
         if (kv_cache)  // prefill of the incremental decoder: keep this layer's keys and values
             TRY(mmvid_kv_store(sv + sl.qkv, 3 * d.E, d.B, d.L, d.E, nullptr, 0, kv_lmax,
                                (char*)kv_cache + (int64_t)i * d.B * kv_lmax * 2 * d.E * 2, stream));
-        // (training forward: the last round's blocks split through the attention workspace; inference keeps the batch-independent
-        //  workspace-free form, whose rounding of a row never depends on its batch mates)
-        TRY(mmvid_attention_fwd_ws(sv + sl.qkv, 3 * d.E, d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0, cfg->r1,
-                                   cfg->c1, sv + sl.o, d.E, (float*)(sv + sl.lse2), saved ? scr + sc.attn_ws : nullptr,
-                                   saved ? sc.attn_ws_bytes : 0, stream));
+        TRY(mmvid_attention_fwd(sv + sl.qkv, 3 * d.E, d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0, cfg->r1,
+                                cfg->c1, sv + sl.o, d.E, (float*)(sv + sl.lse2), stream));
         TRY(linear_fwd(d.M, d.E, d.E, sv + sl.o, ly.out_w, ly.out_b, x, nullptr, 0, xmid, nullptr, stream));
         TRY(mmvid_layernorm_fwd(xmid, d.E, d.M, d.E, ly.ln2_w, ly.ln2_b, cfg->ln_eps, sv + sl.h2, nullptr, d.E,
                                 (float*)(sv + sl.mean2), (float*)(sv + sl.rstd2), stream));

@@ -345,7 +345,7 @@ class DALLE(nn.Module):
         # batch 1-2 in production: the whole token (embedding -> tower -> head -> draw) is ONE persistent launch (MMVID_DECODE_TOKEN=0: the
         # launches below).  The first token is drawn from the prompt's hidden state the usual way; every launch then embeds the token drawn
         # last, files it in `out`, and draws the next one.
-        if (use_graph and sess.persistent and E_all is not None and V in (1024, 2048) and os.environ.get('MMVID_DECODE_TOKEN', '1') != '0'):
+        if (use_graph and sess.persistent and E_all is not None and V <= 2048 and os.environ.get('MMVID_DECODE_TOKEN', '1') != '0'):
             tk = _lib.DecodeToken()
             tk.tok, tk.table, tk.table_rows, tk.pos_rows, tk.pos_off = tok.data_ptr(), iemb.data_ptr(), iemb.shape[0], pos_rows.data_ptr(), 0
             tk.record, tk.record_ld, tk.record_pos0 = out.data_ptr(), out.stride(0), first_pos

@@ -260,17 +260,14 @@ def _mask_args(mask):
     return 2, rows[0][0], rows[0][1], rows[1][0], rows[1][1]
 
 
-def attention_fwd(qkv, B, L, H, mask=None, scale=0.125, workspace=False):
-    """qkv [B*L, 3E] bf16 -> (out [B*L, E] bf16, lse2 [B,H,L] f32).  workspace=True: the training tower's call, whose last,
-    partly filled round of blocks is split over key ranges (mmvid_attention_fwd_ws); False = the batch-independent entry point."""
+def attention_fwd(qkv, B, L, H, mask=None, scale=0.125):
+    """qkv [B*L, 3E] bf16 -> (out [B*L, E] bf16, lse2 [B,H,L] f32)."""
     _chk(qkv, bf16, 'qkv')
     E = H * 64
     out = torch.empty(B * L, E, device=qkv.device, dtype=bf16)
     lse2 = torch.empty(B, H, L, device=qkv.device, dtype=f32)
-    nbytes = _lib.load().mmvid_attention_bwd_workspace_bytes(B, L, H) if workspace else 0
-    ws = torch.empty(max(nbytes, 16), device=qkv.device, dtype=torch.uint8) if workspace else None
-    call('mmvid_attention_fwd_ws', _p(qkv), 3 * E, B, L, H, E, float(scale), *_mask_args(mask), _p(out), E, _p(lse2),
-         _p(ws) if workspace else None, nbytes, _stream())
+    call('mmvid_attention_fwd', _p(qkv), 3 * E, B, L, H, E, float(scale), *_mask_args(mask), _p(out), E, _p(lse2),
+         _stream())
     return out, lse2
 
 

@@ -208,11 +208,22 @@ def test_persistent_decode_step_matches_the_five_launch_form(B, P):
         close(caches[1][:, :, :P + steps], caches[0][:, :, :P + steps], 1e-2, 'key/value cache')
         assert int(per.ws[1]) == 0 and int(per.ws[0]) == steps
         per.check()
-        # a raised failure flag (a poll that timed out) voids the session loudly, and the kernel returns at once from then on
+        # a raised failure flag (a poll that timed out): the kernel returns at once from then on; step() notices, repeats the position
+        # with the five-launch form and stays there (round 5: it used to hand back a void hidden state until somebody called check())
+        extra = torch.randn(B, 768, device=DEV) * 0.5
+        hr = ref.step(extra).clone()
         per.ws[1] = 1
-        per.step(x[:, P].contiguous())
+        hp = per.step(extra).clone()
+        assert not per.persistent and per.fell_back == 1
+        close(hp, hr, 1e-2, 'the step after a failed persistent launch (five-launch fall-back)')
+        per.check()
+        # without verification the caller keeps its own restart point: the failure stays visible
+        per2 = tw.decode_session(caches[1], P + steps + 1, graph=False)
+        per2.ws[1] = 1
+        per2.step(extra, verify=False)
+        assert per2.failed()
         with pytest.raises(_lib.MMVIDError, match='timed out'):
-            per.check()
+            per2.check()
 
 
 @pytest.mark.parametrize('R,V', [(1, 1024), (16, 1024), (3, 1000), (5, 4099)])

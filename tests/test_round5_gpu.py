@@ -1,5 +1,5 @@
 """Round 5 on the GPU: the re-written attention kernels (mask-free tile loops, padding handled without the general predicate, tail
-splits of all three passes), the GroupNorm finalisation folded into the apply launch, the software-pipelined LayerNorm backward, the
+splits of the backward passes), the software-pipelined LayerNorm backward, the
 encoder's bf16 residual stream (index match rate against the reference before / after)."""
 import numpy as np
 import pytest
@@ -58,85 +58,6 @@ def test_attention_ragged_lengths_and_masks(B, L, H, spec, pk):
         close(dqkv[:, sl], qr.grad[:, sl], 2e-2, f'{nm} L={L}')
 
 
-def test_attention_forward_tail_split_matches_whole_blocks_and_is_reproducible():
-    """mmvid_attention_fwd_ws at the training step's shape (1,080 blocks against 1,024 resident slots): the 56 blocks of the second
-    round are cut into four key-range parts whose (O, max, sum) records are merged by a second launch.  Rows of those blocks differ from
-    the workspace-free call by rounding only (one bf16 ulp), every other row is bit-identical, lse2 agrees to fp32 round-off, two runs
-    are bit-identical; the backward of the split forward's (out, lse2) matches torch like the unsplit one."""
-    from mmvid_amd import ops
-    B, L, H, E = 18, 579, 12, 768
-    torch.manual_seed(12)
-    qkv = (torch.randn(B * L, 3 * E, device=DEV) * 0.5).bfloat16()
-    spec = ('rows', [(65, 65), (66, 66)])
-    whole, lse_w = ops.attention_fwd(qkv, B, L, H, spec)
-    split, lse_s = ops.attention_fwd(qkv, B, L, H, spec, workspace=True)
-    again, lse_a = ops.attention_fwd(qkv, B, L, H, spec, workspace=True)
-    assert torch.equal(split, again) and torch.equal(lse_s, lse_a)
-    w, s_ = whole.float(), split.float()
-    diff = (w - s_).abs()
-    frac = float((diff > 0).float().mean())
-    print(f'forward tail split: {frac:.4f} of the outputs differ, max |d| {float(diff.max()):.3e}, max |d lse2| {float((lse_w - lse_s).abs().max()):.3e}')
-    assert frac < 0.06  # 56 of 1,080 blocks
-    assert bool((diff <= 2.0**-7 * w.abs() + 1e-5 * w.abs().max()).all())
-    assert float((lse_w - lse_s).abs().max()) < 1e-4
-    # a batch whose blocks fit the resident slots is never split: the call with a workspace IS the workspace-free call
-    small = qkv[:4 * L].contiguous()
-    a, la = ops.attention_fwd(small, 4, L, H, spec)
-    b, lb = ops.attention_fwd(small, 4, L, H, spec, workspace=True)
-    assert torch.equal(a, b) and torch.equal(la, lb)
-
-
-@pytest.mark.parametrize('N,H,W,C,dt', [(3, 64, 64, 128, 'bf16'), (2, 32, 32, 256, 'f32'), (2, 128, 128, 128, 'bf16'), (5, 24, 24, 64, 'f32'),
-                                        (2, 16, 16, 512, 'bf16')])
-@pytest.mark.parametrize('swish', [True, False])
-def test_groupnorm_finalisation_inside_the_apply_launch_is_bit_identical(N, H, W, C, dt, swish):
-    """Option gn_fused (default 1): per-channel affine computed by every apply block from the partial sums (csrc/norm.hip
-    groupnorm_apply_fused_kernel) against the separate finalize launch + one-chunk-per-thread apply -- the same operations in the same
-    order: bit-identical outputs, own statistics pass and ragged pixel counts included."""
-    from mmvid_amd import _lib, ops
-    torch.manual_seed(C + H)
-    x = torch.randn(N, H, W, C, device=DEV) * 1.5 + 0.3
-    x = x.bfloat16() if dt == 'bf16' else x
-    w, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
-    outs = []
-    try:
-        for flag in (0, 1):
-            _lib.call('mmvid_set_option', b'gn_fused', flag)
-            outs.append(ops.groupnorm_swish(x, w, b, swish=swish))
-            outs.append(ops.groupnorm_swish(x, w, b, swish=swish, out_dtype=torch.float32))
-    finally:
-        _lib.call('mmvid_set_option', b'gn_fused', 1)
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
-    xf = x.float()
-    g = xf.view(N, H * W, 32, C // 32)
-    mu, var = g.mean((1, 3), keepdim=True), g.var((1, 3), unbiased=False, keepdim=True)
-    ref = ((g - mu) * torch.rsqrt(var + 1e-6)).view(N, H, W, C) * w + b
-    if swish:
-        ref = ref * torch.sigmoid(ref)
-    close(outs[3], ref, 2e-4, 'fused groupnorm vs torch')
-
-
-def test_groupnorm_fold_with_conv_fused_statistics_keeps_the_encoder_bit_identical(golden):
-    """The same switch through a whole encode (the partial sums then come from the convolutions' epilogues, per 128 / 64 pixels):
-    z and the token indices are bit-identical."""
-    from mmvid_amd import _lib
-    from mmvid_amd.vae import VQGanVAE1024
-    from oracle.synth import synth_input
-    g = golden('vqgan_full')
-    img = synth_input('img', (g.meta['n'], 3, 128, 128), 11, 'uniform').to(DEV)
-    res = []
-    try:
-        for flag in (0, 1):
-            _lib.call('mmvid_set_option', b'gn_fused', flag)
-            vae = VQGanVAE1024(None, 128)
-            vae.image_size = 128
-            load_synth(vae, g, 11)
-            res.append((vae.get_codebook_indices(img), vae.encode_z(img)))
-    finally:
-        _lib.call('mmvid_set_option', b'gn_fused', 1)
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-
-
 @pytest.mark.parametrize('E,rows', [(768, 10422), (768, 77), (512, 1000)])
 @pytest.mark.parametrize('dy16', [True, False])
 def test_layernorm_backward_pipelined_kernel_is_bit_identical(E, rows, dy16):
@@ -165,8 +86,12 @@ def test_layernorm_backward_pipelined_kernel_is_bit_identical(E, rows, dy16):
             res.append((dx, d16, dw, db, cs, dx2))
     finally:
         _lib.call('mmvid_set_option', b'ln_fast', 1)
-    for a, c in zip(res[0], res[1]):
-        assert torch.equal(a, c)
+    names = ('dx', 'dx bf16', 'dw', 'db', 'colsum', 'dx (store form)')
+    for nm, a, c in zip(names, res[0], res[1]):
+        d = (a.float() - c.float()).abs().max().item()
+        print(f'LN backward, pipelined vs generic, {nm}: max |d| {d:.3e} of max {a.float().abs().max().item():.3e}, equal {torch.equal(a, c)}')
+    for nm, a, c in zip(names, res[0], res[1]):
+        assert torch.equal(a, c), nm
     xr = x.clone().requires_grad_(True)
     wr = w.clone().requires_grad_(True)
     torch.nn.functional.layer_norm(xr, (E, ), wr, b, 1e-5).backward(dy.float())
@@ -219,3 +144,70 @@ def test_bert_golden_frames_token_match_with_both_streams(golden):
             rate = float((tt == g['target_tok']).float().mean())
             print(f'{name}, encoder stream {stream}: {100 * rate:.2f} % of the reference tokens')
             assert rate > 0.9
+
+
+def test_artv_one_launch_token_step_pinned_to_the_reference_logits(golden):
+    """mmvid_artv_token_step_persistent (what generate_images runs at batch 1-2) teacher-forced on artv_tiny.npz's token sequence: the
+    logits it hands out at prefix lengths 5 and 31 against the REFERENCE's (logits_k5_img / logits_k31_img), every step's logits against
+    the five-launch decode step + head, and every drawn token against oracle/sampling.py::token_race on the same injected variates --
+    directly, not through the chain of kernel-vs-kernel comparisons of round 4."""
+    from mmvid_amd import _lib, ops
+    from mmvid_amd.dalle_artv import DALLE
+    from oracle import sampling as S
+    from oracle import vqgan
+    from conftest import synth_model_sd
+    from test_host_logic import tiny_vae
+    g = golden('artv_tiny')
+    m = DALLE(dim=768, vae=tiny_vae(), cvae=None, num_text_tokens=49408, text_seq_len=16, which_transformer='openai_clip_visual',
+              num_visuals=1, num_targets=2, transformer_layers=2)
+    load_synth(m, g, 19)
+    m.eval()
+    text, tt = g['text'].to(DEV), g['target_tok'].to(DEV)
+    sd = synth_model_sd(g, 19)
+    vt = vqgan.get_codebook_indices(sd, g['visual'].reshape(-1, 3, 64, 64), 64, 'vae.model.').view(2, -1).to(DEV)
+    B, tsl = text.shape[0], m.text_seq_len
+    torch.manual_seed(3)
+    with torch.no_grad():
+        pad_ids = torch.arange(tsl, device=DEV) + (m.num_text_tokens - tsl)
+        tx = torch.nn.functional.pad(torch.where(text == 0, pad_ids, text), (1, 0), value=0)
+        prompt = torch.cat((tx, vt), 1)
+        P = prompt.shape[1]
+        c0, c1 = m._allowed_range(m.control_seq_len)
+        V = c1 - c0
+        caches = [m.transformer.new_kv_cache(B, m.total_seq_len, DEV) for _ in range(2)]
+        for c in caches:
+            m.transformer.prefill(m._embed_rows(prompt, 0), c)
+        one = m.transformer.decode_session(caches[0], P, graph=False)
+        ref = m.transformer.decode_session(caches[1], P, graph=False, fused='launches')
+        assert one.persistent, 'the persistent step must take the tiny ART-V tower (2 layers, batch 2)'
+        lin, ln = m.to_logits[1], m.to_logits[0]
+        w_blk, b_blk = m._w16()[c0:c1], lin.bias.detach()[c0:c1].contiguous()
+        pos_rows, iemb = m._pos_rows().detach().contiguous(), m.image_emb.weight.detach()
+        lnw, lnb = ln.weight.detach(), ln.bias.detach()
+        steps = 31
+        Eall = torch.empty(steps + 1, B, V, device=DEV).exponential_()
+        tok = torch.empty(B, dtype=torch.long, device=DEV)
+        record = torch.full((B, steps + 1), -1, dtype=torch.long, device=DEV)
+        logits_o = torch.empty(B, V, device=DEV)
+        tk = _lib.DecodeToken()
+        tk.tok, tk.table, tk.table_rows, tk.pos_rows, tk.pos_off = tok.data_ptr(), iemb.data_ptr(), iemb.shape[0], pos_rows.data_ptr(), 0
+        tk.record, tk.record_ld, tk.record_pos0 = record.data_ptr(), record.stride(0), P
+        tk.lnf_w, tk.lnf_b, tk.lnf_eps, tk.head_w, tk.head_b, tk.V = lnw.data_ptr(), lnb.data_ptr(), ln.eps, w_blk.data_ptr(), b_blk.data_ptr(), V
+        tk.E, tk.e_step_stride, tk.e_pos0, tk.temperature, tk.tok_offset, tk.logits_out = Eall.data_ptr(), B * V, P, 1.0, 0, logits_o.data_ptr()
+        seen = 0
+        for k in range(steps):
+            tok.copy_(tt[:, k])  # teacher forcing: the golden token k goes in, the logits for token k + 1 come out
+            one.token_step(tk)
+            torch.cuda.synchronize()
+            h_r = ref.step(m._embed_rows(tt[:, k:k + 1], P + k)[:, 0, :])
+            logits_r = torch.empty(B, V, device=DEV)
+            ops.gemv_rows(h_r, w_blk, b_blk, ln=(lnw, lnb, ln.eps), round_in=True, out=logits_r)
+            close(logits_o, logits_r, 1e-2, f'one-launch token step vs five-launch step + head, {k + 1} image tokens')
+            if f'logits_k{k + 1}_img' in g:
+                close(logits_o, g[f'logits_k{k + 1}_img'], 3e-2, f'one-launch token step vs the REFERENCE logits, {k + 1} image tokens')
+                seen += 1
+            assert torch.equal(record[:, k], tt[:, k]) and int(one.pos) == P + k + 1
+            want, _, _ = S.token_race(logits_o, Eall[k + 1], logit_div=1.0)
+            assert np.array_equal(tok.cpu().numpy(), want), (k, tok.tolist(), want.tolist())
+        assert seen >= 2
+        one.check()

@@ -32,8 +32,7 @@ def attention():
     rows = (2, 65, 65, 66, 66)
 
     def fwd(w):
-        _lib.call('mmvid_attention_fwd_ws', ops._p(qkv), 3 * E, B, L, H, E, 0.125, *rows, ops._p(out), E, ops._p(lse), ops._p(ws) if w else None,
-                  nws if w else 0, st())
+        _lib.call('mmvid_attention_fwd', ops._p(qkv), 3 * E, B, L, H, E, 0.125, *rows, ops._p(out), E, ops._p(lse), st())
 
     def bwd(w):
         _lib.call('mmvid_attention_bwd_ws', ops._p(qkv), 3 * E, ops._p(out), E, ops._p(dO), E, ops._p(lse), ops._p(delta), B, L, H, E, 0.125, *rows,
@@ -43,7 +42,7 @@ def attention():
     fwd(1)
     for pk in (3, 0):  # bit 0: forward packed, bit 1: dQ packed
         opt('attn_pk', pk)
-        for tail in (0, 1, 2, 4, 7):  # bit 0: forward split, bit 1: dQ, bit 2: dK / dV
+        for tail in (0, 2, 4, 6):  # bit 1: dQ split, bit 2: dK / dV split
             opt('attn_tail', tail)
             tf, tb = timeit(lambda: fwd(1), 40), timeit(lambda: bwd(1), 40)
             print(f'attention pk={pk} tail bits={tail}: fwd {tf*1e3:6.1f} us {fl/tf/1e9:6.1f} TF | bwd (dQ + dK/dV) {tb*1e3:6.1f} us {2.5*fl/tb/1e9:6.1f} TF')
