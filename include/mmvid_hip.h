@@ -46,9 +46,8 @@ int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void*
                     int64_t ldc, float* out_colsum,
                     void* stream);
 
-/* Measurement only (tools/gemm_timeline.py): per-block time stamps of the next 256x128 GEMM launches; NULL switches it off. */
-int mmvid_gemm_trace(void* dev_buf);
-/* and for the decode gemv (csrc/decode.hip): [512 blocks][8] stamps of the next mmvid_gemv_rows launches (tools/bench_decode_step.py). */
+/* Measurement only: [512 blocks][8] time stamps (100-MHz wall clock) of the next mmvid_gemv_rows launches (csrc/decode.hip;
+ * tools/bench_decode_step.py); NULL switches it off. */
 int mmvid_decode_trace(void* dev_buf);
 /* and for the persistent decode step (csrc/decode_persistent.hip): [4 blocks][12 layers][16] stamps (tools/decode_persistent_timeline.py). */
 int mmvid_decode_persistent_trace(void* dev_buf);
@@ -138,16 +137,6 @@ int mmvid_attention_bwd(const void* qkv, int64_t ld, const void* O, int64_t ldo,
 int mmvid_attention_bwd_bias(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
                              const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode, int r0,
                              int c0, int r1, int c1, void* dqkv, int64_t ldg, float* dbias, void* stream);
-/* The same with a caller-provided device workspace of mmvid_attention_bwd_workspace_bytes(B, L, H) bytes (contents undefined on entry and
- * exit; nullptr / 0 = mmvid_attention_bwd_bias).  With it the dQ and the dK/dV pass cut the blocks of their last, partly filled round of
- * resident blocks into parts over disjoint key / query ranges and add the parts in a fixed order: results stay bit-reproducible run to
- * run, and differ from the workspace-free call only by fp32 summation order in those blocks.  (Not used under the causal mask.) */
-int mmvid_attention_bwd_ws(const void* qkv, int64_t ld, const void* O, int64_t ldo, const void* dO, int64_t lddo,
-                           const float* lse2, float* delta, int B, int L, int H, int E, float scale, int mask_mode, int r0,
-                           int c0, int r1, int c1, void* dqkv, int64_t ldg, float* dbias, void* workspace,
-                           int64_t workspace_bytes, void* stream);
-int64_t mmvid_attention_bwd_workspace_bytes(int B, int L, int H);
-
 /* ---- sequence assembly + losses: dalle_bert.py:899-973,1030-1040; dalle_artv.py:441-491,526-539. */
 int mmvid_assemble_sequence(const float* const* tables, const int64_t* table_rows, int ntables, const int64_t* ids,
                             const int32_t* seg, const float* pos, int64_t B, int L, int E, float* out, void* stream);
@@ -567,10 +556,8 @@ int mmvid_prof_end(double* ms, int64_t* sampled, double* flops, int64_t* launche
  * counts[0..2] = sequences run directly / captured / replayed since the library was loaded. */
 int mmvid_graph_stats(int64_t* counts);
 
-/* ---- tuning knobs for A/B measurements (tools/ab_graph.py); each is also read from an environment variable at first
- * use.  "gemm_tile" (MMVID_GEMM_TILE): 0 = GEMM / conv block shape by grid fill, 128 | 256 = forced.
- * "tower_streams" (MMVID_TOWER_STREAMS): 1 = tower backward on the caller's stream (default), 2 = weight-gradient
- * chains on an internal side stream.  "graphs" (MMVID_GRAPHS): 1 = library-level graph replay (default 0). */
+/* ---- run-time options; each is also read from an environment variable at first use.  "graphs" (MMVID_GRAPHS): 1 = library-level
+ * graph replay (default 0).  Unknown names return MMVID_ERR_ARG. */
 int mmvid_set_option(const char* name, int value);
 
 #ifdef __cplusplus

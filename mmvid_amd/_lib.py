@@ -61,7 +61,6 @@ SIGNATURES = {
     'mmvid_attention_fwd': [P, I64, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
     'mmvid_attention_bwd': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P],
     'mmvid_attention_bwd_bias': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P, P],
-    'mmvid_attention_bwd_ws': [P, I64, P, I64, P, I64, P, P, I, I, I, I, F, I, I, I, I, I, P, I64, P, P, I64, P],
     'mmvid_assemble_sequence': [POINTER(P), POINTER(I64), I, P, P, P, I64, I, I, P, P],
     'mmvid_assemble_sequence_bwd': [POINTER(P), POINTER(I64), I, P, P, P, I64, I, I, P, I, P],
     'mmvid_cross_entropy_fwd': [P, I64, P, P, I64, I, P, P, P],
@@ -128,7 +127,6 @@ SIGNATURES = {
     'mmvid_groupnorm_swish_nhwc_f32': [P, I, I64, I, P, P, F, I, P, P, P],
     'mmvid_spatial_attention_f32': [P, P, P, I, I, I, F, P, P, P],
     'mmvid_probe': [I, P, P, P],
-    'mmvid_gemm_trace': [P],
     'mmvid_prof_begin': [I],
     'mmvid_prof_enable': [I],
     'mmvid_graph_stats': [P],
@@ -144,7 +142,6 @@ SIGNATURES = {
 }
 OTHER = {'mmvid_last_error': ([], c_char_p), 'mmvid_abi_version': ([], I), 'mmvid_device_count': ([], I),
          'mmvid_warp_params_bytes': ([], I), 'mmvid_gemm_dw_multi_fill': ([I, P, I], ctypes.c_double),
-         'mmvid_attention_bwd_workspace_bytes': ([I, I, I], I64),
          'mmvid_tower_decode_persistent_supported': ([POINTER(TowerCfg), I], I),
          'mmvid_tower_decode_persistent_workspace_bytes': ([I], I64)}
 

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
             compute_tile(cur);
         }
     } else if constexpr (PP != 0) {  // two-group ping-pong (gemm_core.h)
-        k_loop_pingpong<false, false, PP == 2>(
+        k_loop_pingpong<false, false>(
             smem, nt, wave, lane, wm, wn, acc, [&](int t, char* buf) { sa.issue(p, (kt0 + t) * BK, buf, wave); },
             [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); });
     } else {  // 3-stage ring with counted vmcnt (see gemm.hip)
@@ -511,25 +511,19 @@ static int conv2d_launch(int terms, int mode, const void* x, int N, int Hin, int
     MMVID_REQUIRE((long)N * Hin * Win * Cin * 2 * (terms > 1 ? 2 : 1) < (1ll << 31) && (long)Cout * p.K * 2 < (1ll << 31),
                   "conv2d_nhwc: input or weight of 2 GiB or more (32-bit buffer offsets)");
     MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * p.K, (hipStream_t)stream);  // executed MFMA work (3x for split)
-    const int tile = mmvid_tile_override();
     bool big = false;
     // with fused GroupNorm statistics the block shape must not depend on the batch size: the order in which a
     // 128-pixel block's partial sums are formed differs between the shapes, and a frame's tokens must not depend on
     // which other frames share its batch (tests/test_models_gpu.py::test_vqgan_roundtrip_full_size).  It is therefore
     // chosen from the layer's own geometry.
     if (gn_partial) {
-        big = tile == 256 || (tile != 128 && (long)p.Hout * p.Wout >= 4096);
-    } else if (splitk == 1 && (tile == 256 || (tile != 128 && (long)cdiv(p.M, 256) * cdiv(Cout, BN) >= 200))) {
+        big = (long)p.Hout * p.Wout >= 4096;
+    } else if (splitk == 1 && (long)cdiv(p.M, 256) * cdiv(Cout, BN) >= 200) {
         big = true;
     }
     const bool fast = Cin % 64 == 0 && mode != 2;
-    const int sched = mmvid_option(MMVID_OPT_GEMM_SCHED);
-    if (big && fast && sched == 2)
-        launch_conv<4, true, 2>(p, (hipStream_t)stream);
-    else if (big && fast && sched == 1)
-        launch_conv<4, true, 1>(p, (hipStream_t)stream);
-    else if (big && fast)
-        launch_conv<4, true>(p, (hipStream_t)stream);
+    if (big && fast)
+        launch_conv<4, true, 1>(p, (hipStream_t)stream);  // two-group ping-pong K loop
     else if (big)
         launch_conv<4, false>(p, (hipStream_t)stream);
     else if (fast)

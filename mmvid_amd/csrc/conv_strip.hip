@@ -44,11 +44,9 @@ struct StripParams {
     float* gn_partial;  // [N][H*W/64][32][2] or null
 };
 
-// SCHED 0: the LDS-DMA requests of tile t+1 are issued right after the barrier that starts tile t (all eight waves at once);
-// SCHED 1: they are spread over the first three k-steps of tile t (three pieces behind each group of eight MFMAs), so that a
-//          wave's DMA issue stalls fall into its SIMD partner's MFMA time instead of lining up across the block;
-// SCHED 2: two-group ping-pong: the block's halves alternate between a load part and a 16-MFMA cluster, one barrier apart.
-template <int SCHED>
+// K loop: two-group ping-pong -- the block's halves alternate between a load part and a 16-MFMA cluster, one barrier apart.  (Rounds
+// 1-2 also carried a one-barrier-per-tile loop with the LDS-DMA requests right behind the barrier, and one with the requests spread
+// over the first three k-steps: 18.59 / 18.53 / 18.49 ms per step, profiles/r01_ab_gemm_sched*.log; removed in round 5.)
 __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -147,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     };
-    if constexpr (SCHED == 2) {
+    {
         // ---- two-group ping-pong (MI355X_MICROARCH.md "Two waves per SIMD"): waves 0-3 and 4-7 -- one of each per SIMD -- run one
         // barrier apart, so that on every SIMD one wave is in its MFMA cluster while the other requests operands.  A phase is one
         // kx (two k-steps): LOAD part = 12 fragment reads (+ this wave's LDS-DMA requests of the next tile), COMPUTE part = 16
@@ -204,41 +202,7 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
             }
         }
         if (wave < 4) __builtin_amdgcn_s_barrier();  // the leading group waits for the trailing one
-    } else {
-    stage_tile(0, smem);
-        int ky_n = 0, ch_n = 0, term_n = 0;  // (term, kernel row, channel chunk) of the NEXT tile, advanced without a division
-        for (int t = 0; t < nt; ++t) {
-            const uint32_t st = (uint32_t)(t & 1) * STAGE;
-            char* nxt = smem + ((t + 1) & 1) * STAGE;
-            if (++ch_n == chunks) {
-                ch_n = 0;
-                if (++ky_n == 3) ky_n = 0, ++term_n;
-            }
-            const bool more = t + 1 < nt;
-            dma_publish_barrier();  // tile t has landed for every wave; buffer (t+1)&1 is free
-            if (SCHED == 0 && more) stage_tile(t + 1, nxt);
-            // descriptor / offsets of the next tile's requests: scalar work, once per tile
-            const rsrc_t arsrc = make_rsrc(reinterpret_cast<const char*>(p.x) + (more ? a_disp(term_n, ky_n, ch_n) : 0), 0x7fffffffu);
-            const uint32_t bit = 1u << ky_n;
-            const uint32_t bsoff = b_soff(term_n, ky_n, ch_n);
-            bf16x8_t fa[2][2], fb[2][4];
-            load_frags(st, 0, fa[0], fb[0]);
-    #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                if (q < 5) load_frags(st, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);  // next k-step's operands fly under these MFMAs
-                mma8(fa[q & 1], fb[q & 1]);
-                if (SCHED == 1 && q < 3 && more) {  // one third of the next tile's LDS-DMA requests behind each of the first three groups
-    #pragma unroll
-                    for (int jj = 0; jj < PA; ++jj)
-                        if (jj / 2 == q) blds16(arsrc, (amask[jj] & bit) ? avoff[jj] : OOB, 0, nxt + (wave * PA + jj) * 1024);
-    #pragma unroll
-                    for (int jj = 0; jj < PB; ++jj)
-                        if (jj == q || (q == 2 && jj == 3)) blds16(brsrc, bvoff[jj], bsoff, nxt + A_STAGE + (wave * PB + jj) * 1024);
-                }
-            }
-        }
-    
-}
+    }
     // ---- epilogue: per wave a private [32][132] fp32 slab, two passes (i = 0, 1); global traffic is row-contiguous
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -361,19 +325,12 @@ static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, 
     if (p.M == 0) return MMVID_OK;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_strip_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_strip_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_strip_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
         attr = true;
     }
     MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * 9 * Cin * terms, (hipStream_t)stream);
     const int blocks = cdiv(p.M, ST_M) * (Cout / ST_N);
-    if (mmvid_option(MMVID_OPT_STRIP_SCHED) >= 2)
-        hipLaunchKernelGGL(conv_strip_kernel<2>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
-    else if (mmvid_option(MMVID_OPT_STRIP_SCHED) == 1)
-        hipLaunchKernelGGL(conv_strip_kernel<1>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv_strip_kernel<0>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv_strip_kernel, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
     MMVID_LAUNCH_CHECK("conv3x3_strip");
     return MMVID_OK;
 }

@@ -398,11 +398,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
     __shared__ float stat[2][NW];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = tid >> 3, dc = tid & 7;
-    const int n = min((pos_dev ? *pos_dev : pos0) + 1, Lmax);  // (never beyond the cache)
-    // a short cache is one round trip for four waves already: the others leave (the block size is fixed when the step is captured,
-    // the position is not; 16 waves at position 129 cost the step 12 us)
-    const int nw = (NW > 4 && n <= 512) ? 4 : NW;
-    if (wave >= nw) return;
+    const int n_all = min((pos_dev ? *pos_dev : pos0) + 1, Lmax);  // (never beyond the cache)
+    // a short cache is one round trip for four waves already: the others do nothing (the block size is fixed when the step is captured,
+    // the position is not; 16 waves at position 129 cost the step 12 us).  They stay alive with an empty key range -- no loads, no
+    // stores -- so that every wave of the block reaches every barrier below.
+    const int nw = (NW > 4 && n_all <= 512) ? 4 : NW;
+    const int n = wave < nw ? n_all : 0;
     const int NT = nw * 64, NG = nw * 8;
     const bf16_t* kv = cache + (long)b * Lmax * 2 * E + h * 64 + dc * 8;
     // the first batch of keys does not depend on q: requested before it

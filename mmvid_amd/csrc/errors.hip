@@ -33,31 +33,7 @@ struct Opt {
     int dflt, value;
     bool set;
 };
-Opt g_opts[MMVID_OPT_COUNT] = {{"gemm_tile", "MMVID_GEMM_TILE", 0, 0, false},
-                               {"tower_streams", "MMVID_TOWER_STREAMS", 1, 0, false},
-                               {"graphs", "MMVID_GRAPHS", 0, 0, false},
-                               {"ln_bwd_blocks", "MMVID_LN_BWD_BLOCKS", 512, 0, false},
-                               {"gemm_sched", "MMVID_GEMM_SCHED", 2, 0, false},
-                               {"fuse_colsum", "MMVID_FUSE_COLSUM", 1, 0, false},
-                               {"strip_sched", "MMVID_STRIP_SCHED", 2, 0, false},
-                               {"gemm_debug", "MMVID_GEMM_DEBUG", 0, 0, false},
-                               {"gemm_wshape", "MMVID_GEMM_WSHAPE", 0, 0, false},
-                               {"attn_occ", "MMVID_ATTN_OCC", 0, 0, false},
-                               {"gemm_persist", "MMVID_GEMM_PERSIST", 1, 0, false},
-                               {"gemm_epi", "MMVID_GEMM_EPI", 1, 0, false},
-                               {"dh_bf16", "MMVID_DH_BF16", 1, 0, false},
-                               {"gemm_loader", "MMVID_GEMM_LOADER", 1, 0, false},
-                               {"gemm_groupn", "MMVID_GEMM_GROUPN", 1, 0, false},
-                               {"attn_res", "MMVID_ATTN_RES", 0, 0, false},
-                               {"gemm_fused_reduce", "MMVID_GEMM_FUSED_REDUCE", 0, 0, false},
-                               {"dw_grouped", "MMVID_DW_GROUPED", 1, 0, false},
-                               {"gemm_loaders", "MMVID_GEMM_LOADERS", 4, 0, false},
-                               {"dw_order", "MMVID_DW_ORDER", 1, 0, false},
-                               {"gn_fused", "MMVID_GN_FUSED", 1, 0, false},
-                               {"attn_tail", "MMVID_ATTN_TAIL", 7, 0, false},
-                               {"gemm_fat", "MMVID_GEMM_FAT", 0, 0, false},
-                               {"ln_fast", "MMVID_LN_FAST", 1, 0, false},
-                               {"attn_pk", "MMVID_ATTN_PK", 3, 0, false}};
+Opt g_opts[MMVID_OPT_COUNT] = {{"graphs", "MMVID_GRAPHS", 0, 0, false}};
 }  // namespace
 
 int mmvid_option(int which) {
@@ -77,7 +53,7 @@ extern "C" int mmvid_set_option(const char* name, int value) {
             g_opts[i].value = value, g_opts[i].set = true;
             return MMVID_OK;
         }
-    mmvid_set_error("set_option: unknown option '%s' (gemm_tile, tower_streams, graphs, ln_bwd_blocks, gemm_sched, fuse_colsum, strip_sched, gemm_debug, gemm_wshape, attn_occ, gemm_persist, gemm_epi, dh_bf16, gemm_loader, gemm_groupn, attn_res, gemm_fused_reduce, dw_grouped, gemm_loaders, dw_order, gn_fused, attn_tail, gemm_fat)", name);
+    mmvid_set_error("set_option: unknown option '%s' (graphs)", name);
     return MMVID_ERR_ARG;
 }
 

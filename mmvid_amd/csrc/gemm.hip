@@ -62,17 +62,8 @@ struct GemmParams {
     long ldc;
     float* partial;  // split-K workspace [splitk][M][N] (plain stores, reduced by splitk_reduce_kernel) or null
     float* colsum;   // [N] += column sums of the stored result (the bias gradient when the result is a dY), or null
-    int debug;       // option gemm_debug (measurement only): 1 = no global stores, 2 = no K loop
-    int tiles_n, tiles_m;  // > 0: persistent blocks walk this tile grid (option gemm_persist); 0: one block per tile
+    int tiles_n, tiles_m;  // > 0: persistent blocks walk this tile grid (more tiles than CUs); 0: one block per tile
     int group_n;     // persistent blocks: tiles are walked column-GROUP-major (groups of group_n column tiles), see launch_shape
-    int defer;       // EPI >= 2: issue a tile's stores from inside the next tile's K loop (persistent blocks)
-    unsigned long long* trace;  // measurement only (mmvid_gemm_trace): per block, wave group and tile 8 time stamps (100 MHz)
-    // split-K slabs reduced inside the GEMM (option gemm_fused_reduce): the block that finishes a tile LAST adds the tile's slabs in
-    // slab order (+ red_out when red_accumulate) into red_out [M][red_ld]; counters = one int per output tile, zero between launches
-    float* red_out;
-    long red_ld;
-    int red_accumulate;
-    int* counters;
 };
 // Second kernel argument of the grouped launch (mmvid_gemm_bf16_dw_multi): grid.x = all tiles of all kinds and groups; a block finds
 // its (kind, group, tile) here and patches its private copy of GemmParams (A, B, M, N, lda, ldb, ldc, out_f32).  The outputs are
@@ -82,15 +73,6 @@ struct GroupTable {
     GroupKind kinds[KIND_MAX];
     float* out_list[GROUP_MAX];
 };
-// counters of the fused split-K reduction: a ring (every launch takes the next `tiles` entries), zero-initialised with the module
-// and left zero by every launch, so neither an allocation nor a memset is ever needed (graph capture safe)
-constexpr int RED_RING = 16384;
-__device__ int g_red_counters[RED_RING];
-int g_red_cursor = 0;
-thread_local bool g_last_launch_fused = false;
-unsigned long long* g_gemm_trace = nullptr;
-constexpr int TRACE_TILES = 8;
-
 // sigmoid(1.702 x) on the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 right after): an IEEE division here is
 // ~10 VALU instructions per element, and the epilogue of the c_fc GEMM evaluates 32,768 of them per tile with no MFMA to hide under
 __device__ __forceinline__ float sigmoid1702(float x) {
@@ -161,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, char* smem, f
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int m = mrow[k];
-            if (!n_ok || m >= p.M || p.debug == 1) continue;
+            if (!n_ok || m >= p.M) continue;
             float v[4] = {v4[k].x * p.alpha + bias4.x, v4[k].y * p.alpha + bias4.y, v4[k].z * p.alpha + bias4.z,
                           v4[k].w * p.alpha + bias4.w};
             if (p.partial) {
@@ -209,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, char* smem, f
 }
 
 
-// ---- register-direct epilogue (option gemm_epi = 1; 256x128 blocks).  A lane of the swapped-operand 32x32x16 MFMA holds, for
+// ---- register-direct epilogue (256x128 blocks).  A lane of the swapped-operand 32x32x16 MFMA holds, for
 // fragment (i, j) and q = 0..3, four consecutive columns n = bn0 + wn*64 + j*32 + 8q + 4*(lane>>5) of row m = bm0 + wm*64 + i*32 +
 // (lane&31): one 16-B (fp32) / 8-B (bf16) piece, so a store instruction writes 32 B / 16 B into each of 32 rows and the eight
 // (j, q) stores of a fragment row fill one 128-B line.  Poorly coalesced per instruction -- but it needs no LDS slab and no
@@ -218,7 +200,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, char* smem, f
 // 32-row slab behind two barriers, then the first-tile latency of the next tile behind the in-order vmcnt of the stores:
 // profiles/r02_gemm_anatomy.log).  Every global access goes through a buffer descriptor with out-of-range lanes pointed at the
 // OOB marker: the instruction count per wave is then a compile-time constant (no exec-masked branches skipping stores), which
-// is what lets k_loop_pingpong's first waits be counted exactly (stores_after_prologue).
+// keeps the MFMA waves' instruction stream free of divergence.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 struct DirectEpi {
@@ -240,59 +222,28 @@ struct DirectEpi {
         nst = 16 * ((has_save ? 1 : 0) + (has_f32 ? 1 : 0) + (has_bf16 ? 1 : 0));
     }
 };
-// ---- deferred form (persistent blocks, bf16 outputs, N % 128 == 0): the finished tile is turned into its PACKED bf16 results
-// (bias / activation applied; 32 dwords per output tensor and lane) and the stores are issued a few at a time from inside the
-// NEXT tile's K loop (k_loop_pingpong's `drain`).  Measured why (tools/gemm_timeline.py, profiles/r03_gemm_timeline_*): all 256
-// blocks reach their epilogue together and the chip takes a 16-32 MB write burst at ~2.5-4 TB/s -- 3.8-11 us per round during
-// which the matrix pipe idles, against 10.7 us of K loop; spread over the next K loop the same bytes are ~1.6 TB/s of
-// background traffic.
+// ---- packed bf16 form (bf16 outputs, N % 128 == 0): the finished tile is turned into its PACKED bf16 results (bias / activation
+// applied; 32 dwords per output tensor and lane) and stored with eight 16-B stores per tensor.  (Round 3 also issued these stores a
+// few at a time from inside the next tile's K loop of the loader-less kernel; with the loader waves the MFMA waves' stores drain on
+// their own and that form was removed.)
 template <int NOUT>
 struct Pending {
     u32x4_t v[NOUT][2][2][2];   // [tensor][i][j][k]: 16 B = 8 consecutive bf16 columns of one row (after the half-wave exchange)
     uint32_t row[NOUT][2];      // byte offset of (row m_i, this lane's first column of j = k = 0), or OOB
-    int left;                   // store slots not yet issued (counts down from 8; a slot = one store per tensor)
 };
+// the 8 * NOUT stores of a tile, one store per tensor in (i, j, k) order
 template <int NOUT>
-__device__ __forceinline__ void pending_store(const DirectEpi& d, const Pending<NOUT>& pd, int o, int s) {
-    // s = 0..7 -> (i, j, k); a uniform switch: the register operands must be static
-    const rsrc_t r = (NOUT == 2 && o == 0) ? d.r_pre_out : d.r_bf16;
-#define MMVID_PS(I, J, K) __builtin_amdgcn_raw_buffer_store_b128(pd.v[o][I][J][K], r, pd.row[o][I] + (J * 64 + K * 32), 0, 0)
-    switch (s) {
-        case 0: MMVID_PS(0, 0, 0); break;
-        case 1: MMVID_PS(0, 0, 1); break;
-        case 2: MMVID_PS(0, 1, 0); break;
-        case 3: MMVID_PS(0, 1, 1); break;
-        case 4: MMVID_PS(1, 0, 0); break;
-        case 5: MMVID_PS(1, 0, 1); break;
-        case 6: MMVID_PS(1, 1, 0); break;
-        default: MMVID_PS(1, 1, 1); break;
-    }
-#undef MMVID_PS
-}
-// one drain slot = one store per output tensor, in (i, j, k) order; returns how many instructions were issued
-template <int NOUT>
-struct DrainSlot {
-    const DirectEpi* d;
-    Pending<NOUT>* pd;
-    __device__ __forceinline__ int operator()(int) const {
-        if (pd->left <= 0) return 0;
-        const int s = 8 - pd->left;
+__device__ __forceinline__ void pending_flush(const DirectEpi& d, const Pending<NOUT>& pd) {
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) pending_store<NOUT>(*d, *pd, o, s);
-        pd->left -= 1;
-        return NOUT;
-    }
-};
-template <int NOUT>
-__device__ __forceinline__ int pending_flush(const DirectEpi& d, Pending<NOUT>& pd) {
-    const int n = pd.left > 0 ? pd.left * NOUT : 0;
-    while (pd.left > 0) {
-        const int s = 8 - pd.left;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) pending_store<NOUT>(d, pd, o, s);
-        pd.left -= 1;
-    }
-    return n;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o)
+                    __builtin_amdgcn_raw_buffer_store_b128(pd.v[o][i][j][k], (NOUT == 2 && o == 0) ? d.r_pre_out : d.r_bf16,
+                                                           pd.row[o][i] + (j * 64 + k * 32), 0, 0);
 }
 // the half-wave exchange of MI355X_MICROARCH / cdna_hip_programming.md T21: a lane holds columns 8q + 4 fh .. +3 of its row for q =
 // 0..3; v_permlane32_swap on (q = 2k, q = 2k+1) leaves lanes 0-31 with columns 16k .. 16k+7 and lanes 32-63 with 16k+8 .. 16k+15:
@@ -370,7 +321,7 @@ __device__ __forceinline__ void pending_fill(const GemmParams& p, const BiasRegs
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = bm0 + wm * 64 + i * 32 + frow;
-        const bool ok = m < p.M && p.debug != 1;
+        const bool ok = m < p.M;
         if constexpr (NOUT == 2) pd.row[0][i] = ok ? (uint32_t)(((long)m * p.ldp + n0) * 2) : OOB;
         pd.row[NOUT - 1][i] = ok ? (uint32_t)(((long)m * p.ldc + n0) * 2) : OOB;
 #pragma unroll
@@ -396,7 +347,6 @@ __device__ __forceinline__ void pending_fill(const GemmParams& p, const BiasRegs
             }
         }
     }
-    pd.left = 8;
 }
 
 // accumulators * QuickGELU'(pre) -> packed bf16 (+ column sums of what is stored): the d_pre GEMM of the tower backward
@@ -413,7 +363,7 @@ __device__ __forceinline__ void pending_fill_dact(const GemmParams& p, const Pre
     for (int i = 0; i < 2; ++i) {
         const int m = bm0 + wm * 64 + i * 32 + frow;
         const bool live = m < p.M;
-        pd.row[0][i] = (live && p.debug != 1) ? (uint32_t)(((long)m * p.ldc + n0) * 2) : OOB;
+        pd.row[0][i] = live ? (uint32_t)(((long)m * p.ldc + n0) * 2) : OOB;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             u32x2_t out[4];
@@ -440,7 +390,6 @@ __device__ __forceinline__ void pending_fill_dact(const GemmParams& p, const Pre
             for (int k = 0; k < 2; ++k) pd.v[0][i][j][k] = widen_pair(out[2 * k], out[2 * k + 1]);
         }
     }
-    pd.left = 8;
     if (p.colsum) colsum_wave(cs, p.colsum, bn0, wn, lane, p.N);
 }
 
@@ -450,11 +399,10 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
 #pragma unroll
     for (int i = 0; i < 2; ++i) mfma_settle(acc[i][0]), mfma_settle(acc[i][1]);
     const int frow = lane & 31, fh = lane >> 5;
-    const bool no_store = p.debug == 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = bm0 + wm * 64 + i * 32 + frow;
-        const bool m_ok = m < p.M && !no_store;
+        const bool m_ok = m < p.M;
         f32x4 add4[2][4];
         u32x2_t pre2[2][4];
         uint32_t eoff[2][4];  // element offsets m * ld + n for ld = ldc; OOB when out of range
@@ -516,40 +464,21 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
     }
 }
 
-template <bool AKM, bool BKM, int WM, int PP, int EPI = 0>
+// The LDS-epilogue kernel: 128x128 blocks (WM = 2: small grids, two LDS stages, two blocks per CU) and the 256x128 ping-pong block
+// for what the loader-wave kernel below does not take (split-K with atomics, column sums of a general result, N > 4096).
+template <bool AKM, bool BKM, int WM>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(GemmParams p) {
     using S = BlockShape<WM>;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSTAGE][A sub-tiles | B tile]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS bases stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
-    // p.tiles_n > 0: PERSISTENT blocks (option gemm_persist) -- gridDim.x blocks walk the p.tiles_n x p.tiles_m output tiles in
-    // XCD-aware order, so a CU pays the block turnover once per launch instead of once per tile
+    // p.tiles_n > 0: PERSISTENT blocks -- gridDim.x blocks walk the p.tiles_n x p.tiles_m output tiles in XCD-aware order, so a CU
+    // pays the block turnover once per launch instead of once per tile
     const int ntiles = p.tiles_n > 0 ? p.tiles_n * p.tiles_m : 1;
     const int tile_step = p.tiles_n > 0 ? (int)gridDim.x : 1;
     const int batch = blockIdx.z / p.splitk, ks = blockIdx.z % p.splitk;
-    // EPI = 1 (ping-pong 256x128 blocks only): register-direct epilogue.  The bias vector lives in the 16 KiB of LDS above the
-    // three stages (read with ds_read: no vmcnt traffic between the prologue loads and the stores)
-    [[maybe_unused]] DirectEpi de;
-    [[maybe_unused]] float* bias_lds = nullptr;
-    [[maybe_unused]] int stores_after_prologue = -1;
-    constexpr int NOUT = EPI == 3 ? 2 : 1;
-    [[maybe_unused]] Pending<NOUT> pend;
-    if constexpr (EPI >= 2) pend.left = 0;
-    if constexpr (EPI >= 1) {
-        de.init(p, batch);
-        if (p.bias) {
-            bias_lds = reinterpret_cast<float*>(smem + S::LDS_BYTES);
-            for (int e = tid; e < p.N; e += S::THREADS) bias_lds[e] = p.bias[e];
-            __syncthreads();
-        }
-    }
-  int tile_no = 0;
-  for (int tile = p.tiles_n > 0 ? (int)blockIdx.x : 0; tile < ntiles; tile += tile_step, ++tile_no) {
-    unsigned long long* stamp = nullptr;
-    if (p.trace && lane == 0 && (wave & 3) == 0 && tile_no < TRACE_TILES)
-        stamp = p.trace + ((((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 2 + (wave >> 2)) * TRACE_TILES + tile_no) * 8;
-    if (stamp) stamp[0] = wall_clock64();
+  for (int tile = p.tiles_n > 0 ? (int)blockIdx.x : 0; tile < ntiles; tile += tile_step) {
     const int gx = p.tiles_n > 0 ? p.tiles_n : (int)gridDim.x;
     const int wg = p.tiles_n > 0 ? xcd_remap(tile, ntiles) : xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
     const int bn0 = (wg % gx) * BN, bm0 = (wg / gx) * S::ROWS;
@@ -562,7 +491,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     const int kt0 = ks * per;
     int kt1 = kt0 + per;
     if (kt1 > ktiles_total) kt1 = ktiles_total;
-    const int nt = p.debug == 2 ? 0 : kt1 - kt0;
+    const int nt = kt1 - kt0;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -576,119 +505,46 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_bf16_kernel(Ge
     OperandStage<BKM, 1, S::PPW> sb;
     sa.init(A, p.lda, p.M, p.K, bm0, wave, lane);
     sb.init(B, p.ldb, p.N, p.K, bn0, wave, lane);
-    if constexpr (EPI >= 2) {
-        // packed bf16 result(s): stored with 16-B-per-lane buffer stores AFTER the next tile's first two K tiles have been
-        // requested; with p.defer the stores are issued from inside the next tile's K loop instead (one slot per K tile)
-        auto issueA = [&](int t, char* buf) { sa.issue((kt0 + t) * BK, p.K, buf, wave, lane); };
-        auto issueB = [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); };
-        k_loop_pingpong<AKM, BKM, PP == 2>(smem, nt, wave, lane, wm, wn, acc, issueA, issueB, stores_after_prologue, stamp,
-                                           DrainSlot<NOUT>{&de, &pend});
-        if (stamp) stamp[2] = wall_clock64();
-        int pre_stores = pending_flush<NOUT>(de, pend);  // what the K loop had no slot for (short K), before the registers are reused
-        // bias registers (LDS reads) -> the next tile's prologue -> the math -> this tile's stores
-        BiasRegs br;
-        bias_load(bias_lds, bn0, wn, lane, br);
-        const int next = tile + tile_step;
-        if (next < ntiles) {
-            const int wg2 = xcd_remap(next, ntiles);
-            const int bn2 = (wg2 % gx) * BN, bm2 = (wg2 / gx) * S::ROWS;
-            sa.init(A, p.lda, p.M, p.K, bm2, wave, lane);
-            sb.init(B, p.ldb, p.N, p.K, bn2, wave, lane);
-            if (pre_stores) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (rare) keep the counted waits exact
-            pp_prologue(smem, nt, issueA, issueB);
-            stores_after_prologue = 0;
-        }
-        if (stamp) stamp[3] = wall_clock64();
-        pending_fill<NOUT>(p, br, acc, pend, bm0, bn0, wm, wn, lane);
-        if (next >= ntiles || !p.defer) {
-            const int n = pending_flush<NOUT>(de, pend);
-            if (next < ntiles) stores_after_prologue = n;  // 8 or 16, younger than the prologue
-        }
-        if (stamp) stamp[4] = wall_clock64();
-        continue;
-    }
-    if constexpr (EPI == 1) {
-        auto issueA = [&](int t, char* buf) { sa.issue((kt0 + t) * BK, p.K, buf, wave, lane); };
-        auto issueB = [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); };
-        // (the first tile's prologue is issued inside the loop call; later tiles' were issued before the previous epilogue)
-        k_loop_pingpong<AKM, BKM, PP == 2>(smem, nt, wave, lane, wm, wn, acc, issueA, issueB, stores_after_prologue, stamp);
-        if (stamp) stamp[2] = wall_clock64();
-        // every wave is past its last MFMA cluster (the loop's closing barrier), i.e. past its last LDS read: all three stages
-        // are free.  Request the NEXT tile's first two K tiles, then store this tile from the registers.
-        const int next = tile + tile_step;
-        if (next < ntiles) {
-            const int wg2 = xcd_remap(next, ntiles);
-            const int bn2 = (wg2 % gx) * BN, bm2 = (wg2 / gx) * S::ROWS;
-            sa.init(A, p.lda, p.M, p.K, bm2, wave, lane);
-            sb.init(B, p.ldb, p.N, p.K, bn2, wave, lane);
-            pp_prologue(smem, nt, issueA, issueB);
-            stores_after_prologue = de.nst;
-        }
-        if (stamp) stamp[3] = wall_clock64();
-        gemm_epilogue_direct(p, de, bias_lds, acc, bm0, bn0, wm, wn, lane);
-        if (stamp) stamp[4] = wall_clock64();
-        continue;
-    }
-    auto stage_tile = [&](int t, char* buf) {
-        const int k0 = (kt0 + t) * BK;
-        sa.issue(k0, p.K, buf, wave, lane);
-        sb.issue(k0, p.K, buf + S::NSUB * TILE_BYTES, wave, lane);
-    };
-    auto compute_tile = [&](const char* buf) {
-        mma_tile<AKM, BKM>(buf + (wm >> 1) * TILE_BYTES, buf + S::NSUB * TILE_BYTES, acc, wm & 1, wn, lane);
-    };
     if constexpr (S::NSTAGE == 2) {
         // 2 stages, one barrier per K tile: the barrier (behind an explicit vmcnt(0)) makes tile t
         // visible to every wave and proves everyone is done reading the buffer tile t+1 overwrites.
+        auto stage_tile = [&](int t, char* buf) {
+            const int k0 = (kt0 + t) * BK;
+            sa.issue(k0, p.K, buf, wave, lane);
+            sb.issue(k0, p.K, buf + S::NSUB * TILE_BYTES, wave, lane);
+        };
         if (nt > 0) stage_tile(0, smem);
         for (int t = 0; t < nt; ++t) {
             char* cur = smem + (t & 1) * S::STAGE_BYTES;
             char* nxt = smem + ((t + 1) & 1) * S::STAGE_BYTES;
             dma_publish_barrier();
             if (t + 1 < nt) stage_tile(t + 1, nxt);
-            compute_tile(cur);
+            mma_tile<AKM, BKM>(cur + (wm >> 1) * TILE_BYTES, cur + S::NSUB * TILE_BYTES, acc, wm & 1, wn, lane);
         }
-    } else if constexpr (PP != 0) {
-        k_loop_pingpong<AKM, BKM, PP == 2>(
+    } else {  // three stages, two-group ping-pong (gemm_core.h)
+        k_loop_pingpong<AKM, BKM>(
             smem, nt, wave, lane, wm, wn, acc, [&](int t, char* buf) { sa.issue((kt0 + t) * BK, p.K, buf, wave, lane); },
-            [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); }, -1, stamp);
-        if (stamp) stamp[2] = wall_clock64();
-    } else {
-        // 3-stage ring: tile t+2 is requested right after the barrier that ends tile t-1 (its buffer is free then);
-        // each wave only waits for ITS OWN pieces of tile t (counted vmcnt: tile t+1's stay in flight).
-        char* b0 = smem;
-        char* b1 = smem + S::STAGE_BYTES;
-        char* b2 = smem + 2 * S::STAGE_BYTES;
-        if (nt > 0) stage_tile(0, b0);
-        if (nt > 1) stage_tile(1, b1);
-        for (int t = 0; t < nt; ++t) {
-            if (t + 1 < nt)
-                wait_dma_and_barrier<S::DMA_PER_TILE>();
-            else
-                wait_dma_and_barrier<0>();
-            if (t + 2 < nt) stage_tile(t + 2, b2);
-            compute_tile(b0);
-            char* tmp = b0;
-            b0 = b1, b1 = b2, b2 = tmp;
-        }
+            [&](int t, char* buf) { sb.issue((kt0 + t) * BK, p.K, buf + S::NSUB * TILE_BYTES, wave, lane); });
     }
 
     gemm_epilogue<S::THREADS, 64, 2>(p, smem, acc, bm0, bn0, batch, ks, tid, wm, wn, lane);
-    if (stamp) stamp[4] = wall_clock64();
     if (tile + tile_step < ntiles) __syncthreads();  // the slab has been read: the next tile's DMA may overwrite the stages
   }
 }
 
 // ================================================================================================================
-// Loader-wave form of the 256x128 block (option gemm_loader, default): 8 MFMA waves + NLOAD loader waves (gemm_core.h,
-// k_loop_loader / k_loop_consumer), register-direct epilogues only (EPI 1: general, 2 / 3: packed bf16 with one / two outputs).
-// The loader requests the next output tile's first two K tiles while the MFMA waves are in their epilogue, so a persistent block
-// streams operands continuously; the MFMA waves never wait on vmcnt (their epilogue stores drain on their own).
-// FAT (option gemm_fat): four MFMA waves of 128 x 64 instead of eight of 64 x 64 (gemm_core.h, k_loop_consumer_fat) + the NL loader waves
-template <bool AKM, bool BKM, int EPI, bool GROUPED, int NL = mmvid_core::NLOAD, bool FAT = false>
+// Loader-wave form of the 256x128 block: 8 MFMA waves + NLOAD loader waves (gemm_core.h, k_loop_loader / k_loop_consumer),
+// register-direct epilogues only (EPI 1: general, 2 / 3: packed bf16 with one / two outputs, 4: packed bf16 x QuickGELU'(pre) + column
+// sums).  The loader requests the next output tile's first two K tiles while the MFMA waves are in their epilogue, so a persistent
+// block streams operands continuously; the MFMA waves never wait on vmcnt (their epilogue stores drain on their own).
+// (Measured and removed in round 5, logs under profiles/: four 128x64 "fat" MFMA waves (r04_gemm_fat_wave_experiment.log: 0.93-1.02x
+//  per shape), sixteen waves with eight loaders, storer waves (r04_gemm_storer_wave_experiment.log), split-K slabs reduced by the last
+//  block of a tile (a device-scope release = a write-back of the XCD's L2 per block: +105 us per weight-gradient GEMM), staggered
+//  starts of the persistent blocks (r05_gemm_layer_calls_stagger_sweep_rejected.log).)
+template <bool AKM, bool BKM, int EPI, bool GROUPED>
 __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt) {
     using S = BlockShape<4>;
-    constexpr int NMW = FAT ? 4 : 8;  // MFMA waves
+    constexpr int NMW = 8, NL = NLOAD;  // MFMA waves, loader waves
     int multi_bm0 = 0, multi_bn0 = 0;
     if constexpr (GROUPED) {  // this block's (kind, group, tile): every XCD walks a contiguous stretch of the (kind, group, row, column) order
         const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -714,7 +570,7 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // three stages, then the bias vector
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = FAT ? (wave & 3) >> 1 : (wave & 7) >> 1, wn = wave & 1;  // (FAT: wm = the wave's 128-row half)
+    const int wm = (wave & 7) >> 1, wn = wave & 1;
     const int ntiles = p.tiles_n > 0 ? p.tiles_n * p.tiles_m : 1;
     const int tile_step = p.tiles_n > 0 ? (int)gridDim.x : 1;
     // blockIdx.z = batch entry, or (split-K: batch 1) the K range whose partial product goes to slab z of the workspace
@@ -726,7 +582,7 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
     const int ktiles_total = (p.K + BK - 1) / BK;
     const int per = (ktiles_total + p.splitk - 1) / p.splitk;
     const int kt0 = ks * per;
-    const int nt = p.debug == 2 ? 0 : (kt0 + per > ktiles_total ? (ktiles_total - kt0 > 0 ? ktiles_total - kt0 : 0) : per);
+    const int nt = kt0 + per > ktiles_total ? (ktiles_total - kt0 > 0 ? ktiles_total - kt0 : 0) : per;
     float* bias_lds = nullptr;
     if (p.bias) {
         bias_lds = reinterpret_cast<float*>(smem + S::LDS_BYTES);
@@ -759,20 +615,13 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
             int bm0, bn0;
             if (!have) {
                 tile_origin(tile, bm0, bn0);
-                if (p.debug == 11) bm0 = bn0 = 0;  // (timing experiment: every block streams the same operand tiles)
                 sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0), sa.init_offsets(2, w, lane), sb.init_offsets(1, w, lane);
                 loader_prologue<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
             }
-            if constexpr (FAT)
-                k_loop_loader_fat<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
-            else if (p.debug > 2)
-                k_loop_loader<AKM, BKM, NL, true>(sa, sb, smem, kt0, nt, p.K, w, lane, p.debug);
-            else
-                k_loop_loader<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
+            k_loop_loader<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
             have = false;
             if (tile + tile_step < ntiles) {  // every stage is free: stream the next output tile's first K tiles during the epilogue
                 tile_origin(tile + tile_step, bm0, bn0);
-                if (p.debug == 11) bm0 = bn0 = 0;
                 sa.init(A, p.lda, p.M, p.K, bm0), sb.init(B, p.ldb, p.N, p.K, bn0), sa.init_offsets(2, w, lane), sb.init_offsets(1, w, lane);
                 loader_prologue<AKM, BKM, NL>(sa, sb, smem, kt0, nt, p.K, w, lane);
                 have = true;
@@ -784,48 +633,8 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
     de.init(p, batch);
     constexpr int NOUT = EPI == 3 ? 2 : 1;
     [[maybe_unused]] Pending<NOUT> pend;
-    if constexpr (FAT) {  // ---------------------------------------------------------------- the four 128 x 64 MFMA waves
-        for (int tile = first; tile < ntiles; tile += tile_step) {
-            int bm0, bn0;
-            tile_origin(tile, bm0, bn0);
-            f32x16 acc[2][2][2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
-            [[maybe_unused]] PreRegs pre_in[2];
-            if constexpr (EPI == 4) pre_load(p, de, bm0, bn0, 2 * wm, wn, lane, pre_in[0]), pre_load(p, de, bm0, bn0, 2 * wm + 1, wn, lane, pre_in[1]);
-            k_loop_consumer_fat<AKM, BKM>(smem, nt, lane, wm, wn, acc);
-            // the epilogues of a 64 x 64 wave, once per 64-row half (acc[h] has that wave's layout at wave row 2 wm + h)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int wr = 2 * wm + h;
-                if constexpr (EPI == 4) {
-                    pending_fill_dact(p, pre_in[h], acc[h], pend, bm0, bn0, wr, wn, lane);
-                    pending_flush<1>(de, pend);
-                } else if constexpr (EPI >= 2) {
-                    BiasRegs br;
-                    bias_load(bias_lds, bn0, wn, lane, br);
-                    pending_fill<NOUT>(p, br, acc[h], pend, bm0, bn0, wr, wn, lane);
-                    pending_flush<NOUT>(de, pend);
-                } else {
-                    gemm_epilogue_direct(p, de, bias_lds, acc[h], bm0, bn0, wr, wn, lane);
-                }
-            }
-        }
-        return;  // (the fused split-K reduction below is an eight-wave form; the launcher does not combine it with gemm_fat)
-    }
     // ------------------------------------------------------------------------------------- the eight MFMA waves
-    int tile_no = 0;
-    for (int tile = first; tile < ntiles; tile += tile_step, ++tile_no) {
-        unsigned long long* stamp = nullptr;
-        if (p.trace && lane == 0 && (wave & 3) == 0 && tile_no < TRACE_TILES)
-            stamp = p.trace + ((((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 2 + (wave >> 2)) * TRACE_TILES + tile_no) * 8;
-        if (stamp) stamp[0] = wall_clock64();
+    for (int tile = first; tile < ntiles; tile += tile_step) {
         int bm0, bn0;
         tile_origin(tile, bm0, bn0);
         f32x16 acc[2][2];
@@ -837,242 +646,28 @@ __device__ __forceinline__ void gemm_lw_body(GemmParams p, const GroupTable* gt)
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
         [[maybe_unused]] PreRegs pre_in;
         if constexpr (EPI == 4) pre_load(p, de, bm0, bn0, wm, wn, lane, pre_in);
-        if (stamp) stamp[5] = __builtin_readcyclecounter();  // shader clock (s_memtime), against the 100-MHz stamps: the actual frequency
-        if (p.debug || p.trace)
-            k_loop_consumer<AKM, BKM, true>(smem, nt, wave, lane, wm, wn, acc, stamp, p.debug);
-        else
-            k_loop_consumer<AKM, BKM>(smem, nt, wave, lane, wm, wn, acc);
-        if (stamp) stamp[2] = wall_clock64(), stamp[6] = __builtin_readcyclecounter(), stamp[7] = wall_clock64();
+        k_loop_consumer<AKM, BKM>(smem, nt, wave, lane, wm, wn, acc);
         if constexpr (EPI == 4) {
-            if (stamp) stamp[3] = wall_clock64();
             pending_fill_dact(p, pre_in, acc, pend, bm0, bn0, wm, wn, lane);
             pending_flush<1>(de, pend);
         } else if constexpr (EPI >= 2) {
             BiasRegs br;
             bias_load(bias_lds, bn0, wn, lane, br);
-            if (stamp) stamp[3] = wall_clock64();
             pending_fill<NOUT>(p, br, acc, pend, bm0, bn0, wm, wn, lane);
             pending_flush<NOUT>(de, pend);
         } else {
-            if (stamp) stamp[3] = wall_clock64();
             gemm_epilogue_direct(p, de, bias_lds, acc, bm0, bn0, wm, wn, lane);
-        }
-        if (stamp) stamp[4] = wall_clock64();
-    }
-    // ---- split-K slabs (option gemm_fused_reduce, default OFF): the last block to finish this tile adds its slabs in slab order (the
-    // arithmetic of splitk_reduce_kernel, bit for bit) -- no reduce launch.  Release: this block's slab stores, device-wide, before
-    // its count; acquire: the counter value before any slab is read.  MEASURED NEGATIVE on this 8-XCD part: the device-scope
-    // release is a write-back of the XCD's whole L2 (buffer_wbl2), paid by every block -- the captured training step went from
-    // 16.03 to 21.17 ms (+105 us per weight-gradient GEMM) against the 0.4 ms the 49 reduce launches cost (tools/ab_graph.py).
-    if constexpr (EPI == 1) {
-        if (p.red_out) {
-            // (the flag lives in the first stage: the K loop is over, and the dynamic LDS of this kernel is already the CU's 160 KiB)
-            volatile int* s_last = reinterpret_cast<volatile int*>(smem);
-            __threadfence();
-            __syncthreads();  // (the loader waves have returned: the barrier counts the eight MFMA waves)
-            const int tile = blockIdx.x + gridDim.x * blockIdx.y;
-            if (tid == 0) *s_last = atomicAdd(p.counters + tile, 1) == p.splitk - 1;
-            __syncthreads();
-            if (*s_last) {
-                __threadfence();
-                int bm0, bn0;
-                tile_origin(0, bm0, bn0);
-                const long mn = (long)p.M * p.N;
-#pragma unroll 4
-                for (int k = 0; k < 16; ++k) {
-                    const int idx = tid + 512 * k, r = idx >> 5, c = (idx & 31) * 4;
-                    const int m = bm0 + r, n = bn0 + c;
-                    if (m >= p.M || n >= p.N) continue;
-                    float4 a = p.red_accumulate ? *reinterpret_cast<const float4*>(p.red_out + (long)m * p.red_ld + n) : make_float4(0, 0, 0, 0);
-                    const float* src = p.out_f32 + (long)m * p.N + n;
-                    for (int sidx = 0; sidx < p.splitk; ++sidx) {
-                        const float4 v = *reinterpret_cast<const float4*>(src + sidx * mn);
-                        a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
-                    }
-                    *reinterpret_cast<float4*>(p.red_out + (long)m * p.red_ld + n) = a;
-                }
-                if (tid == 0) p.counters[tile] = 0;
-            }
         }
     }
 }
 
-template <bool AKM, bool BKM, int EPI, int NL = mmvid_core::NLOAD>
-__global__ __launch_bounds__(512 + 64 * NL, 1) void gemm_bf16_lw_kernel(GemmParams p) {
-    gemm_lw_body<AKM, BKM, EPI, false, NL>(p, nullptr);
-}
 template <bool AKM, bool BKM, int EPI>
-__global__ __launch_bounds__(256 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_fat_kernel(GemmParams p) {
-    gemm_lw_body<AKM, BKM, EPI, false, mmvid_core::NLOAD, true>(p, nullptr);
-}
-__global__ __launch_bounds__(256 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_fat_grouped_kernel(GemmParams p, GroupTable gt) {
-    gemm_lw_body<true, true, 1, true, mmvid_core::NLOAD, true>(p, &gt);
+__global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_kernel(GemmParams p) {
+    gemm_lw_body<AKM, BKM, EPI, false>(p, nullptr);
 }
 // the grouped weight-gradient launch: both operands k-major, general register-direct epilogue (fp32 += result)
 __global__ __launch_bounds__(512 + 64 * mmvid_core::NLOAD, 1) void gemm_bf16_lw_grouped_kernel(GemmParams p, GroupTable gt) {
     gemm_lw_body<true, true, 1, true>(p, &gt);
-}
-
-// ================================================================================================================
-// Block shape "W": 256x128 output tile computed by FOUR waves (2x2), each 128x64 = 4x2 MFMA tiles; K tile 32; three
-// 24-KiB LDS stages (72 KiB) and __launch_bounds__(256, 2): TWO blocks per CU.
-//
-// Why it was built (tools/bench_gemm.py anatomy, profiles/r02_gemm_anatomy.log): the 8-wave 256x128 kernel above multiplies
-// at ~1,000 TFLOP/s inside its K loop, but at K = 768 the loop is only 12 tiles long and what surrounds it (first-tile
-// latency, accumulators -> LDS -> bias / activation / residual -> stores, block turnover) costs about as much: 36 + 29 us
-// for the qkv projection, strictly one after the other because the block owns its CU (144 KiB of LDS).  Here a wave's tile
-// is twice as tall, so the same 256x128 block needs half the waves and, with 32-deep K tiles, half the LDS: two blocks share
-// a CU, and the taller wave tile reads less LDS per MFMA (6 fragments per 8 MFMAs instead of 4 per 4).
-// What it measured: bit-identical results, but 5-25 % SLOWER (K loop 850 instead of 1,030 TFLOP/s; no overlap gained).  Two
-// co-resident blocks start together and stay in phase for the ~3 tiles a CU gets at these sizes, so their epilogues coincide
-// instead of hiding under each other's K loops.  Kept behind option gemm_wshape (default 0) as the measured record of that
-// design; the 8-wave ping-pong shape stays the default.
-//
-//   LDS stage (24 KiB): A [256 rows][32 k] as 64-B rows, 16-B chunk ^= (row>>2)&3 (conflict-free for the ds_read_b128
-//   lane groups: rows r, r+4, r+8, r+12 of a group land in different chunk columns), then B: row-major [128 rows][32 k] in
-//   the same layout, or k-major [32 k][128 rows] exactly as in gemm_core.h (first half of its 64-deep tile).
-//   Staging: 24 one-KiB LDS-DMA pieces per tile, 6 per wave; three stages with counted vmcnt as in the 8-wave kernel.
-namespace wshape {
-constexpr int WBK = 32;
-constexpr int A_BYTES = 256 * 64, B_BYTES = 128 * 64;  // 16 KiB + 8 KiB
-constexpr int STAGE = A_BYTES + B_BYTES, NSTAGE = 3, LDS = NSTAGE * STAGE;
-constexpr int PA = 4, PB = 2;  // DMA pieces per wave and tile
-
-// row-major operand with 64-B LDS rows: this wave's PPW pieces (16 rows each) of an NROWS-row tile
-template <int PPW>
-struct RowStage32 {
-    rsrc_t rsrc;
-    uint32_t voff[PPW];
-    __device__ __forceinline__ void init(const bf16_t* base, long ld, int rows, int K, int r0, int wave, int lane) {
-        rsrc = make_rsrc(base, (uint32_t)(((long)(rows - 1) * ld + K) * 2));
-#pragma unroll
-        for (int jj = 0; jj < PPW; ++jj) {
-            const int row = (wave * PPW + jj) * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
-            const int gr = r0 + row;
-            voff[jj] = gr < rows ? (uint32_t)(((long)gr * ld + c * 8) * 2) : OOB;
-        }
-    }
-    __device__ __forceinline__ void issue(int k0, int K, char* tile, int wave, int lane) const {
-        const uint32_t soff = (uint32_t)k0 * 2;
-        if (k0 + WBK > K) {  // K tail: chunks at or beyond K must read as zeros (they would be the next row's data)
-            asm volatile("; K-tail tile" ::: "memory");
-#pragma unroll
-            for (int jj = 0; jj < PPW; ++jj) {
-                const int row = (wave * PPW + jj) * 16 + (lane >> 2);
-                const int c = (lane & 3) ^ ((row >> 2) & 3);
-                blds16(rsrc, k0 + c * 8 < K ? voff[jj] : OOB, soff, tile + (wave * PPW + jj) * 1024);
-            }
-        } else {
-#pragma unroll
-            for (int jj = 0; jj < PPW; ++jj) blds16(rsrc, voff[jj], soff, tile + (wave * PPW + jj) * 1024);
-        }
-    }
-};
-}  // namespace wshape
-
-template <bool BKM>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_w_kernel(GemmParams p) {
-    using namespace wshape;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int wg = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-    const int bn0 = (wg % gridDim.x) * BN, bm0 = (wg / gridDim.x) * 256;
-    const int batch = blockIdx.z;
-    const bf16_t* A = p.A + (long)batch * p.strideA;
-    const bf16_t* B = p.B + (long)batch * p.strideB;
-    const int nt = p.debug == 2 ? 0 : (p.K + WBK - 1) / WBK;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    RowStage32<PA> sa;
-    sa.init(A, p.lda, p.M, p.K, bm0, wave, lane);
-    RowStage32<PB> sbr;
-    OperandStage<true, 1, PB> sbk;
-    if constexpr (BKM)
-        sbk.init(B, p.ldb, p.N, p.K, bn0, wave, lane);
-    else
-        sbr.init(B, p.ldb, p.N, p.K, bn0, wave, lane);
-    auto stage_tile = [&](int t, char* buf) {
-        sa.issue(t * WBK, p.K, buf, wave, lane);
-        if constexpr (BKM)
-            sbk.issue(t * WBK, p.K, buf + A_BYTES, wave, lane);
-        else
-            sbr.issue(t * WBK, p.K, buf + A_BYTES, wave, lane);
-    };
-
-    // fragment addresses inside a stage: row-major chunk (2 ks + h) ^ swz(row); swz(row) = (row >> 2) & 3 depends on the lane
-    // only (the row bases are multiples of 32), so one lane constant e = h ^ swz and k-step 1 is address ^ 32
-    const int l32 = lane & 31, e = (lane >> 5) ^ ((l32 >> 2) & 3);
-    uint32_t aoff[4], boff[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) aoff[i] = (uint32_t)((wm * 128 + i * 32 + l32) * 64 + (e << 4));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if constexpr (BKM)
-            boff[j] = (uint32_t)(A_BYTES + km_lane_off(wn * 64 + j * 32, lane));
-        else
-            boff[j] = (uint32_t)(A_BYTES + (wn * 64 + j * 32 + l32) * 64 + (e << 4));
-    }
-    const uint32_t lds0 = lds_addr(smem);
-
-    auto compute_tile = [&](uint32_t st) {  // st = byte offset of the stage (a multiple of 64)
-        bf16x8_t a0[4], b0[2], a1[4], b1[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a0[i] = *reinterpret_cast<const bf16x8_t*>(smem + st + aoff[i]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if constexpr (BKM)
-                b0[j] = frag_kmajor<0>(lds0 + st + boff[j]);
-            else
-                b0[j] = *reinterpret_cast<const bf16x8_t*>(smem + st + boff[j]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a1[i] = *reinterpret_cast<const bf16x8_t*>(smem + st + (aoff[i] ^ 32u));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if constexpr (BKM)
-                b1[j] = frag_kmajor<1>(lds0 + st + boff[j]);
-            else
-                b1[j] = *reinterpret_cast<const bf16x8_t*>(smem + st + (boff[j] ^ 32u));
-        }
-        // the transpose reads are asm (untracked by the compiler): 8 younger LDS operations (a1: 4, b1: 2 x 2) may be in flight
-        if constexpr (BKM) lgkm_wait_tied<8>(b0[0], b0[1]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
-        if constexpr (BKM) lgkm_wait_tied<0>(b1[0], b1[1]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
-    };
-
-    // 3-stage ring: tile t+2 is requested right after the barrier that starts tile t (its buffer held tile t-1, which every
-    // wave finished reading before that barrier); a wave waits for ITS OWN pieces of tile t (tile t+1's six may stay in flight)
-    if (nt > 0) stage_tile(0, smem);
-    if (nt > 1) stage_tile(1, smem + STAGE);
-    uint32_t s0 = 0, s1 = STAGE, s2 = 2 * STAGE;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt)
-            wait_dma_and_barrier<PA + PB>();
-        else
-            wait_dma_and_barrier<0>();
-        if (t + 2 < nt) stage_tile(t + 2, smem + s2);
-        compute_tile(s0);
-        const uint32_t tmp = s0;
-        s0 = s1, s1 = s2, s2 = tmp;
-    }
-    gemm_epilogue<256, 128, 4>(p, smem, acc, bm0, bn0, batch, 0, tid, wm, wn, lane);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s partial[s][i]   (fixed order: deterministic)
@@ -1090,54 +685,47 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Block shape by grid fill: the 256x128 / 3-stage kernel runs one block per CU, so it needs ~a full wave of blocks.
 bool use_big_tile(long M, long N, long zdim) {
-    const int o = mmvid_tile_override();
-    if (o == 128) return false;
-    if (o == 256) return true;
     const long blocks = (long)cdiv(M, 256) * cdiv(N, BN) * zdim;
     return M >= 256 && blocks >= 200;
 }
 
-constexpr int BIAS_LDS_BYTES = 16384;  // EPI = 1: the bias vector above the stages (N <= 4096)
+constexpr int BIAS_LDS_BYTES = 16384;  // the bias vector above the stages (N <= 4096)
 // register-direct epilogue: everything elementwise; not split-K, no column sums (those reduce across rows), N fits the bias slab,
 // outputs addressable through 32-bit buffer offsets
-bool direct_epilogue_ok(const GemmParams& p, int batch, bool any_mode = false) {
-    if ((mmvid_option(MMVID_OPT_GEMM_EPI) < 1 && !any_mode) || p.splitk != 1 || p.partial || p.colsum || p.N > BIAS_LDS_BYTES / 4) return false;
+bool direct_epilogue_ok(const GemmParams& p) {
+    if (p.splitk != 1 || p.partial || p.colsum || p.N > BIAS_LDS_BYTES / 4) return false;
     const long rows = p.M - 1;
     const long ld = p.ldc > p.ldp ? p.ldc : p.ldp;
     const long ldr = p.residual ? p.ldr : 0;
     return (rows * (ld > ldr ? ld : ldr) + p.N) * 4 < (1ll << 31);
 }
 
-template <bool AKM, bool BKM, int WM, int PP>
+template <bool AKM, bool BKM, int WM>
 void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
     using S = BlockShape<WM>;
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, S::ROWS), batch * p.splitk);
     GemmParams q = p;
     q.tiles_n = q.tiles_m = 0;
-    q.defer = 0, q.group_n = 0;
-    q.red_out = nullptr, q.counters = nullptr;  // (set below when the split-K slabs are reduced inside the kernel)
-    if (WM == 4 && mmvid_option(MMVID_OPT_GEMM_PERSIST) && (long)grid.x * grid.y > 256) {  // more than one tile per CU
+    q.group_n = 0;
+    if (WM == 4 && (long)grid.x * grid.y > 256) {  // more than one tile per CU: persistent blocks
         q.tiles_n = (int)grid.x, q.tiles_m = (int)grid.y;
         grid = dim3(256, 1, grid.z);
         // Several rounds per CU: an XCD's 32 blocks then meet the same B (weight) column tiles again in every round, and with all
         // column tiles in play (qkv: 3.5 MB, c_fc: 4.7 MB of W next to the A panels) they do not survive in its 4-MB L2 -- PMC r02:
         // 34 % L2 misses, 2.4x the algorithmic reads.  Walking the tiles in column GROUPS keeps one group's B tiles resident:
-        // the widest group whose B tiles plus the A panels of one round (32 tiles) fit ~3 MB.
-        if (mmvid_option(MMVID_OPT_GEMM_GROUPN)) {
-            // working set of one round of an XCD (32 tiles) for a group width c: c B tiles + ceil(32 / c) A panels; take the width
-            // that minimises it, when that beats walking all column tiles and fits the 4-MB L2
-            const double b_tile = 128.0 * p.K * 2, a_panel = 256.0 * p.K * 2;
-            auto wset = [&](int c) { return c * b_tile + cdiv(32, c) * a_panel; };
-            int best = q.tiles_n;
-            for (int c = 1; c < q.tiles_n; ++c)
-                if (wset(c) < wset(best)) best = c;
-            if (best < q.tiles_n && wset(best) <= 4.0e6) {
-                const int ngroups = cdiv(q.tiles_n, best);
-                q.group_n = cdiv(q.tiles_n, ngroups);  // equal-width groups
-            }
+        // working set of one round of an XCD (32 tiles) for a group width c: c B tiles + ceil(32 / c) A panels; take the width
+        // that minimises it, when that beats walking all column tiles and fits the 4-MB L2
+        const double b_tile = 128.0 * p.K * 2, a_panel = 256.0 * p.K * 2;
+        auto wset = [&](int c) { return c * b_tile + cdiv(32, c) * a_panel; };
+        int best = q.tiles_n;
+        for (int c = 1; c < q.tiles_n; ++c)
+            if (wset(c) < wset(best)) best = c;
+        if (best < q.tiles_n && wset(best) <= 4.0e6) {
+            const int ngroups = cdiv(q.tiles_n, best);
+            q.group_n = cdiv(q.tiles_n, ngroups);  // equal-width groups
         }
     }
-    if constexpr (WM == 4 && PP == 2) {
+    if constexpr (WM == 4) {
         // the d_pre GEMM (dX of c_proj): packed bf16 result, QuickGELU' of the saved pre-activation, column sums = c_fc's bias gradient
         const bool dact_packed = p.dact_pre && p.out_bf16 && !p.out_f32 && !p.residual && !p.accumulate && !p.save_pre && !p.bias &&
                                  p.act == 0 && p.N % 128 == 0 && batch == 1 && p.ldp == p.ldc;
@@ -1150,20 +738,8 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
             pc.out_f32 = p.partial, pc.partial = nullptr, pc.accumulate = 0, pc.ldc = p.N, pc.strideC = (long)p.M * p.N, pc.strideA = 0,
             pc.strideB = 0, pc.splitk = 1;  // (for the eligibility test; the kernel gets splitk back below)
         }
-        if (mmvid_option(MMVID_OPT_GEMM_LOADER) && mmvid_option(MMVID_OPT_GEMM_EPI) >= 1 &&
-            direct_epilogue_ok((dact_packed || slabs) ? pc : p, batch, true)) {
-            if (slabs) {
-                q.out_f32 = pc.out_f32, q.partial = nullptr, q.accumulate = 0, q.ldc = pc.ldc, q.strideC = pc.strideC, q.strideA = 0, q.strideB = 0;
-                const int tiles = (int)(grid.x * grid.y);
-                if (mmvid_option(MMVID_OPT_GEMM_FUSED_REDUCE) && p.red_out && tiles <= RED_RING && p.N % 4 == 0 && p.tiles_n == 0 && q.tiles_n == 0) {
-                    if (g_red_cursor + tiles > RED_RING) g_red_cursor = 0;
-                    void* base = nullptr;
-                    (void)hipGetSymbolAddress(&base, HIP_SYMBOL(g_red_counters));
-                    q.counters = (int*)base + g_red_cursor, q.red_out = p.red_out;
-                    g_red_cursor += tiles;
-                    g_last_launch_fused = true;
-                }
-            }
+        if (direct_epilogue_ok((dact_packed || slabs) ? pc : p)) {
+            if (slabs) q.out_f32 = pc.out_f32, q.partial = nullptr, q.accumulate = 0, q.ldc = pc.ldc, q.strideC = pc.strideC, q.strideA = 0, q.strideB = 0;
             const bool packed = p.out_bf16 && !p.out_f32 && !p.residual && !p.dact_pre && !p.accumulate && p.N % 128 == 0 && batch == 1;
             const int epi = dact_packed ? 4 : (packed ? (p.save_pre ? 3 : 2) : 1);
             const size_t lds = S::LDS_BYTES + BIAS_LDS_BYTES;
@@ -1175,34 +751,6 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
                 }
                 hipLaunchKernelGGL(kern, grid, dim3(512 + 64 * NLOAD), lds, stream, q);
             };
-            if (epi == 2 && mmvid_option(MMVID_OPT_GEMM_LOADERS) == 8) {  // sixteen waves: 8 MFMA + 8 loaders, 128 registers each
-                static bool attr8 = false;
-                if (!attr8) {
-                    (void)hipFuncSetAttribute((const void*)gemm_bf16_lw_kernel<AKM, BKM, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    attr8 = true;
-                }
-                hipLaunchKernelGGL((gemm_bf16_lw_kernel<AKM, BKM, 2, 8>), grid, dim3(512 + 64 * 8), lds, stream, q);
-                return;
-            }
-            if (mmvid_option(MMVID_OPT_GEMM_FAT) && !q.red_out) {  // four 128 x 64 MFMA waves + the loader waves
-                static bool fattr[5] = {false, false, false, false, false};
-                auto gof = [&](auto kern) {
-                    if (!fattr[epi]) {
-                        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                        fattr[epi] = true;
-                    }
-                    hipLaunchKernelGGL(kern, grid, dim3(256 + 64 * NLOAD), lds, stream, q);
-                };
-                if (epi == 4)
-                    gof(gemm_bf16_fat_kernel<AKM, BKM, 4>);
-                else if (epi == 3)
-                    gof(gemm_bf16_fat_kernel<AKM, BKM, 3>);
-                else if (epi == 2)
-                    gof(gemm_bf16_fat_kernel<AKM, BKM, 2>);
-                else
-                    gof(gemm_bf16_fat_kernel<AKM, BKM, 1>);
-                return;
-            }
             if (epi == 4)
                 go(gemm_bf16_lw_kernel<AKM, BKM, 4>);
             else if (epi == 3)
@@ -1213,96 +761,26 @@ void launch_shape(const GemmParams& p, int batch, hipStream_t stream) {
                 go(gemm_bf16_lw_kernel<AKM, BKM, 1>);
             return;
         }
-        // packed-bf16 epilogue: bf16 result(s) only, nothing read in the epilogue, whole 128-column tiles
-        const int epi = mmvid_option(MMVID_OPT_GEMM_EPI);
-        const bool packed = epi >= 1 && direct_epilogue_ok(p, batch, true) && p.out_bf16 && !p.out_f32 && !p.residual && !p.dact_pre &&
-                            !p.accumulate && p.N % 128 == 0 && batch == 1;
-        if (packed) {
-            q.defer = (epi >= 2 && q.tiles_n > 0) ? 1 : 0;
-            static bool attr2 = false, attr3 = false;
-            if (p.save_pre) {
-                if (!attr3) {
-                    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM, PP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              S::LDS_BYTES + BIAS_LDS_BYTES);
-                    attr3 = true;
-                }
-                hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP, 3>), grid, dim3(S::THREADS), S::LDS_BYTES + BIAS_LDS_BYTES, stream, q);
-            } else {
-                if (!attr2) {
-                    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM, PP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              S::LDS_BYTES + BIAS_LDS_BYTES);
-                    attr2 = true;
-                }
-                hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP, 2>), grid, dim3(S::THREADS), S::LDS_BYTES + BIAS_LDS_BYTES, stream, q);
-            }
-            return;
-        }
-    }
-    if constexpr (WM == 4 && PP != 0) {
-        if (direct_epilogue_ok(p, batch)) {
-            static bool attr1 = false;
-            if (!attr1) {
-                (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM, PP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          S::LDS_BYTES + BIAS_LDS_BYTES);
-                attr1 = true;
-            }
-            hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP, 1>), grid, dim3(S::THREADS), S::LDS_BYTES + BIAS_LDS_BYTES, stream, q);
-            return;
-        }
     }
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  S::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKM, BKM, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM, PP>), grid, dim3(S::THREADS), S::LDS_BYTES, stream, q);
-}
-
-template <bool BKM>
-void launch_w(const GemmParams& p, int batch, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_w_kernel<BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, wshape::LDS);
-        attr = true;
-    }
-    dim3 grid(cdiv(p.N, BN), cdiv(p.M, 256), batch);
-    hipLaunchKernelGGL((gemm_bf16_w_kernel<BKM>), grid, dim3(256), wshape::LDS, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM, WM>), grid, dim3(S::THREADS), S::LDS_BYTES, stream, q);
 }
 
 template <bool AKM, bool BKM>
 int launch(const GemmParams& p, int batch, hipStream_t stream) {
     MmvidProfScope prof(AKM ? PROF_GEMM_TN : (BKM ? PROF_GEMM_NN : PROF_GEMM_NT), 2.0 * p.M * p.N * (double)p.K * batch, stream);
-    if constexpr (!AKM) {
-        // the 4-wave / two-blocks-per-CU shape: row-major A, no split-K, enough tiles that two blocks per CU exist
-        const int w = mmvid_option(MMVID_OPT_GEMM_WSHAPE);
-        if (w && p.splitk == 1 && p.M >= 256 && (w == 2 || (long)cdiv(p.M, 256) * cdiv(p.N, BN) * batch >= 200)) {  // default: off
-            launch_w<BKM>(p, batch, stream);
-            return 0;
-        }
-    }
-    if (use_big_tile(p.M, p.N, (long)batch * p.splitk)) {
-        const int sched = mmvid_option(MMVID_OPT_GEMM_SCHED);
-        if (sched == 2)
-            launch_shape<AKM, BKM, 4, 2>(p, batch, stream);
-        else if (sched == 1)
-            launch_shape<AKM, BKM, 4, 1>(p, batch, stream);
-        else
-            launch_shape<AKM, BKM, 4, 0>(p, batch, stream);
-    } else {
-        launch_shape<AKM, BKM, 2, 0>(p, batch, stream);
-    }
+    if (use_big_tile(p.M, p.N, (long)batch * p.splitk))
+        launch_shape<AKM, BKM, 4>(p, batch, stream);
+    else
+        launch_shape<AKM, BKM, 2>(p, batch, stream);
     return 0;
 }
 
 }  // namespace
-
-// Measurement only: device buffer of [blocks][2 wave groups][8 tiles][8] uint64 time stamps (100-MHz wall clock) written by the
-// next 256x128 GEMM launches: 0 tile start, 1 first K tile visible, 2 K loop done, 3 next prologue issued, 4 epilogue issued.
-extern "C" int mmvid_gemm_trace(void* dev_buf) {
-    g_gemm_trace = (unsigned long long*)dev_buf;
-    return MMVID_OK;
-}
 
 // See include/mmvid_hip.h for the contract.
 extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int64_t lda,
@@ -1339,10 +817,7 @@ extern "C" int mmvid_gemm_bf16(int a_kmajor, int b_kmajor, int M, int N, int K, 
     p.act = act, p.accumulate = accumulate, p.alpha = alpha;
     p.out_f32 = out_f32, p.out_bf16 = (bf16_t*)out_bf16, p.ldc = ldc;
     p.partial = nullptr, p.colsum = out_colsum;
-    p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
-    p.tiles_n = p.tiles_m = 0;
-    p.trace = g_gemm_trace;
-    p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
+    p.tiles_n = p.tiles_m = 0, p.group_n = 0;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor)
         launch<false, false>(p, batch, s);
@@ -1383,16 +858,10 @@ extern "C" int mmvid_gemm_bf16_dw(int64_t M, int N, int K, const void* dY, int64
     p.out_f32 = dW, p.out_bf16 = nullptr, p.ldc = K;
     p.partial = splitk > 1 ? workspace : nullptr;
     p.colsum = nullptr;
-    p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
-    p.tiles_n = p.tiles_m = 0;
-    p.trace = nullptr;
-    // split-K: the slabs are added in slab order either by the last block of each output tile inside the GEMM (option
-    // gemm_fused_reduce, the 256x128 loader-wave kernel) or by splitk_reduce_kernel -- the same additions in the same order
-    p.red_out = splitk > 1 ? dW : nullptr, p.red_ld = K, p.red_accumulate = accumulate, p.counters = nullptr;
+    p.tiles_n = p.tiles_m = 0, p.group_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    g_last_launch_fused = false;
     launch<true, true>(p, 1, s);
-    if (splitk > 1 && !g_last_launch_fused) {
+    if (splitk > 1) {  // the slabs are added in slab order: deterministic
         const long mn = (long)N * K;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(mn / 4, 256)), dim3(256), 0, s, workspace, splitk, mn, dW, accumulate);
     }
@@ -1411,8 +880,6 @@ extern "C" int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_ki
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_lw_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(S::LDS_BYTES + BIAS_LDS_BYTES));
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_fat_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(S::LDS_BYTES + BIAS_LDS_BYTES));
         attr = true;
     }
@@ -1448,7 +915,8 @@ extern "C" int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_ki
             // PMC (profiles/r03_pmc_fetch_size.csv, FETCH_SIZE doubled per the gfx950 rule, calibrated in r04_pmc_fetch_calibration.txt):
             // the round-3 launch fetched 6.6 GB for 3.1 GB of operands -- row-major tile order re-reads the 64-MB activation of the
             // c_proj weight gradient (a 768 x 3072 output: 3 tile rows x 24 tile columns) once per tile row
-            o.colmajor = (mmvid_option(MMVID_OPT_DW_ORDER) && kd.K > kd.N) ? 1 : 0;
+            // once per tile row; column-major order for the kinds whose X operand is the wider one: 5.55 GB (r04)
+            o.colmajor = kd.K > kd.N ? 1 : 0;
             tiles += o.tiles_n * o.tiles_m * n;
             for (int g = 0; g < n; ++g) {
                 gt.out_list[o.out0 + g] = kd.dW_list[g0 + g];
@@ -1464,17 +932,9 @@ extern "C" int mmvid_gemm_bf16_dw_multi(int64_t M, int nkinds, const mmvid_dw_ki
         p.act = 0, p.accumulate = accumulate, p.alpha = 1.0f;
         p.out_f32 = nullptr, p.out_bf16 = nullptr, p.ldc = gt.kinds[0].N;
         p.partial = nullptr, p.colsum = nullptr;
-        p.debug = mmvid_option(MMVID_OPT_GEMM_DEBUG);
-        p.tiles_n = p.tiles_m = 0, p.group_n = 0, p.defer = 0;
-        p.trace = nullptr;
-        p.red_out = nullptr, p.red_ld = 0, p.red_accumulate = 0, p.counters = nullptr;
+        p.tiles_n = p.tiles_m = 0, p.group_n = 0;
         MmvidProfScope prof(PROF_GEMM_TN, flops, (hipStream_t)stream);
-        if (mmvid_option(MMVID_OPT_GEMM_FAT))
-            hipLaunchKernelGGL(gemm_bf16_fat_grouped_kernel, dim3(tiles), dim3(256 + 64 * NLOAD), S::LDS_BYTES + BIAS_LDS_BYTES,
-                           (hipStream_t)stream, p, gt);
-        else
-            hipLaunchKernelGGL(gemm_bf16_lw_grouped_kernel, dim3(tiles), dim3(512 + 64 * NLOAD), S::LDS_BYTES + BIAS_LDS_BYTES,
-                           (hipStream_t)stream, p, gt);
+        hipLaunchKernelGGL(gemm_bf16_lw_grouped_kernel, dim3(tiles), dim3(512 + 64 * NLOAD), S::LDS_BYTES + BIAS_LDS_BYTES, (hipStream_t)stream, p, gt);
     }
     MMVID_LAUNCH_CHECK("gemm_bf16_dw_multi");
     return MMVID_OK;

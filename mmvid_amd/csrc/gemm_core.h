@@ -290,87 +290,28 @@ __device__ __forceinline__ void pp_compute_half(bf16x8_t (&a)[2][2], bf16x8_t (&
     mma_step(a[1], b[1], acc);
     __builtin_amdgcn_s_setprio(0);
 }
-// issueA(t, stage) / issueB(t, stage): request this wave's pieces of the A / B part of tile t into `stage`
-// DMA_IN_CLUSTER = false: the requests of tile t+2 are issued in the load parts (A pieces in phase A, B pieces in phase
-// B); true: from inside the MFMA clusters (after the first four MFMAs of each), which shortens the load part to the
-// eight fragment reads.  Either way the refilled buffer is tile t-1's, which the other group finished reading before
-// its previous cluster, and the wait before barrier 3 lets exactly the already-issued pieces of tile t+2 stay in flight.
-// s_waitcnt vmcnt(BASE + extra), extra in {0, 16, 32, 48}: `extra` vector-memory operations YOUNGER than the awaited loads
-// (the previous tile's epilogue stores, see below; a multiple of 8 up to 48) may stay in flight on top of the BASE younger loads
-template <int BASE>
-__device__ __forceinline__ void wait_vm_plus(int extra) {
-    static_assert(BASE + 48 <= 63, "vmcnt is a 6-bit counter");
-    switch (extra) {
-        case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 8) : "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 16) : "memory"); break;
-        case 24: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 24) : "memory"); break;
-        case 32: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 32) : "memory"); break;
-        case 40: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 40) : "memory"); break;
-        case 48: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 48) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // unknown count: wait for everything (never under-waits)
-    }
-}
-// s_waitcnt vmcnt(BASE + extra) for a small wave-uniform extra in 0..4 (the deferred epilogue stores issued since the awaited loads)
-template <int BASE>
-__device__ __forceinline__ void wait_vm_small(int extra) {
-    if (extra == 0)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
-    else if (extra == 1)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 1) : "memory");
-    else if (extra == 2)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 2) : "memory");
-    else if (extra == 3)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 3) : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 4) : "memory");
-}
-struct NoDrain {
-    __device__ __forceinline__ int operator()(int) const { return 0; }
-};
-// the first two K tiles of an output tile (stages 0 and 1)
-template <class IssueA, class IssueB>
-__device__ __forceinline__ void pp_prologue(char* smem, int nt, IssueA issueA, IssueB issueB) {
-    using S = BlockShape<4>;
-    if (nt <= 0) return;
-    issueA(0, smem), issueB(0, smem);
-    if (nt > 1) issueA(1, smem + S::STAGE_BYTES), issueB(1, smem + S::STAGE_BYTES);
-}
-// `stores_after_prologue` (wave-uniform; 0 / 16 / 32 / 48, or -1 = the prologue has not been issued: do it here): how many
-// vector-memory operations this wave issued AFTER pp_prologue() -- the register-direct epilogue of the previous output tile
-// stores while the first K tiles of this one are already in flight.  vmcnt retires in order, so the waits for K tiles 0 and 1
-// (older than those stores) let exactly that many more operations stay in flight; every later wait is for loads younger than
-// the stores and is unchanged (by then the stores have had more than a K tile of time).
-// `drain(t)`: called once per K tile from INSIDE the second MFMA cluster, right after the B pieces of tile t+2 have been
-// requested -- the DEFERRED epilogue of the previous output tile issues a few of its (unconditional, buffer-addressed) stores
-// there and returns how many (wave-uniform, at most 4).  A vector-memory instruction costs its wave ~60-100 issue cycles on
-// this chip whatever it moves (MI355X_MICROARCH.md, "store-ISSUE-bound"); inside the cluster that stall is covered by the four
-// MFMAs already queued, in a load part it would hold up the barrier both wave groups meet at (measured: K loop 10.7 -> 23 us).
-// In the in-order vmcnt queue the stores sit behind B(t+2): the wait in K tile t+1 lets them stay in flight together with the
-// A pieces of tile t+3 (exact count); the wait in K tile t+2 is the first that needs them acknowledged (~1.7 K tiles later).
-template <bool AKM, bool BKM, bool DMA_IN_CLUSTER, class IssueA, class IssueB, class Drain = NoDrain>
+// issueA(t, stage) / issueB(t, stage): request this wave's pieces of the A / B part of tile t into `stage`.  The requests of tile t+2
+// are issued from inside the MFMA clusters (after the first four MFMAs of each), which shortens the load part to the eight fragment
+// reads (issued in the load parts instead: +0.5 % step time, profiles/r01_ab_gemm_sched*.log).  The refilled buffer is tile t-1's,
+// which the other group finished reading before its previous cluster, and the wait before barrier 3 lets exactly the already-issued
+// pieces of tile t+2 stay in flight.
+template <bool AKM, bool BKM, class IssueA, class IssueB>
 __device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, int lane, int wm, int wn, f32x16 (&acc)[2][2],
-                                                IssueA issueA, IssueB issueB, int stores_after_prologue = -1,
-                                                unsigned long long* stamp = nullptr, Drain drain = Drain()) {
+                                                IssueA issueA, IssueB issueB) {
     using S = BlockShape<4>;
     constexpr int PIECES_A = S::NSUB * S::PPW;  // this wave's A pieces of a tile; the B pieces are PPW
     char* b0 = smem;
     char* b1 = smem + S::STAGE_BYTES;
     char* b2 = smem + 2 * S::STAGE_BYTES;
     if (nt <= 0) return;
-    int extra = stores_after_prologue;
-    int drained = 0;
-    if (extra < 0) {
-        pp_prologue(smem, nt, issueA, issueB);
-        extra = 0;
-    }
+    issueA(0, smem), issueB(0, smem);  // the first two K tiles of the output tile (stages 0 and 1)
     if (nt > 1) {
-        wait_vm_plus<S::DMA_PER_TILE>(extra);
+        issueA(1, smem + S::STAGE_BYTES), issueB(1, smem + S::STAGE_BYTES);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::DMA_PER_TILE) : "memory");
     } else {
-        wait_vm_plus<0>(extra);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                 // tile 0 is visible to everyone
-    if (stamp) stamp[1] = wall_clock64();
     if (wave >= 4) __builtin_amdgcn_s_barrier();  // the trailing group starts one barrier late
     for (int t = 0; t < nt; ++t) {
         const char* At = b0 + (wm >> 1) * TILE_BYTES;
@@ -384,36 +325,25 @@ __device__ __forceinline__ void k_loop_pingpong(char* smem, int nt, int wave, in
         }
         const bool more = t + 2 < nt;
         bf16x8_t a[2][2], b[2][2];
-        const int drained_prev = drained;  // stores issued in the previous K tile's second cluster (younger than B(t+1))
         // ---- phase A: k-steps 0, 1
         pp_load_half<AKM, BKM, 0>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
-        if (!DMA_IN_CLUSTER && more) issueA(t + 2, b2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 1
         pp_compute_half<AKM, BKM>(a, b, acc, [&]() {
-            if (DMA_IN_CLUSTER && more) issueA(t + 2, b2);
+            if (more) issueA(t + 2, b2);
         });
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 2
         // ---- phase B: k-steps 2, 3
         pp_load_half<AKM, BKM, 1>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
-        if (!DMA_IN_CLUSTER && more) issueB(t + 2, b2);
-        if (more) {  // own pieces of tile t+1 landed; what has been issued of tile t+2 may stay in flight
-            if (t == 0 && extra != 0)
-                wait_vm_plus<DMA_IN_CLUSTER ? PIECES_A : S::DMA_PER_TILE>(extra);  // tile 1 is older than the epilogue stores
-            else  // (the stores drained in the previous K tile are younger than tile t+1's pieces: they may stay in flight too)
-                wait_vm_small<DMA_IN_CLUSTER ? PIECES_A : S::DMA_PER_TILE>(drained_prev);
-        } else if (t + 1 < nt) {
-            if (t == 0)
-                wait_vm_plus<0>(extra);
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (more)  // own pieces of tile t+1 landed; the A pieces of tile t+2 may stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_A) : "memory");
+        else if (t + 1 < nt)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 3
         pp_compute_half<AKM, BKM>(a, b, acc, [&]() {
-            if (DMA_IN_CLUSTER && more) issueB(t + 2, b2);
-            drained = drain(t);
+            if (more) issueB(t + 2, b2);
         });
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 4
@@ -532,16 +462,13 @@ __device__ __forceinline__ void loader_prologue(const LoaderStage<AKM, NL>& sa, 
         for (int g = 0; g < 3; ++g) loader_issue_group<AKM, BKM, NL>(sa, sb, (kt0 + 1) * BK, K, smem + S::STAGE_BYTES, g, w, lane);
     }
 }
-// a loader wave's K loop: the prologue (its pieces of K tiles 0 and 1) has been requested.  DBG: the timing experiments of
-// tools/gemm_kloop_anatomy.py (gemm_debug 4, 6, 7, 9, 10) are compiled into their own instance -- the shipped loop carries none of their
-// tests (the loop is paced by this instruction stream: a dozen extra SALU / VALU per piece here cost the block 20 % of its K loop)
-template <bool AKM, bool BKM, int NL, bool DBG = false>
+// a loader wave's K loop: the prologue (its pieces of K tiles 0 and 1) has been requested.  (The loop is paced by this instruction
+// stream: a dozen extra SALU / VALU per piece here cost the block 20 % of its K loop, profiles/r04_gemm_kloop_anatomy*.log.)
+template <bool AKM, bool BKM, int NL>
 __device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM, NL>& sa, const LoaderStage<BKM, NL>& sb, char* smem, int kt0, int nt, int K,
-                                              int w, int lane, int debug = 0) {
+                                              int w, int lane) {
     using S = BlockShape<4>;
     constexpr int PER_TILE = 48 / NL;  // this wave's pieces of a K tile
-    const bool half_barriers = DBG && debug == 4, skip_half_dma = DBG && debug == 6, no_dma = DBG && (debug == 7 || debug == 9),
-               k_fixed = DBG && debug == 10;
     char* b0 = smem;
     char* b1 = smem + S::STAGE_BYTES;
     char* b2 = smem + 2 * S::STAGE_BYTES;
@@ -552,18 +479,16 @@ __device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM, NL>& sa, co
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile 0 is visible to everyone
     for (int t = 0; t < nt; ++t) {
-        const bool more = t + 2 < nt && !no_dma;
-        const int k0 = k_fixed ? kt0 * BK : (kt0 + t + 2) * BK;
-        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 1: the trailing group has finished its last read of tile t-1 (whose stage b2 is refilled)
+        const bool more = t + 2 < nt;
+        const int k0 = (kt0 + t + 2) * BK;
+        __builtin_amdgcn_s_barrier();  // 1: the trailing group has finished its last read of tile t-1 (whose stage b2 is refilled)
         if (more) loader_issue_group<AKM, BKM, NL>(sa, sb, k0, K, b2, 0, w, lane);
         __builtin_amdgcn_s_barrier();  // 2
-        if (more && !skip_half_dma) loader_issue_group<AKM, BKM, NL>(sa, sb, k0, K, b2, 1, w, lane);
-        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 3
+        if (more) loader_issue_group<AKM, BKM, NL>(sa, sb, k0, K, b2, 1, w, lane);
+        __builtin_amdgcn_s_barrier();  // 3
         if (more) loader_issue_group<AKM, BKM, NL>(sa, sb, k0, K, b2, 2, w, lane);
         if (t + 1 < nt) {  // tile t+1 has landed before the barrier after which the leading group reads it
-            if (more && skip_half_dma)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE - 16 / NL) : "memory");
-            else if (more)
+            if (more)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -574,37 +499,16 @@ __device__ __forceinline__ void k_loop_loader(const LoaderStage<AKM, NL>& sa, co
     }
     __builtin_amdgcn_s_barrier();  // the closing barrier of the leading group
 }
-// the MFMA waves' K loop: the schedule of k_loop_pingpong without any vector-memory instruction or vmcnt wait.  DBG = the instance that
-// carries the timing experiments (gemm_debug 4: half the barriers, 8 / 9: no fragment reads; results are wrong) and the time stamps.
-template <bool AKM, bool BKM, bool DBG = false>
-__device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, int lane, int wm, int wn, f32x16 (&acc)[2][2],
-                                                unsigned long long* stamp = nullptr, int debug = 0) {
+// the MFMA waves' K loop: the schedule of k_loop_pingpong without any vector-memory instruction or vmcnt wait
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, int lane, int wm, int wn, f32x16 (&acc)[2][2]) {
     using S = BlockShape<4>;
-    const bool half_barriers = DBG && debug == 4, no_reads = DBG && (debug == 8 || debug == 9);
     char* b0 = smem;
     char* b1 = smem + S::STAGE_BYTES;
     char* b2 = smem + 2 * S::STAGE_BYTES;
     if (nt <= 0) return;
     __builtin_amdgcn_s_barrier();                 // tile 0 is visible to everyone
-    if (DBG && stamp) stamp[1] = wall_clock64();
     if (wave >= 4) __builtin_amdgcn_s_barrier();  // the trailing group starts one barrier late
-    if (no_reads) {  // the barrier + MFMA skeleton of the loop without its fragment reads
-        bf16x8_t a[2][2], b[2][2];
-        const uint32_t k0[2] = {lds_addr(b0), lds_addr(b0)};
-        pp_load_half<AKM, BKM, 0>(b0 + (wm >> 1) * TILE_BYTES, b0 + S::NSUB * TILE_BYTES, k0, k0, wm & 1, wn, lane, a, b);
-        for (int t = 0; t < nt; ++t) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                pp_compute_half<AKM, BKM>(a, b, acc, []() {});
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-        if (wave < 4) __builtin_amdgcn_s_barrier();
-        return;
-    }
     for (int t = 0; t < nt; ++t) {
         const char* At = b0 + (wm >> 1) * TILE_BYTES;
         const char* Bt = b0 + S::NSUB * TILE_BYTES;
@@ -618,13 +522,13 @@ __device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, in
         bf16x8_t a[2][2], b[2][2];
         pp_load_half<AKM, BKM, 0>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
         __builtin_amdgcn_sched_barrier(0);
-        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 1
+        __builtin_amdgcn_s_barrier();  // 1
         pp_compute_half<AKM, BKM>(a, b, acc, []() {});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 2
         pp_load_half<AKM, BKM, 1>(At, Bt, ka, kb, wm & 1, wn, lane, a, b);
         __builtin_amdgcn_sched_barrier(0);
-        if (!half_barriers) __builtin_amdgcn_s_barrier();  // 3
+        __builtin_amdgcn_s_barrier();  // 3
         pp_compute_half<AKM, BKM>(a, b, acc, []() {});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // 4
@@ -632,125 +536,6 @@ __device__ __forceinline__ void k_loop_consumer(char* smem, int nt, int wave, in
         b0 = b1, b1 = b2, b2 = tmp;
     }
     if (wave < 4) __builtin_amdgcn_s_barrier();  // the leading group waits for the trailing one
-}
-
-// the loader waves' K loop beside k_loop_consumer_fat: two barriers per K tile
-template <bool AKM, bool BKM, int NL>
-__device__ __forceinline__ void k_loop_loader_fat(const LoaderStage<AKM, NL>& sa, const LoaderStage<BKM, NL>& sb, char* smem, int kt0, int nt, int K,
-                                                  int w, int lane) {
-    using S = BlockShape<4>;
-    constexpr int PER_TILE = 48 / NL;
-    char* b0 = smem;
-    char* b1 = smem + S::STAGE_BYTES;
-    char* b2 = smem + 2 * S::STAGE_BYTES;
-    if (nt <= 0) return;
-    if (nt > 1)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile 0 is visible to everyone
-    for (int t = 0; t < nt; ++t) {
-        const bool more = t + 2 < nt;
-        __builtin_amdgcn_s_barrier();  // 1: every MFMA wave has entered tile t, i.e. finished reading tile t-1 (stage b2)
-        if (more) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) loader_issue_group<AKM, BKM, NL>(sa, sb, (kt0 + t + 2) * BK, K, b2, g, w, lane);
-        }
-        if (t + 1 < nt) {
-            if (more)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();  // 2: tile t+1 has landed
-        char* tmp = b0;
-        b0 = b1, b1 = b2, b2 = tmp;
-    }
-    __builtin_amdgcn_s_barrier();  // the closing barrier
-}
-
-// ---- "fat wave" consumer (option gemm_fat): FOUR MFMA waves per 256x128 block, each 128 x 64 = 4 x 2 MFMA tiles, one per SIMD.
-// Why: a 64x64 wave reads 2 A + 2 B fragments (4 KiB) per 4 MFMAs = 1 KiB of LDS per MFMA, and eight such waves plus the 48-KiB DMA
-// write of the stage ask the LDS for 176 KiB per K tile = 1,375 clocks at 128 B/clk, against 1,024 clocks of MFMA: the K loop is bound
-// by LDS bandwidth (tools/power_probe.py: register-only MFMA chains sustain 1.87 PFLOP/s, with 1 KiB of fragment reads per MFMA 1.47 at a
-// HIGHER clock, with 0.75 KiB 1.62).  A 128x64 wave reads 4 A + 2 B fragments per 8 MFMAs = 0.75 KiB per MFMA: 144 KiB per K tile.
-// One wave per SIMD keeps the matrix pipe busy by itself: its eight accumulators are independent, and the fragment reads of k-step
-// s + 1 are issued between the MFMAs of step s.  Two barriers per K tile (k_loop_loader_fat): with a single wave group the stage of tile
-// t-1 is free as soon as every wave has entered tile t, so a loader wave requests all its pieces of tile t+2 at once -- the MFMA waves
-// meet the loaders at the tile boundaries only (a barrier inside the tile drains the matrix pipe when nobody shares the SIMD).
-template <bool AKM, bool BKM, int SS>
-__device__ __forceinline__ void fat_load(const char* At, const char* Bt, const uint32_t (&kl)[2], const uint32_t (&kh)[2], const uint32_t (&kb)[2],
-                                         int wn, int lane, bf16x8_t (&al)[2], bf16x8_t (&ah)[2], bf16x8_t (&b)[2]) {
-    load_frags<AKM, SS>(At, kl, 0, lane, al), load_frags<AKM, SS>(At, kh, 64, lane, ah), load_frags<BKM, SS>(Bt, kb, wn * 64, lane, b);
-}
-template <bool AKM, bool BKM, int N>
-__device__ __forceinline__ void fat_ready(bf16x8_t (&al)[2], bf16x8_t (&ah)[2], bf16x8_t (&b)[2]) {
-    if constexpr (AKM && BKM)
-        lgkm_wait_tied<N>(al[0], al[1], ah[0], ah[1], b[0], b[1]);
-    else if constexpr (AKM)
-        lgkm_wait_tied<N>(al[0], al[1], ah[0], ah[1]);
-    else if constexpr (BKM)
-        lgkm_wait_tied<N>(b[0], b[1]);
-}
-__device__ __forceinline__ void fat_mma(const bf16x8_t (&al)[2], const bf16x8_t (&ah)[2], const bf16x8_t (&b)[2], f32x16 (&acc)[2][2][2]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], al[i], acc[0][i][j], 0, 0, 0);
-            acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], ah[i], acc[1][i][j], 0, 0, 0);
-        }
-}
-// acc[h]: rows 64 h .. 64 h + 63 of the wave's 128 (= rows 128 wm2 + 64 h of the block tile), the layout of a 64x64 wave's acc[2][2]
-template <bool AKM, bool BKM>
-__device__ __forceinline__ void k_loop_consumer_fat(char* smem, int nt, int lane, int wm2, int wn, f32x16 (&acc)[2][2][2]) {
-    using S = BlockShape<4>;
-    constexpr int NASM = (AKM ? 8 : 0) + (BKM ? 4 : 0);  // asm (transpose) reads per k-step
-    char* b0 = smem;
-    char* b1 = smem + S::STAGE_BYTES;
-    char* b2 = smem + 2 * S::STAGE_BYTES;
-    if (nt <= 0) return;
-    __builtin_amdgcn_s_barrier();  // tile 0 is visible to everyone
-    const char* At = b0 + wm2 * TILE_BYTES;
-    const char* Bt = b0 + S::NSUB * TILE_BYTES;
-    uint32_t kl[2] = {0, 0}, kh[2] = {0, 0}, kb[2] = {0, 0};
-    auto set_tile = [&](const char* st) {
-        At = st + wm2 * TILE_BYTES, Bt = st + S::NSUB * TILE_BYTES;
-        if constexpr (AKM) {
-            kl[0] = lds_addr(At) + km_lane_off(0, lane), kl[1] = lds_addr(At) + km_lane_off(32, lane);
-            kh[0] = lds_addr(At) + km_lane_off(64, lane), kh[1] = lds_addr(At) + km_lane_off(96, lane);
-        }
-        if constexpr (BKM) kb[0] = lds_addr(Bt) + km_lane_off(wn * 64, lane), kb[1] = lds_addr(Bt) + km_lane_off(wn * 64 + 32, lane);
-    };
-    set_tile(b0);
-    __builtin_amdgcn_s_setprio(2);  // ahead of the loader wave that shares the SIMD
-    bf16x8_t al0[2], ah0[2], bb0[2], al1[2], ah1[2], bb1[2];
-    fat_load<AKM, BKM, 0>(At, Bt, kl, kh, kb, wn, lane, al0, ah0, bb0);
-    for (int t = 0; t < nt; ++t) {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();  // 1: every wave is past its last read of tile t-1 (its stage is refilled from here on)
-        fat_load<AKM, BKM, 1>(At, Bt, kl, kh, kb, wn, lane, al1, ah1, bb1);
-        fat_ready<AKM, BKM, NASM>(al0, ah0, bb0);
-        fat_mma(al0, ah0, bb0, acc);
-        fat_load<AKM, BKM, 2>(At, Bt, kl, kh, kb, wn, lane, al0, ah0, bb0);
-        fat_ready<AKM, BKM, NASM>(al1, ah1, bb1);
-        fat_mma(al1, ah1, bb1, acc);
-        fat_load<AKM, BKM, 3>(At, Bt, kl, kh, kb, wn, lane, al1, ah1, bb1);
-        fat_ready<AKM, BKM, NASM>(al0, ah0, bb0);
-        fat_mma(al0, ah0, bb0, acc);
-        fat_ready<AKM, BKM, 0>(al1, ah1, bb1);  // (the last reads of this tile have completed before barrier 4)
-        fat_mma(al1, ah1, bb1, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();  // 2: tile t+1 has landed
-        char* tmp = b0;
-        b0 = b1, b1 = b2, b2 = tmp;
-        if (t + 1 < nt) {
-            set_tile(b0);
-            fat_load<AKM, BKM, 0>(At, Bt, kl, kh, kb, wn, lane, al0, ah0, bb0);
-        }
-    }
-    __builtin_amdgcn_s_barrier();  // the closing barrier
-    __builtin_amdgcn_s_setprio(0);
 }
 
 // ---- epilogue staging: one 32-row slab of every wave's accumulators -> LDS [64][SLAB_PITCH] fp32, so that the

@@ -711,16 +711,18 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, int64_t lddy, cons
         }
     }
     if (!partial) {
-        const int cap = mmvid_option(MMVID_OPT_LN_BWD_BLOCKS);
-        if (blocks > cap) blocks = cap;
+        // one-stage form (no workspace): the dw / db atomics scale with the grid -- measured on the whole step 2048 blocks: +0.6 ms,
+        // 1024: +0.11 ms, 256: +0.25 ms against 512
+        if (blocks > 512) blocks = 512;
     }
     // in two-stage mode the kernel needs non-null dw/db to take the reduction branch at all
     float* const a_dw = partial ? (dw ? dw : workspace) : dw;
     float* const a_db = partial ? (db ? db : workspace) : db;
     float* const a_cs = partial ? (dx_colsum ? dx_colsum : nullptr) : dx_colsum;
-    // E = 512 / 768 (the towers): the software-pipelined instance (bit-identical); the prev row is always read, so `dx` must be readable
-    // memory even when it is only stored to (add_into_dx = 0) -- it is the output buffer: it is
-    if ((E == 768 || E == 512) && mmvid_option(MMVID_OPT_LN_FAST)) {
+    // E = 512 / 768 (the towers): the software-pipelined instance (the same arithmetic as the generic kernel up to fma contraction: dx
+    // within 1 ulp, dw / db partial rows equal); the prev row is always read, so `dx` must be readable memory even when it is only
+    // stored to (add_into_dx = 0) -- it is the output buffer: it is
+    if (E == 768 || E == 512) {
 #define MMVID_LN_FAST(DYT, NVI)                                                                                                            \
     hipLaunchKernelGGL((layernorm_bwd_fast_kernel<DYT, NVI>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const DYT*)dy, (long)lddy, x, \
                        (long)ldx, mean, rstd, w, (long)rows, dx, (long)lddx, add_into_dx, (bf16_t*)dx_bf16, a_dw, a_db, a_cs, partial)
@@ -809,7 +811,7 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
     float* ab = stats_scratch;                         // [N][C][2]
     float* partial = stats_scratch + (long)N * C * 2;  // [N][nblk][32][2]
     const long chunks = (long)N * hw * (C / 8);
-    if (partial_blocks == 0 && hw <= pix_per_block && mmvid_option(MMVID_OPT_GN_FUSED)) {  // one block per image does all three steps
+    if (partial_blocks == 0 && hw <= pix_per_block) {  // one block per image does all three steps
         if (x_is_bf16)
             hipLaunchKernelGGL(groupnorm_small_fused_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, (long)hw, C,
                                (float)hw * (float)(C / 32), eps, w, b, swish, (bf16_t*)y_bf16, y_f32);

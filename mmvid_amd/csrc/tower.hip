@@ -52,7 +52,7 @@ SavedLayer saved_layout(const Dims& d) {
     s.h2 = take(d.M * d.E * 2);
     s.pre = take(d.M * d.F * 2);
     s.act = take(d.M * d.F * 2);
-    const int64_t keep = mmvid_option(MMVID_OPT_DW_GROUPED) ? 1 : 0;  // (written by the backward only)
+    const int64_t keep = 1;  // (written by the backward only)
     s.k_gpj = take(keep * d.M * d.E * 2), s.k_dpre = take(keep * d.M * d.F * 2);
     s.k_gout = take(keep * d.M * d.E * 2), s.k_dqkv = take(keep * d.M * 3 * d.E * 2);
     // ... and the partial rows of its two LayerNorm backwards (weight / bias / column-sum gradients), reduced for all layers at once
@@ -62,7 +62,7 @@ SavedLayer saved_layout(const Dims& d) {
 }
 
 struct Scratch {  // byte offsets inside the scratch arena
-    int64_t delta, attn_ws, attn_ws_bytes, dqkv, d_h, d_o, d_pre, g_bf16, splitk_ws, ln_ws, infer, total;
+    int64_t delta, d_h, d_o, splitk_ws, infer, total;
 };
 Scratch scratch_layout(const Dims& d) {
     Scratch s;
@@ -73,15 +73,9 @@ Scratch scratch_layout(const Dims& d) {
         return o;
     };
     s.delta = take((int64_t)d.B * d.H * d.L * 4);
-    s.attn_ws_bytes = mmvid_attention_bwd_workspace_bytes(d.B, d.L, d.H);
-    s.attn_ws = take(s.attn_ws_bytes);
-    s.dqkv = take(d.M * 3 * d.E * 2);
-    s.d_h = take(d.M * d.E * 4);  // (bf16 by default: half of it is used)
+    s.d_h = take(d.M * d.E * 2);  // d(LN output), bf16: written by the dX GEMMs of c_fc / in_proj, read by the LayerNorm backward
     s.d_o = take(d.M * d.E * 2);
-    s.d_pre = take(d.M * d.F * 2);
-    s.g_bf16 = take(d.M * d.E * 2);
-    s.splitk_ws = take((int64_t)kMaxSplitK * d.F * d.E * 4);  // largest weight ([F,E] >= [3E,E]) x splits
-    s.ln_ws = take((int64_t)kLnBwdBlocks * 3 * d.E * 4);  // per-block rows of the LayerNorm backward's two-stage reduction
+    s.splitk_ws = take((int64_t)kMaxSplitK * d.F * d.E * 4);  // largest weight ([F,E] >= [3E,E]) x splits (short calls: per-layer dW)
     s.infer = take(saved_layout(d).total);  // one layer's worth of activations for inference mode
     s.total = off;
     return s;
@@ -215,47 +209,13 @@ extern "C" int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_to
     });
 }
 
-// Weight-gradient side stream.  In the backward of a Linear, dW (+ its split-K reduction and the bias column sum)
-// and dX both only read dY: the dW chain runs on a second stream while the main stream continues with dX, the
-// attention backward and the LayerNorm backwards.  Every kernel here is a few tens of microseconds with a fixed
-// ramp-up (workgroup dispatch ~22 ns each, first-tile latency) and a drain; two streams fill each other's ramps and
-// tails.  Fork / join are events, so the pattern is capturable (the side stream joins the capture and rejoins the
-// main stream before the call returns).  OFF by default (option tower_streams = 2 enables it): measured with
-// tools/ab_graph.py on the captured step it LOSES 1.8 % (22.68 vs 22.27 ms/step) -- the two chains compete for the
-// same CUs and L2 more than they fill each other's gaps.
-struct SideStream {
-    hipStream_t s = nullptr;
-    std::vector<hipEvent_t> ev;
-    size_t next = 0;
-    bool ok = false, tried = false;
-    hipEvent_t get() {
-        if (next == ev.size()) {
-            hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-            ev.push_back(e);
-        }
-        return ev[next++];
-    }
-};
-static SideStream& side_stream() {
-    static SideStream ss;
-    const bool want = mmvid_option(MMVID_OPT_TOWER_STREAMS) == 2;
-    if (want && !ss.tried) {
-        ss.tried = true;
-        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.s = nullptr;
-    }
-    ss.ok = want && ss.s != nullptr;
-    ss.next = 0;
-    return ss;
-}
-
 // The layer loop with the weight gradients taken out of it: every layer writes its four dY tensors into its own slice of the
 // scratch arena's `keep` region (no copies: the kernels that produce them are pointed there), and after the loop the weight
 // gradients of each kind -- c_proj, c_fc, out_proj, in_proj -- are ONE launch over all layers of this call, each block reducing
 // over all tokens (no split-K slabs, no reduce launches).  A kind whose group would leave the chip mostly idle (few layers per
 // call: the chunked backward of the multi-GPU engine) keeps the per-layer split-K launches, run after the loop on the same data.
 // Same arithmetic per element up to the fp32 summation order of the token reduction (one chain instead of split-K slabs).
-static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g, void* saved,
+static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g, void* saved,
                                   void* scratch, void* stream) {
     const Dims d = dims_of(*cfg);
     const SavedLayer sl = saved_layout(d);
@@ -264,21 +224,11 @@ static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_towe
     char* keep = (char*)saved;  // (the kept tensors are the backward's own: written here, read by the launches after the loop)
     struct { int64_t g_pj, d_pre, g_out, dqkv, total; } kl = {sl.k_gpj, sl.k_dpre, sl.k_gout, sl.k_dqkv, sl.total};
     const float scale = 0.125f;
-    const bool dh16 = mmvid_option(MMVID_OPT_DH_BF16) != 0;
-    const bool fuse_fc_bias = mmvid_option(MMVID_OPT_FUSE_COLSUM) != 0;
     void* d_h = scr + sc.d_h;
     float* ws = (float*)(scr + sc.splitk_ws);
     const int64_t ln_ws_floats = (int64_t)kLnBwdBlocks * 3 * d.E;
     std::vector<mmvid_ln_reduce_t> ln_items;
     int ln_blocks = 0;
-    const bool ln_now = mmvid_option(MMVID_OPT_DW_GROUPED) == 3;  // measurement: every LayerNorm backward reduces its own rows at once
-    auto ln_flush = [&]() -> int {
-        if (ln_now && !ln_items.empty()) {
-            TRY(mmvid_layernorm_bwd_reduce_multi((int)ln_items.size(), ln_items.data(), ln_blocks, d.E, stream));
-            ln_items.clear();
-        }
-        return MMVID_OK;
-    };
     for (int i = d.layers - 1; i >= 0; --i) {
         const mmvid_tower_layer_t& ly = layers[i];
         const char* sv = (const char*)saved + (int64_t)i * sl.total;
@@ -288,34 +238,31 @@ static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_towe
             TRY(mmvid_cast_f32_to_bf16(g, g_pj, d.M * d.E, stream));
             if (ly.g_pj_b) TRY(mmvid_colsum_bf16(g_pj, d.E, d.M, d.E, ly.g_pj_b, stream));
         }
-        TRY(linear_dx(d.M, d.E, d.F, g_pj, ly.pj_w, sv + sl.pre, nullptr, kp + kl.d_pre, stream, fuse_fc_bias ? ly.g_fc_b : nullptr));
-        if (!fuse_fc_bias && ly.g_fc_b) TRY(mmvid_colsum_bf16(kp + kl.d_pre, d.F, d.M, d.F, ly.g_fc_b, stream));
-        TRY(linear_dx(d.M, d.F, d.E, kp + kl.d_pre, ly.fc_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
+        // d_pre = (g W_proj) * QuickGELU'(pre); its column sums are c_fc's bias gradient: taken in this epilogue (unrounded fp32 sums)
+        TRY(linear_dx(d.M, d.E, d.F, g_pj, ly.pj_w, sv + sl.pre, nullptr, kp + kl.d_pre, stream, ly.g_fc_b));
+        TRY(linear_dx(d.M, d.F, d.E, kp + kl.d_pre, ly.fc_w, nullptr, nullptr, d_h, stream));
         {
             mmvid_ln_reduce_t r = {(const float*)(kp + sl.k_ln2), ly.g_ln2_w, ly.g_ln2_b, ly.g_out_b};
             int nb = 0;
-            TRY(mmvid_layernorm_bwd_partial(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
+            TRY(mmvid_layernorm_bwd_partial(d_h, 1, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
                                             (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, kp + kl.g_out, r.dw != nullptr,
                                             r.db != nullptr, r.dx_colsum != nullptr, (float*)(kp + sl.k_ln2), ln_ws_floats, &nb, stream));
             if (r.dw || r.db || r.dx_colsum) ln_items.push_back(r), ln_blocks = nb;
-            TRY(ln_flush());
         }
         TRY(linear_dx(d.M, d.E, d.E, kp + kl.g_out, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
-        TRY(mmvid_attention_bwd_ws(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
+        // (the in-projection's bias gradient -- column sums of dqkv -- comes out of the attention backward's registers)
+        TRY(mmvid_attention_bwd_bias(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
                                      (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
-                                     cfg->r1, cfg->c1, kp + kl.dqkv, 3 * d.E, fuse_fc_bias ? ly.g_in_b : nullptr, scr + sc.attn_ws, sc.attn_ws_bytes, stream));
-        // (option fuse_colsum 0: the bias gradient as column sums of the bf16-rounded dqkv -- the values the weight gradient uses)
-        if (!fuse_fc_bias && ly.g_in_b) TRY(mmvid_colsum_bf16(kp + kl.dqkv, 3 * d.E, d.M, 3 * d.E, ly.g_in_b, stream));
-        TRY(linear_dx(d.M, 3 * d.E, d.E, kp + kl.dqkv, ly.in_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
+                                     cfg->r1, cfg->c1, kp + kl.dqkv, 3 * d.E, ly.g_in_b, stream));
+        TRY(linear_dx(d.M, 3 * d.E, d.E, kp + kl.dqkv, ly.in_w, nullptr, nullptr, d_h, stream));
         {
             mmvid_ln_reduce_t r = {(const float*)(kp + sl.k_ln1), ly.g_ln1_w, ly.g_ln1_b, i > 0 ? layers[i - 1].g_pj_b : nullptr};
             int nb = 0;
-            TRY(mmvid_layernorm_bwd_partial(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
+            TRY(mmvid_layernorm_bwd_partial(d_h, 1, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
                                             (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1,
                                             i > 0 ? (void*)(keep + (int64_t)(i - 1) * kl.total + kl.g_pj) : nullptr, r.dw != nullptr,
                                             r.db != nullptr, r.dx_colsum != nullptr, (float*)(kp + sl.k_ln1), ln_ws_floats, &nb, stream));
             if (r.dw || r.db || r.dx_colsum) ln_items.push_back(r), ln_blocks = nb;
-            TRY(ln_flush());
         }
     }
     // ---- LayerNorm weight / bias gradients and the column sums that are the biases' gradients: one reduction for all layers
@@ -347,104 +294,11 @@ static int tower_backward_grouped(const mmvid_tower_cfg_t* cfg, const mmvid_towe
         ++nk;
     }
     if (nk == 0) return MMVID_OK;
-    if (mmvid_option(MMVID_OPT_DW_GROUPED) == 2) {  // measurement: one launch per kind (each with its own partial last round)
-        for (int k = 0; k < nk; ++k) TRY(mmvid_gemm_bf16_dw_multi(d.M, 1, kd + k, d.layers, 1, stream));
-        return MMVID_OK;
-    }
     if (mmvid_gemm_dw_multi_fill(nk, kd, d.layers) >= 0.7) return mmvid_gemm_bf16_dw_multi(d.M, nk, kd, d.layers, /*accumulate=*/1, stream);
     for (int k = 0; k < nk; ++k)  // few tiles (short calls of a chunked backward on a small model): per layer, split-K
         for (int i = d.layers - 1; i >= 0; --i)
             TRY(linear_dw(d.M, kd[k].N, kd[k].K, (const char*)kd[k].dY + (int64_t)i * kl.total, (const char*)kd[k].X + (int64_t)i * sl.total,
                           kd[k].dW_list[i], nullptr, ws, stream));
-    return MMVID_OK;
-}
-
-static int tower_backward_enqueue(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
-                                  void* saved, void* scratch, void* stream) {
-    const Dims d = dims_of(*cfg);
-    const SavedLayer sl = saved_layout(d);
-    const Scratch sc = scratch_layout(d);
-    char* scr = (char*)scratch;
-    const float scale = 0.125f;
-    void* gb = scr + sc.g_bf16;
-    // d(LN output), produced by the dX GEMMs of c_fc / in_proj and consumed by the LayerNorm backward: bf16 (option dh_bf16, the
-    // default) halves the GEMM's store burst and the LayerNorm backward's read; fp32 as round 2 had it otherwise
-    const bool dh16 = mmvid_option(MMVID_OPT_DH_BF16) != 0;
-    void* d_h = scr + sc.d_h;
-    float* ws = (float*)(scr + sc.splitk_ws);
-    float* ln_ws = (float*)(scr + sc.ln_ws);
-    const int64_t ln_ws_floats = (int64_t)kLnBwdBlocks * 3 * d.E;
-    SideStream& ss = side_stream();
-    hipStream_t s0 = (hipStream_t)stream;
-    void* wst = ss.ok ? (void*)ss.s : stream;  // where the dW chains go
-    bool hip_ok = true;
-    // s1 continues from s0's current point (the tensor a dW reads is ready)
-    auto fork = [&]() {
-        if (!ss.ok) return;
-        hipEvent_t e = ss.get();
-        hip_ok = hip_ok && e && hipEventRecord(e, s0) == hipSuccess && hipStreamWaitEvent(ss.s, e, 0) == hipSuccess;
-    };
-    // marks s1's current point (a dW chain has been queued); s0 waits for it before the buffer that chain reads is reused
-    auto mark = [&]() -> hipEvent_t {
-        if (!ss.ok) return nullptr;
-        hipEvent_t e = ss.get();
-        hip_ok = hip_ok && e && hipEventRecord(e, ss.s) == hipSuccess;
-        return e;
-    };
-    auto wait = [&](hipEvent_t e) {
-        if (e) hip_ok = hip_ok && hipStreamWaitEvent(s0, e, 0) == hipSuccess;
-    };
-    if (mmvid_option(MMVID_OPT_DW_GROUPED) && !ss.ok) return tower_backward_grouped(cfg, layers, g, saved, scratch, stream);
-    hipEvent_t ev_fc = nullptr, ev_in = nullptr;  // previous layer's dW chains that read d_pre / dqkv
-    for (int i = d.layers - 1; i >= 0; --i) {
-        const mmvid_tower_layer_t& ly = layers[i];
-        const char* sv = (const char*)saved + (int64_t)i * sl.total;
-        // ---- MLP branch: x_out = x_mid + c_proj(gelu(c_fc(LN2 x_mid)))
-        // gb = bf16(g): cast once for the top layer, afterwards written by the LayerNorm backward that updates g
-        if (i == d.layers - 1) TRY(mmvid_cast_f32_to_bf16(g, gb, d.M * d.E, stream));
-        // bias gradients of c_proj / out_proj = column sums of gb: produced by the LayerNorm backward that wrote gb
-        // (dx_colsum), except for the top layer of this call, whose gb comes from the cast above
-        fork();
-        TRY(linear_dw(d.M, d.E, d.F, gb, sv + sl.act, ly.g_pj_w, i == d.layers - 1 ? ly.g_pj_b : nullptr, ws, wst));
-        const hipEvent_t ev_pj = mark();
-        wait(ev_fc);  // the previous layer's c_fc dW still reads d_pre
-        // d_pre = (gb W_proj) * QuickGELU'(pre); its column sums are c_fc's bias gradient: taken in this epilogue
-        const bool fuse_fc_bias = mmvid_option(MMVID_OPT_FUSE_COLSUM) != 0;
-        TRY(linear_dx(d.M, d.E, d.F, gb, ly.pj_w, sv + sl.pre, nullptr, scr + sc.d_pre, stream,
-                      fuse_fc_bias ? ly.g_fc_b : nullptr));
-        fork();
-        TRY(linear_dw(d.M, d.F, d.E, scr + sc.d_pre, sv + sl.h2, ly.g_fc_w, fuse_fc_bias ? nullptr : ly.g_fc_b, ws, wst));
-        ev_fc = mark();
-        TRY(linear_dx(d.M, d.F, d.E, scr + sc.d_pre, ly.fc_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
-        wait(ev_pj);  // the LayerNorm backward overwrites gb
-        TRY(mmvid_layernorm_bwd_ex(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_mid), d.E, (const float*)(sv + sl.mean2),
-                                   (const float*)(sv + sl.rstd2), ly.ln2_w, d.M, d.E, g, d.E, 1, gb, ly.g_ln2_w, ly.g_ln2_b,
-                                   ly.g_out_b, ln_ws, ln_ws_floats, stream));
-        // ---- attention branch: x_mid = x_in + out_proj(MHA(LN1 x_in))
-        fork();
-        TRY(linear_dw(d.M, d.E, d.E, gb, sv + sl.o, ly.g_out_w, nullptr, ws, wst));
-        const hipEvent_t ev_out = mark();
-        TRY(linear_dx(d.M, d.E, d.E, gb, ly.out_w, nullptr, nullptr, scr + sc.d_o, stream));
-        wait(ev_in);  // the previous layer's in_proj dW still reads dqkv
-        // the in-projection's bias gradient (column sums of dqkv) comes out of the attention backward's registers
-        TRY(mmvid_attention_bwd_ws(sv + sl.qkv, 3 * d.E, sv + sl.o, d.E, scr + sc.d_o, d.E, (const float*)(sv + sl.lse2),
-                                     (float*)(scr + sc.delta), d.B, d.L, d.H, d.E, scale, cfg->mask_mode, cfg->r0, cfg->c0,
-                                     cfg->r1, cfg->c1, scr + sc.dqkv, 3 * d.E, fuse_fc_bias ? ly.g_in_b : nullptr, scr + sc.attn_ws, sc.attn_ws_bytes, stream));
-        if (!fuse_fc_bias && ly.g_in_b) TRY(mmvid_colsum_bf16(scr + sc.dqkv, 3 * d.E, d.M, 3 * d.E, ly.g_in_b, stream));
-        fork();
-        TRY(linear_dw(d.M, 3 * d.E, d.E, scr + sc.dqkv, sv + sl.h1, ly.g_in_w, nullptr, ws, wst));
-        ev_in = mark();
-        TRY(linear_dx(d.M, 3 * d.E, d.E, scr + sc.dqkv, ly.in_w, nullptr, dh16 ? nullptr : (float*)d_h, dh16 ? d_h : nullptr, stream));
-        wait(ev_out);  // the LayerNorm backward overwrites gb
-        TRY(mmvid_layernorm_bwd_ex(d_h, dh16 ? 1 : 0, d.E, (const float*)(sv + sl.x_in), d.E, (const float*)(sv + sl.mean1),
-                                   (const float*)(sv + sl.rstd1), ly.ln1_w, d.M, d.E, g, d.E, 1, i > 0 ? gb : nullptr, ly.g_ln1_w,
-                                   ly.g_ln1_b, i > 0 ? layers[i - 1].g_pj_b : nullptr, ln_ws, ln_ws_floats, stream));
-    }
-    wait(mark());  // join: every weight gradient of this call is complete for whatever follows on the caller's stream
-    if (!hip_ok) {
-        mmvid_set_error("tower_backward: stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
-        return MMVID_ERR_HIP;
-    }
     return MMVID_OK;
 }
 

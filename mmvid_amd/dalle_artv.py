@@ -309,8 +309,10 @@ class DALLE(nn.Module):
         hbuf, logits = h.clone(), torch.empty(B, V, device=dev)
         tok, E = torch.empty(B, dtype=torch.long, device=dev), torch.empty(B, V, device=dev)
         # production: the race variates of the whole loop in one draw (an exponential_ inside the captured step costs its launch and two
-        # generator-state fills per replay: 12 us per token); the draw of token n reads block n = position - first_pos
-        E_all = torch.empty(steps, B, V, device=dev).exponential_() if (race is None and steps * B * V <= (1 << 28)) else None
+        # generator-state fills per replay: 12 us per token); the draw of token n reads block n = position - first_pos.  Capped at
+        # 256 MB on top of the KV cache (batch 64 at 1,024 steps x 1,024 codes) and at the 1,024 rows the indexed draw kernel takes: larger
+        # calls draw per step (the `E.exponential_()` path below)
+        E_all = torch.empty(steps, B, V, device=dev).exponential_() if (race is None and steps * B * V <= (1 << 26) and B <= 1024) else None
 
         hid = [hbuf]  # the hidden state the next draw reads: the prompt's last position, then the session's output buffer
 

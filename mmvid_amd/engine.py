@@ -569,6 +569,9 @@ class GraphedStep:
         return self.loss
 
 
+_CAPTURABLE = {}  # (world size, device) -> the answer of collectives_capturable, once per process
+
+
 def collectives_capturable(device):
     """Can this runtime capture a collective of the current backend into a hipGraph?  Asked BEFORE the training step is captured, on a
     throw-away process group: a collective that fails inside a capture leaves the group's internal streams in capture mode (HIP does not
@@ -579,12 +582,30 @@ def collectives_capturable(device):
         return True
     if dist.get_backend() != 'nccl':
         return False
-    ok = True
+    key = (dist.get_world_size(), str(device))
+    if key in _CAPTURABLE:
+        return _CAPTURABLE[key]
+
+    def vote(ok):  # every rank learns whether EVERY rank got this far (the default group: untouched by the trial)
+        flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    pg = None
     try:
         pg = dist.new_group(backend='nccl')
+    except Exception:
+        pg = None
+    ok = vote(pg is not None)  # (no rank enters a collective of the trial group unless all of them have it)
+    if ok:
         t = torch.zeros(64, device=device)
-        dist.all_reduce(t, group=pg)  # (the communicator is built by the first, eager, collective)
-        torch.cuda.synchronize()
+        try:
+            dist.all_reduce(t, group=pg)  # (the communicator is built by the first, eager, collective)
+            torch.cuda.synchronize()
+        except Exception:
+            ok = False
+        ok = vote(ok)
+    if ok:
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
@@ -597,11 +618,11 @@ def collectives_capturable(device):
                 torch.cuda.synchronize()
             except Exception:
                 pass
-    except Exception:
-        ok = False
-    flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # (the default group: untouched by the trial)
-    return bool(int(flag.item()))
+        ok = vote(ok)
+    # (the trial group is kept: destroying a group whose collective sits in a captured graph aborts the process on this runtime; the
+    #  answer is cached per process, so exactly one extra communicator exists however often steps are captured)
+    _CAPTURABLE[key] = ok
+    return ok
 
 
 def backward_order(params):

@@ -271,16 +271,13 @@ def attention_fwd(qkv, B, L, H, mask=None, scale=0.125):
     return out, lse2
 
 
-def attention_bwd(qkv, out, dout, lse2, B, L, H, mask=None, scale=0.125, dbias=None, workspace=True):
-    """-> dqkv [B*L, 3E] bf16; dbias [3E] f32 (optional) += its column sums.  workspace: let the library split the blocks of the last,
-    partly filled round (mmvid_attention_bwd_ws); False = the workspace-free entry point."""
+def attention_bwd(qkv, out, dout, lse2, B, L, H, mask=None, scale=0.125, dbias=None):
+    """-> dqkv [B*L, 3E] bf16; dbias [3E] f32 (optional) += its column sums."""
     E = H * 64
     delta = torch.empty(B, H, L, device=qkv.device, dtype=f32)
     dqkv = torch.empty_like(qkv)
-    nbytes = _lib.load().mmvid_attention_bwd_workspace_bytes(B, L, H) if workspace else 0
-    ws = torch.empty(nbytes, device=qkv.device, dtype=torch.uint8) if nbytes else None
-    call('mmvid_attention_bwd_ws', _p(qkv), 3 * E, _p(out), E, _p(dout), E, _p(lse2), _p(delta), B, L, H, E, float(scale),
-         *_mask_args(mask), _p(dqkv), 3 * E, _p(dbias) if dbias is not None else None, _p(ws) if ws is not None else None, nbytes, _stream())
+    call('mmvid_attention_bwd_bias', _p(qkv), 3 * E, _p(out), E, _p(dout), E, _p(lse2), _p(delta), B, L, H, E, float(scale),
+         *_mask_args(mask), _p(dqkv), 3 * E, _p(dbias) if dbias is not None else None, _stream())
     return dqkv
 
 

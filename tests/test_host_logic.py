@@ -361,8 +361,7 @@ def test_library_host_side_policies():
     assert abs(ops.gemm_dw_multi_fill(four, 3) - 648 / (3 * 256)) < 1e-12     # chunks of 3 layers (multi-GPU engine)
     assert abs(ops.gemm_dw_multi_fill([(768, 768)], 12) - 216 / 256) < 1e-12
     assert ops.gemm_dw_multi_fill([(768, 768)], 3) < 0.7 and ops.gemm_dw_multi_fill([(512, 512)], 2) < 0.7
-    _lib.call('mmvid_set_option', b'dw_grouped', 1)
-    _lib.call('mmvid_set_option', b'gemm_tile', 0)
+    _lib.call('mmvid_set_option', b'graphs', 0)
     with pytest.raises(_lib.MMVIDError, match='unknown option'):
         _lib.call('mmvid_set_option', b'no_such_knob', 1)
 

@@ -149,35 +149,6 @@ def test_gemm_epilogues(ops):
     close(ops.gemm(Ab, Bb, out_dtype=torch.float32), Ab.float() @ Bb.float().transpose(1, 2), 1e-4, 'batched')
 
 
-@pytest.mark.parametrize('b_km', [False, True])
-@pytest.mark.parametrize('M,N,K', [(256, 128, 32), (300, 136, 200), (1000, 768, 776), (579, 2304, 768), (2100, 264, 72)])
-def test_gemm_four_wave_shape(ops, b_km, M, N, K):
-    """The 4-wave 256x128 block shape (two blocks per CU, 32-deep K tiles) forced on ragged M / N / K, both B layouts, and
-    on every epilogue the forward / dX GEMMs use; it must agree with the 8-wave shape to the last bit (same k order)."""
-    from mmvid_amd import _lib
-    A = rnd(M, K, seed=21, dtype=torch.bfloat16)
-    B = rnd(*((K, N) if b_km else (N, K)), seed=22, dtype=torch.bfloat16)
-    bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
-    pre_in = rnd(M, N, seed=25, dtype=torch.bfloat16)
-    ref = _ref_mm(A, B, False, b_km)
-    outs = {}
-    try:
-        for w in (2, 0):
-            _lib.call('mmvid_set_option', b'gemm_wshape', w)
-            save = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
-            cs = torch.zeros(N, device=DEV)
-            outs[w] = (ops.gemm(A, B, b_kmajor=b_km, out_dtype=torch.float32),
-                       ops.gemm(A, B, b_kmajor=b_km, bias=bias, act=1, save_pre=save), save,
-                       ops.gemm(A, B, b_kmajor=b_km, bias=bias, residual=res, out_dtype=torch.float32),
-                       ops.gemm(A, B, b_kmajor=b_km, dact_pre=pre_in, colsum=cs), cs)
-    finally:
-        _lib.call('mmvid_set_option', b'gemm_wshape', 0)
-    close(outs[2][0], ref, 1e-5 * math.sqrt(K) + 1e-4, f'four-wave gemm f32 {b_km} {M}x{N}x{K}')
-    for k, (a, b) in enumerate(zip(outs[2][:5], outs[0][:5])):
-        assert torch.equal(a, b), f'four-wave vs eight-wave shape differ (output {k})'
-    close(outs[2][5], outs[0][5], 1e-4, 'fused column sums (atomics: order differs)')
-
-
 def test_gemm_rejects_bad_shapes(ops):
     from mmvid_amd._lib import MMVIDError
     with pytest.raises(MMVIDError):

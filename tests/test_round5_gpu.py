@@ -1,6 +1,5 @@
-"""Round 5 on the GPU: the re-written attention kernels (mask-free tile loops, padding handled without the general predicate, tail
-splits of the backward passes), the software-pipelined LayerNorm backward, the
-encoder's bf16 residual stream (index match rate against the reference before / after)."""
+"""Round 5 on the GPU: the re-written attention kernels (mask-free tile loops, padding handled without the general predicate), the
+software-pipelined LayerNorm backward, the encoder's bf16 residual stream (index match rate against the reference before / after)."""
 import numpy as np
 import pytest
 import torch
@@ -30,15 +29,14 @@ def _mask_tensor(L, spec):
     return m
 
 
-@pytest.mark.parametrize('pk', [1, 0])
 @pytest.mark.parametrize('B,L,H,spec', [(1, 33, 2, None), (2, 97, 2, ('rows', [(70, 70), (71, 71)])), (2, 161, 3, None),
                                         (1, 577, 2, ('rows', [(65, 65), (66, 66)])), (1, 608, 2, None), (1, 609, 2, ('rows', [(129, 129), (130, 130)])),
                                         (1, 640, 2, None), (1, 641, 2, 'causal'), (2, 200, 2, 'causal'), (1, 643, 12, ('rows', [(129, 129), (130, 130)]))])
-def test_attention_ragged_lengths_and_masks(B, L, H, spec, pk):
+def test_attention_ragged_lengths_and_masks(B, L, H, spec):
     """Sequence lengths on every side of the 32- / 64- / 128-position boundaries, all three mask shapes: the forward's padding compare,
     the backward passes that need no padding mask at all (zero-filled K rows in dQ, never-stored lanes in dK / dV), the mask-free tile
-    pairs next to general tiles, both softmax instruction forms (option attn_pk) -- against fp32 torch on the bf16 inputs."""
-    from mmvid_amd import _lib, ops
+    pairs next to general tiles -- against fp32 torch on the bf16 inputs."""
+    from mmvid_amd import ops
     E = H * 64
     torch.manual_seed(L + H)
     qkv = (torch.randn(B * L, 3 * E, device=DEV) * 0.7).bfloat16()
@@ -46,25 +44,22 @@ def test_attention_ragged_lengths_and_masks(B, L, H, spec, pk):
     qr = qkv.float().requires_grad_(True)
     ref = _attn_ref(qr, B, L, H, _mask_tensor(L, spec))
     ref.backward(dO.float())
-    _lib.call('mmvid_set_option', b'attn_pk', pk)
-    try:
-        out, lse2 = ops.attention_fwd(qkv, B, L, H, spec)
-        dqkv = ops.attention_bwd(qkv, out, dO, lse2, B, L, H, spec, workspace=False)
-    finally:
-        _lib.call('mmvid_set_option', b'attn_pk', 1)
+    out, lse2 = ops.attention_fwd(qkv, B, L, H, spec)
+    dqkv = ops.attention_bwd(qkv, out, dO, lse2, B, L, H, spec)
     assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all() and torch.isfinite(lse2).all()
     close(out, ref, 1e-2, f'fwd L={L}')
     for nm, sl in (('dQ', slice(0, E)), ('dK', slice(E, 2 * E)), ('dV', slice(2 * E, 3 * E))):
         close(dqkv[:, sl], qr.grad[:, sl], 2e-2, f'{nm} L={L}')
 
 
-@pytest.mark.parametrize('E,rows', [(768, 10422), (768, 77), (512, 1000)])
+@pytest.mark.parametrize('E,rows', [(768, 10422), (768, 77), (512, 1000), (256, 300)])
 @pytest.mark.parametrize('dy16', [True, False])
-def test_layernorm_backward_pipelined_kernel_is_bit_identical(E, rows, dy16):
-    """Option ln_fast (default 1): the software-pipelined LayerNorm backward (next row's operands requested before this row is reduced)
-    against the generic kernel -- dx (added into the residual gradient), its bf16 copy and the partial rows of dw / db / colsum are
-    bit-identical; few rows per wave, both dy precisions, both tower widths."""
-    from mmvid_amd import _lib, ops
+def test_layernorm_backward_kernels_vs_torch(E, rows, dy16):
+    """The LayerNorm backward: E = 768 / 512 (the towers) run the software-pipelined kernel (next row's operands requested before this
+    row is reduced), other widths the generic kernel (E = 256 here) -- dx added into the residual gradient, its bf16 copy, the store
+    form, and the partial rows of dw / db / colsum reduced by mmvid_layernorm_bwd_reduce_multi, against torch autograd in fp32; few
+    rows per wave, both dy precisions; bit-reproducible."""
+    from mmvid_amd import ops
     torch.manual_seed(E + rows)
     x = torch.randn(rows, E, device=DEV) * 2 + 0.5
     w, b = torch.randn(E, device=DEV), torch.randn(E, device=DEV)
@@ -73,30 +68,28 @@ def test_layernorm_backward_pipelined_kernel_is_bit_identical(E, rows, dy16):
     dy = dy.bfloat16() if dy16 else dy
     base = torch.randn(rows, E, device=DEV)
     res = []
-    try:
-        for flag in (0, 1):
-            _lib.call('mmvid_set_option', b'ln_fast', flag)
-            ws = torch.zeros(512 * 3 * E, device=DEV)
-            dx, d16 = base.clone(), torch.zeros(rows, E, device=DEV, dtype=torch.bfloat16)
-            _, nb = ops.layernorm_bwd_partial(dy, x, mean, rstd, w, ws, dx=dx, add=True, dx_bf16=d16)
-            dw, db, cs = (torch.zeros(E, device=DEV) for _ in range(3))
-            ops.layernorm_bwd_reduce_multi([(ws, dw, db, cs)], nb, E)
-            # and the store form (no residual gradient to add to)
-            dx2, _ = ops.layernorm_bwd_partial(dy, x, mean, rstd, w, torch.zeros(512 * 3 * E, device=DEV), want=(True, True, False))
-            res.append((dx, d16, dw, db, cs, dx2))
-    finally:
-        _lib.call('mmvid_set_option', b'ln_fast', 1)
-    names = ('dx', 'dx bf16', 'dw', 'db', 'colsum', 'dx (store form)')
-    for nm, a, c in zip(names, res[0], res[1]):
-        d = (a.float() - c.float()).abs().max().item()
-        print(f'LN backward, pipelined vs generic, {nm}: max |d| {d:.3e} of max {a.float().abs().max().item():.3e}, equal {torch.equal(a, c)}')
-    for nm, a, c in zip(names, res[0], res[1]):
-        assert torch.equal(a, c), nm
+    for rep in range(2):
+        ws = torch.zeros(512 * 3 * E, device=DEV)
+        dx, d16 = base.clone(), torch.zeros(rows, E, device=DEV, dtype=torch.bfloat16)
+        _, nb = ops.layernorm_bwd_partial(dy, x, mean, rstd, w, ws, dx=dx, add=True, dx_bf16=d16)
+        dw, db, cs = (torch.zeros(E, device=DEV) for _ in range(3))
+        ops.layernorm_bwd_reduce_multi([(ws, dw, db, cs)], nb, E)
+        # and the store form (no residual gradient to add to)
+        dx2, _ = ops.layernorm_bwd_partial(dy, x, mean, rstd, w, torch.zeros(512 * 3 * E, device=DEV), want=(True, True, False))
+        res.append((dx, d16, dw, db, cs, dx2))
+    for nm, a, c in zip(('dx', 'dx bf16', 'dw', 'db', 'colsum', 'dx (store form)'), res[0], res[1]):
+        assert torch.equal(a, c), f'{nm}: not reproducible'
+    dx, d16, dw, db, cs, dx2 = res[0]
     xr = x.clone().requires_grad_(True)
     wr = w.clone().requires_grad_(True)
-    torch.nn.functional.layer_norm(xr, (E, ), wr, b, 1e-5).backward(dy.float())
-    close(res[1][0] - base, xr.grad, 1e-4, 'LN dx')
-    close(res[1][2], wr.grad, 1e-4, 'LN dw')
+    br = b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (E, ), wr, br, 1e-5).backward(dy.float())
+    close(dx - base, xr.grad, 1e-4, 'LN dx (added into the residual gradient)')
+    close(dx2, xr.grad, 1e-5, 'LN dx (store form)')
+    close(d16, dx, 1e-2, 'LN dx bf16 copy')
+    close(dw, wr.grad, 1e-4, 'LN dw')
+    close(db, br.grad, 1e-4, 'LN db')
+    close(cs, dx.sum(0), 1e-4, 'LN colsum of the updated residual gradient')
 
 
 def test_encoder_bf16_residual_stream_index_match_rate(golden):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of SEVERAL configurations of the whole training step (tools/ab_graph.py compares the values of one knob).
 
-    python tools/ab_multi.py base ln_fast=0 gn_fused=0 py:vae.stream=f32 attn_tail=0 "ln_fast=0,gn_fused=0,py:vae.stream=f32"
+    python tools/ab_multi.py base py:vae.stream=f32 py:vae.strict=split
 
 Every argument is one configuration = the defaults + its comma-separated overrides (`base` = none).  The step is captured once per
 configuration (engine.GraphedStep) and the graphs are replayed alternately in groups of 5 (GPU-bound timing, ~0.2 %; box-to-box and
@@ -18,7 +18,7 @@ import bench
 from mmvid_amd import _lib
 from mmvid_amd.engine import FlatTrainer, GraphedStep, backward_order
 
-DEFAULTS = {'ln_fast': 1, 'gn_fused': 1, 'attn_tail': 7, 'attn_pk': 3, 'py:vae.stream': 'bf16'}
+DEFAULTS = {'py:vae.stream': 'bf16'}
 
 
 def apply(model, name, v):

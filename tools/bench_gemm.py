@@ -26,8 +26,7 @@ def timeit(fn, iters=20):
 
 
 def strip():
-    """The strip convolution on the encoder's mode-0 layers (54 frames), both DMA schedules, against the per-tap kernel."""
-    from mmvid_amd import _lib
+    """The strip convolution on the encoder's mode-0 layers (54 frames) against the per-tap kernel."""
     for name, N, H, Cin, Cout in (('c128@128', 54, 128, 128, 128), ('c128@64', 54, 64, 128, 128), ('c256@32', 54, 32, 256, 256),
                                   ('c128->256@32', 54, 32, 128, 256)):
         x = torch.randn(N, H, H, Cin, device=dev).to(bf)
@@ -37,45 +36,15 @@ def strip():
         fl = 2.0 * N * H * H * Cout * 9 * Cin
         t = timeit(lambda: ops.conv2d_nhwc(x, w, b, 0), 5)
         line = f'{name:13s} per-tap {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF |'
-        for sched in (0, 1, 2):
-            _lib.call('mmvid_set_option', b'strip_sched', sched)
-            t = timeit(lambda: ops.conv3x3_strip(x, w, b), 5)
-            t2 = timeit(lambda: ops.conv3x3_strip(x, w, b, residual=r32, out_dtype=torch.float32), 5)
-            line += f' strip sched {sched}: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF, +res f32: {t2*1e3:7.1f} us {fl/t2/1e9:7.1f} TF |'
+        t = timeit(lambda: ops.conv3x3_strip(x, w, b), 5)
+        t2 = timeit(lambda: ops.conv3x3_strip(x, w, b, residual=r32, out_dtype=torch.float32), 5)
+        line += f' strip: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF, +res f32: {t2*1e3:7.1f} us {fl/t2/1e9:7.1f} TF |'
         print(line)
-
-
-def anatomy():
-    """What a transformer GEMM's time is made of: the launch as it is, without the epilogue's global stores (K loop + operand
-    traffic only), and without the K loop (prologue + epilogue + output traffic only).  Options gemm_debug 1 / 2."""
-    from mmvid_amd import _lib
-    M = 10422
-    for name, N, K, kw in (('qkv fwd', 2304, 768, {}), ('out fwd', 768, 768, {}), ('fc fwd (+gelu, pre saved)', 3072, 768, {'gelu': True}),
-                           ('proj fwd', 768, 3072, {}), ('K=6144 probe', 768, 6144, {})):
-        X = torch.randn(M, K, device=dev).to(bf)
-        W = (torch.randn(N, K, device=dev) * 0.03).to(bf)
-        bias = torch.zeros(N, device=dev)
-        pre = torch.empty(M, N, device=dev, dtype=bf) if kw.get('gelu') else None
-        fl = 2.0 * M * N * K
-        row = f'{name:28s} {M}x{N}x{K}:'
-        for w, dbg, label in ((0, 0, 'full'), (0, 1, 'no stores'), (0, 2, 'no K loop'), (2, 0, '| 4-wave shape: full'), (2, 1, 'no stores'), (2, 2, 'no K loop')):
-            _lib.call('mmvid_set_option', b'gemm_debug', dbg)
-            _lib.call('mmvid_set_option', b'gemm_wshape', w)
-            if pre is not None:
-                t = timeit(lambda: ops.gemm(X, W, bias=bias, act=1, save_pre=pre))
-            else:
-                t = timeit(lambda: ops.gemm(X, W, bias=bias))
-            row += f'  {label} {t*1e3:6.1f} us' + (f' ({fl/t/1e9:6.1f} TF)' if dbg < 2 else '')
-        _lib.call('mmvid_set_option', b'gemm_debug', 0)
-        _lib.call('mmvid_set_option', b'gemm_wshape', 0)
-        print(row)
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'strip':
         return strip()
-    if len(sys.argv) > 1 and sys.argv[1] == 'anatomy':
-        return anatomy()
     M = 10422
     for name, N, K in (('qkv', 2304, 768), ('out', 768, 768), ('fc', 3072, 768), ('proj', 768, 3072)):
         X = torch.randn(M, K, device=dev).to(bf)
@@ -83,15 +52,10 @@ def main():
         dY = torch.randn(M, N, device=dev).to(bf)
         dW = torch.zeros(N, K, device=dev)
         fl = 2.0 * M * N * K
-        from mmvid_amd import _lib
-        for w in (0, 2):
-            _lib.call('mmvid_set_option', b'gemm_wshape', w)
-            tag = 'four-wave' if w else 'eight-wave'
-            t = timeit(lambda: ops.gemm(X, W))
-            print(f'{name:5s} fwd  NT {M}x{N}x{K} {tag:10s}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
-            t = timeit(lambda: ops.gemm(dY, W, b_kmajor=True))
-            print(f'{name:5s} dX   NN {M}x{K}x{N} {tag:10s}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
-        _lib.call('mmvid_set_option', b'gemm_wshape', 0)
+        t = timeit(lambda: ops.gemm(X, W))
+        print(f'{name:5s} fwd  NT {M}x{N}x{K}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
+        t = timeit(lambda: ops.gemm(dY, W, b_kmajor=True))
+        print(f'{name:5s} dX   NN {M}x{K}x{N}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
         for sk in (None, 3, 4, 8, 14):
             t = timeit(lambda: ops.gemm_dw(dY, X, dW, splitk=sk))
             print(f'{name:5s} dW   TN sk={sk} {N}x{K}x{M}: {t*1e3:8.1f} us {fl/t/1e9:8.1f} TF')
