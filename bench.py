@@ -434,7 +434,7 @@ def main():
     ap.add_argument('--dry-run', action='store_true', help='rank plumbing only (gloo, no GPU work): start the ranks, all-reduce '
                     'one scalar, print the JSON skeleton')
     ap.add_argument('--no-exact', action='store_true', help="skip the extra leg that times the step with vae.strict = 'split'")
-    ap.add_argument('--strict', nargs='?', const='fp32', default=None, choices=['fp32', 'split'],
+    ap.add_argument('--strict', nargs='?', const='fp32', default=None, choices=['fp32', 'split', 'mixed'],
                     help="run the VQGAN encoder in an exact-index mode: 'fp32' (vae.strict = True, fp32 matrix pipe) or 'split' "
                     "(vae.strict = 'split': bf16-pair convolutions, 3 products each, on the bf16 pipe)")
     args = ap.parse_args()
@@ -496,7 +496,7 @@ def main():
         return
     model = build_model(args.config, device, args.layers)
     if args.strict:  # exact-index tokenisation (vae.strict; 'split' = 3-term bf16 split on the MFMA pipe, True = f32 MFMA)
-        model.vae.strict = True if args.strict == 'fp32' else 'split'
+        model.vae.strict = True if args.strict == 'fp32' else args.strict
         if model.cvae is not None:
             model.cvae.strict = model.vae.strict
     model.frontend.seed = seed  # every rank draws its own masks / warps
@@ -580,25 +580,34 @@ def main():
     # golden; the headline above tokenises with the bf16 operator).  Reported beside the headline, never as `value`.
     exact = None
     if world == 1 and not args.strict and not args.eager and not args.no_exact:
+        what = {'mixed': "the pair operator of 'split' except the 3x3 residual-block convolutions of the 128x128, 64x64 and 32x32 levels (82 % of the "
+                         'multiply-adds), which are ONE product of fp16 operands, fp32 accumulate: token indices equal the reference on all '
+                         'goldens and the top-2 gap stays above 8x its error (tests/test_round3_gpu.py::test_split_index_safety_margin)',
+                'split': 'every VQGAN convolution as three bf16 products of hi/lo pairs (fp32 accumulate), fp32 GroupNorm / attention / residual '
+                         'stream: token indices equal the reference on all goldens'}
         try:
-            model.vae.strict = 'split'
-            if model.cvae is not None:
-                model.cvae.strict = 'split'
-            ex_step = GraphedStep(trainer, fn, batch, warmup=2)
-            n_ex = max(5, min(20, args.steps))
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(n_ex):
-                ex_step()
-            fence()
-            ex_ms = (time.perf_counter() - t1) / n_ex * 1e3
-            exact = {'vae.strict': 'split', 'steps': n_ex, 'ms_per_step': ex_ms, 'value': B * tok_per_sample / (ex_ms * 1e-3),
-                     'unit': 'video-tokens/s', 'ratio_to_headline_step': ex_ms / (dt / args.steps * 1e3),
-                     'launch': 'hipGraph replay' if ex_step.graph is not None else 'eager',
-                     'what': 'VQGAN convolutions as three bf16 products of hi/lo pairs (fp32 accumulate), fp32 GroupNorm / attention '
-                             '/ residual stream: token indices equal the reference on all goldens (tests/test_round3_gpu.py)'}
+            for mode in ('mixed', 'split'):
+                model.vae.strict = mode
+                if model.cvae is not None:
+                    model.cvae.strict = mode
+                ex_step = GraphedStep(trainer, fn, batch, warmup=2)
+                n_ex = max(5, min(20, args.steps))
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(n_ex):
+                    ex_step()
+                fence()
+                ex_ms = (time.perf_counter() - t1) / n_ex * 1e3
+                leg = {'vae.strict': mode, 'steps': n_ex, 'ms_per_step': ex_ms, 'value': B * tok_per_sample / (ex_ms * 1e-3),
+                       'unit': 'video-tokens/s', 'ratio_to_headline_step': ex_ms / (dt / args.steps * 1e3),
+                       'launch': 'hipGraph replay' if ex_step.graph is not None else 'eager', 'what': what[mode]}
+                if exact is None:
+                    exact = leg
+                else:
+                    exact['all_pair_operator'] = leg
+                del ex_step
         except Exception as e:
-            exact = {'error': repr(e)}
+            exact = dict(exact or {}, error=repr(e))
         finally:
             model.vae.strict = False
             if model.cvae is not None:
@@ -643,10 +652,12 @@ def main():
             'unit': 'video-tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {None: 'bf16', 'fp32': 'bf16 (transformer) + fp32 (VQGAN encoder, exact token indices)',
-                      'split': 'bf16 (transformer) + bf16-pair convolutions / fp32 elsewhere (VQGAN encoder)'}[args.strict],
+                      'split': 'bf16 (transformer) + bf16-pair convolutions / fp32 elsewhere (VQGAN encoder)',
+                      'mixed': 'bf16 (transformer) + fp16 / bf16-pair convolutions / fp32 elsewhere (VQGAN encoder)'}[args.strict],
             'data': 'synthetic',
             'config': {'workload': WORKLOADS[args.config] + {None: '', 'fp32': ' [vae.strict: fp32 encoder]',
-                                                             'split': " [vae.strict = 'split': bf16-pair encoder]"}[args.strict],
+                                                             'split': " [vae.strict = 'split': bf16-pair encoder]",
+                                                             'mixed': " [vae.strict = 'mixed': fp16 + bf16-pair encoder]"}[args.strict],
                        'config_id': args.config, 'per_gpu_batch': B, 'global_batch': world * B,
                        'seq_len': L, 'parallelism': f'dp{world}' + (' (ranks SHARE the visible GPUs, gloo exchange: a path check, not a measurement)' if os.environ.get('MMVID_BENCH_SHARED_GPU', '0') == '1' and torch.cuda.device_count() < world else ''), 'step_launch': step_launch, 'layers': args.layers},
             'loss': loss_value, 'roofline': roofline, 'kernels': kernels,

@@ -493,6 +493,19 @@ int mmvid_image_to_nhwc8_split(const float* img, int N, int H, int W, void* plan
  * mmvid_groupnorm_swish_nhwc (0: a statistics pass runs here).  stats_scratch: fp32 [N*(2*C + 64*ceil(hw/64))]. */
 int mmvid_groupnorm_swish_nhwc_split(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
                                      int swish, float* stats_scratch, int partial_blocks, void* planes_bf16, void* stream);
+/* ---- the fp16 layers of the exact-index mode `vae.strict = 'mixed'` (mmvid_amd/vae.py; the same reference lines).  The per-layer
+ * sweep (profiles/r05_exact_index_layer_sensitivity_sweep.log) shows where the pair operator's 2^-17 per operand is needed: one layer
+ * in plain bf16 (2^-9) raises the z error 50-100x, one layer with IEEE-half operands (2^-12; the matrix pipe's f16 rate equals its
+ * bf16 rate) 6-18x.  The 3x3 residual-block convolutions of the 128x128, 64x64 and 32x32 levels (82 % of the encoder's multiply-adds)
+ * run as ONE product of fp16 operands with fp32 accumulation and everything else stays the pair operator: the reference's top-2
+ * distance gap stays above 8x the error of that gap on every golden frame (the acceptance test of the split mode) at 1.35x instead of
+ * 3x the plain bf16 work.
+ * x_f16 [N,H,W,Cin] IEEE half, w_f16 [Cout][9][Cin] IEEE half; residual / output fp32; gn_partial64 as in the strip kernel. */
+int mmvid_conv3x3_strip_nhwc_f16(const void* x_f16, int N, int H, int W, int Cin, const void* w_f16, const float* bias, int Cout,
+                                 const float* residual_f32, float* out_f32, float* gn_partial64, void* stream);
+/* mmvid_groupnorm_swish_nhwc_split with the result stored as one plane of IEEE-half values [N,hw,C] */
+int mmvid_groupnorm_swish_nhwc_f16out(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
+                                      int swish, float* stats_scratch, int partial_blocks, void* y_f16, void* stream);
 
 /* ---- native op-list executor for the VQGAN encoder / decoder (model.py:439-466, 551-582; vae.py:38-56): the host
  * plans the op sequence once per input shape, every call is then one host->native transition.  Offsets are bytes
@@ -521,6 +534,9 @@ enum {
  * form, flags&32 split-K by 4 through `scratch`, flags&4 GroupNorm partial sums of the output into the stats area `scratch`);
  * GROUPNORM flags&2 / flags&8 as for the bf16 operator (partial sums written by the producing CONV). */
 #define MMVID_VQFLAG_SPLIT 64
+/* flags & 128, together with SPLIT: GROUPNORM writes ONE fp16 plane at out_bf16 (mmvid_groupnorm_swish_nhwc_f16out); CONV (strip form,
+ * flags&8) reads such a plane at in0 with w = fp16 [Cout][9][Cin] (mmvid_conv3x3_strip_nhwc_f16). */
+#define MMVID_VQFLAG_F16 128
 typedef struct {
     int32_t op, mode;
     int32_t N, H, W, C;

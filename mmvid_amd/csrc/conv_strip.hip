@@ -47,6 +47,7 @@ struct StripParams {
 // K loop: two-group ping-pong -- the block's halves alternate between a load part and a 16-MFMA cluster, one barrier apart.  (Rounds
 // 1-2 also carried a one-barrier-per-tile loop with the LDS-DMA requests right behind the barrier, and one with the requests spread
 // over the first three k-steps: 18.59 / 18.53 / 18.49 ms per step, profiles/r01_ab_gemm_sched*.log; removed in round 5.)
+template <bool F16>  // F16: the operands are IEEE half (v_mfma_f32_32x32x16_f16: same rate, same layouts; 11 significand bits against 8)
 __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +144,12 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (F16)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, fb[j]), __builtin_bit_cast(f16x8_t, fa[i]), acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
     };
     {
         // ---- two-group ping-pong (MI355X_MICROARCH.md "Two waves per SIMD"): waves 0-3 and 4-7 -- one of each per SIMD -- run one
@@ -291,23 +297,30 @@ extern "C" int mmvid_conv3x3_strip_supported(int H, int W, int Cin, int Cout) {
 
 static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
                         const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32, float* gn_partial64,
-                        void* stream);
+                        void* stream, bool f16);
 
 extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
                                         const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32,
                                         float* gn_partial64, void* stream) {
-    return strip_launch(1, x, N, H, W, Cin, w, bias, Cout, residual_bf16, residual_f32, out_bf16, out_f32, gn_partial64, stream);
+    return strip_launch(1, x, N, H, W, Cin, w, bias, Cout, residual_bf16, residual_f32, out_bf16, out_f32, gn_partial64, stream, false);
 }
 
 // the split operator of conv.hip (mmvid_conv2d_nhwc_split3) in strip form: x_planes [2][N,H,W,Cin], w3 [Cout][3][9][Cin]
 extern "C" int mmvid_conv3x3_strip_nhwc_split3(const void* x_planes, int N, int H, int W, int Cin, const void* w3, const float* bias,
                                                int Cout, const float* residual_f32, float* out_f32, float* gn_partial64, void* stream) {
-    return strip_launch(3, x_planes, N, H, W, Cin, w3, bias, Cout, nullptr, residual_f32, nullptr, out_f32, gn_partial64, stream);
+    return strip_launch(3, x_planes, N, H, W, Cin, w3, bias, Cout, nullptr, residual_f32, nullptr, out_f32, gn_partial64, stream, false);
+}
+
+// one product of IEEE-half operands, fp32 in / out around it: x fp16 [N,H,W,Cin], w fp16 [Cout][9][Cin] (the exact-index mode's 128x128 and
+// 64x64 levels, mmvid_amd/vae.py strict = 'mixed': 2^-12 per operand against the pair's 2^-17 and plain bf16's 2^-9)
+extern "C" int mmvid_conv3x3_strip_nhwc_f16(const void* x_f16, int N, int H, int W, int Cin, const void* w_f16, const float* bias, int Cout,
+                                            const float* residual_f32, float* out_f32, float* gn_partial64, void* stream) {
+    return strip_launch(1, x_f16, N, H, W, Cin, w_f16, bias, Cout, nullptr, residual_f32, nullptr, out_f32, gn_partial64, stream, true);
 }
 
 static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
                         const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32, float* gn_partial64,
-                        void* stream) {
+                        void* stream, bool f16) {
     MMVID_REQUIRE(x && w && (out_bf16 || out_f32), "conv3x3_strip: null pointer");
     MMVID_REQUIRE(W >= 8 && W <= 128 && (W & (W - 1)) == 0 && Cin >= 32 && (Cin & (Cin - 1)) == 0 && Cout % 128 == 0 &&
                       ((long)H * W) % 64 == 0,
@@ -325,12 +338,16 @@ static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, 
     if (p.M == 0) return MMVID_OK;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_strip_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_strip_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
         attr = true;
     }
     MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * 9 * Cin * terms, (hipStream_t)stream);
     const int blocks = cdiv(p.M, ST_M) * (Cout / ST_N);
-    hipLaunchKernelGGL(conv_strip_kernel, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
+    if (f16)
+        hipLaunchKernelGGL(conv_strip_kernel<true>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_strip_kernel<false>, dim3(blocks), dim3(512), ST_LDS, (hipStream_t)stream, p);
     MMVID_LAUNCH_CHECK("conv3x3_strip");
     return MMVID_OK;
 }

@@ -610,7 +610,8 @@ __global__ __launch_bounds__(256) void groupnorm_finalize_f64_kernel(const float
 }
 
 // y = swish?(((x - mean) * rstd) * w + b) evaluated like ATen (expf, true division), stored as hi = bf16(y), lo = bf16(y - hi)
-// in planes [2][N*hw*C]; 8 channels per thread
+// in planes [2][N*hw*C]; 8 channels per thread.  F16: ONE plane of IEEE-half values instead (the input of the fp16 single-product convolutions)
+template <bool F16>
 __global__ __launch_bounds__(256) void groupnorm_apply_split_kernel(const float* __restrict__ x, long hw, int C,
                                                                     const float* __restrict__ mr, const float* __restrict__ w,
                                                                     const float* __restrict__ b, int swish,
@@ -636,6 +637,16 @@ __global__ __launch_bounds__(256) void groupnorm_apply_split_kernel(const float*
         float v = ((f[e] - mu[e]) * rs[e]) * wv[e] + bv[e];
         if (swish) v = v * (1.0f / (1.0f + expf(-v)));
         o[e] = v;
+    }
+    if constexpr (F16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+            const h2_t p2 = {(_Float16)o[2 * e], (_Float16)o[2 * e + 1]};  // round to nearest even
+            h[e] = __builtin_bit_cast(uint32_t, p2);
+        }
+        *reinterpret_cast<uint4*>(planes + t * 8) = make_uint4(h[0], h[1], h[2], h[3]);
+        return;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -846,8 +857,21 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
 // GroupNorm(32) [+ swish] of the split operator: x fp32 NHWC -> bf16 pair planes [2][N,hw,C].  Partial sums in fp32 -- per 256
 // pixels by a statistics pass here (partial_blocks = 0), or per 128 / 64 pixels by the producing convolution's epilogue
 // (partial_blocks = hw/128 or hw/64) -- combined and finalised in fp64.  stats_scratch: fp32 [N*(2*C + 64*ceil(hw/64))].
+static int groupnorm_split_launch(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps, int swish,
+                                  float* stats_scratch, int partial_blocks, void* planes_bf16, void* stream, bool f16);
+
 extern "C" int mmvid_groupnorm_swish_nhwc_split(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
                                                 int swish, float* stats_scratch, int partial_blocks, void* planes_bf16, void* stream) {
+    return groupnorm_split_launch(x, N, hw, C, w, b, eps, swish, stats_scratch, partial_blocks, planes_bf16, stream, false);
+}
+// the same statistics and arithmetic, the result stored as ONE plane of IEEE-half values [N*hw*C]
+extern "C" int mmvid_groupnorm_swish_nhwc_f16out(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
+                                                 int swish, float* stats_scratch, int partial_blocks, void* y_f16, void* stream) {
+    return groupnorm_split_launch(x, N, hw, C, w, b, eps, swish, stats_scratch, partial_blocks, y_f16, stream, true);
+}
+
+static int groupnorm_split_launch(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps, int swish,
+                                  float* stats_scratch, int partial_blocks, void* planes_bf16, void* stream, bool f16) {
     MMVID_REQUIRE(x && w && b && stats_scratch && planes_bf16, "groupnorm_split: null pointer");
     MMVID_REQUIRE(C % 32 == 0 && C <= 512 && 256 % (C / 8) == 0, "groupnorm_split: C=%d unsupported", C);
     MMVID_REQUIRE(partial_blocks >= 0 && partial_blocks <= cdiv(hw, 64), "groupnorm_split: partial_blocks %d", partial_blocks);
@@ -864,8 +888,12 @@ extern "C" int mmvid_groupnorm_swish_nhwc_split(const float* x, int N, int64_t h
     hipLaunchKernelGGL(groupnorm_finalize_f64_kernel, dim3(cdiv((long)N * 32, 4)), dim3(256), 0, s, partial, nblk, N, C,
                        (double)hw * (double)(C / 32), eps, mr);
     const long chunks = (long)N * hw * (C / 8);
-    hipLaunchKernelGGL(groupnorm_apply_split_kernel, dim3(cdiv(chunks, 256)), dim3(256), 0, s, x, (long)hw, C, mr, w, b, swish,
-                       (bf16_t*)planes_bf16, chunks);
+    if (f16)
+        hipLaunchKernelGGL(groupnorm_apply_split_kernel<true>, dim3(cdiv(chunks, 256)), dim3(256), 0, s, x, (long)hw, C, mr, w, b, swish,
+                           (bf16_t*)planes_bf16, chunks);
+    else
+        hipLaunchKernelGGL(groupnorm_apply_split_kernel<false>, dim3(cdiv(chunks, 256)), dim3(256), 0, s, x, (long)hw, C, mr, w, b, swish,
+                           (bf16_t*)planes_bf16, chunks);
     MMVID_LAUNCH_CHECK("groupnorm_split");
     return MMVID_OK;
 }

@@ -61,7 +61,11 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
                     rc = mmvid_image_to_nhwc8_split((const float*)o.ext_in, o.N, o.H, o.W, at(arena, o.out_bf16), stream);
                     break;
                 case MMVID_VQOP_CONV:
-                    if (o.flags & 8)
+                    if ((o.flags & 8) && (o.flags & MMVID_VQFLAG_F16))  // one fp16 product (in0 = an fp16 tensor written by the GroupNorm below)
+                        rc = mmvid_conv3x3_strip_nhwc_f16(at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout, (const float*)at(arena, o.in1),
+                                                          (float*)at(arena, o.out_f32),
+                                                          (o.flags & 4) ? (float*)at(arena, o.scratch) + (int64_t)o.N * o.Cout * 2 : nullptr, stream);
+                    else if (o.flags & 8)
                         rc = mmvid_conv3x3_strip_nhwc_split3(at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
                                                              (const float*)at(arena, o.in1), (float*)at(arena, o.out_f32),
                                                              (o.flags & 4) ? (float*)at(arena, o.scratch) + (int64_t)o.N * o.Cout * 2 : nullptr,
@@ -74,10 +78,9 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
                                                       stream);
                     break;
                 case MMVID_VQOP_GROUPNORM:
-                    rc = mmvid_groupnorm_swish_nhwc_split((const float*)at(arena, o.in0), o.N, (int64_t)o.H * o.W, o.C,
-                                                          (const float*)o.w, o.b, o.eps, o.mode, (float*)at(arena, o.scratch),
-                                                          (o.flags & 2) ? (o.H * o.W) / ((o.flags & 8) ? 64 : 128) : 0,
-                                                          at(arena, o.out_bf16), stream);
+                    rc = ((o.flags & MMVID_VQFLAG_F16) ? mmvid_groupnorm_swish_nhwc_f16out : mmvid_groupnorm_swish_nhwc_split)(
+                        (const float*)at(arena, o.in0), o.N, (int64_t)o.H * o.W, o.C, (const float*)o.w, o.b, o.eps, o.mode,
+                        (float*)at(arena, o.scratch), (o.flags & 2) ? (o.H * o.W) / ((o.flags & 8) ? 64 : 128) : 0, at(arena, o.out_bf16), stream);
                     break;
                 case MMVID_VQOP_CAST:
                     rc = mmvid_split_f32_bf16x2((const float*)at(arena, o.in0), (int64_t)o.N * o.H * o.W * o.C, at(arena, o.out_bf16),

@@ -443,6 +443,26 @@ def groupnorm_swish_split(x, w, b, eps=1e-6, swish=True):
     return out
 
 
+def groupnorm_swish_f16(x, w, b, eps=1e-6, swish=True):
+    """x NHWC fp32 -> fp16 [N,H,W,C] of GroupNorm(32)(x) [* sigmoid] (the input of conv3x3_strip_f16)."""
+    _chk(x, f32, 'x')
+    N, H, W, C = x.shape
+    out = torch.empty(N, H, W, C, device=x.device, dtype=torch.float16)
+    st = torch.empty(N * (2 * C + 64 * ((H * W + 63) // 64)), device=x.device, dtype=f32)
+    call('mmvid_groupnorm_swish_nhwc_f16out', _p(x), N, H * W, C, _p(w), _p(b), float(eps), int(swish), _p(st), 0, _p(out), _stream())
+    return out
+
+
+def conv3x3_strip_f16(x, w, bias, residual=None):
+    """x fp16 [N,H,W,Cin], w fp16 [Cout,9,Cin] -> fp32 [N,H,W,Cout]: one product of IEEE-half operands, fp32 accumulate (+ fp32 residual)."""
+    _chk(x, torch.float16, 'x'), _chk(w, torch.float16, 'w')
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    out = torch.empty(N, H, W, Cout, device=x.device, dtype=f32)
+    call('mmvid_conv3x3_strip_nhwc_f16', _p(x), N, H, W, Cin, _p(w), _p(bias), Cout, _p(residual), _p(out), None, _stream())
+    return out
+
+
 def image_to_nhwc8(img):
     _chk(img, f32, 'img')
     N, C, H, W = img.shape

@@ -423,3 +423,29 @@ def test_vqgan_plan_structure_split_mode(monkeypatch):
     assert torch.equal(w3[:, 0], w3[:, 1]) and (w3[:, 0, :, :3].float() + w3[:, 2, :, :3].float() - w).abs().max() < 2.0**-16
     for o in ops_:
         assert max(o.in0, o.in1, o.in2, o.out_bf16, o.out_f32, o.scratch) < pl.top
+
+
+def test_vqgan_plan_structure_mixed_mode(monkeypatch):
+    """vae.strict = 'mixed': the plan of 'split' with the F16 flag (128) on exactly the 3x3 residual-block convolutions of the 128x128,
+    64x64 and 32x32 levels and on the GroupNorms that feed them -- 12 of the encoder's 45 convolutions, 82 % of its multiply-adds; the
+    decoder's plan is the pair operator's."""
+    from mmvid_amd import vae as V
+    v = V.VQGanVAE1024(None, 128)
+    v.image_size, v.strict = 128, 'mixed'
+    monkeypatch.setattr(v, '_ee', lambda: torch.zeros(1024))
+    pl = V._Planner(v, strict='split', f16_side=v.mixed_f16_side)
+    v._plan_encode(pl, 4, 128)
+    convs = [o for o in pl.ops if o.op == pl.OP_CONV]
+    f16 = [o for o in convs if o.flags & pl.F16]
+    assert len(convs) == 45 and len(f16) == 12 and all(o.flags & pl.SPLIT and o.flags & 8 and o.H >= 32 and o.C in (128, 256) for o in f16)
+    gns = [o for o in pl.ops if o.op == pl.OP_GN and o.flags & pl.F16]
+    assert len(gns) == 12 and {o.out_bf16 for o in gns} == {o.in0 for o in f16}  # each reads the plane its GroupNorm wrote
+
+    def work(o):
+        return o.N * (o.H // (2 if o.mode == 1 else 1))**2 * o.Cout * o.C * (9 if o.mode in (0, 1, 2) else 1)
+    assert 0.81 < sum(work(o) for o in f16) / sum(work(o) for o in convs) < 0.84
+    w16, b, cout = v._cw_f16(v.model.encoder.down[0].block[0].conv1)
+    assert w16.shape == (128, 9, 128) and w16.dtype == torch.float16 and cout == 128
+    pd = V._Planner(v, strict='split', f16_side=0)
+    v._plan_decode(pd, 2, 8)
+    assert not any(o.flags & pd.F16 for o in pd.ops)

@@ -583,10 +583,49 @@ def test_split_groupnorm_vs_fp64():
         assert err < 2e-5
 
 
+@pytest.mark.parametrize('n,h,cin,cout', [(2, 128, 128, 128), (3, 64, 128, 128), (1, 32, 256, 256), (2, 64, 32, 128)])
+def test_fp16_single_product_convolution_and_groupnorm_vs_fp64(n, h, cin, cout):
+    """The fp16 layer forms of vae.strict = 'mixed': GroupNorm + swish written as one fp16 plane (the fp32 result rounded to nearest
+    even: bit-exact against torch's .half()), and the 3x3 strip convolution as ONE product of fp16 operands with fp32 accumulation --
+    against an fp64 convolution of the SAME fp16-rounded operands (what is left is the fp32 accumulation: 1e-6), and against the
+    unrounded operands (the format's own 2^-12 per operand), with a residual."""
+    import torch.nn.functional as F
+    from mmvid_amd import ops
+    torch.manual_seed(n + h + cin)
+    x = torch.randn(n, h, h, cin, device=DEV) * 1.5 + 0.2
+    gw, gb = torch.randn(cin, device=DEV) * 0.1 + 1, torch.randn(cin, device=DEV) * 0.1
+    y16 = ops.groupnorm_swish_f16(x, gw, gb)
+    pair = ops.groupnorm_swish_split(x, gw, gb)
+    y32 = pair[0].double() + pair[1].double()  # the same arithmetic to 2^-17
+    assert y16.dtype == torch.float16 and ((y16.double() - y32).abs() <= 2.0**-11 * y32.abs() + 1e-7).all()
+    ref = F.group_norm(x.double().permute(0, 3, 1, 2), 32, gw.double(), gb.double(), 1e-6)
+    ref = (ref * torch.sigmoid(ref)).permute(0, 2, 3, 1)
+    assert ((y16.double() - ref).abs().max() / ref.abs().max()).item() < 1e-3
+    w = torch.randn(cout, 9, cin, device=DEV) / (9 * cin)**0.5
+    b = torch.randn(cout, device=DEV) * 0.02
+    res = torch.randn(n, h, h, cout, device=DEV)
+    w16 = w.half()
+    out = ops.conv3x3_strip_f16(y16, w16, b, residual=res)
+
+    def conv64(a, wt):
+        wt4 = wt.double().view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+        return (F.conv2d(a.double().permute(0, 3, 1, 2), wt4, b.double(), padding=1).permute(0, 2, 3, 1) + res.double())
+    same = conv64(y16, w16)
+    e_same = ((out.double() - same).abs().max() / same.abs().max()).item()
+    full = conv64(y32, w)
+    e_full = ((out.double() - full).abs().max() / full.abs().max()).item()
+    print(f'fp16 conv {n}x{h}x{h} {cin}->{cout}: vs fp64 on the fp16 operands {e_same:.2e}, vs fp64 on the unrounded operands {e_full:.2e}')
+    assert e_same < 3e-6 and e_full < 1.5e-3
+    assert torch.equal(out, ops.conv3x3_strip_f16(y16, w16, b, residual=res))
+
+
+@pytest.mark.parametrize('mode', ['split', 'mixed'])
 @pytest.mark.parametrize('name,tiny', [('vqgan_tiny', True), ('vqgan_full', False)])
-def test_split_encoder_indices_equal_reference(golden, name, tiny):
+def test_split_encoder_indices_equal_reference(golden, name, tiny, mode):
     """vae.strict = 'split' (bf16-pair convolutions on the bf16 matrix pipe): the indices equal the reference's on the VQGAN
-    goldens, z_e / decode agree to ~1e-4 (between the bf16 operator's 3e-2 and the fp32 operator's 4e-6)."""
+    goldens, z_e / decode agree to ~1e-4 (between the bf16 operator's 3e-2 and the fp32 operator's 4e-6).  'mixed' (round 5: the 3x3
+    residual-block convolutions of the encoder's 128x128 / 64x64 levels as one fp16 product): the same indices, z_e to 4e-3; its
+    decoder is the pair operator's."""
     from mmvid_amd.vae import VQGanVAE1024
     from oracle.synth import synth_input
     from test_host_logic import tiny_vae
@@ -596,12 +635,12 @@ def test_split_encoder_indices_equal_reference(golden, name, tiny):
     vae = tiny_vae() if tiny else VQGanVAE1024(None, 128)
     vae.image_size = s
     load_synth(vae, g, 11)
-    vae.strict = 'split'
+    vae.strict = mode
     img = synth_input('img', (g.meta['n'], 3, s, s), 11, 'uniform').to(DEV)
     z = vae.encode_z(img)
     ref = g['z_e'].permute(0, 2, 3, 1)
-    print(f"{name} split z_e: max |dz| {(z.cpu() - ref).abs().max().item():.3e} (max |z| {ref.abs().max().item():.2f})")
-    close(z, ref, 2e-4, f'{name} split z_e')
+    print(f"{name} {mode} z_e: max |dz| {(z.cpu() - ref).abs().max().item():.3e} (max |z| {ref.abs().max().item():.2f})")
+    close(z, ref, 2e-4 if mode == 'split' else 4e-3, f'{name} {mode} z_e')
     idx = vae.get_codebook_indices(img).cpu()
     assert torch.equal(idx, g['indices']), f'{name}: {(idx != g["indices"]).sum().item()} of {idx.numel()} indices differ'
     dec = vae.decode(g['indices'].to(DEV))
@@ -612,15 +651,16 @@ def test_split_encoder_indices_equal_reference(golden, name, tiny):
     assert vae.get_codebook_indices(img).shape == idx.shape
 
 
+@pytest.mark.parametrize('mode', ['split', 'mixed'])
 @pytest.mark.parametrize('name,nv,cvae', [('bert_tiny', 0, False), ('bert_tiny_visual', 1, True)])
-def test_split_tokens_of_bert_goldens(golden, name, nv, cvae):
+def test_split_tokens_of_bert_goldens(golden, name, nv, cvae, mode):
     from test_host_logic import tiny_bert
     from test_models_gpu import load_synth
     g = golden(name)
     m = load_synth(tiny_bert(nv, cvae), g, 17)
-    m.vae.strict = 'split'
+    m.vae.strict = mode
     if m.cvae is not None:
-        m.cvae.strict = 'split'
+        m.cvae.strict = mode
     assert torch.equal(m.get_image_tokens(g['frames'].to(DEV)).cpu(), g['target_tok'])
     assert torch.equal(m.get_image_tokens(g['warped_frames'].to(DEV)).cpu(), g['warp_tok'])
     if nv:
@@ -783,7 +823,10 @@ def test_tower_backward_chunked_calls_match_one_call():
         b = res[True][1][k]
         e = ((a - b).abs().max() / a.abs().max().clamp_min(1e-20)).item()
         worst = max(worst, e)
-        assert e < 5e-5, (k, e)  # (bias gradients are atomically accumulated column sums: not bit-stable run to run either way)
+        # (bias gradients are atomically accumulated column sums: not bit-stable run to run either way; c_proj's bias gradient of the
+        #  TOP layer of a call is the column sum of the bf16-rounded incoming gradient -- the cast in front of that layer's GEMMs --
+        #  while below it comes unrounded out of the LayerNorm backward above: layer 2 heads the second chunk)
+        assert e < (4e-3 if k.endswith('resblocks.2.mlp.c_proj.bias') else 5e-5), (k, e)
     print('worst relative difference of a parameter gradient, one call vs chunks of 3 layers:', worst)
 
 
@@ -825,8 +868,9 @@ def test_layernorm_backward_deferred_reduction():
             assert torch.equal(targets[k], ref_t[k]), 'deferred reduction differs from the single-call reduction'
 
 
+@pytest.mark.parametrize('mode', ['split', 'mixed'])
 @pytest.mark.parametrize('case', ['vqgan_tiny', 'vqgan_full', 'bert_tiny', 'bert_tiny_visual'])
-def test_split_index_safety_margin(golden, case):
+def test_split_index_safety_margin(golden, case, mode):
     """How far the exact-index mode (`vae.strict = 'split'`) is from flipping an index, on every golden frame.  Only distance
     DIFFERENCES decide an argmin (|z|^2 is common to all codes), so per token: gap = d(z_ref, c2) - d(z_ref, c1) for the reference's
     best code c1 and its runner-up c2, err = |gap(z_split) - gap(z_ref)| (both in fp64 from the fp32 z: the encoder's error alone).
@@ -860,7 +904,7 @@ def test_split_index_safety_margin(golden, case):
             sd = {'model.' + k: v.detach().float().cpu() for k, v in vae.model.state_dict().items()}
             z4 = ov.encode_z(sd, img, vae.image_size)
             zr = z4.permute(0, 2, 3, 1).reshape(-1, z4.shape[1])
-        vae.strict = 'split'
+        vae.strict = mode
         zs = vae.encode_z(img.to(DEV)).reshape(-1, zr.shape[1]).double().cpu()
         idx = vae.get_codebook_indices(img.to(DEV)).reshape(-1).cpu()
         vae.strict = False
@@ -886,7 +930,7 @@ def test_split_index_safety_margin(golden, case):
     r = torch.cat(ratios)
     edges = [0, 1, 8, 64, 512, 4096, 1e30]
     hist = np.histogram(r.numpy(), edges)[0].tolist()
-    print(f'{case}: {r.numel()} tokens; reference top-2 gap / split-mode error of that gap: min {r.min().item():.1f} '
+    print(f'{case}, {mode}: {r.numel()} tokens; reference top-2 gap / error of that gap: min {r.min().item():.1f} '
           f'(gap {worst[1]:.3e}, err {worst[2]:.3e}), median {r.median().item():.0f}; histogram (edges {edges[:-1]}): {hist}')
     assert r.min().item() > SAFETY
 

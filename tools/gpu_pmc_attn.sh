@@ -11,7 +11,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_INSTS_MFMA"; do
   i=$((i+1))
-  (cd /tmp && timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc/attn_g$i -o p -- python $ROOT/tools/bench_attn.py > $ROOT/gpurun_out/pmc/attn_g$i.log 2>&1)
+  (cd /tmp && timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc/attn_g$i -o p -- python $ROOT/tools/microbench.py attention > $ROOT/gpurun_out/pmc/attn_g$i.log 2>&1)
 done
 python - <<'PY'
 import csv, glob, collections, os
