@@ -146,12 +146,13 @@ class TextVideoDataset(torch.utils.data.Dataset):
     Videos shorter than max(8, (frame_num - 1) * frame_step + 1) frames are dropped (loader.py:252-262, 343-349)."""
 
     def __init__(self, folder, text_len=256, image_size=128, truncate_captions=False, resize_ratio=0.75, tokenizer=None,
-                 frame_step=2, frame_num=8, deterministic=False, video_only=False, keys=None, generator=None):
+                 frame_step=2, frame_num=8, deterministic=False, video_only=False, keys=None, generator=None, shuffle=False):
         super().__init__()
         self.root, self.text_len, self.image_size = str(folder), text_len, image_size
         self.truncate_captions, self.resize_ratio, self.tokenizer = truncate_captions, resize_ratio, tokenizer
         self.frame_step, self.frame_num, self.deterministic, self.video_only = frame_step, frame_num, deterministic, video_only
         self.generator = generator
+        self.shuffle = shuffle  # loader.py:227, 247: decides what replaces a sample that cannot be loaded (skip_sample)
         self.min_len = max(8, (frame_num - 1) * frame_step + 1)
         vroot, troot = os.path.join(self.root, 'video'), os.path.join(self.root, 'txt')
         captions = set(os.listdir(troot)) if os.path.isdir(troot) else set()
@@ -206,7 +207,7 @@ class TextVideoDataset(torch.utils.data.Dataset):
 
     def skip_sample(self, index):
         """loader.py:478-489: a random sample when the set is shuffled, else the next one (wrapping)."""
-        if getattr(self, 'shuffle', False):
+        if self.shuffle:
             return self[self._rand(len(self))]
         return self[0 if index >= len(self) - 1 else index + 1]
 
@@ -214,11 +215,9 @@ class TextVideoDataset(torch.utils.data.Dataset):
         """-> (tokenized_text, frames [T,3,S,S], visual [3,S,S]) as loader.py:500-562 (`text, frames, visuals = batch`).
         video_only: the text is the reference's 'dummy text' placeholder."""
         key = self.keys[index]
-        frames = self._frames(key)
-        visual = self._visual(key)
         if self.video_only:
             caption = 'dummy text'
-        else:
+        else:  # (the caption is read first: a sample without one is replaced before any frame is decoded)
             with open(self.texts[key]) as fh:
                 lines = [t for t in fh.read().split('\n') if len(t) > 0]  # loader.py:518-519: empty lines dropped
             if not lines:  # loader.py:533-536: a caption file without captions is skipped, not fatal
@@ -226,6 +225,8 @@ class TextVideoDataset(torch.utils.data.Dataset):
                 print(f"Skipping index {index}")
                 return self.skip_sample(index)
             caption = lines[0] if self.deterministic else lines[self._rand(len(lines))]  # loader.py:521-524
+        frames = self._frames(key)
+        visual = self._visual(key)
         tokens = self.tokenizer.tokenize(caption, self.text_len, truncate_text=self.truncate_captions).squeeze(0)
         return tokens, frames, visual
 

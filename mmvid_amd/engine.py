@@ -277,8 +277,11 @@ class FlatTrainer:
         if z is not None and not getattr(self, '_stepped_since_zero', True):
             # a backward may have run since the last zero_grad() without a step() (e.g. a step skipped on a non-finite loss): its
             # table rows were never recorded as dirty -- clear the whole table rather than leave stale rows behind unflagged rows
-            ids = self.model.sparse_grad_rows().get(z['name']) if hasattr(self.model, 'sparse_grad_rows') else None
-            if ids is None or ids.numel() > 0:
+            # (an EMPTY id log = no forward since the reset: nothing to clear -- two zero_grad() calls in a row must not turn into a
+            #  152-MB table fill; sparse_grad_rows() reports an empty log as None, so the log itself is asked)
+            log = getattr(self.model, '_text_id_log', None)
+            overflow = getattr(self.model, '_text_id_overflow', False)
+            if log is None or overflow or len(log) > 0:
                 z['all_dirty'] = True
         self._stepped_since_zero = False
         if z is None or z['all_dirty']:
