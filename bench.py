@@ -115,7 +115,7 @@ def eager_step(trainer, fn, batch):
 PMC_KERNELS = {  # bench kernel family -> kernel-name prefixes in the rocprofv3 PMC summaries
     'gemm_bf16_kernel<A.B^T> (forward)': ('gemm_bf16_kernel<false, false', 'gemm_bf16_lw_kernel<false, false'),
     'gemm_bf16_kernel<dX>': ('gemm_bf16_kernel<false, true', 'gemm_bf16_lw_kernel<false, true'),
-    'gemm_bf16_kernel<dW>': ('gemm_bf16_kernel<true, true', 'gemm_bf16_lw_kernel<true, true'),
+    'gemm_bf16_kernel<dW>': ('gemm_bf16_kernel<true, true', 'gemm_bf16_lw_kernel<true, true', 'gemm_bf16_lw_grouped_kernel'),
     'conv_igemm_kernel (VQGAN)': ('conv_igemm_kernel', 'conv_strip_kernel'),
     'attn_fwd_kernel': ('attn_fwd_kernel', ),
     'attn_bwd (dq+dkv)': ('attn_bwd_', ),
@@ -131,7 +131,7 @@ def pmc_traffic(family):
     instance per GEMM layout)."""
     import csv
     prefixes = PMC_KERNELS.get(family, (family.split('<')[0].split(' ')[0], ))
-    for rnd in ('r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
         tot, disp = 0.0, {}
         try:
             for name, mult in (('fetch', 2.0), ('write', 1.0)):
