@@ -288,10 +288,9 @@ int mmvid_tower_workspace(const mmvid_tower_cfg_t* cfg, int64_t* saved_bytes, in
 /* saved == NULL: inference (activations are not kept).  x_out may alias x_in only when saved == NULL. */
 int mmvid_tower_forward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                         float* x_out, void* saved, void* scratch, void* stream);
-/* g: dL/dx_out on entry, dL/dx_in on exit (in place, fp32 [B*L, E]).  With option dw_grouped (default) each layer's slice of the
- * saved arena ends in room for that layer's four dY tensors (bf16): the backward writes them there (the forward part of
- * the arena is only read) and computes the weight gradients of all `cfg->layers` layers of a kind in one launch after the layer loop
- * (mmvid_gemm_bf16_dw_grouped).  The option must not change between a forward and its backward (the slice size follows it). */
+/* g: dL/dx_out on entry, dL/dx_in on exit (in place, fp32 [B*L, E]).  Each layer's slice of the saved arena ends in room for that
+ * layer's four dY tensors (bf16): the backward writes them there (the forward part of the arena is only read) and computes the weight
+ * gradients of all `cfg->layers` layers of this call in one launch after the layer loop (mmvid_gemm_bf16_dw_multi). */
 int mmvid_tower_backward(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, float* g,
                          void* saved, void* scratch, void* stream);
 

@@ -414,9 +414,9 @@ class OpenAICLIPTransformer(nn.Module):
         _, scratch = self._workspace(cfg, g.device, False)
         sb = ctypes.c_int64()
         _lib.call('mmvid_tower_workspace', ctypes.byref(cfg), ctypes.byref(sb), None)
-        if sb.value != saved.numel():  # the arena's layout follows option dw_grouped (kept dY tensors): it must not change in between
+        if sb.value != saved.numel():  # the arena's layout (kept dY tensors) must not change in between
             raise _lib.MMVIDError(f'tower backward: the saved arena holds {saved.numel()} bytes, the current layout needs {sb.value} '
-                                  '(option dw_grouped changed between forward and backward)')
+                                  '(the library changed between forward and backward)')
         per_layer = saved.numel() // self.layers
         for lo, hi in self.backward_chunks():
             sub = self._cfg(B, L)

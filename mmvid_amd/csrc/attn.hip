@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restri
     f32x16 oacc[2] = {zero16(), zero16()};
     // restricted rows (mode 2): row r0 / r1 may not see keys below c0 / c1 -- only the wave that holds such a row, and only on key
     // sub-tiles that begin below that bound, evaluates the predicate (it is ~200 instructions per sub-tile: applied to all 19
-    // sub-tiles it made the blocks holding rows 65 / 66 run 40 % longer than the rest, tools/attn_timeline.py)
+    // sub-tiles it made the blocks holding rows 65 / 66 run 40 % longer than the rest, profiles/r03_attention_timeline*.log)
     const int row_kmax = mask.mode != 2 ? 0
                                         : max((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) ? mask.c0 : 0,
                                               (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32) ? mask.c1 : 0);

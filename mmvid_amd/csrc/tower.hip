@@ -27,7 +27,7 @@ Dims dims_of(const mmvid_tower_cfg_t& c) {
     return d;
 }
 
-// Grouped weight gradients (option dw_grouped, default on): the backward keeps every layer's four dY tensors -- bf16(g) in front
+// Grouped weight gradients: the backward keeps every layer's four dY tensors -- bf16(g) in front
 // of c_proj (k_gpj) and of out_proj (k_gout), d_pre (k_dpre), dqkv (k_dqkv): M * (E + F + E + 3E) * 2 bytes per layer, 1.7 GB for
 // the 12-layer training step -- in the layer's slice of the saved arena (which exists only for a forward that will be
 // differentiated), so that the weight gradients of ALL layers of a kind go out as one launch after the layer loop.

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of a library tuning knob on the whole training step.
 
-    python tools/ab_graph.py <option> <value> <value> [...]      e.g.  tower_streams 1 2   |   gemm_tile 0 128 256   |   py:vae.streams 1 2
+    python tools/ab_graph.py <option> <value> <value> [...]      e.g.  py:vae.stream f32 bf16   |   py:vae.strict mixed split   |   graphs 0 1
 
 The step is captured once per value (engine.GraphedStep; the knob is baked into the capture) and the graphs are
 replayed alternately in groups of 5: GPU-bound timing, stable to ~0.2 %, and box-to-box / run-to-run drift cancels

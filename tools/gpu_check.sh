@@ -2,7 +2,7 @@
 # One parameterised GPU check (replaces the per-experiment gpu_r3_*.sh scripts):
 #   tools/gpu_check.sh "<pytest -k expression>" ["<command>" ...]
 # runs the selected `-m gpu` tests, then every further argument as a shell command; everything is logged under gpurun_out/check.log.
-#   e.g.  gpurun -- 'bash tools/gpu_check.sh "attention or tower" "python tools/bench_attn.py" "python tools/ab_graph.py attn_res 0 1"'
+#   e.g.  gpurun -- 'bash tools/gpu_check.sh "attention or tower" "python tools/microbench.py attention" "python tools/ab_graph.py py:vae.stream f32 bf16"'
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 {
