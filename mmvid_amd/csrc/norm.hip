@@ -521,24 +521,28 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
     }
 }
 
-// Small maps (hw <= 256 pixels: the 8x8 and 16x16 levels of the VQGAN, one statistics block per image): statistics, finalisation and the
-// apply pass of ONE image in ONE block -- the three launches of the general path were 15 us per GroupNorm for 4 us of work, ten times
-// per encode.  The arithmetic is the general path's, operation for operation (groupnorm_stats_kernel's fixed-order sums with one block,
-// groupnorm_finalize_kernel's formulas, groupnorm_apply_kernel's element math): bit-identical outputs.
+// Small maps (hw <= 256 pixels: the 8x8 and 16x16 levels of the VQGAN): statistics, finalisation and the apply pass in ONE launch -- the
+// three launches of the general path were 15 us per GroupNorm for 4 us of work, ten times per encode.  GroupNorm's groups are independent,
+// so a block takes one image's channels [64 j, 64 j + 64) (whole groups: C / 32 channels each) -- C / 64 blocks per image instead of one
+// (round 5: with one block per image the 54-frame encode ran 54 blocks on 256 CUs, 13.4 us per launch for 3.5 MB; the kernel is a chain
+// of two global round trips and three block barriers, so more, smaller blocks shorten it).  Same formulas as the general path
+// (groupnorm_stats_kernel's sums, groupnorm_finalize_kernel's statistics, groupnorm_apply_kernel's element math); the order of the
+// per-channel pixel sums is this kernel's own (32 pixel rows per block), fixed: bit-reproducible, independent of the batch.
 template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_small_fused_kernel(const T* __restrict__ x, long hw, int C, float cnt, float eps,
                                                                     const float* __restrict__ w, const float* __restrict__ b, int swish,
                                                                     bf16_t* __restrict__ y_bf16, float* __restrict__ y_f32) {
-    __shared__ float red[2][2048];
-    __shared__ float sh[2][512];
-    __shared__ float ab[512][2];
+    __shared__ float red[2][2048];  // [sum | sum of squares][pixel row][channel of the block]
+    __shared__ float sh[2][64];
+    __shared__ float ab[64][2];
     const int n = blockIdx.x;
-    const int cchunks = C >> 3;
+    const int CB = C < 64 ? C : 64, c0 = blockIdx.y * CB;  // this block's channels
+    const int cchunks = CB >> 3;
     const int cc = threadIdx.x % cchunks, prow = threadIdx.x / cchunks, pstep = 256 / cchunks;
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-    const T* base = x + ((long)n * hw) * C + cc * 8;
+    const T* base = x + ((long)n * hw) * C + c0 + cc * 8;
     for (long p = prow; p < hw; p += pstep) {
         float f[8];
         load8<T>(base + p * C, f);
@@ -547,19 +551,19 @@ __global__ __launch_bounds__(256) void groupnorm_small_fused_kernel(const T* __r
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        red[0][prow * C + cc * 8 + e] = s[e];
-        red[1][prow * C + cc * 8 + e] = q[e];
+        red[0][prow * CB + cc * 8 + e] = s[e];
+        red[1][prow * CB + cc * 8 + e] = q[e];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * C; c += 256) {
-        const int which = c / C, ch = c - which * C;
+    for (int c = threadIdx.x; c < 2 * CB; c += 256) {
+        const int which = c / CB, ch = c - which * CB;
         float a = 0.f;
-        for (int r = 0; r < pstep; ++r) a += red[which][r * C + ch];
+        for (int r = 0; r < pstep; ++r) a += red[which][r * CB + ch];
         sh[which][ch] = a;
     }
     __syncthreads();
     const int cpg = C / 32;
-    if (threadIdx.x < 32) {  // one lane per group: the sums of groupnorm_stats_kernel, the formulas of groupnorm_finalize_kernel
+    if (threadIdx.x < CB / cpg) {  // one lane per group of this block
         const int grp = threadIdx.x;
         float sm = 0.f, sq = 0.f;
         for (int e = 0; e < cpg; ++e) sm += sh[0][grp * cpg + e];
@@ -570,8 +574,8 @@ __global__ __launch_bounds__(256) void groupnorm_small_fused_kernel(const T* __r
         const float rstd = rsqrtf(var + eps);
         for (int e = 0; e < cpg; ++e) {
             const int ch = grp * cpg + e;
-            const float a = rstd * w[ch];
-            ab[ch][0] = a, ab[ch][1] = b[ch] - mu * a;
+            const float a = rstd * w[c0 + ch];
+            ab[ch][0] = a, ab[ch][1] = b[c0 + ch] - mu * a;
         }
     }
     __syncthreads();
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(256) void groupnorm_small_fused_kernel(const T* __r
             if (swish) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
             o[e] = v;
         }
-        const long at = ((long)n * hw + p) * C + cc * 8;
+        const long at = ((long)n * hw + p) * C + c0 + cc * 8;
         if (y_bf16)
             *reinterpret_cast<uint4*>(y_bf16 + at) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
         if (y_f32) {
@@ -837,12 +841,12 @@ extern "C" int mmvid_groupnorm_swish_nhwc(const void* x, int x_is_bf16, int N, i
     float* ab = stats_scratch;                         // [N][C][2]
     float* partial = stats_scratch + (long)N * C * 2;  // [N][nblk][32][2]
     const long chunks = (long)N * hw * (C / 8);
-    if (partial_blocks == 0 && hw <= pix_per_block) {  // one block per image does all three steps
+    if (partial_blocks == 0 && hw <= pix_per_block && (C & (C - 1)) == 0) {  // one launch does all three steps (whole groups per 64-channel block)
         if (x_is_bf16)
-            hipLaunchKernelGGL(groupnorm_small_fused_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, (long)hw, C,
+            hipLaunchKernelGGL(groupnorm_small_fused_kernel<bf16_t>, dim3(N, C < 64 ? 1 : C / 64), dim3(256), 0, s, (const bf16_t*)x, (long)hw, C,
                                (float)hw * (float)(C / 32), eps, w, b, swish, (bf16_t*)y_bf16, y_f32);
         else
-            hipLaunchKernelGGL(groupnorm_small_fused_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)x, (long)hw, C,
+            hipLaunchKernelGGL(groupnorm_small_fused_kernel<float>, dim3(N, C < 64 ? 1 : C / 64), dim3(256), 0, s, (const float*)x, (long)hw, C,
                                (float)hw * (float)(C / 32), eps, w, b, swish, (bf16_t*)y_bf16, y_f32);
         MMVID_LAUNCH_CHECK("groupnorm");
         return MMVID_OK;

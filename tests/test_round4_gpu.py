@@ -115,7 +115,7 @@ def test_sparse_exchange_pack_and_merge_kernels():
 
 @pytest.mark.parametrize('n,h,c,dt,swish,out', [(54, 8, 512, torch.float32, True, torch.bfloat16), (7, 8, 512, torch.bfloat16, True, torch.bfloat16),
                                                 (3, 16, 256, torch.float32, False, torch.float32), (5, 4, 128, torch.float32, True, torch.bfloat16),
-                                                (2, 16, 32, torch.bfloat16, True, torch.bfloat16)])
+                                                (2, 16, 32, torch.bfloat16, True, torch.bfloat16), (2, 8, 64, torch.bfloat16, True, torch.bfloat16)])
 def test_small_map_groupnorm_single_launch_vs_torch(n, h, c, dt, swish, out):
     """GroupNorm of a map of <= 256 pixels without fused statistics (the VQGAN's 8x8 / 16x16 levels): one launch, one block per image
     (statistics, finalisation, apply) -- against torch, and bit-reproducible."""
