@@ -13,8 +13,10 @@
 // with ds_read_b128; operands whose REDUCTION index is the position (V^T, K^T, Q^T, dO^T) are read from the
 // same row-major tile with the hardware transpose read ds_read_b64_tr_b16 -- there are no transposed copies
 // in HBM.  One 16-B-chunk XOR swizzle (chunk ^= swz(row), applied on the DMA source address) serves both, conflict-free for both.
-// The inner loops are written for instruction count (they are issue-bound: PMC round 4, 28 % of a wave's cycles issuing x 4 waves
-// per SIMD): packed fp32 fma/add, hardware bf16 pack, v_permlane32_swap for the cross-half max, a LAZY softmax rescale (the running
+// The inner loops are written for the vector ALU (at head dimension 64 a key tile needs as many vector-ALU cycles for its softmax as
+// matrix-pipe cycles for its products: PMC rounds 4-5, profiles/r05_pmc_attention.txt): single-lane fp32 fma / add for the scale-and-shift
+// and the row sum (the packed forms halve the instruction count and were measured SLOWER: a packed fp32 instruction takes two passes),
+// hardware bf16 pack, v_max3, v_permlane32_swap for the cross-half max, a LAZY softmax rescale (the running
 // max is only raised when a tile exceeds it by 2^8; P <= 256 is exact enough in bf16), and -- round 5 -- tile loops unrolled by the
 // LDS stage so that every fragment address is a per-lane base computed once + an immediate, a mask-free body for the tiles that
 // cannot contain a masked pair, a two-instruction-per-element padding mask, and no padding mask at all where padded positions
