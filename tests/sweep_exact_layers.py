@@ -63,7 +63,7 @@ ov._conv = _conv
 
 def main():
     nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(8, os.cpu_count() or 1))  # (more threads than cores with fp64 convolutions: minutes of spinning)
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'vqgan_full.npz'))
     manifest = json.loads(bytes(g['manifest']).decode())  # the reference state_dict's key -> shape list
     sd = {k: synth_tensor(k, tuple(s), 11).double() for k, s in manifest}
@@ -120,6 +120,10 @@ def main():
             if f / total < 0.02 and fmt == 'bf16':
                 continue
             measure(f'one layer {fmt}: {n.replace("encoder.", "")} ({100 * f / total:.1f}% of the work)', {n: fmt}, 'split')
+    def blocks(*levels):  # the 3x3 convolutions of the residual blocks of these levels (what vae.strict = 'mixed' switches to fp16)
+        return [n for n, _ in layers if any(f'.down.{k}.block' in n for k in levels) and 'nin_shortcut' not in n]
+    measure("levels 0-1 residual-block 3x3 convolutions fp16, rest split", {n: 'fp16' for n in blocks(0, 1)}, 'split')
+    measure("levels 0-2 residual-block 3x3 convolutions fp16, rest split  [= vae.strict = 'mixed']", {n: 'fp16' for n in blocks(0, 1, 2)}, 'split')
     lvl0 = [n for n, _ in layers if '.down.0.block' in n]
     lvl1 = [n for n, _ in layers if '.down.1.block' in n]
     ds0 = [n for n, _ in layers if 'down.0.downsample' in n]
