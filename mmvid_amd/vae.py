@@ -215,12 +215,18 @@ class _Planner:
         if strip:
             flags |= 8
         gn_op = getattr(x, 'gn_op', None)
-        if strip and gn_op is not None and self.f16_side and min(h, wd) >= self.f16_side and holder.weight.shape[2] == 3:
-            # the fp16 form: this convolution is the ONLY reader of that GroupNorm's output (a residual block's norm -> conv), so the
+        if (strip and gn_op is not None and self.f16_side and min(h, wd) >= self.f16_side and holder.weight.shape[2] == 3
+                and getattr(x, 'pair_readers', 0) == 0):
+            # the fp16 form: this convolution is the FIRST reader of that GroupNorm's output (a residual block's norm -> conv), so the
             # GroupNorm op already planned is switched to its fp16 output (first plane of the same buffer) and the weights are fp16
             gn_op.flags |= self.F16
+            x.f16_plane = True
             flags |= self.F16
             w3 = self.vae._cw_f16(holder)[0]
+        else:  # a pair-plane reader: the buffer must still hold (hi, lo) planes, and no later reader may turn it into an fp16 plane
+            assert not getattr(x, 'f16_plane', False), 'a GroupNorm output switched to fp16 has a second reader that needs bf16 pairs'
+            if gn_op is not None:
+                x.pair_readers = getattr(x, 'pair_readers', 0) + 1
         if feeds_gn and _FUSE_GN and (ho * wo) % 128 == 0 and cout % 128 == 0:  # the epilogue emits the GroupNorm partial sums
             out.gn_stats = self._gn_stats(n, ho * wo, cout)
             out.gn_stats.blocks64 = strip
