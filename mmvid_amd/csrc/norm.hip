@@ -10,31 +10,27 @@ namespace {
 
 constexpr int LN_MAXV = 4;  // float4 per lane -> E <= 1024
 
-// y = (x - mean) * rstd * w + b ; writes bf16 and/or f32; saves mean/rstd.  A wave owns R rows (r, r + ceil(rows / R), ...): all their
-// loads are in flight before any is reduced and the reductions interleave -- the kernel is bound by a wave's load -> reduce -> reduce ->
-// store chain, not by HBM (R = 2: 2,606 short blocks at the training shape, 3.4 TB/s; R = 4, round 5: half the waves, twice the loads in
-// flight per wave).  The arithmetic of a row does not depend on R.
-template <int R>
+// y = (x - mean) * rstd * w + b ; writes bf16 and/or f32; saves mean/rstd.  A wave owns TWO rows (r, r + rows/2 rounded): both rows'
+// loads are in flight before either is reduced and the two reductions interleave -- the kernel is bound by a wave's load -> reduce
+// -> reduce -> store chain (2,606 short blocks), not by HBM.
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx, long rows, int E,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ b, float eps,
                                                             bf16_t* __restrict__ y_bf16, float* __restrict__ y_f32,
                                                             long ldy, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out) {
-    const long part = (rows + R - 1) / R;
+    const long half = (rows + 1) >> 1;
     const long r0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r0 >= part) return;
-    long rr[R];
-    bool live[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) rr[k] = r0 + k * part, live[k] = rr[k] < rows;
+    if (r0 >= half) return;
+    const long rr[2] = {r0, r0 + half};
+    const bool live1 = rr[1] < rows;
     const int lane = threadIdx.x & 63;
     const int nv = E >> 2;  // float4 count
-    float4 v[R][LN_MAXV];
-    float s[R];
+    float4 v[2][LN_MAXV];
+    float s[2] = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const float4* xr = reinterpret_cast<const float4*>(x + (live[k] ? rr[k] : rr[0]) * ldx);
+    for (int k = 0; k < 2; ++k) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (k == 0 || live1 ? rr[k] : rr[0]) * ldx);
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + 64 * i;
@@ -42,32 +38,25 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         }
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        s[k] = 0.f;
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) s[k] += (v[k][i].x + v[k][i].y) + (v[k][i].z + v[k][i].w);  // (columns >= E hold 0)
-    }
-    float mean[R], rstd[R];
+    const float mean[2] = {wave_sum_fast(s[0]) / (float)E, wave_sum_fast(s[1]) / (float)E};  // (DPP / permlane reductions, common.h)
+    float q[2] = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < R; ++k) mean[k] = wave_sum_fast(s[k]) / (float)E;  // (DPP / permlane reductions, common.h)
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        float q = 0.f;
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
                 const float a = v[k][i].x - mean[k], b2 = v[k][i].y - mean[k], c2 = v[k][i].z - mean[k], d = v[k][i].w - mean[k];
-                q += (a * a + b2 * b2) + (c2 * c2 + d * d);
+                q[k] += (a * a + b2 * b2) + (c2 * c2 + d * d);
             }
         }
-        s[k] = q;
-    }
+    const float rstd[2] = {rsqrtf(wave_sum_fast(q[0]) / (float)E + eps), rsqrtf(wave_sum_fast(q[1]) / (float)E + eps)};
 #pragma unroll
-    for (int k = 0; k < R; ++k) rstd[k] = rsqrtf(wave_sum_fast(s[k]) / (float)E + eps);
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        if (!live[k]) continue;
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !live1) break;
         const long r = rr[k];
         if (lane == 0) {
             if (mean_out) mean_out[r] = mean[k];
@@ -682,11 +671,7 @@ extern "C" int mmvid_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, in
                   "layernorm_fwd: E=%d must be a multiple of 4 and <= %d; row strides multiples of 4", E,
                   64 * 4 * LN_MAXV);
     if (rows == 0) return MMVID_OK;
-    if (rows >= 4096 && E <= 768)  // (four rows per wave: 48 registers of loads in flight; wider rows keep two)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<4>, dim3(cdiv((rows + 3) / 4, 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
-                       (long)rows, E, w, b, eps, (bf16_t*)y_bf16, y_f32, (long)ldy, mean, rstd);
-    else
-        hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(cdiv((rows + 1) / 2, 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv((rows + 1) / 2, 4)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
                        (long)rows, E, w, b, eps, (bf16_t*)y_bf16, y_f32, (long)ldy, mean, rstd);
     MMVID_LAUNCH_CHECK("layernorm_fwd");
     return MMVID_OK;
