@@ -482,8 +482,12 @@ int mmvid_spatial_attention_f32(const float* q, const float* k, const float* v, 
 int mmvid_conv2d_nhwc_split3(int mode, const void* x_planes, int N, int Hin, int Win, int Cin, const void* w3, const float* bias,
                              int Cout, const float* residual_f32, int clamp01, float* out_f32, float* gn_partial, int splitk,
                              float* workspace, void* stream);
+/* out_planes (optional; with it out_f32 may be null): the result also / only as a bf16 pair [2][N,H,W,Cout] -- what
+ * mmvid_split_f32_bf16x2 would make of out_f32 -- for a result whose only reader is another pair-operator convolution (the last
+ * convolution of an encoder level in front of its Downsample: no fp32 store and no cast pass, 8 bytes per element less traffic). */
 int mmvid_conv3x3_strip_nhwc_split3(const void* x_planes, int N, int H, int W, int Cin, const void* w3, const float* bias,
-                                    int Cout, const float* residual_f32, float* out_f32, float* gn_partial64, void* stream);
+                                    int Cout, const float* residual_f32, float* out_f32, float* gn_partial64, void* out_planes,
+                                    void* stream);
 /* fp32 [n] -> bf16 pair planes [2][n] (n % 8 == 0). */
 int mmvid_split_f32_bf16x2(const float* x, int64_t n, void* planes_bf16, void* stream);
 /* img NCHW fp32 [N,3,H,W] in [0,1] -> bf16 pair planes [2][N,H,W,8] of 2x-1 (vae.py:41). */
@@ -501,7 +505,7 @@ int mmvid_groupnorm_swish_nhwc_split(const float* x, int N, int64_t hw, int C, c
  * 3x the plain bf16 work.
  * x_f16 [N,H,W,Cin] IEEE half, w_f16 [Cout][9][Cin] IEEE half; residual / output fp32; gn_partial64 as in the strip kernel. */
 int mmvid_conv3x3_strip_nhwc_f16(const void* x_f16, int N, int H, int W, int Cin, const void* w_f16, const float* bias, int Cout,
-                                 const float* residual_f32, float* out_f32, float* gn_partial64, void* stream);
+                                 const float* residual_f32, float* out_f32, float* gn_partial64, void* out_planes, void* stream);
 /* mmvid_groupnorm_swish_nhwc_split with the result stored as one plane of IEEE-half values [N,hw,C] */
 int mmvid_groupnorm_swish_nhwc_f16out(const float* x, int N, int64_t hw, int C, const float* w, const float* b, float eps,
                                       int swish, float* stats_scratch, int partial_blocks, void* y_f16, void* stream);
@@ -534,7 +538,8 @@ enum {
  * GROUPNORM flags&2 / flags&8 as for the bf16 operator (partial sums written by the producing CONV). */
 #define MMVID_VQFLAG_SPLIT 64
 /* flags & 128, together with SPLIT: GROUPNORM writes ONE fp16 plane at out_bf16 (mmvid_groupnorm_swish_nhwc_f16out); CONV (strip form,
- * flags&8) reads such a plane at in0 with w = fp16 [Cout][9][Cin] (mmvid_conv3x3_strip_nhwc_f16). */
+ * flags&8) reads such a plane at in0 with w = fp16 [Cout][9][Cin] (mmvid_conv3x3_strip_nhwc_f16).  A split CONV in strip form with
+ * out_bf16 >= 0 also / only (out_f32 < 0) writes its result as pair planes there. */
 #define MMVID_VQFLAG_F16 128
 typedef struct {
     int32_t op, mode;

@@ -92,8 +92,8 @@ SIGNATURES = {
     'mmvid_spatial_attention': [P, P, P, I, I, I, F, P, P, P],
     'mmvid_spatial_attention_ld': [P, P, P, I64, I, I, I, F, P, P, P],
     'mmvid_conv2d_nhwc_split3': [I, P, I, I, I, I, P, P, I, P, I, P, P, I, P, P],
-    'mmvid_conv3x3_strip_nhwc_split3': [P, I, I, I, I, P, P, I, P, P, P, P],
-    'mmvid_conv3x3_strip_nhwc_f16': [P, I, I, I, I, P, P, I, P, P, P, P],
+    'mmvid_conv3x3_strip_nhwc_split3': [P, I, I, I, I, P, P, I, P, P, P, P, P],
+    'mmvid_conv3x3_strip_nhwc_f16': [P, I, I, I, I, P, P, I, P, P, P, P, P],
     'mmvid_split_f32_bf16x2': [P, I64, P, P],
     'mmvid_image_to_nhwc8_split': [P, I, I, I, P, P],
     'mmvid_groupnorm_swish_nhwc_split': [P, I, I64, I, P, P, F, I, P, I, P, P],

@@ -42,6 +42,8 @@ struct StripParams {
     bf16_t* out_bf16;
     float* out_f32;
     float* gn_partial;  // [N][H*W/64][32][2] or null
+    bf16_t* out_planes;  // split operator: the result as a bf16 pair (hi plane, lo plane `out_plane` elements further) or null
+    long out_plane;
 };
 
 // K loop: two-group ping-pong -- the block's halves alternate between a load part and a 16-MFMA cluster, one barrier apart.  (Rounds
@@ -254,6 +256,11 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
                 if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
                 const uint2 packed = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 if (p.out_bf16) *reinterpret_cast<uint2*>(p.out_bf16 + o) = packed;
+                if (p.out_planes) {  // hi = bf16(v), lo = bf16(v - hi): what mmvid_split_f32_bf16x2 would make of the fp32 result
+                    *reinterpret_cast<uint2*>(p.out_planes + o) = packed;
+                    *reinterpret_cast<uint2*>(p.out_planes + p.out_plane + o) =
+                        make_uint2(pack_bf2(v[0] - bf_lo(packed.x), v[1] - bf_hi(packed.x)), pack_bf2(v[2] - bf_lo(packed.y), v[3] - bf_hi(packed.y)));
+                }
                 if (p.gn_partial) {  // statistics of the values the GroupNorm will read (bf16-rounded unless fp32 is stored)
                     const float u[4] = {p.out_f32 ? v[0] : bf_lo(packed.x), p.out_f32 ? v[1] : bf_hi(packed.x),
                                         p.out_f32 ? v[2] : bf_lo(packed.y), p.out_f32 ? v[3] : bf_hi(packed.y)};
@@ -297,7 +304,7 @@ extern "C" int mmvid_conv3x3_strip_supported(int H, int W, int Cin, int Cout) {
 
 static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
                         const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32, float* gn_partial64,
-                        void* stream, bool f16);
+                        void* stream, bool f16, void* out_planes = nullptr);
 
 extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
                                         const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32,
@@ -307,21 +314,22 @@ extern "C" int mmvid_conv3x3_strip_nhwc(const void* x, int N, int H, int W, int 
 
 // the split operator of conv.hip (mmvid_conv2d_nhwc_split3) in strip form: x_planes [2][N,H,W,Cin], w3 [Cout][3][9][Cin]
 extern "C" int mmvid_conv3x3_strip_nhwc_split3(const void* x_planes, int N, int H, int W, int Cin, const void* w3, const float* bias,
-                                               int Cout, const float* residual_f32, float* out_f32, float* gn_partial64, void* stream) {
-    return strip_launch(3, x_planes, N, H, W, Cin, w3, bias, Cout, nullptr, residual_f32, nullptr, out_f32, gn_partial64, stream, false);
+                                               int Cout, const float* residual_f32, float* out_f32, float* gn_partial64, void* out_planes,
+                                               void* stream) {
+    return strip_launch(3, x_planes, N, H, W, Cin, w3, bias, Cout, nullptr, residual_f32, nullptr, out_f32, gn_partial64, stream, false, out_planes);
 }
 
 // one product of IEEE-half operands, fp32 in / out around it: x fp16 [N,H,W,Cin], w fp16 [Cout][9][Cin] (the exact-index mode's 128x128 and
 // 64x64 levels, mmvid_amd/vae.py strict = 'mixed': 2^-12 per operand against the pair's 2^-17 and plain bf16's 2^-9)
 extern "C" int mmvid_conv3x3_strip_nhwc_f16(const void* x_f16, int N, int H, int W, int Cin, const void* w_f16, const float* bias, int Cout,
-                                            const float* residual_f32, float* out_f32, float* gn_partial64, void* stream) {
-    return strip_launch(1, x_f16, N, H, W, Cin, w_f16, bias, Cout, nullptr, residual_f32, nullptr, out_f32, gn_partial64, stream, true);
+                                            const float* residual_f32, float* out_f32, float* gn_partial64, void* out_planes, void* stream) {
+    return strip_launch(1, x_f16, N, H, W, Cin, w_f16, bias, Cout, nullptr, residual_f32, nullptr, out_f32, gn_partial64, stream, true, out_planes);
 }
 
 static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, const void* w, const float* bias, int Cout,
                         const void* residual_bf16, const float* residual_f32, void* out_bf16, float* out_f32, float* gn_partial64,
-                        void* stream, bool f16) {
-    MMVID_REQUIRE(x && w && (out_bf16 || out_f32), "conv3x3_strip: null pointer");
+                        void* stream, bool f16, void* out_planes) {
+    MMVID_REQUIRE(x && w && (out_bf16 || out_f32 || out_planes), "conv3x3_strip: null pointer");
     MMVID_REQUIRE(W >= 8 && W <= 128 && (W & (W - 1)) == 0 && Cin >= 32 && (Cin & (Cin - 1)) == 0 && Cout % 128 == 0 &&
                       ((long)H * W) % 64 == 0,
                   "conv3x3_strip: unsupported geometry H=%d W=%d Cin=%d Cout=%d", H, W, Cin, Cout);
@@ -335,6 +343,8 @@ static int strip_launch(int terms, const void* x, int N, int H, int W, int Cin, 
     p.M = (long)N * H * W;
     p.bias = bias, p.res_bf16 = (const bf16_t*)residual_bf16, p.res_f32 = residual_f32;
     p.out_bf16 = (bf16_t*)out_bf16, p.out_f32 = out_f32, p.gn_partial = gn_partial64;
+    p.out_planes = (bf16_t*)out_planes, p.out_plane = (long)N * H * W * Cout;
+    MMVID_REQUIRE(!(out_planes && gn_partial64 && !out_f32), "conv3x3_strip: GroupNorm statistics of a planes-only result are not defined");
     if (p.M == 0) return MMVID_OK;
     static bool attr = false;
     if (!attr) {

@@ -64,12 +64,13 @@ static int vqgan_enqueue(const mmvid_vqgan_op_t* ops, int nops, void* arena, voi
                     if ((o.flags & 8) && (o.flags & MMVID_VQFLAG_F16))  // one fp16 product (in0 = an fp16 tensor written by the GroupNorm below)
                         rc = mmvid_conv3x3_strip_nhwc_f16(at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout, (const float*)at(arena, o.in1),
                                                           (float*)at(arena, o.out_f32),
-                                                          (o.flags & 4) ? (float*)at(arena, o.scratch) + (int64_t)o.N * o.Cout * 2 : nullptr, stream);
+                                                          (o.flags & 4) ? (float*)at(arena, o.scratch) + (int64_t)o.N * o.Cout * 2 : nullptr,
+                                                          at(arena, o.out_bf16), stream);
                     else if (o.flags & 8)
                         rc = mmvid_conv3x3_strip_nhwc_split3(at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
                                                              (const float*)at(arena, o.in1), (float*)at(arena, o.out_f32),
                                                              (o.flags & 4) ? (float*)at(arena, o.scratch) + (int64_t)o.N * o.Cout * 2 : nullptr,
-                                                             stream);
+                                                             at(arena, o.out_bf16), stream);
                     else
                         rc = mmvid_conv2d_nhwc_split3(o.mode, at(arena, o.in0), o.N, o.H, o.W, o.C, o.w, o.b, o.Cout,
                                                       (const float*)at(arena, o.in1), (o.flags >> 1) & 1, (float*)at(arena, o.out_f32),

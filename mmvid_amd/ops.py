@@ -415,7 +415,7 @@ def split_weights(w):
     return torch.stack([hi, hi, lo], 1).contiguous()
 
 
-def conv2d_nhwc_split3(x_planes, w3, bias, mode, residual=None, clamp01=False, splitk=1, strip=False):
+def conv2d_nhwc_split3(x_planes, w3, bias, mode, residual=None, clamp01=False, splitk=1, strip=False, planes_out=None):
     """x_planes [2,N,H,W,Cin] bf16, w3 [Cout,3,taps,Cin] bf16 -> fp32 [N,Ho,Wo,Cout] = conv of (x_hi + x_lo) with (w_hi + w_lo)
     without the lo.lo term, fp32 accumulate (mmvid_conv2d_nhwc_split3 / the strip form for mode 0)."""
     _chk(x_planes, bf16, 'x_planes'), _chk(w3, bf16, 'w3')
@@ -425,7 +425,8 @@ def conv2d_nhwc_split3(x_planes, w3, bias, mode, residual=None, clamp01=False, s
     out = torch.empty(N, Ho, Wo, Cout, device=x_planes.device, dtype=f32)
     if strip:
         assert mode == 0 and not clamp01 and splitk == 1
-        call('mmvid_conv3x3_strip_nhwc_split3', _p(x_planes), N, H, W, Cin, _p(w3), _p(bias), Cout, _p(residual), _p(out), None, _stream())
+        call('mmvid_conv3x3_strip_nhwc_split3', _p(x_planes), N, H, W, Cin, _p(w3), _p(bias), Cout, _p(residual), _p(out), None, _p(planes_out),
+             _stream())
         return out
     ws = torch.empty(splitk * N * Ho * Wo * Cout, device=out.device, dtype=f32) if splitk > 1 else None
     call('mmvid_conv2d_nhwc_split3', mode, _p(x_planes), N, H, W, Cin, _p(w3), _p(bias), Cout, _p(residual), int(clamp01), _p(out),
@@ -453,13 +454,13 @@ def groupnorm_swish_f16(x, w, b, eps=1e-6, swish=True):
     return out
 
 
-def conv3x3_strip_f16(x, w, bias, residual=None):
+def conv3x3_strip_f16(x, w, bias, residual=None, planes_out=None):
     """x fp16 [N,H,W,Cin], w fp16 [Cout,9,Cin] -> fp32 [N,H,W,Cout]: one product of IEEE-half operands, fp32 accumulate (+ fp32 residual)."""
     _chk(x, torch.float16, 'x'), _chk(w, torch.float16, 'w')
     N, H, W, Cin = x.shape
     Cout = w.shape[0]
     out = torch.empty(N, H, W, Cout, device=x.device, dtype=f32)
-    call('mmvid_conv3x3_strip_nhwc_f16', _p(x), N, H, W, Cin, _p(w), _p(bias), Cout, _p(residual), _p(out), None, _stream())
+    call('mmvid_conv3x3_strip_nhwc_f16', _p(x), N, H, W, Cin, _p(w), _p(bias), Cout, _p(residual), _p(out), None, _p(planes_out), _stream())
     return out
 
 

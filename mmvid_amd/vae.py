@@ -200,7 +200,7 @@ class _Planner:
         self._op(op=self.OP_CAST, N=n, H=h, W=wd, C=c, flags=self.SPLIT, in0=x.off, out_bf16=out.off)
         return out
 
-    def _conv_split(self, x, holder, mode, residual, clamp01, feeds_gn=False):
+    def _conv_split(self, x, holder, mode, residual, clamp01, feeds_gn=False, planes_only=False):
         x = self._planes(x)
         w3, b, _ = self.vae._cw_split(holder)
         n, h, wd, cin = x.shape
@@ -208,12 +208,19 @@ class _Planner:
         ho, wo = (h // 2, wd // 2) if mode == 1 else ((2 * h, 2 * wd) if mode == 2 else (h, wd))
         cout = w3.shape[0]
         assert residual is None or residual.dtype == f32
-        out = self.alloc((n, ho, wo, cout), f32)
         flags = self.SPLIT | (2 if clamp01 else 0)
         scratch, ws = -1, None
         strip = _STRIP and mode == 0 and not clamp01 and bool(_lib.load().mmvid_conv3x3_strip_supported(h, wd, cin, cout))
         if strip:
             flags |= 8
+        # planes_only: the result's only reader is another pair-operator convolution (a level's last tensor in front of its Downsample):
+        # the strip kernel's epilogue stores the bf16 pair itself -- no fp32 store, no cast pass (the same planes bit for bit)
+        planes_only = planes_only and strip and not feeds_gn
+        if planes_only:
+            out = self.alloc((2, n, ho, wo, cout), bf16)
+            out.is_planes, out.shape = True, (n, ho, wo, cout)
+        else:
+            out = self.alloc((n, ho, wo, cout), f32)
         gn_op = getattr(x, 'gn_op', None)
         if (strip and gn_op is not None and self.f16_side and min(h, wd) >= self.f16_side and holder.weight.shape[2] == 3
                 and getattr(x, 'pair_readers', 0) == 0):
@@ -237,8 +244,8 @@ class _Planner:
             flags |= 32
             scratch = ws.off
         self._op(op=self.OP_CONV, mode=mode, N=n, H=h, W=wd, C=cin, Cout=cout, flags=flags, in0=x.off,
-                 in1=residual.off if residual is not None else -1, out_f32=out.off, scratch=scratch, w=w3.data_ptr(),
-                 b=b.data_ptr())
+                 in1=residual.off if residual is not None else -1, out_f32=-1 if planes_only else out.off,
+                 out_bf16=out.off if planes_only else -1, scratch=scratch, w=w3.data_ptr(), b=b.data_ptr())
         del ws
         return out
 
@@ -290,7 +297,7 @@ class _Planner:
         also_bf16 (with out32): the epilogue stores a bf16 copy too (`out.bf16`), instead of a later cast pass.
         keep32: fp32 output even with a bf16 residual stream (the VQ rows, the decoded image)."""
         if self.split:
-            return self._conv_split(x, holder, mode, residual, clamp01, feeds_gn)
+            return self._conv_split(x, holder, mode, residual, clamp01, feeds_gn, planes_only=not out32 and not keep32)
         if self.stream16 and not keep32:
             out32 = also_bf16 = False
         w, b, _ = self.vae._cw(holder, self.strict)

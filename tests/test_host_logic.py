@@ -412,7 +412,13 @@ def test_vqgan_plan_structure_split_mode(monkeypatch):
     v._plan_encode(pl, 4, 128)
     ops_ = pl.ops
     convs = [o for o in ops_ if o.op == pl.OP_CONV]
-    assert len(convs) == 45 and all(o.flags & pl.SPLIT and o.out_f32 >= 0 and o.out_bf16 < 0 for o in convs)
+    assert len(convs) == 45 and all(o.flags & pl.SPLIT for o in convs)
+    # every convolution writes fp32, except the last one of levels 0-2 (strip form, read only by the level's Downsample convolution): it
+    # stores the bf16 pair itself -- no fp32 store, no cast pass in front of the Downsample
+    planes_only = [o for o in convs if o.out_f32 < 0]
+    assert len(planes_only) == 3 and all(o.out_bf16 >= 0 and o.flags & 8 and o.in1 >= 0 for o in planes_only)
+    assert all(o.out_bf16 < 0 for o in convs if o.out_f32 >= 0)
+    assert sum(1 for o in ops_ if o.op == pl.OP_CAST) == 7     # fp32 -> pair planes in front of the remaining non-GroupNorm readers
     assert sum(1 for o in convs if o.flags & 8) == 12          # the strip form at 32x32 and above
     assert sum(1 for o in convs if o.flags & 32) >= 4          # split-K on the 8x8 layers
     assert all(o.flags & pl.SPLIT for o in ops_ if o.op in (pl.OP_GN, pl.OP_CAST, pl.OP_IMG))

@@ -617,6 +617,16 @@ def test_fp16_single_product_convolution_and_groupnorm_vs_fp64(n, h, cin, cout):
     print(f'fp16 conv {n}x{h}x{h} {cin}->{cout}: vs fp64 on the fp16 operands {e_same:.2e}, vs fp64 on the unrounded operands {e_full:.2e}')
     assert e_same < 3e-6 and e_full < 1.5e-3
     assert torch.equal(out, ops.conv3x3_strip_f16(y16, w16, b, residual=res))
+    # the same result stored as a bf16 pair by the epilogue (what the encoder's last convolution of a level hands its Downsample): the
+    # planes mmvid_split_f32_bf16x2 makes of the fp32 result, bit for bit -- for this kernel and for the three-product pair operator
+    planes = torch.empty(2, n, h, h, cout, device=DEV, dtype=torch.bfloat16)
+    out2 = ops.conv3x3_strip_f16(y16, w16, b, residual=res, planes_out=planes)
+    assert torch.equal(out2, out) and torch.equal(planes, ops.split_planes(out))
+    w3 = ops.split_weights(w)
+    o3 = ops.conv2d_nhwc_split3(pair, w3, b, 0, residual=res, strip=True)
+    planes.zero_()
+    o3b = ops.conv2d_nhwc_split3(pair, w3, b, 0, residual=res, strip=True, planes_out=planes)
+    assert torch.equal(o3b, o3) and torch.equal(planes, ops.split_planes(o3))
 
 
 @pytest.mark.parametrize('mode', ['split', 'mixed'])
