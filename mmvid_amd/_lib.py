@@ -164,7 +164,7 @@ class PosSegment(ctypes.Structure):
                 ('naxes', ctypes.c_int32), ('src0', ctypes.c_int32), ('d', ctypes.c_int32 * 3), ('pad', ctypes.c_int32)]
 
 
-ABI_VERSION = 2  # include/mmvid_hip.h: mmvid_abi_version()
+ABI_VERSION = 3  # include/mmvid_hip.h: mmvid_abi_version()
 _lib = None
 
 
@@ -184,15 +184,18 @@ def load():
             raise MMVIDError(f'{LIB_PATH} is missing: run `python -m mmvid_amd.build` (hipcc, gfx950). '
                              'There is no CPU/PyTorch fallback for the kernels.')
         lib = ctypes.CDLL(LIB_PATH)
+        # the version is checked BEFORE any other symbol is bound: a stale build must say "rebuild", not fail on a missing entry point
+        ver = getattr(lib, 'mmvid_abi_version', None)
+        have = ver() if ver is not None else None
+        if have != ABI_VERSION:
+            raise MMVIDError(f'{LIB_PATH} has ABI version {have}, this package needs {ABI_VERSION}: '
+                             'rebuild with `python -m mmvid_amd.build --force`')
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = args, I
         for name, (args, res) in OTHER.items():
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = args, res
-        if lib.mmvid_abi_version() != ABI_VERSION:
-            raise MMVIDError(f'{LIB_PATH} has ABI version {lib.mmvid_abi_version()}, this package needs {ABI_VERSION}: '
-                             'rebuild with `python -m mmvid_amd.build --force`')
         _lib = lib
     return _lib
 

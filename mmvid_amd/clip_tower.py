@@ -93,7 +93,7 @@ class DecodeSession:
         self.x = torch.zeros(B, tower.width, device=dev, dtype=torch.float32)
         self.y = torch.zeros_like(self.x)
         self.pos = torch.tensor([first_pos], dtype=torch.int32, device=dev)
-        self._first_pos = int(first_pos)
+        self.host_pos = int(first_pos)  # host mirror of the device position (explicit: not derived from the number of step() calls)
         self.graph, self.want_graph, self.calls = None, graph, 0
         self._slice_cfgs = {}
         # the whole step as one launch of 256 co-resident blocks (csrc/decode_persistent.hip) where the tower / batch / device allow it;
@@ -133,6 +133,7 @@ class DecodeSession:
         assert self.persistent
         _lib.call('mmvid_artv_token_step_persistent', ctypes.byref(self.cfg), self.layers, ctypes.byref(tk), ops._p(self.y), ops._p(self.cache),
                   self.cache.shape[2], ops._p(self.pos), ops._p(self.ws), ops._stream())
+        self.host_pos += 1
 
     def failed(self):
         """True when a poll of the persistent step has timed out on this session's workspace (its 256 blocks were not resident together:
@@ -145,19 +146,21 @@ class DecodeSession:
         self.persistent, self.graph = False, None
         self.fell_back = getattr(self, 'fell_back', 0) + 1
         self.pos.fill_(int(pos))
+        self.host_pos = int(pos)
 
     def check(self):
         """Raise if the persistent step failed and nobody recovered from it (`step(verify=True)` and the ART-V sampling loop do, by
-        repeating the affected positions with the five-launch step)."""
+        repeating the affected positions with the launch-per-layer step)."""
         if self.failed():
             raise _lib.MMVIDError('persistent decode step: a poll timed out (the device was shared while it ran); results are invalid. '
                                   'Set MMVID_DECODE_PERSISTENT=0 to use the five-launch step.')
 
     @torch.no_grad()
-    def step(self, x_new, verify=True):
-        """One position.  verify (persistent sessions only; one device read per step): a step whose polls timed out is repeated with the
-        five-launch form and the session stays there -- the returned hidden state is always valid.  verify=False for loops that keep their
-        own restart point and call failed() / check() themselves."""
+    def step(self, x_new, verify=False):
+        """One position.  Asynchronous by default: steps can be pipelined / replayed without a host read; a persistent session's caller
+        calls failed() / check() at its own restart points (the ART-V sampler: every 64 tokens).  verify=True (persistent sessions only)
+        reads the failure flag after the step -- one device sync per token -- and repeats a step whose polls timed out with the
+        launch-per-layer form, staying there: the returned hidden state is then always valid."""
         self.x.copy_(x_new)
         self.calls += 1
         if self.want_graph and self.graph is None and self.calls == 2:
@@ -175,8 +178,9 @@ class DecodeSession:
         else:
             self._enqueue()
         if verify and self.persistent and self.failed():
-            self.fall_back(self._first_pos + self.calls - 1)
+            self.fall_back(self.host_pos)
             self._enqueue()
+        self.host_pos += 1
         return self.y
 
 

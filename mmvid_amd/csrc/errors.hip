@@ -16,7 +16,7 @@ void mmvid_set_error(const char* fmt, ...) {
 extern "C" const char* mmvid_last_error() { return g_err; }
 
 // 2: the front-end state buffer grew from one float (the step counter) to four 32-bit words {step, seed lo, seed hi, reserved}
-extern "C" int mmvid_abi_version() { return 2; }
+extern "C" int mmvid_abi_version() { return 3; }
 
 // Number of visible HIP devices (0 when none) -- lets the host side fail loudly and early.
 extern "C" int mmvid_device_count() {

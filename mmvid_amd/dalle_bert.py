@@ -212,6 +212,14 @@ class BERT(nn.Module):
             return {'text_emb.weight': None}   # trainer falls back to the dense all-reduce for this table
         return {'text_emb.weight': log[0] if len(log) == 1 else torch.cat(log)}
 
+    def _note_table_backward(self, _g):
+        self.table_grad_pending = True
+
+    # public: True from the moment a backward of this model has (possibly) written rows of a table gradient until the trainer has
+    # accounted for them (FlatTrainer.step() records them as dirty, zero_grad() clears them).  A backward whose forward was logged
+    # BEFORE the last zero_grad() is caught by this flag and by nothing else (forward, zero_grad, backward, zero_grad).
+    table_grad_pending = False
+
     def reset_sparse_grad_rows(self):
         """Called by FlatTrainer.zero_grad(): the gradients start from zero, so does the list of touched rows."""
         self._text_id_log, self._text_id_overflow = [], False
@@ -365,6 +373,8 @@ class BERT(nn.Module):
     def _assemble(self, ids, length, text_rows=None):
         pos = self._pos_table()[:length]
         x = AssembleSequence.apply(pos, ids.contiguous(), self._seg[:length].contiguous(), *self._tables())
+        if x.requires_grad:  # the backward of this node scatter-adds into the tables' gradients: say so when it runs (see below)
+            x.register_hook(self._note_table_backward)
         if text_rows is not None:  # fixed language model: the text position holds the mapped feature (dalle_bert.py:924-925)
             x[:, self.txt_tok_index].add_(text_rows)
         return x

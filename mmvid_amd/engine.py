@@ -274,14 +274,16 @@ class FlatTrainer:
     # ---------------------------------------------------------------------------------------------
     def zero_grad(self):
         z = self._lazy
-        if z is not None and not getattr(self, '_stepped_since_zero', True):
-            # a backward may have run since the last zero_grad() without a step() (e.g. a step skipped on a non-finite loss): its
-            # table rows were never recorded as dirty -- clear the whole table rather than leave stale rows behind unflagged rows
-            # (an EMPTY id log = no forward since the reset: nothing to clear -- two zero_grad() calls in a row must not turn into a
-            #  152-MB table fill; sparse_grad_rows() reports an empty log as None, so the log itself is asked)
-            log = getattr(self.model, '_text_id_log', None)
-            overflow = getattr(self.model, '_text_id_overflow', False)
-            if log is None or overflow or len(log) > 0:
+        if z is not None:
+            # Table rows a backward wrote that no step() recorded as dirty (a step skipped on a non-finite loss; a backward whose forward
+            # ran before the previous zero_grad()) must not survive as stale rows behind unflagged rows: the model raises
+            # `table_grad_pending` from a hook on the backward itself and step() lowers it once the rows are recorded, so a raised flag
+            # here means "unaccounted rows" -> clear the whole table.  Two zero_grad() calls in a row raise nothing (no 152-MB fill).
+            # A model without the flag: any zero_grad() that does not follow a step() clears the whole table.
+            pending = getattr(self.model, 'table_grad_pending', None)
+            if pending is None:
+                pending = not getattr(self, '_stepped_since_zero', True)
+            if pending or getattr(self.model, '_text_id_overflow', False):
                 z['all_dirty'] = True
         self._stepped_since_zero = False
         if z is None or z['all_dirty']:
@@ -294,6 +296,8 @@ class FlatTrainer:
                 self.G[lo:hi].view(z['rows'], z['rowlen']).index_fill_(0, z['dirty'][:z['dirty_n']], 0.0)
         if z is not None:
             z['all_dirty'], z['dirty_n'] = False, 0
+            if hasattr(self.model, 'table_grad_pending'):
+                self.model.table_grad_pending = False
         reset = getattr(self.model, 'reset_sparse_grad_rows', None)
         if reset is not None:
             reset()
@@ -471,6 +475,8 @@ class FlatTrainer:
             # too, and this rank's id log does not know them: every row counts from now on
             dense_exchange = (self.world > 1 or self.force_exchange) and self.exchange_enabled and not self.sparse_tables
             self._lazy_mark(None if dense_exchange else ids)
+            if hasattr(self.model, 'table_grad_pending'):
+                self.model.table_grad_pending = False  # (the rows are now recorded as dirty)
         self._stepped_since_zero = True
         self.step_count += 1
         gscale = 1.0 / self.world

@@ -298,7 +298,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/mmvid_hip.h but not exported'
     assert set(_lib.SIGNATURES) | set(_lib.OTHER) == declared
-    assert lib.mmvid_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.mmvid_abi_version() == _lib.ABI_VERSION == 3
     assert ctypes.sizeof(_lib.TowerLayer) == 24 * 8 and ctypes.sizeof(_lib.TowerCfg) == 12 * 4
 
 

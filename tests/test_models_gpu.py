@@ -74,14 +74,13 @@ def test_vqgan_encode_decode_vs_reference(golden, name, tiny):
     close(z, zref, 3e-2, f'{name} z_e')
     idx = vae.get_codebook_indices(img).cpu()
     ref = g['indices']
-    mism = (idx != ref)
-    gap = (g['top2_d'][:, 1] - g['top2_d'][:, 0]).view_as(ref)
-    zerr = (z.cpu() - zref).abs().max().item()
-    print(f'{name}: index match {1 - mism.float().mean().item():.4f}; max |dz| {zerr:.3e}; '
-          f'gaps at mismatches {gap[mism].tolist()[:8]}; median gap {gap.median().item():.3f}')
-    # no mismatch allowance: every disagreement must be a near-tie relative to the encoder's bf16 error budget (exact
-    # indices are the strict mode's job: tests/test_parity_gpu.py)
-    assert (gap[mism] < 64 * zerr + 1e-3).all()
+    # default (bf16) mode: not an exact mode -- every disagreement must be explained by the measured error of that token's own two
+    # distances (conftest.flip_report: gap <= 4 x |dd|), and the rate is bounded (census: 2.1-2.4 % on 40,960 tokens; the wide goldens of
+    # tests/test_round6_gpu.py hold 1,024 tokens per case).  Exact indices are the exact modes' job.
+    from conftest import flip_report
+    n, rate, ratio = flip_report(idx, ref, z.cpu(), zref, vae.model.quantize.embedding.weight.detach().cpu(), name)
+    print(f'{name}: {n} of {ref.numel()} indices differ; reference gap / error min {ratio.min().item():.2f} median {ratio.median().item():.0f}')
+    assert rate <= 0.05
     dec = vae.decode(ref.to(DEV))
     # pixels: ~25 bf16 conv layers deep; bar = 5e-2 max, 6e-3 mean absolute error on the [0,1] range
     close(dec, g['decoded'], 5e-2, f'{name} decode')

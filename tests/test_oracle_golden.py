@@ -49,6 +49,27 @@ def test_vqgan_encode_decode(golden, name):
     assert relerr(dec, g['decoded']) <= TOL
 
 
+@pytest.mark.parametrize('name', ['vqgan_full16', 'vqgan_full16_refinit'])
+def test_vqgan_wide_index_goldens(golden, name):
+    """Round 6: 16 full-size frames = 1,024 tokens per case, two weight seeds, the synthetic (well separated) codebook and the
+    reference's own near-uniform initialisation: the oracle's indices, distances and z equal the reference's."""
+    from conftest import wide_vqgan_case
+    g = golden(name)
+    sd, img = wide_vqgan_case(g)
+    with torch.no_grad():
+        idx = vqgan.get_codebook_indices(sd, img, 128)
+        z = vqgan.encode_z(sd, img[:g.meta['z_frames']], 128)
+    assert g['indices'].numel() >= 1024
+    assert torch.equal(idx, g['indices'])
+    assert relerr(z, g['z_e']) <= TOL
+    # the C oracle on the reference's z rows reproduces index and both top-2 distances' winner
+    zf = g['z_e'].permute(0, 2, 3, 1).reshape(-1, g['z_e'].shape[1]).contiguous()
+    ci, cd = vq_argmin(zf, sd['model.quantize.embedding.weight'])
+    n = zf.shape[0]
+    assert torch.equal(ci, g['indices'].reshape(-1)[:n])
+    assert torch.allclose(cd, g['top2_d'][:n, 0], rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize('tag,L,mt,idx', [('L51', 51, 'mask_prev', [17, 18]), ('L579', 579, 'mask_prev', [65, 66]),
                                           ('causal40', 40, 'causal', [])])
 def test_tower_forward_backward(golden, tag, L, mt, idx):

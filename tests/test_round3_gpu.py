@@ -990,3 +990,17 @@ def test_lazy_rows_with_dense_table_exchange_and_skipped_step(golden):
     assert float(m2.text_emb.weight.grad.abs().sum()) > 0
     tr2.zero_grad()
     assert float(m2.text_emb.weight.grad.abs().sum()) == 0.0, 'zero_grad() after a skipped step left table rows behind'
+    # (3) ADVICE r5: a backward whose forward ran BEFORE the previous zero_grad() (forward, zero_grad, backward, zero_grad): the id log
+    # was reset in between, only the backward's own flag (BERT.table_grad_pending) knows that rows were written
+    lm, lr, lv = m2(text, target=frames, return_loss=True, rel=True, vid=True)
+    tr2.zero_grad()
+    assert not m2.table_grad_pending
+    (7 * lm + 0.5 * lr + 0.5 * lv).backward()
+    assert m2.table_grad_pending and float(m2.text_emb.weight.grad.abs().sum()) > 0
+    tr2.zero_grad()
+    assert float(m2.text_emb.weight.grad.abs().sum()) == 0.0, 'rows of a backward whose forward preceded zero_grad() were left behind'
+    # ... and two zero_grad() calls in a row decide "nothing to clear" without touching the table
+    assert not m2.table_grad_pending
+    tr2._lazy['all_dirty'] = False
+    tr2.zero_grad()
+    assert tr2._lazy['all_dirty'] is False

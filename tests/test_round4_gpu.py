@@ -167,14 +167,15 @@ def test_persistent_decode_step_matches_the_five_launch_form(B, P):
         extra = torch.randn(B, 768, device=DEV) * 0.5
         hr = ref.step(extra).clone()
         per.ws[1] = 1
-        hp = per.step(extra).clone()
+        assert per.host_pos == P + steps
+        hp = per.step(extra, verify=True).clone()
         assert not per.persistent and per.fell_back == 1
         close(hp, hr, 1e-2, 'the step after a failed persistent launch (five-launch fall-back)')
         per.check()
         # without verification the caller keeps its own restart point: the failure stays visible
         per2 = tw.decode_session(caches[1], P + steps + 1, graph=False)
         per2.ws[1] = 1
-        per2.step(extra, verify=False)
+        per2.step(extra)  # (the default: no host read)
         assert per2.failed()
         with pytest.raises(_lib.MMVIDError, match='timed out'):
             per2.check()

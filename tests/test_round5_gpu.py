@@ -116,27 +116,36 @@ def test_encoder_bf16_residual_stream_index_match_rate(golden):
         rates[stream] = 1.0 - float(mism.float().mean())
         print(f'encoder stream {stream}: {int(mism.sum())}/{idx.numel()} indices differ from the reference ({100 * rates[stream]:.2f} % match); '
               f'max |dz| {zerr:.3e}, relative L2 {zrel:.3e}')
-        assert (gap.view_as(idx)[mism] < 64 * zerr + 1e-3).all()
+        from conftest import flip_report
+        flip_report(idx, g['indices'], z, ref_z, vae.model.quantize.embedding.weight.detach().cpu(), f'stream {stream}')  # every flip explained by its own |dd|
         assert zrel < 3e-2
         vae.strict = 'split'  # the exact-index mode does not look at `stream`
         assert torch.equal(vae.get_codebook_indices(img).cpu(), g['indices'])
-    assert rates['bf16'] > 0.9
+    assert rates['bf16'] >= 61 / 64 and rates['f32'] >= 61 / 64  # 64 tokens: at most 3 flips (census rate 2.3 %; the 1,024-token cases: test_round6_gpu.py)
 
 
 def test_bert_golden_frames_token_match_with_both_streams(golden):
-    """The same before / after on the frames of the BERT goldens (the 98.4 % of DESIGN.md section 4): tokens through the default
-    encoder against the reference's, fp32 stream and bf16 stream."""
+    """The same before / after on the frames of the BERT goldens: tokens through the default encoder against the reference's, fp32 stream
+    and bf16 stream.  Round 6: the bar can fail -- every differing token must be explained by the measured error of its own two distances
+    (z of the oracle's fp32 encoder as the reference z), and at most 4 % of the tokens may differ (census: 2.1-2.4 %)."""
+    from conftest import flip_report
+    from oracle import vqgan as ov
     from test_host_logic import tiny_bert
     for name, nv, cvae in (('bert_tiny', 0, False), ('bert_tiny_visual', 1, True)):
         g = golden(name)
         m = load_synth(tiny_bert(nv, cvae), g, 17).eval()
         frames = g['frames'].to(DEV)
+        flat = g['frames'].reshape(-1, *g['frames'].shape[2:])
+        sd = {'model.' + k: v.detach().float().cpu() for k, v in m.vae.model.state_dict().items()}
+        with torch.no_grad():
+            zr = ov.encode_z(sd, flat, m.vae.image_size).permute(0, 2, 3, 1).contiguous()
         for stream in ('f32', 'bf16'):
             m.vae.stream = stream
             tt = m.get_image_tokens(frames).cpu()
-            rate = float((tt == g['target_tok']).float().mean())
-            print(f'{name}, encoder stream {stream}: {100 * rate:.2f} % of the reference tokens')
-            assert rate > 0.9
+            z = m.vae.encode_z(flat.to(DEV)).cpu()
+            n, rate, _ = flip_report(tt, g['target_tok'], z, zr, sd['model.quantize.embedding.weight'], f'{name} {stream}')
+            print(f'{name}, encoder stream {stream}: {100 * (1 - rate):.2f} % of the reference tokens ({n} of {tt.numel()} differ)')
+            assert rate <= 0.04
 
 
 def test_artv_one_launch_token_step_pinned_to_the_reference_logits(golden):

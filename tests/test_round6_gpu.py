@@ -1,0 +1,87 @@
+"""Round 6: the token-index contract on evidence wider than one frame, the MFMA decode layer (item 2) and the
+advisor's round-5 findings.  Stated flip-rate bounds come from the census of 40,960 fresh tokens per mode
+(tools/flip_census.py -> profiles/r06_flip_census.log): bf16 2.1-2.4 %, 'mixed' 0.06-0.25 %, 'split' 1 token in 40,960, fp32 0 of
+4,096 against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import flip_report, relerr, wide_vqgan_case
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+# mode -> (vae.strict, flip-rate bound on >= 1,024 tokens, relative L2 bound of z against the reference).  'split' may differ from the
+# reference only on ties at the reference's OWN resolution: a top-2 gap of at most TIE_ULPS fp32 spacings of the distance (the reference's
+# z is not bit-reproducible across hosts either: the oracle on the GPU box's CPU differs from the container's in the last bits); fp32: none.
+MODES = {'bf16': (False, 0.04, 3e-2), 'mixed': ('mixed', 0.005, 3e-3), 'split': ('split', 2 / 1024, 1e-4), 'fp32': (True, 0.0, 1e-5)}
+TIE_ULPS = 16
+
+
+def _vae_of(sd):
+    from mmvid_amd.vae import VQGanVAE1024
+    vae = VQGanVAE1024(None, 128)
+    vae.load_state_dict(sd)
+    vae = vae.to(DEV)
+    vae.image_size = 128
+    return vae
+
+
+@pytest.mark.parametrize('mode', list(MODES))
+@pytest.mark.parametrize('name', ['vqgan_full16', 'vqgan_full16_refinit'])
+def test_wide_golden_tokens_every_mode(golden, name, mode):
+    """1,024 tokens of 16 full-size frames per case (two weight seeds; the synthetic well-separated codebook and the reference's own
+    near-uniform initialisation), indices from the REFERENCE (tools/make_golden.py::_vqgan_wide).  fp32: every index equal.  'split': equal
+    except ties at the reference's own fp32 resolution (gap <= 16 spacings of the distance; at most 2 per 1,024).  'mixed' / bf16: flip rate under the stated bound, and every flip explained by the measured error of that token's two
+    distances (conftest.flip_report).  The reference z of all 16 frames comes from the oracle (pinned to the reference's z on the 4 stored
+    frames: tests/test_oracle_golden.py::test_vqgan_wide_index_goldens)."""
+    from oracle import vqgan as ov
+    g = golden(name)
+    sd, img = wide_vqgan_case(g)
+    strict, max_rate, z_tol = MODES[mode]
+    vae = _vae_of(sd)
+    vae.strict = strict
+    with torch.no_grad():
+        zr = ov.encode_z(sd, img, 128).permute(0, 2, 3, 1).contiguous()
+    assert relerr(zr[:4], g['z_e'].permute(0, 2, 3, 1)) <= 1e-5  # (bit-identical in the build container; this host's conv kernels may order sums differently)
+    idx = torch.cat([vae.get_codebook_indices(img[i:i + 8].to(DEV)).cpu() for i in range(0, 16, 8)])
+    z = torch.cat([vae.encode_z(img[i:i + 8].to(DEV)).cpu() for i in range(0, 16, 8)])
+    zrel = ((z - zr).norm() / zr.norm()).item()
+    n, rate, ratio = flip_report(idx, g['indices'], z, zr, sd['model.quantize.embedding.weight'], f'{name} {mode}')
+    hist = np.histogram(ratio.numpy(), [0, 1, 8, 64, 512, 4096, 1e30])[0].tolist()
+    print(f'{name}, {mode}: {n} of {idx.numel()} indices differ from the reference ({100 * (1 - rate):.2f} % equal); z relative L2 {zrel:.2e}; '
+          f'reference top-2 gap / error: min {ratio.min().item():.2f} median {ratio.median().item():.0f}, histogram [0,1,8,64,512,4096): {hist}')
+    assert idx.numel() >= 1024
+    assert zrel <= z_tol
+    assert rate <= max_rate, f'{n} flips'
+    if mode == 'split':
+        print(f'   split: flipped tokens have reference gaps of {[round(u, 1) for u in flip_report.last_gaps]} fp32 spacings of their distance')
+        assert all(u <= TIE_ULPS for u in flip_report.last_gaps), flip_report.last_gaps
+
+
+def test_flip_census_2048_fresh_tokens(golden):
+    """A small instance of tools/flip_census.py inside the suite: 32 fresh frames (16 uniform noise + 16 smooth fields; none a golden)
+    through every mode.  'split' against fp32: 0 flips; 'mixed' <= 0.5 %, bf16 <= 4 %; fp32 against the CPU oracle on 8 frames: 0."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from flip_census import frames_of
+    from oracle import vqgan as ov
+    g = golden('vqgan_full16')
+    sd, _ = wide_vqgan_case(g)
+    vae = _vae_of(sd)
+    img = torch.cat([frames_of('noise', 16, 777), frames_of('smooth', 16, 778)])
+    res = {}
+    for mode, (strict, _, _) in MODES.items():
+        vae.strict = strict
+        res[mode] = (vae.get_codebook_indices(img.to(DEV)).cpu(), vae.encode_z(img.to(DEV)).cpu())
+    i32, z32 = res['fp32']
+    with torch.no_grad():
+        pick = torch.cat([img[:4], img[16:20]])
+        oi = ov.get_codebook_indices(sd, pick, 128)
+    assert torch.equal(torch.cat([i32[:4], i32[16:20]]), oi), 'fp32 mode differs from the CPU oracle'
+    for mode in ('bf16', 'mixed', 'split'):
+        n, rate, ratio = flip_report(res[mode][0], i32, res[mode][1], z32, sd['model.quantize.embedding.weight'], mode)
+        print(f'{mode}: {n} of {i32.numel()} flips against the fp32 mode; gap/err < 8 on {int((ratio < 8).sum())} tokens, median {ratio.median().item():.0f}')
+        assert rate <= MODES[mode][1]
+        if mode == 'split':
+            assert all(u <= TIE_ULPS for u in flip_report.last_gaps), flip_report.last_gaps

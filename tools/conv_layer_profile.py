@@ -18,7 +18,8 @@ dev = torch.device('cuda', 0)
 torch.manual_seed(0)
 vae = VQGanVAE1024(None, 128).to(dev)
 vae.image_size = 128
-vae.strict = len(sys.argv) > 2 and sys.argv[2] == 'strict'
+MODE = sys.argv[2] if len(sys.argv) > 2 else 'bf16'  # bf16 | strict | split | mixed
+vae.strict = {'bf16': False, 'strict': True}.get(MODE, MODE)
 img = torch.rand(N, 3, 128, 128, device=dev)
 vae.get_codebook_indices(img)
 plan = vae._plan('enc', N, 128)
@@ -46,13 +47,21 @@ for i in range(len(plan.ops)):
     if kind == 'conv':
         taps = 1 if o.mode == 3 else 9
         flops = 2.0 * N * Ho * Wo * o.Cout * taps * o.C
-        byts = N * H * W * o.C * 2 + N * Ho * Wo * o.Cout * ((2 if o.out_bf16 >= 0 else 0) + (4 if o.out_f32 >= 0 else 0)) + \
-            (N * Ho * Wo * o.Cout * (4 if o.flags & 1 else 2) if o.in1 >= 0 else 0)
+        in_b = 4 if (o.flags & 64 and not o.flags & 128) else 2  # pair planes / one fp16 or bf16 plane
+        byts = N * H * W * o.C * in_b + N * Ho * Wo * o.Cout * ((2 if o.out_bf16 >= 0 else 0) + (4 if o.out_f32 >= 0 else 0)) + \
+            (N * Ho * Wo * o.Cout * (4 if (o.flags & 1 or o.flags & 64) else 2) if o.in1 >= 0 else 0)
         key = (kind, f'm{o.mode} {H}x{W} {o.C}->{o.Cout}' + (' +res' if o.in1 >= 0 else '') + (' f32out' if o.out_f32 >= 0 else '') +
-               (' +bf16' if o.out_f32 >= 0 and o.out_bf16 >= 0 else '') + (' +gnstats' if o.flags & 4 else ''))
+               (' +bf16' if o.out_f32 >= 0 and o.out_bf16 >= 0 else '') + (' +gnstats' if o.flags & 4 else '') + (' f16' if o.flags & 128 else (' pair' if o.flags & 64 else '')) +
+               (' splitk' if o.flags & 32 else ''))
     elif kind == 'gn':
-        byts = N * H * W * o.C * ((4 if o.flags & 1 else 2) + 2)
-        key = (kind, f'{H}x{W} C{o.C} ' + ('f32in' if o.flags & 1 else 'bf16in') + (' fused-stats' if o.flags & 2 else ' own-stats'))
+        f32in = bool(o.flags & 1 or o.flags & 64)
+        outb = 4 if (o.flags & 64 and not o.flags & 128) else 2
+        byts = N * H * W * o.C * ((4 if f32in else 2) + outb)
+        key = (kind, f'{H}x{W} C{o.C} ' + ('f32in' if f32in else 'bf16in') + (' fused-stats' if o.flags & 2 else ' own-stats') +
+               (' ->f16' if o.flags & 128 else (' ->pair' if o.flags & 64 else '')))
+    elif kind == 'cast':
+        byts = N * H * W * o.C * 8
+        key = (kind, f'{H}x{W} C{o.C}')
     else:
         key = (kind, f'{H}x{W} C{o.C}')
     r = rows.setdefault(key, [0, 0.0, 0.0, 0.0])
@@ -61,11 +70,11 @@ for i in range(len(plan.ops)):
     r[2] += flops
     r[3] += byts
 tot = sum(r[1] for r in rows.values())
-print(f'VQGAN encode of {N} frames, per-op timing (sum {tot:.3f} ms; ops run back to back are faster than this sum by the launch gaps)')
+print(f'VQGAN encode of {N} frames, mode {MODE}, per-op timing (sum {tot:.3f} ms; ops run back to back are faster than this sum by the launch gaps)')
 print(f'{"op":6s} {"geometry":52s} {"n":>3s} {"ms":>8s} {"%":>5s} {"TFLOP/s":>8s} {"GB/s":>7s}')
 for (kind, geo), (n, ms, fl, by) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
     print(f'{kind:6s} {geo:52s} {n:3d} {ms:8.3f} {100 * ms / tot:5.1f} {fl / ms / 1e9 if fl else 0:8.1f} {by / ms / 1e6 if by else 0:7.0f}')
-for kind in ('conv', 'gn', 'attn'):
+for kind in ('conv', 'gn', 'attn', 'cast'):
     ms = sum(r[1] for (k, _), r in rows.items() if k == kind)
     fl = sum(r[2] for (k, _), r in rows.items() if k == kind)
     print(f'total {kind}: {ms:.3f} ms' + (f', {fl / ms / 1e9:.1f} TFLOP/s' if fl else ''))

@@ -8,7 +8,7 @@ layout), and the reference's outputs.  Run:
 
     PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [case ...]
 
-Cases: vq vqgan_tiny vqgan_full tower tower12 bert_tiny bert_tiny_visual bert_negvc bert_flm bert_flm_bottleneck artv_tiny mask_predict
+Cases: vq vqgan_tiny vqgan_full vqgan_full16 vqgan_full16_refinit tower tower12 bert_tiny bert_tiny_visual bert_negvc bert_flm bert_flm_bottleneck artv_tiny mask_predict
        frontend mask_predict_race
 """
 import json
@@ -135,6 +135,40 @@ def case_vqgan_tiny():
 
 def case_vqgan_full():
     _vqgan('vqgan_full', False, 1)
+
+
+def _vqgan_wide(name, seed, n, codebook):
+    """Round 6: the index contract on more than one frame.  n full-size frames through the reference's encoder + quantiser on the
+    synthetic weights of `seed`; `codebook` = 'synthetic' keeps oracle.synth's 0.5 N(0,1) rows (well separated), 'reference_init'
+    overwrites them with the reference's own initialisation U(-1/n_e, 1/n_e) (quantize.py:254: near-uniform, the near-tie stress
+    case of SURVEY 8c; the rows are a function of the seed, see `wide_codebook` in tests/conftest.py).  Kept per token: index, the
+    two smallest distances of the reference expression and their codes; z_e for the first 4 frames only (the file stays < 1 MB)."""
+    vae, man = build_vae(False, seed)
+    cb = vae.model.quantize.embedding.weight
+    if codebook == 'reference_init':
+        cb.data.copy_((synth_input('codebook_reference_init', tuple(cb.shape), seed, 'uniform') * 2 - 1) / cb.shape[0])
+    img = synth_input('img_wide', (n, 3, 128, 128), seed, 'uniform')
+    with torch.no_grad():
+        h = torch.cat([vae.model.quant_conv(vae.model.encoder(2 * img[i:i + 4] - 1)) for i in range(0, n, 4)])
+        idx = torch.cat([vae.get_codebook_indices(img[i:i + 4]) for i in range(0, n, 4)])
+        zf = h.permute(0, 2, 3, 1).reshape(-1, cb.shape[1])
+        d = torch.sum(zf**2, 1, keepdim=True) + torch.sum(cb**2, 1) - 2 * zf @ cb.t()
+        top2 = torch.topk(d, 2, dim=1, largest=False)
+        dec = vae.decode(idx[:1])
+    assert torch.equal(top2.indices[:, 0].view_as(idx), idx) or codebook == 'reference_init'
+    gap = (top2.values[:, 1] - top2.values[:, 0])
+    print(f'{name}: {idx.numel()} tokens, {idx.unique().numel()} distinct codes; top-2 gap min {gap.min().item():.3e} '
+          f'median {gap.median().item():.3e}; |z| rms {zf.pow(2).mean().sqrt().item():.3f}')
+    save(name, meta=dict(seed=seed, n=n, image_size=128, tiny=False, codebook=codebook, z_frames=4), manifest=man,
+         z_e=h[:4], indices=idx, top2_d=top2.values, top2_i=top2.indices.to(torch.int16), decoded=dec)
+
+
+def case_vqgan_full16():
+    _vqgan_wide('vqgan_full16', 11, 16, 'synthetic')
+
+
+def case_vqgan_full16_refinit():
+    _vqgan_wide('vqgan_full16_refinit', 23, 16, 'reference_init')
 
 
 def case_tower():
@@ -695,7 +729,8 @@ def case_mask_predict_race():
                                                    b=dict(videos=1, steps=9, dynamic=True, B=1))), **res)
 
 
-CASES = dict(vq=case_vq, vqgan_tiny=case_vqgan_tiny, vqgan_full=case_vqgan_full, tower=case_tower, tower12=case_tower12,
+CASES = dict(vq=case_vq, vqgan_tiny=case_vqgan_tiny, vqgan_full=case_vqgan_full, vqgan_full16=case_vqgan_full16,
+             vqgan_full16_refinit=case_vqgan_full16_refinit, tower=case_tower, tower12=case_tower12,
              bert_tiny=case_bert_tiny, bert_tiny_visual=case_bert_tiny_visual, bert_negvc=case_bert_negvc, bert_flm=case_bert_flm,
              bert_flm_bottleneck=case_bert_flm_bottleneck, artv_tiny=case_artv_tiny,
              mask_predict=case_mask_predict, frontend=case_frontend, mask_predict_race=case_mask_predict_race)
