@@ -305,17 +305,21 @@ int mmvid_tower_prefill(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t*
 int mmvid_tower_decode(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in, float* x_out,
                        void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch, void* stream);
 /* The same step as five matrix-vector launches per layer (weights streamed once, rows in LDS, 256 CUs busy) instead of
- * the M = B corner of the training GEMM: ~10x less time per token.  B <= 16 (9-16: a wide instance of the gemv).  scratch: B * (7E + F) floats.
+ * the M = B corner of the training GEMM: ~10x less time per token.  B <= 16.  scratch: B * (7E + F) floats.
  * mmvid_gemv_rows is the building block (y = act(LN?(x) W^T + b) (+ residual), x / y fp32 [NB, *], W bf16 [N, K]);
  * mmvid_decode_embed writes the embedding row of the token just sampled (table[tok] + pos_rows[*pos_dev + pos_off]). */
 int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                              float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
                              void* stream);
 /* ... for cfg->B consecutive sequences of a cache of cache_batch sequences (kv_cache = the first of them in layer 0; x_in / x_out = their
- * rows): how batches above 16 run, as slices of 16. */
+ * rows): how batches above 16 run, as slices of 16.  Round 6: with 3..16 sequences the four linear layers run on the matrix pipe
+ * (csrc/decode.hip::gemv16_mfma_kernel: 16 rows = one v_mfma_f32_16x16x32_bf16 row block, weights streamed once straight into registers,
+ * K split over the block's eight waves; the attention output and the activation travel as bf16); 1-2 sequences keep the vector-ALU
+ * kernels (the form the persistent step falls back to).  advance_pos != 0: *pos_dev += 1 when the step is done (by the last layer's
+ * last launch: no separate launch per token). */
 int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
-                                   float* x_out, void* kv_cache, int Lmax, int cache_batch, const int32_t* pos_dev, int pos,
-                                   void* scratch, void* stream);
+                                   float* x_out, void* kv_cache, int Lmax, int cache_batch, int32_t* pos_dev, int pos,
+                                   int advance_pos, void* scratch, void* stream);
 /* The same step as ONE launch: 256 co-resident blocks walk the 60 phases and hand values to each other as tagged 8-byte words that
  * the consumers poll (csrc/decode_persistent.hip) -- no launch boundary, no barrier.  _supported: the 768 / 3072 / 12-head causal tower,
  * <= 12 layers, B <= 2, Lmax <= 4096, a device with >= 256 CUs and nothing else running beside the step.

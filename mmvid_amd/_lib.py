@@ -77,7 +77,7 @@ SIGNATURES = {
     'mmvid_tower_decode_fused': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, I, P, P],
     'mmvid_tower_decode_persistent': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, P, I, I, P, P],
     'mmvid_artv_token_step_persistent': [POINTER(TowerCfg), POINTER(TowerLayer), POINTER(DecodeToken), P, P, I, P, P, P],
-    'mmvid_tower_decode_fused_slice': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, I, P, I, P, P],
+    'mmvid_tower_decode_fused_slice': [POINTER(TowerCfg), POINTER(TowerLayer), P, P, P, I, I, P, I, I, P, P],
     'mmvid_gemv_rows': [P, I64, I, I, P, P, F, P, P, I, I, P, I64, I, I, P, I64, P],
     'mmvid_decode_embed': [P, P, I64, P, P, I, I, I, P, P],
     'mmvid_decode_embed_record': [P, P, I64, P, P, I, I, I, P, P, I64, I, P],

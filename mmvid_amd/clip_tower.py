@@ -104,27 +104,23 @@ class DecodeSession:
         self.ws = torch.zeros(lib.mmvid_tower_decode_persistent_workspace_bytes(B) // 8, dtype=torch.int64, device=dev) if self.persistent else None
 
     def _enqueue(self):
-        # batches of up to 8 sequences take the matrix-vector path (five launches per layer, csrc/decode.hip); larger
-        # ones the M = B corner of the MFMA GEMM
-        # the fused small-batch kernels stage the whole [B, K] input block as bf16: B <= 16, B * 3072 * 2 B <= 96 KiB (csrc/decode.hip)
         B, E = self.x.shape[0], self.x.shape[-1]
         if self.persistent:
             _lib.call('mmvid_tower_decode_persistent', ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
                       ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, 1, ops._p(self.ws), ops._stream())  # (advances pos itself)
             return
-        if self.fused and B > 16 and E <= 768:
-            # slices of 16 sequences through the matrix-vector kernels (the M = B corner of the training GEMM: 2.2 ms per token at batch 16)
-            Lmax = self.cache.shape[2]
+        Lmax = self.cache.shape[2]
+        if self.fused and min(B, 16) * 4 * E <= 49152:  # (the decode kernels stage up to 16 rows of the layer input in LDS)
+            # slices of up to 16 sequences through the decode kernels of csrc/decode.hip (3..16 rows: the linear layers on the matrix pipe;
+            # the M = B corner of the training GEMM took 2.2 ms per token at batch 16); the last slice's last launch advances the position
             for b0 in range(0, B, 16):
                 nb = min(16, B - b0)
-                cfg = self._slice_cfgs.setdefault(nb, self.tower._cfg(nb, Lmax))
+                cfg = self.cfg if nb == B else self._slice_cfgs.setdefault(nb, self.tower._cfg(nb, Lmax))
                 _lib.call('mmvid_tower_decode_fused_slice', ctypes.byref(cfg), self.layers, self.x[b0:].data_ptr(), self.y[b0:].data_ptr(),
-                          self.cache[0, b0].data_ptr(), Lmax, B, ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
-            self.pos.add_(1)
+                          self.cache[0, b0].data_ptr(), Lmax, B, ops._p(self.pos), 0, int(b0 + 16 >= B), ops._p(self.scratch), ops._stream())
             return
-        fn = 'mmvid_tower_decode_fused' if (self.fused and B <= 16 and B * 4 * E <= 49152) else 'mmvid_tower_decode'
-        _lib.call(fn, ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
-                  ops._p(self.cache), self.cache.shape[2], ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
+        _lib.call('mmvid_tower_decode', ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
+                  ops._p(self.cache), Lmax, ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
         self.pos.add_(1)
 
     def token_step(self, tk):

@@ -384,6 +384,184 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned lon
 #undef GV_STAMP
 }
 
+
+// ---- Round 6: the same linear layer for 3..16 rows on the matrix pipe.  gemv_rows_kernel multiplies on the vector
+// ALU: at 16 rows every wave reads the 16 staged rows from LDS for each pair of output features and ends in a 16-value reduce-scatter --
+// 10.5 / 14.2 us per launch at batch 16 for a few MB of weights.  16 rows are exactly one v_mfma_f32_16x16x32_bf16 row block:
+//   block = 16 output features x 16 rows, 8 waves, wave w owns the K slice [w K/8, (w+1) K/8): S = K/256 MFMAs per wave;
+//   B operand = weights straight from HBM into registers (lane (n, g) holds chunk 4 s + g of feature row n's slice for MFMA step s: the
+//   four lanes of a row read 64 contiguous bytes -- a first form gave every lane S CONSECUTIVE chunks, 64 separate lines per load
+//   instruction: the K = 3,072 layer then spent its time in the texture addresser, not in HBM);
+//   A operand = the rows: LayerNorm'd fp32 rows staged once per block in LDS as bf16 (in_proj, c_fc), or bf16 rows read as fragments
+//   straight from global memory (out_proj reads the attention's bf16 output, c_proj the bf16 activation: no LDS staging at all);
+//   the eight K-slice partial tiles meet in 8 KiB of LDS, 256 threads finish one output each (bias, QuickGELU, residual, K|V append).
+// Same rounding points as gemv_rows_kernel (rows bf16-exact, fp32 accumulate); the summation order differs.
+struct Gemv16Args {
+    const float* x;      // fp32 rows [NB][ldx] (LayerNorm path) ...
+    const bf16_t* xb;    // ... or bf16 rows [NB][ldx] (direct path)
+    long ldx;
+    const float *ln_w, *ln_b;
+    float eps;
+    const bf16_t* W;     // [N][K]
+    const float* bias;
+    const float* residual;
+    long ldr;
+    float* out;          // fp32 [NB][ldo] or null
+    bf16_t* out_bf;      // bf16 [NB][ldo] or null (the value rounded once: what the next layer's operand is anyway)
+    long ldo;
+    int NB, N, K, act, round_out;
+    bf16_t* kv_cache;
+    int kv_lo, kv_width, Lmax;
+    const int* pos_dev;
+    int pos0;
+    int* pos_inc;        // not null: *pos_inc += 1 when the launch is done with it (the step's last layer: a launch less per token)
+};
+
+// HALF: a block = 8 features x 8 rows (grid (N/8, 2)): the tile of the narrow, long-K layer (c_proj: N = 768, K = 3,072).  With 16 x 16 tiles
+// that layer is 48 blocks which each pull 96 KiB of weights + the 96 KiB of all 16 rows through ONE CU's memory path (8.3 us against 4.8 for
+// the K = 768 layers); 8 x 8 tiles are 192 blocks of 48 + 48 KiB.  The MFMA runs a quarter full, which costs nothing here.
+template <int S, bool DIRECT, bool HALF = false>
+__global__ __launch_bounds__(512) void gemv16_mfma_kernel(Gemv16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    float* red = reinterpret_cast<float*>(smem16);                  // [8 waves][16 rows][16 features]
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem16 + 8 * 256 * 4);   // [16][K + 8] (LayerNorm path only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int FT = HALF ? 8 : 16;                 // features / rows per block
+    const int K = a.K, NB = a.NB, n0 = blockIdx.x * FT, rb0 = HALF ? blockIdx.y * 8 : 0;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int rf = HALF ? (r16 & 7) : r16;            // this lane's feature (B operand) / row (A operand) inside the block's tile
+    const int kw = wave * (S * 32) + g * 8;  // k of this lane's chunk in MFMA step 0; step s is 32 further (the four lanes of a row read 64 contiguous bytes)
+    // ---- 1. weights -> registers (do not depend on the rows: requested first)
+    bf16x8_t wf[S];
+    {
+        const bf16_t* wp = a.W + (long)(n0 + rf) * K + kw;
+#pragma unroll
+        for (int s = 0; s < S; ++s) wf[s] = *reinterpret_cast<const bf16x8_t*>(wp + s * 32);
+    }
+    // epilogue operands of thread t < 256: output (row eb, feature en)
+    const int eb = rb0 + (HALF ? tid >> 3 : tid >> 4), en = n0 + (HALF ? tid & 7 : tid & 15);
+    const bool elane = tid < FT * FT && eb < NB;
+    const float ebias = (elane && a.bias) ? a.bias[en] : 0.f;
+    const float eres = (elane && a.residual) ? a.residual[(long)eb * a.ldr + en] : 0.f;
+    const int epos = a.kv_cache ? (a.pos_dev ? *a.pos_dev : a.pos0) : 0;
+    bf16x8_t af[S];
+    if constexpr (DIRECT) {
+        const int xrow = rb0 + rf;
+        const bf16_t* xp = a.xb + (long)(xrow < NB ? xrow : 0) * a.ldx + kw;
+#pragma unroll
+        for (int s = 0; s < S; ++s) af[s] = *reinterpret_cast<const bf16x8_t*>(xp + s * 32);
+        // every request of the block is in flight before the first MFMA waits (hipcc sinks the row loads between the MFMAs otherwise,
+        // three at a time: four dependent L2 round trips in the K = 3,072 instance, 9.8 us against 4.9 for K = 768)
+        __builtin_amdgcn_sched_barrier(0);
+        if (xrow >= NB) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) af[s] = bf16x8_t{};
+        }
+    } else {
+        // ---- 2. rows: wave w owns rows w and w + 8; LayerNorm statistics are in-wave reductions; the normalised row goes to LDS as bf16
+        const int ldsk = K + 8;
+        float4 xr[2][S], lg[S], lb[S];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = wave + 8 * rr;
+#pragma unroll
+            for (int jj = 0; jj < S; ++jj)
+                xr[rr][jj] = r < NB ? *reinterpret_cast<const float4*>(a.x + (long)r * a.ldx + (jj * 64 + lane) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int jj = 0; jj < S; ++jj) {
+            const int k = (jj * 64 + lane) * 4;
+            lg[jj] = a.ln_w ? *reinterpret_cast<const float4*>(a.ln_w + k) : make_float4(1.f, 1.f, 1.f, 1.f);
+            lb[jj] = a.ln_w ? *reinterpret_cast<const float4*>(a.ln_b + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = wave + 8 * rr;
+            float mu = 0.f, rs = 1.f;
+            if (a.ln_w && r < NB) {
+                float t = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < S; ++jj) t += (xr[rr][jj].x + xr[rr][jj].y) + (xr[rr][jj].z + xr[rr][jj].w);
+                mu = wave_sum_fast(t) / (float)K;
+                float q = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < S; ++jj) {
+                    const float d0 = xr[rr][jj].x - mu, d1 = xr[rr][jj].y - mu, d2 = xr[rr][jj].z - mu, d3 = xr[rr][jj].w - mu;
+                    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+                rs = rsqrtf(wave_sum_fast(q) / (float)K + a.eps);
+            }
+#pragma unroll
+            for (int jj = 0; jj < S; ++jj) {
+                const int k = (jj * 64 + lane) * 4;
+                float v0 = xr[rr][jj].x, v1 = xr[rr][jj].y, v2 = xr[rr][jj].z, v3 = xr[rr][jj].w;
+                if (a.ln_w) {
+                    v0 = (v0 - mu) * rs * lg[jj].x + lb[jj].x, v1 = (v1 - mu) * rs * lg[jj].y + lb[jj].y;
+                    v2 = (v2 - mu) * rs * lg[jj].z + lb[jj].z, v3 = (v3 - mu) * rs * lg[jj].w + lb[jj].w;
+                }
+                const uint2 pk = r < NB ? make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3)) : make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(xs + (long)r * ldsk + k) = pk;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; ++s) af[s] = *reinterpret_cast<const bf16x8_t*>(xs + (long)r16 * ldsk + kw + s * 32);
+    }
+    // ---- 3. S MFMAs: C[row = 4 g + i][feature = r16] over this wave's K slice
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], wf[s], acc, 0, 0, 0);
+    mfma_settle(acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave * 256 + (g * 4 + i) * 16 + r16] = acc[i];
+    __syncthreads();
+    // (no block of this launch reads the position when pos_inc is set: the key/value append belongs to the in-projection)
+    if (a.pos_inc && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *a.pos_inc += 1;
+    if (!elane) return;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[w * 256 + (HALF ? (tid >> 3) * 16 + (tid & 7) : tid)];
+    v += ebias;
+    if (a.act == 1) v = v * sigmoidf_(1.702f * v);  // QuickGELU (clip_model.py:196-198)
+    v += eres;
+    if (a.round_out) v = round_bf16(v);
+    if (a.out) a.out[(long)eb * a.ldo + en] = v;
+    if (a.out_bf) a.out_bf[(long)eb * a.ldo + en] = f2bf(v);
+    if (a.kv_cache && en >= a.kv_lo && en < a.kv_lo + a.kv_width && epos < a.Lmax)
+        a.kv_cache[((long)eb * a.Lmax + epos) * a.kv_width + (en - a.kv_lo)] = f2bf(v);
+}
+
+bool gemv16_supported(int NB, int N, int K) {
+    const int S = K / 256;
+    return NB >= 1 && NB <= 16 && N % 16 == 0 && K % 256 == 0 && (S == 2 || S == 3 || S == 8 || S == 12);
+}
+
+int gemv16_launch(const Gemv16Args& a, hipStream_t s) {
+    if (!gemv16_supported(a.NB, a.N, a.K) || a.ldx % 8 != 0 || (!a.x && !a.xb) || (!a.xb && a.K > 1024)) {  // (fp32 rows: K <= 1024)
+        mmvid_set_error("decode gemv (MFMA form): NB=%d (<= 16), N=%d (multiple of 16), K=%d (512 / 768 / 2048 / 3072), ldx %% 8 == 0", a.NB, a.N, a.K);
+        return MMVID_ERR_ARG;
+    }
+    const bool direct = a.xb != nullptr;
+    const bool half = direct && a.N <= 1024 && a.K >= 2048;  // (narrow and long: see HALF)
+    const dim3 grid(half ? a.N / 8 : a.N / 16, (half && a.NB > 8) ? 2 : 1);
+    const size_t lds = 8 * 256 * 4 + (direct ? 0 : (size_t)16 * (a.K + 8) * 2);
+    auto go = [&](auto kern) {
+        static bool attr = false;  // (per instantiation)
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 256 * 4 + 16 * (3072 + 8) * 2);
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    };
+    switch (a.K / 256) {
+        case 2: direct ? go(gemv16_mfma_kernel<2, true>) : go(gemv16_mfma_kernel<2, false>); break;
+        case 3: direct ? go(gemv16_mfma_kernel<3, true>) : go(gemv16_mfma_kernel<3, false>); break;
+        case 8: half ? go(gemv16_mfma_kernel<8, true, true>) : go(gemv16_mfma_kernel<8, true>); break;
+        default: half ? go(gemv16_mfma_kernel<12, true, true>) : go(gemv16_mfma_kernel<12, true>); break;
+    }
+    return MMVID_OK;
+}
+
 // One block per (head, batch): q fp32 [B][ldq] (already bf16-rounded), K|V rows from the cache (position `pos` included).
 // Thread (kg, dc) = (tid >> 3, tid & 7) holds dims [8 dc, 8 dc + 8) of q in registers and takes that 16-byte slice of the keys kg, kg + NG,
 // ... (NG = 8 NW key groups): a key's row is read by 8 adjacent lanes, its score is the sum over them (three DPP steps), 8 loads per
@@ -392,7 +570,8 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvArgs a, unsigned lon
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __restrict__ q, long ldq, const bf16_t* __restrict__ cache,
                                                                int Lmax, int E, const int* __restrict__ pos_dev, int pos0,
-                                                               float scale_log2, float* __restrict__ out, long ldo) {
+                                                               float scale_log2, float* __restrict__ out, long ldo,
+                                                               bf16_t* __restrict__ out_bf = nullptr) {
     __shared__ float sc[DEC_MAXL];
     __shared__ float red[NW][64];
     __shared__ float stat[2][NW];
@@ -405,13 +584,27 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
     const int nw = (NW > 4 && n_all <= 512) ? 4 : NW;
     const int n = wave < nw ? n_all : 0;
     const int NT = nw * 64, NG = nw * 8;
+    const long rs = 2 * (long)E;  // elements between two positions
+    const int vo = E;             // from a key row to its value row
     const bf16_t* kv = cache + (long)b * Lmax * 2 * E + h * 64 + dc * 8;
-    // the first batch of keys does not depend on q: requested before it
-    uint4 u[8];
+    // Round 6: the kernel is a chain of memory round trips (K batch -> scores -> V batch -> ...), 11 us on average at batch 16 for 31 MB.
+    // Neither the keys nor the values depend on q or on the scores, so the first TWO key batches (2 x 8 NG keys: 2,048 with 16 waves) and the
+    // first value batch are requested before anything else (96 registers), the second value batch as soon as the key registers are free --
+    // i.e. before the softmax statistics and their two barriers: one round trip for a cache of up to 1,024 positions, two up to 2,048.
+    // (What is left is the fixed chain: 7.2 us at 129 keys, 4.8 TB/s marginal from there to 1,100; a head-major cache layout changes 3-6 %:
+    // profiles/r06_decode_attention_cache_layout_experiment.log.)
+    uint4 uk[2][8], uv[2][8];
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kg + NG * (j + 8 * bt);
+            uk[bt][j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * rs) : make_uint4(0u, 0u, 0u, 0u);
+        }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = kg + NG * j;
-        u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E) : make_uint4(0u, 0u, 0u, 0u);
+        uv[0][j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * rs + vo) : make_uint4(0u, 0u, 0u, 0u);
     }
     float qv[8];
     {
@@ -419,15 +612,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
         const float4 q1 = *reinterpret_cast<const float4*>(q + (long)b * ldq + h * 64 + dc * 8 + 4);
         qv[0] = q0.x, qv[1] = q0.y, qv[2] = q0.z, qv[3] = q0.w, qv[4] = q1.x, qv[5] = q1.y, qv[6] = q1.z, qv[7] = q1.w;
     }
+    __builtin_amdgcn_sched_barrier(0);  // (all of the above in flight before the first score waits)
     float mx = -INFINITY;
-    for (int k0 = kg; k0 < n; k0 += NG * 8) {
-        if (k0 != kg) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + NG * j;
-                u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E) : make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
+    auto scores = [&](const uint4 (&u)[8], int k0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + NG * j;
@@ -439,12 +626,22 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
                 mx = fmaxf(mx, d);
             }
         }
+    };
+    scores(uk[0], kg);
+    if (kg + NG * 8 < n) scores(uk[1], kg + NG * 8);
+    for (int k0 = kg + NG * 16; k0 < n; k0 += NG * 8) {  // caches beyond two batches (Lmax > 2,048 with 16 waves)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + NG * j;
+            uk[0][j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * rs) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        scores(uk[0], k0);
     }
-    // the values do not depend on the scores: request the first batch of V rows now, under the softmax statistics
+    // the second value batch, under the softmax statistics
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int k = kg + NG * j;
-        u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E) : make_uint4(0u, 0u, 0u, 0u);
+        const int k = kg + NG * (j + 8);
+        uv[1][j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * rs + vo) : make_uint4(0u, 0u, 0u, 0u);
     }
     mx = wave_max_fast(mx);
     if (lane == 0) stat[0][wave] = mx;
@@ -463,14 +660,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
     sum = 0.f;
     for (int w = 0; w < nw; ++w) sum += stat[1][w];
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kg; k0 < n; k0 += NG * 8) {  // 8 independent 16-byte loads per round trip (the first batch is already here)
-        if (k0 != kg) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + NG * j;
-                u[j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * 2 * E + E) : make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
+    auto values = [&](const uint4 (&u)[8], int k0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + NG * j;
@@ -478,6 +668,16 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
             acc[0] += p * bf_lo(u[j].x), acc[1] += p * bf_hi(u[j].x), acc[2] += p * bf_lo(u[j].y), acc[3] += p * bf_hi(u[j].y);
             acc[4] += p * bf_lo(u[j].z), acc[5] += p * bf_hi(u[j].z), acc[6] += p * bf_lo(u[j].w), acc[7] += p * bf_hi(u[j].w);
         }
+    };
+    values(uv[0], kg);
+    if (kg + NG * 8 < n) values(uv[1], kg + NG * 8);
+    for (int k0 = kg + NG * 16; k0 < n; k0 += NG * 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + NG * j;
+            uv[0][j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * rs + vo) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        values(uv[0], k0);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = over_groups_sum(acc[e]);  // the wave's 8 key groups
@@ -489,7 +689,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
     if (tid < 64) {
         float s = 0.f;
         for (int w = 0; w < nw; ++w) s += red[w][tid];
-        out[(long)b * ldo + h * 64 + tid] = round_bf16(s / sum);  // the full forward stores the attention output in bf16
+        // the full forward stores the attention output in bf16 (out_bf: as bf16 bits for the MFMA out-projection, same values)
+        if (out_bf)
+            out_bf[(long)b * ldo + h * 64 + tid] = f2bf(s / sum);
+        else
+            out[(long)b * ldo + h * 64 + tid] = round_bf16(s / sum);
     }
 }
 
@@ -585,6 +789,16 @@ extern "C" int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const
     a.x = x, a.ldx = ldx, a.ln_w = ln_w, a.ln_b = ln_b, a.eps = eps, a.W = (const bf16_t*)W, a.bias = bias;
     a.residual = residual, a.ldr = ldr, a.out = out, a.ldo = ldo, a.NB = NB, a.N = N, a.K = K, a.act = act;
     a.round_in = round_in, a.round_out = round_out;
+    static const int g16_min = getenv("MMVID_GEMV16_MIN") ? atoi(getenv("MMVID_GEMV16_MIN")) : 3;
+    if (round_in && NB >= g16_min && K <= 1024 && ldx % 8 == 0 && gemv16_supported(NB, N, K)) {  // 3..16 bf16-exact rows: the matrix-pipe form
+        Gemv16Args g = {};
+        g.x = x, g.ldx = ldx, g.ln_w = ln_w, g.ln_b = ln_b, g.eps = eps, g.W = (const bf16_t*)W, g.bias = bias, g.residual = residual, g.ldr = ldr;
+        g.out = out, g.ldo = ldo, g.NB = NB, g.N = N, g.K = K, g.act = act, g.round_out = round_out;
+        int rc16 = gemv16_launch(g, (hipStream_t)stream);
+        if (rc16) return rc16;
+        MMVID_LAUNCH_CHECK("gemv_rows");
+        return MMVID_OK;
+    }
     int rc = gemv_launch(a, (hipStream_t)stream);
     if (rc) return rc;
     MMVID_LAUNCH_CHECK("gemv_rows");
@@ -612,15 +826,18 @@ extern "C" int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvi
                                         float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
                                         void* stream) {
     MMVID_REQUIRE(cfg, "tower_decode_fused: null pointer");
-    return mmvid_tower_decode_fused_slice(cfg, layers, x_in, x_out, kv_cache, Lmax, cfg->B, pos_dev, pos, scratch, stream);
+    return mmvid_tower_decode_fused_slice(cfg, layers, x_in, x_out, kv_cache, Lmax, cfg->B, const_cast<int32_t*>(pos_dev), pos, 0, scratch, stream);
 }
 
 // The same for cfg->B consecutive sequences of a cache that holds cache_batch >= cfg->B of them: kv_cache points at the first of these
 // sequences in layer 0, a layer is cache_batch * Lmax * 2E elements further.  (Batches above 16 run as slices of 16: the M = B corner of
 // the training GEMM takes 2.2 ms per token at batch 16.)
+__global__ void pos_advance_kernel(int* p) { *p += 1; }
+
 extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
-                                              float* x_out, void* kv_cache, int Lmax, int cache_batch, const int32_t* pos_dev, int pos,
-                                              void* scratch, void* stream) {
+                                              float* x_out, void* kv_cache, int Lmax, int cache_batch, int32_t* pos_dev, int pos,
+                                              int advance_pos, void* scratch, void* stream) {
+    MMVID_REQUIRE(!advance_pos || pos_dev, "tower_decode_fused: advance_pos needs the device position");
     MMVID_REQUIRE(cfg && layers && x_in && x_out && kv_cache && scratch, "tower_decode_fused: null pointer");
     MMVID_REQUIRE(cache_batch >= cfg->B, "tower_decode_fused: cache_batch %d < batch %d", cache_batch, cfg->B);
     MMVID_REQUIRE(cfg->mask_mode == 1 && cfg->E == cfg->H * 64 && cfg->B <= GV_MAXB && Lmax <= DEC_MAXL,
@@ -640,10 +857,47 @@ extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, cons
     p += (long)B * E;
     float* xb = p;
     const float* x = x_in;
+    // 3..16 sequences: the linear layers on the matrix pipe (gemv16_mfma_kernel); 1-2: the vector-ALU form (what the persistent step falls back to)
+    static const int g16_min = getenv("MMVID_GEMV16_MIN") ? atoi(getenv("MMVID_GEMV16_MIN")) : 3;
+    const bool mfma = B >= g16_min && gemv16_supported(B, 3 * E, E) && gemv16_supported(B, E, F) && gemv16_supported(B, F, E);
+    bf16_t* o_bf = (bf16_t*)o;      // (MFMA form: the attention output and the activation travel as bf16 -- the operand the next layer
+    bf16_t* act_bf = (bf16_t*)act;  //  would round them to anyway)
     for (int i = 0; i < cfg->layers; ++i) {
         const mmvid_tower_layer_t& ly = layers[i];
         bf16_t* cache = (bf16_t*)kv_cache + (long)i * cache_batch * Lmax * 2 * E;
         float* xnext = (i == cfg->layers - 1) ? x_out : ((i & 1) ? xb : xa);
+        if (mfma) {
+            Gemv16Args g = {};
+            g.NB = B, g.eps = cfg->ln_eps, g.x = x, g.ldx = E, g.ln_w = ly.ln1_w, g.ln_b = ly.ln1_b, g.W = (const bf16_t*)ly.in_w, g.bias = ly.in_b;
+            g.N = 3 * E, g.K = E, g.out = qkv, g.ldo = 3 * E, g.round_out = 1, g.kv_cache = cache, g.kv_lo = E, g.kv_width = 2 * E, g.Lmax = Lmax;
+            g.pos_dev = pos_dev, g.pos0 = pos;
+            int rc = gemv16_launch(g, s);
+            if (rc) return rc;
+            if (Lmax > 512)
+                hipLaunchKernelGGL(attn_decode2_kernel<16>, dim3(H, B), dim3(1024), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
+                                   0.125f * 1.4426950408889634f, (float*)nullptr, (long)E, o_bf);
+            else
+                hipLaunchKernelGGL(attn_decode2_kernel<4>, dim3(H, B), dim3(256), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
+                                   0.125f * 1.4426950408889634f, (float*)nullptr, (long)E, o_bf);
+            Gemv16Args g2 = {};
+            g2.NB = B, g2.xb = o_bf, g2.ldx = E, g2.W = (const bf16_t*)ly.out_w, g2.bias = ly.out_b, g2.N = E, g2.K = E, g2.residual = x, g2.ldr = E;
+            g2.out = xmid, g2.ldo = E;
+            rc = gemv16_launch(g2, s);
+            if (rc) return rc;
+            Gemv16Args g3 = {};
+            g3.NB = B, g3.eps = cfg->ln_eps, g3.x = xmid, g3.ldx = E, g3.ln_w = ly.ln2_w, g3.ln_b = ly.ln2_b, g3.W = (const bf16_t*)ly.fc_w;
+            g3.bias = ly.fc_b, g3.N = F, g3.K = E, g3.act = 1, g3.out_bf = act_bf, g3.ldo = F;
+            rc = gemv16_launch(g3, s);
+            if (rc) return rc;
+            Gemv16Args g4 = {};
+            g4.NB = B, g4.xb = act_bf, g4.ldx = F, g4.W = (const bf16_t*)ly.pj_w, g4.bias = ly.pj_b, g4.N = E, g4.K = F, g4.residual = xmid, g4.ldr = E;
+            g4.out = xnext, g4.ldo = E;
+            if (advance_pos && i == cfg->layers - 1) g4.pos_inc = pos_dev;
+            rc = gemv16_launch(g4, s);
+            if (rc) return rc;
+            x = xnext;
+            continue;
+        }
         GemvArgs g = {};
         g.NB = B, g.eps = cfg->ln_eps;
         // q,k,v (+ cache append)
@@ -675,6 +929,7 @@ extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, cons
         if (rc) return rc;
         x = xnext;
     }
+    if (advance_pos && !mfma) hipLaunchKernelGGL(pos_advance_kernel, dim3(1), dim3(1), 0, s, pos_dev);
     MMVID_LAUNCH_CHECK("tower_decode_fused");
     return MMVID_OK;
 }

@@ -360,7 +360,8 @@ class DALLE(nn.Module):
             # out, the launch and all later ones on the session's workspace are void, and the failure flag says so.  Every CHECK tokens
             # the flag is read (one sync per ~15 ms of work) and the token to embed next is kept; after a failure the loop goes back to
             # the last verified token and finishes with the launches below (five per layer), which need no co-residency.
-            CHECK = 64
+            CHECK = getattr(self, '_decode_check_every', 64)
+            hook = getattr(self, '_token_step_hook', None)  # tests: called as hook(tokens launched so far, session) after every launch
             good_step, good_tok = 0, tok.clone()
             step = 0
             while step < steps - 1:
@@ -377,6 +378,8 @@ class DALLE(nn.Module):
                                 sess.token_step(tk)
                         torch.cuda.current_stream().wait_stream(side)
                 step += 1
+                if hook is not None:
+                    hook(step, sess)
                 if step % CHECK == 0 or step == steps - 1:
                     if sess.failed():
                         break

@@ -596,8 +596,9 @@ def gemv_rows(x, W, bias=None, ln=None, act=0, residual=None, round_in=False, ro
     if out is None:
         out = torch.empty(NB, N, device=x.device, dtype=f32)
     lw, lb, eps = (ln[0], ln[1], ln[2]) if ln is not None else (None, None, 0.0)
-    for r0 in range(0, NB, 8):  # the kernel takes up to 8 rows per launch; larger batches go through in slices
-        nb = min(8, NB - r0)
+    step = 16 if round_in else 8  # rows per launch: 16 bf16-exact rows (3..16: the MFMA form), 8 fp32 rows; larger batches in slices
+    for r0 in range(0, NB, step):
+        nb = min(step, NB - r0)
         res = residual[r0:r0 + nb] if residual is not None else None
         call('mmvid_gemv_rows', _p(x[r0:r0 + nb]), K, nb, K, _p(lw), _p(lb), float(eps), _p(W), _p(bias), N, int(act), _p(res), N,
              int(round_in), int(round_out), _p(out[r0:r0 + nb]), N, _stream())
