@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmmvid_hip.so')
+LIB_PATH = os.environ.get('MMVID_LIB') or os.path.join(HERE, 'libmmvid_hip.so')  # (MMVID_LIB: another build of the same ABI, for same-box A/Bs)
 
 P = c_void_p
 I, I64, F, U64 = c_int, c_int64, c_float, c_uint64

@@ -311,7 +311,10 @@ template <int V>
 using ic = std::integral_constant<int, V>;
 
 // ------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int L, int H, int E, FastDiv nrt_d,
+// Three blocks per CU (round 6; four until then): at four the 128-register cap left 26 registers of the masked tile body in scratch -- the body
+// that runs for the tail tile and the two restricted rows of EVERY block.  154 registers, no scratch: 40.3 -> 38.0 us per layer at the training
+// shape, captured step 15.21 -> 15.12 ms, same box, alternating runs (profiles/r06_same_box_attention_forward_occupancy.log).
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long ld, int L, int H, int E, FastDiv nrt_d,
                                                            FastDiv h_d, float scale_log2, MaskSpec mask, bf16_t* __restrict__ out,
                                                            long ldo, float* __restrict__ lse2) {
     __shared__ __attribute__((aligned(16))) char smem[2][2 * TILE];  // K tile, V tile, two stages
