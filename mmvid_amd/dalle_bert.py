@@ -475,9 +475,7 @@ class BERT(nn.Module):
             assert B >= 2 and B % 2 == 0  # for REL swapping (dalle_bert.py:1045-1046)
         text_neg_ids = None
         if rel and negvc:
-            if self.num_visuals > 0:
-                raise NotImplementedError('negvc with visuals: the reference builds a control_neg sequence without the '
-                                          'visual segment (dalle_bert.py:923-930, 974-975), whose length is inconsistent')
+            # `visual_neg` is accepted and ignored, as in the reference (dalle_bert.py:869-892 takes it, nothing reads it)
             text_neg_ids = ops._chk(text_neg.contiguous(), torch.int64, 'text_neg')
         ids, sel, tfull, cnt = ops.bert_build_ids(text, vis_tok, self.visual_seq_len, target, target_warp, mask1, pad_base, MASK,
                                                   bool(rel), bool(do_vid), text_neg=text_neg_ids)
@@ -488,7 +486,23 @@ class BERT(nn.Module):
                 ([text_rows] if do_vid else [])
             text_rows = torch.cat(per_pass)
         x_seq = self._assemble(ids, self.total_seq_len, text_rows)
-        y = self.transformer_forward(x_seq)  # [nseq*B, L, dim]
+        if text_neg_ids is not None and self.num_visuals > 0 and self.visual_seq_len > 0:
+            # negvc with a visual control (dalle_bert.py:908-909, 927-935, 974-975, 1047-1054): the reference's control_neg is
+            # [REL] + text_neg + [ST1] [VID] WITHOUT the visual segment, so its REL-negative pass is a shorter sequence (the tower's
+            # restricted rows keep their absolute positions: clip_model.py:218-222 slices the mask).  The REL third of the batch is
+            # assembled at full length like the others, its visual positions are dropped, and it goes through the tower on its own;
+            # the result returns to its full-length rows (the dropped positions stay zero: the heads read row 0 of that pass only).
+            L = self.total_seq_len
+            v0 = 1 + self.text_seq_len
+            keep = torch.cat((torch.arange(0, v0, device=device), torch.arange(v0 + self.visual_seq_len, L, device=device)))
+            x_neg = x_seq[B:2 * B].index_select(1, keep).contiguous()
+            x_main = torch.cat((x_seq[:B], x_seq[2 * B:])) if do_vid else x_seq[:B]
+            y_main = self.transformer_forward(x_main.contiguous())
+            y_neg = self.transformer_forward(x_neg)
+            y_rel = torch.zeros(B, L, y_neg.shape[-1], device=device, dtype=y_neg.dtype).index_copy(1, keep, y_neg)
+            y = torch.cat((y_main[:B], y_rel, y_main[B:])) if do_vid else torch.cat((y_main, y_rel))
+        else:
+            y = self.transformer_forward(x_seq)  # [nseq*B, L, dim]
         if self._debug_keep is not None:  # tools/stress_nan2.py: the stage tensors of the last (replayed) forward
             self._debug_keep.update(mask1=mask1, nfm=not_fully_masked, target=target, target_warp=target_warp, ids=ids, sel=sel,
                                     tfull=tfull, cnt=cnt, x_seq=x_seq, y=y)

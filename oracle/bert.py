@@ -60,8 +60,9 @@ def text_feature_mapping(sd, feat):
     return h
 
 
-def control_embedding(sd, cfg, text, visual_tok=None):
-    """dalle_bert.py:899-978 -> [B, 1+Ttxt+Nvis+2, dim]."""
+def control_embedding(sd, cfg, text, visual_tok=None, with_visual=True):
+    """dalle_bert.py:899-978 -> [B, 1+Ttxt+Nvis+2, dim].  with_visual=False: the `control_neg_emb` of the negvc branch, which the
+    reference builds WITHOUT the visual segment even when the model has one (909-910, 927-935, 974-975)."""
     B = text.shape[0]
     sp, spp = sd['special_emb.weight'], sd['special_pos_emb.weight']
     rel = (sp[0] + spp[0]).expand(B, 1, -1)
@@ -72,7 +73,7 @@ def control_embedding(sd, cfg, text, visual_tok=None):
         text = torch.where(text == 0, text_range, text)  # unique pad id per position, 917-919
         te = sd['text_emb.weight'][text] + sd['text_pos_emb.weight'][:cfg.text_seq_len]
     parts = [rel, te]
-    if cfg.num_visuals > 0:
+    if cfg.num_visuals > 0 and with_visual:
         if visual_tok is None:
             visual_tok = torch.full((B, cfg.visual_seq_len), cfg.MASK, dtype=torch.long)
         vtab = sd['visual_emb.weight'] if 'visual_emb.weight' in sd else sd['image_emb.weight']
@@ -102,8 +103,9 @@ def tower_fwd(sd, cfg, tokens, stable=False):
 
 def forward_losses(sd, cfg, text, target_tok, mask1, warp_tok=None, visual_tok=None, rel=True, vid=True,
                    rel_no_fully_masked=True, not_fully_masked=None, stable=False, text_neg=None):
-    """dalle_bert.py:1030-1127 given the injected mask / warped tokens.  Returns dict.  `text_neg` = the negvc branch without
-    visuals (909-910, 927-935, 974-975, 1047-1054): the REL negative's control sequence is [REL] + text_neg + [VID] [SEP]."""
+    """dalle_bert.py:1030-1127 given the injected mask / warped tokens.  Returns dict.  `text_neg` = the negvc branch
+    (909-910, 927-935, 974-975, 1047-1054): the REL negative's control sequence is [REL] + text_neg + [ST1] [VID] -- never with the
+    visual segment, so with visuals that pass is a SHORTER sequence (the tower slices its mask to the length, clip_model.py:218-222)."""
     B = text.shape[0]
     ctrl = control_embedding(sd, cfg, text, visual_tok)
     tpos = target_pos(sd, cfg)
@@ -121,8 +123,7 @@ def forward_losses(sd, cfg, text, target_tok, mask1, warp_tok=None, visual_tok=N
     if rel:
         half = B // 2
         if text_neg is not None:
-            assert cfg.num_visuals == 0
-            ctrl_swap = control_embedding(sd, cfg, text_neg)
+            ctrl_swap = control_embedding(sd, cfg, text_neg, with_visual=False)
         else:
             ctrl_swap = torch.cat([ctrl[half:], ctrl[:half]], 0)  # swap(): chunk(2)[::-1], 110-114
         out_neg = tower_fwd(sd, cfg, torch.cat([ctrl_swap, temb], 1), stable)

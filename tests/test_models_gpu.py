@@ -184,6 +184,38 @@ def test_bert_negvc_text_only_vs_reference(golden):
     assert rows is not None and set(g['g_text_emb_row_ids'].tolist()) <= set(rows.cpu().tolist())
 
 
+def test_bert_negvc_with_visuals_vs_reference(golden):
+    """negvc=True together with a visual control (dalle_bert.py:908-909, 927-935, 974-975, 1047-1054; train.py:312-314 with --negvc
+    --visual): the REL-negative pass has no visual segment (51 positions against 67) and `visual_neg` is ignored.  Losses, that pass's
+    output and gradients against the reference's own run (tests/golden/bert_negvc_visual.npz; rounds 1-5 raised NotImplementedError)."""
+    g, m = _bert_case(golden, 'bert_negvc_visual', 1, True)
+    text, text_neg, frames = g['text'].to(DEV), g['text_neg'].to(DEV), g['frames'].to(DEV)
+    visual, visual_neg = g['visual'].to(DEV), g['visual_neg'].to(DEV)
+    seen = []
+    tf = m.transformer_forward
+    m.transformer_forward = lambda t: (seen.append(tuple(t.shape)), tf(t))[1]
+
+    def run():
+        return m(text, visual=visual, target=frames, return_loss=True, rel=True, vid=True, rel_no_fully_masked=True, negvc=True,
+                 text_neg=text_neg, visual_neg=visual_neg, _mask1=g['mask1'], _target_warp=g['warped_frames'])
+    lm, lr, lv = _with_tokens(m, g, run)
+    m.transformer_forward = tf
+    assert sorted(s[1] for s in seen) == [51, 67], seen  # one pass over MSM + VID at 67, the REL negative at 51
+    losses = torch.stack([lm, lr, lv]).detach().cpu()
+    print('losses', losses.tolist(), 'ref', g['losses'].tolist())
+    assert torch.allclose(losses, g['losses'], rtol=2e-2, atol=2e-2)
+    (7 * lm + 0.5 * lr + 0.5 * lv).backward()
+    G = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    close(G['special_emb.weight'], g['g_special_emb'], 5e-2, 'g special_emb')
+    close(G['text_pos_emb.weight'][:, ::5], g['g_text_pos'], 5e-2, 'g text_pos')
+    close(G['to_logits_rel.1.weight'], g['g_relw'], 5e-2, 'g relw')
+    close(G['visual_emb.weight'][::3, ::5], g['g_visual_emb'], 5e-2, 'g visual_emb')
+    close(G['transformer.transformer.resblocks.1.mlp.c_fc.bias'], g['g_fcb'], 5e-2, 'g c_fc bias')
+    close(G['text_emb.weight'][g['g_text_emb_row_ids'].to(DEV)][:, ::11], g['g_text_emb_rows'], 5e-2, 'g text_emb rows')
+    tn = torch.sqrt(sum((v.double()**2).sum() for v in G.values())).item()
+    assert abs(tn / g['g_total_norm'].item() - 1) < 3e-2
+
+
 def _with_tokens(m, g, fn):
     """Run fn with the VAEs answering the reference's token indices for the golden frames (isolates the
     transformer path from bf16 index flips in the encoder)."""

@@ -185,6 +185,40 @@ def test_bert_negvc_text_only(golden):
     assert abs(tn.item() / g['g_total_norm'].item() - 1) < 1e-5
 
 
+def test_bert_negvc_with_visuals(golden):
+    """negvc=True together with a visual control: the reference's own run (tools/make_golden.py::case_bert_negvc_visual).  Its REL-negative
+    pass has no visual segment -- 51 positions against 67 -- and `visual_neg` is ignored."""
+    g = golden('bert_negvc_visual')
+    assert g.meta['pass_lengths'] == [67, 51, 67]
+    sd = synth_model_sd(g, 17)
+    for k in sd:
+        sd[k].requires_grad_(not k.startswith(('vae.', 'cvae.')))
+    cfg = bert.Cfg(sd, 16, 1, 2, 64, use_cvae=True)
+    with torch.no_grad():
+        tt = bert.get_image_tokens(sd, cfg, g['frames'])
+        wt = bert.get_image_tokens(sd, cfg, g['warped_frames'])
+        vt = bert.get_image_tokens(sd, cfg, g['visual'], 'cvae')
+    assert torch.equal(tt, g['target_tok']) and torch.equal(wt, g['warp_tok']) and torch.equal(vt, g['visual_tok'])
+    r = bert.forward_losses(sd, cfg, g['text'], tt, g['mask1'], wt, vt, text_neg=g['text_neg'])
+    assert r['tokens_rel'].shape[1] == 51
+    assert relerr(r['tokens_rel'][:, :, ::5], g['tokens_rel']) <= TOL
+    assert relerr(r['out_msm'][:, ::3, ::7], g['out_msm_s']) <= TOL
+    assert relerr(r['out_rel'][:, :, ::7], g['out_rel']) <= TOL
+    assert relerr(r['out_vid'][:, ::3, ::7], g['out_vid_s']) <= TOL
+    losses = torch.stack([r['loss_msm'], r['loss_rel'], r['loss_vid']])
+    assert torch.allclose(losses, g['losses'], rtol=1e-5)
+    (7 * r['loss_msm'] + .5 * r['loss_rel'] + .5 * r['loss_vid']).backward()
+    G = {k: v.grad for k, v in sd.items() if v.grad is not None}
+    for key, name in (('special_emb.weight', 'g_special_emb'), ('to_logits_rel.1.weight', 'g_relw'),
+                      ('transformer.transformer.resblocks.1.mlp.c_fc.bias', 'g_fcb')):
+        assert relerr(G[key], g[name]) <= TOL
+    assert relerr(G['text_pos_emb.weight'][:, ::5], g['g_text_pos']) <= TOL
+    assert relerr(G['visual_emb.weight'][::3, ::5], g['g_visual_emb']) <= TOL
+    assert relerr(G['text_emb.weight'][g['g_text_emb_row_ids']][:, ::11], g['g_text_emb_rows']) <= TOL
+    tn = torch.sqrt(sum((v.double()**2).sum() for v in G.values()))
+    assert abs(tn.item() / g['g_total_norm'].item() - 1) < 1e-5
+
+
 @pytest.mark.parametrize('name', ['bert_flm', 'bert_flm_bottleneck'])
 def test_bert_fixed_language_model(golden, name):
     """dalle_bert.py:307-322, 924-925: the text is one mapped sentence feature (single Linear / LayerNorm-Linear bottleneck)."""

@@ -8,7 +8,7 @@ layout), and the reference's outputs.  Run:
 
     PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [case ...]
 
-Cases: vq vqgan_tiny vqgan_full vqgan_full16 vqgan_full16_refinit tower tower12 bert_tiny bert_tiny_visual bert_negvc bert_flm bert_flm_bottleneck artv_tiny mask_predict
+Cases: vq vqgan_tiny vqgan_full vqgan_full16 vqgan_full16_refinit tower tower12 bert_tiny bert_tiny_visual bert_negvc bert_negvc_visual bert_flm bert_flm_bottleneck artv_tiny mask_predict
        frontend mask_predict_race
 """
 import json
@@ -383,6 +383,70 @@ def case_bert_negvc():
          g_total_norm=torch.sqrt(sum((v.double()**2).sum() for v in g.values())).view(1))
 
 
+def case_bert_negvc_visual():
+    """Round 6: negvc=True TOGETHER with a visual control (dalle_bert.py:908-909, 927-935, 974-975, 1047-1054; reachable from
+    train.py:312-314 with --negvc --visual).  The reference builds control_neg = [REL] + text_neg + ([ST1], [VID]) WITHOUT the visual
+    segment and `visual_neg` is accepted and ignored: the REL-negative pass is a SHORTER sequence (the attention mask is sliced to its
+    length, clip_model.py:218-222, so the restricted rows then fall on target tokens).  Captured: that pass's input / output slices."""
+    import mmvid_pytorch.dalle_bert as db
+    m, man = _build_bert(1, True, 17)
+    B, T, S, TL = 2, 2, 64, 16
+    text = synth_tokens('text', (B, TL), 49408, 17, low=1)
+    text[0, 11:] = 0
+    text[1, 5:] = 0
+    text_neg = synth_tokens('text_neg', (B, TL), 49408, 17, low=1)
+    text_neg[0, 7:] = 0
+    text_neg[1, 13:] = 0
+    frames = synth_input('frames', (B, T, 3, S, S), 17, 'uniform')
+    visual = synth_input('visual', (B, 1, 3, S, S), 17, 'uniform')
+    visual_neg = synth_input('visual_neg', (B, 1, 3, S, S), 17, 'uniform')  # (ignored by the reference)
+    cap = {'emb_in': [], 'tf_in': [], 'tf_out': [], 'warp': []}
+    h1 = m.image_emb.register_forward_hook(lambda mod, i, o: cap['emb_in'].append(i[0].clone()))
+
+    def tf_hook(mod, i, o):
+        cap['tf_in'].append(i[0].detach().clone())
+        cap['tf_out'].append(o.detach().clone())
+
+    h2 = m.transformer.register_forward_hook(tf_hook)
+    warp_orig = db.warp
+
+    def warp_cap(x, p):
+        y = warp_orig(x, p)
+        cap['warp'].append(y.clone())
+        return y
+
+    db.warp = warp_cap
+    m.train()
+    seed_all(123)
+    loss_msm, loss_rel, loss_vid = m(text, visual=visual, target=frames, return_loss=True, rel=True, vid=True, negvc=True,
+                                     text_neg=text_neg.clone(), visual_neg=visual_neg,
+                                     msm_strategy_prob=np.array([0.7, 0.1, 0.1, 0.1]), msm_bernoulli_prob=[0.2, 0.5],
+                                     rel_no_fully_masked=True, vid_strategy_prob=np.array([0.25, 0.25, 0.25, 0.25]))
+    (7 * loss_msm + 0.5 * loss_rel + 0.5 * loss_vid).backward()
+    db.warp = warp_orig
+    h1.remove(), h2.remove()
+    with torch.no_grad():
+        target_tok = m.get_image_tokens(frames)
+        warp_tok = m.get_image_tokens(cap['warp'][0])
+        visual_tok = m.get_image_tokens(visual, which_vae='cvae')
+    mask1 = cap['emb_in'][0] != m.image_token_lut['[MASK]']
+    g = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    ids = torch.cat((text.view(-1), text_neg.view(-1))).unique()
+    ids = ids[ids != 0]
+    lens = [int(t.shape[1]) for t in cap['tf_in']]
+    print('tower passes (sequence lengths):', lens)
+    save('bert_negvc_visual', meta=dict(seed=17, vae_seed=11, cvae_seed=12, B=B, T=T, image_size=S, text_seq_len=TL, num_visuals=1, layers=2,
+                                        py_seed=123, pass_lengths=lens),
+         manifest=man, text=text, text_neg=text_neg, frames=frames, visual=visual, visual_neg=visual_neg, target_tok=target_tok,
+         warp_tok=warp_tok, visual_tok=visual_tok, mask1=mask1, warped_frames=cap['warp'][0],
+         tokens_rel=cap['tf_in'][1][:, :, ::5], out_msm_s=cap['tf_out'][0][:, ::3, ::7], out_rel=cap['tf_out'][1][:, :, ::7],
+         out_vid_s=cap['tf_out'][2][:, ::3, ::7], losses=torch.stack([loss_msm, loss_rel, loss_vid]).detach(),
+         g_special_emb=g['special_emb.weight'], g_text_pos=g['text_pos_emb.weight'][:, ::5], g_relw=g['to_logits_rel.1.weight'],
+         g_visual_emb=g['visual_emb.weight'][::3, ::5], g_text_emb_rows=g['text_emb.weight'][ids][:, ::11], g_text_emb_row_ids=ids,
+         g_fcb=g['transformer.transformer.resblocks.1.mlp.c_fc.bias'],
+         g_total_norm=torch.sqrt(sum((v.double()**2).sum() for v in g.values())).view(1))
+
+
 def _bert_flm_case(name, bottleneck):
     """BERT with a fixed language model (dalle_bert.py:307-322, 924-925): the text is one sentence feature per sample (what
     utils_train.py:194-215 takes from RoBERTa-large, 1024 wide); the model maps it to one token."""
@@ -731,7 +795,7 @@ def case_mask_predict_race():
 
 CASES = dict(vq=case_vq, vqgan_tiny=case_vqgan_tiny, vqgan_full=case_vqgan_full, vqgan_full16=case_vqgan_full16,
              vqgan_full16_refinit=case_vqgan_full16_refinit, tower=case_tower, tower12=case_tower12,
-             bert_tiny=case_bert_tiny, bert_tiny_visual=case_bert_tiny_visual, bert_negvc=case_bert_negvc, bert_flm=case_bert_flm,
+             bert_tiny=case_bert_tiny, bert_tiny_visual=case_bert_tiny_visual, bert_negvc=case_bert_negvc, bert_negvc_visual=case_bert_negvc_visual, bert_flm=case_bert_flm,
              bert_flm_bottleneck=case_bert_flm_bottleneck, artv_tiny=case_artv_tiny,
              mask_predict=case_mask_predict, frontend=case_frontend, mask_predict_race=case_mask_predict_race)
 
