@@ -12,6 +12,7 @@
 // Roofline: bf16 MFMA; algorithmic FLOPs = 2 * M * Cout * taps * Cin.
 #include "../../include/mmvid_hip.h"
 #include "gemm_core.h"
+#include "wave_reduce.h"
 #include "prof.h"
 
 namespace {
@@ -435,6 +436,110 @@ void launch_conv(const ConvParams& p, hipStream_t stream) {
                        S::LDS_BYTES, stream, p);
 }
 
+
+// ---- conv_in (model.py:382-386: Conv2d(3, 128, 3, padding 1) on the 128x128 frame; round 6) ------------------------------------------------
+// The per-tap kernel above spends this layer in its epilogue: K = 72 is two K tiles per 256x128 output tile, 27 tiles per CU, each with an
+// LDS-staged epilogue of ~7 us -- 189 us for 226 MB of bf16 stores, four times the HBM time.  This kernel is built
+// around the stores instead: a block = two image rows (256 pixels) x 128 channels; the 4 x 130 pixel input strip (8 channels = 16 B per
+// pixel, zero border) is staged once in LDS; wave w owns channels [32 w, 32 w + 32) -- its 5 weight fragments (two taps of 8 channels per
+// v_mfma_f32_32x32x16_bf16 k step) live in registers, the pixel operand is read from the strip at (row + ky, x + kx); results leave the
+// registers directly: after a half-wave exchange a lane holds 8 consecutive channels of its pixel = one 16-byte store (2 per 32x32
+// tile), or four float4 stores for fp32 outputs; GroupNorm partial sums per 128-pixel row come from the same registers (a lane's four
+// accumulators of a quad are exactly one group of 128 / 32 = 4 channels), reduced over the 32 pixel lanes in a fixed order.
+// TERMS = 3: the bf16-pair operator (x_hi w_hi + x_lo w_hi + x_hi w_lo: three times the k steps, both planes staged).
+template <int TERMS, bool F32OUT>
+__global__ __launch_bounds__(256, 2) void conv_in_kernel(const bf16_t* __restrict__ x, long x_plane, const bf16_t* __restrict__ w,
+                                                         const float* __restrict__ bias, int H, bf16_t* __restrict__ out_bf16,
+                                                         float* __restrict__ out_f32, float* __restrict__ gn_partial) {
+    constexpr int W = 128, PW = W + 2, ROWS = 4, PLANES = TERMS > 1 ? 2 : 1, NK = 5 * TERMS;
+    __shared__ uint4 strip[PLANES][ROWS * PW];
+    const int tid = threadIdx.x, lane = tid & 63, ct = tid >> 6, l32 = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.x / (H >> 1), y0 = (blockIdx.x - n * (H >> 1)) * 2;
+    for (int i = tid; i < PLANES * ROWS * PW; i += 256) {
+        const int pl = i / (ROWS * PW), rc = i - pl * (ROWS * PW), r = rc / PW, c = rc - r * PW;
+        const int y = y0 - 1 + r, xx = c - 1;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (y >= 0 && y < H && xx >= 0 && xx < W) v = *reinterpret_cast<const uint4*>(x + pl * x_plane + (((long)n * H + y) * W + xx) * 8);
+        strip[pl][rc] = v;
+    }
+    bf16x8_t wf[NK];
+    int boff[NK];  // strip offset of this lane's tap in k step ks (pixel (0, 0) of a tile), plane folded in
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int term = ks / 5, tap = 2 * (ks % 5) + kh;
+        const int tc = tap < 9 ? tap : 8;
+        wf[ks] = tap < 9 ? *reinterpret_cast<const bf16x8_t*>(w + (((long)(ct * 32 + l32) * TERMS + term) * 9 + tap) * 8) : bf16x8_t{};
+        boff[ks] = (term == 1 ? ROWS * PW : 0) + (tc / 3) * PW + (tc % 3) + l32;
+    }
+    float4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = bias ? *reinterpret_cast<const float4*>(bias + ct * 32 + 8 * j + 4 * kh) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const uint4* sp = &strip[0][0];
+    float gs[2][4], gq[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gs[r][j] = gq[r][j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int row = t >> 2, x0 = (t & 3) * 32;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const uint4 u = sp[boff[ks] + row * PW + x0];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], __builtin_bit_cast(bf16x8_t, u), acc, 0, 0, 0);
+        }
+        mfma_settle(acc);
+        const long pix = ((long)n * H + y0 + row) * W + x0 + l32;
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[4 * j] + b4[j].x, acc[4 * j + 1] + b4[j].y, acc[4 * j + 2] + b4[j].z, acc[4 * j + 3] + b4[j].w};
+            if constexpr (F32OUT) {
+                *reinterpret_cast<float4*>(out_f32 + pix * 128 + ct * 32 + 8 * j + 4 * kh) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                pk[j][0] = pack_bf2(v[0], v[1]), pk[j][1] = pack_bf2(v[2], v[3]);
+                v[0] = bf_lo(pk[j][0]), v[1] = bf_hi(pk[j][0]), v[2] = bf_lo(pk[j][1]), v[3] = bf_hi(pk[j][1]);  // what the GroupNorm reads
+            }
+            gs[row][j] += (v[0] + v[1]) + (v[2] + v[3]);
+            gq[row][j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        if constexpr (!F32OUT) {
+            // quads (j, j + 1): the lower half-wave ends with channels [8 j, 8 j + 8) of its pixel, the upper with [8 (j + 1), 8 (j + 1) + 8)
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const auto a = __builtin_amdgcn_permlane32_swap(pk[j][0], pk[j + 1][0], false, false);
+                const auto b = __builtin_amdgcn_permlane32_swap(pk[j][1], pk[j + 1][1], false, false);
+                *reinterpret_cast<uint4*>(out_bf16 + pix * 128 + ct * 32 + 8 * (j + kh)) = make_uint4(a[0], b[0], a[1], b[1]);
+            }
+        }
+    }
+    if (gn_partial) {  // [img][128-pixel block = image row][group][2]; group = 8 ct + 2 j + kh
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = gs[r][j], q = gq[r][j];
+                a = bfly_add<0>(a), q = bfly_add<0>(q);
+                a = bfly_add<1>(a), q = bfly_add<1>(q);
+                a = bfly_add<2>(a), q = bfly_add<2>(q);
+                a = bfly_add<3>(a), q = bfly_add<3>(q);
+                a = bfly_add<4>(a), q = bfly_add<4>(q);
+                if (l32 == 0)
+                    *reinterpret_cast<float2*>(gn_partial + ((((long)n * H + y0 + r) * 32) + ct * 8 + 2 * j + kh) * 2) = make_float2(a, q);
+            }
+    }
+}
+
+bool conv_in_shape(int mode, int Hin, int Win, int Cin, int Cout, const void* rb, const void* rf, int clamp01, int splitk, const void* o16,
+                   const void* o32) {
+    return mode == 0 && Cin == 8 && Cout == 128 && Win == 128 && Hin % 2 == 0 && Hin >= 2 && !rb && !rf && !clamp01 && splitk == 1 &&
+           ((o16 != nullptr) != (o32 != nullptr));
+}
+
 int ilog2_exact(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -511,6 +616,19 @@ static int conv2d_launch(int terms, int mode, const void* x, int N, int Hin, int
     MMVID_REQUIRE((long)N * Hin * Win * Cin * 2 * (terms > 1 ? 2 : 1) < (1ll << 31) && (long)Cout * p.K * 2 < (1ll << 31),
                   "conv2d_nhwc: input or weight of 2 GiB or more (32-bit buffer offsets)");
     MmvidProfScope prof(PROF_CONV, 2.0 * (double)p.M * Cout * p.K, (hipStream_t)stream);  // executed MFMA work (3x for split)
+    if (conv_in_shape(mode, Hin, Win, Cin, Cout, residual_bf16, residual_f32, clamp01, splitk, out_bf16, out_f32)) {
+        // the full-size encoder's first layer (geometry only, like every kernel choice of the encoder): conv_in_kernel
+        const dim3 grid(N * (Hin / 2));
+        hipStream_t st = (hipStream_t)stream;
+        if (terms == 3)
+            hipLaunchKernelGGL((conv_in_kernel<3, true>), grid, dim3(256), 0, st, p.x, p.x_plane, p.w, bias, Hin, (bf16_t*)nullptr, out_f32, gn_partial);
+        else if (out_f32)
+            hipLaunchKernelGGL((conv_in_kernel<1, true>), grid, dim3(256), 0, st, p.x, 0l, p.w, bias, Hin, (bf16_t*)nullptr, out_f32, gn_partial);
+        else
+            hipLaunchKernelGGL((conv_in_kernel<1, false>), grid, dim3(256), 0, st, p.x, 0l, p.w, bias, Hin, (bf16_t*)out_bf16, (float*)nullptr, gn_partial);
+        MMVID_LAUNCH_CHECK("conv2d_nhwc (conv_in)");
+        return MMVID_OK;
+    }
     bool big = false;
     // with fused GroupNorm statistics the block shape must not depend on the batch size: the order in which a
     // 128-pixel block's partial sums are formed differs between the shapes, and a frame's tokens must not depend on

@@ -156,3 +156,46 @@ def test_artv_sampler_recovers_from_a_failed_persistent_launch(golden):
         del os.environ['MMVID_DECODE_TOKEN']
         m._token_step_hook = None
     assert torch.equal(a_img, b_img), 'recovered run differs from the launch-per-layer run on the same variates'
+
+
+@pytest.mark.parametrize('N,H', [(3, 6), (1, 128), (2, 2)])
+def test_conv_in_kernel_vs_torch(N, H):
+    """csrc/conv.hip::conv_in_kernel (the full-size encoder's first layer: 3(8) -> 128 channels on 128-pixel-wide frames; two image rows per
+    block, weights in registers, stores straight from the accumulators): bf16 and fp32 outputs and the bf16-pair operator against an
+    fp64 convolution of the same rounded operands; the GroupNorm partial sums (one block per image row) against sums of what it stored."""
+    import ctypes
+    import torch.nn.functional as F
+    from mmvid_amd import ops
+    from mmvid_amd.ops import _p, _stream, call
+    from test_models_gpu import close
+    torch.manual_seed(N * 131 + H)
+    W, Cin, Cout = 128, 8, 128
+    x32 = torch.randn(N, H, W, Cin, device=DEV)
+    x32[..., 3:] = 0  # (the image has 3 channels; 8 are stored)
+    w32 = torch.randn(Cout, 9, Cin, device=DEV) * 0.2
+    bias = torch.randn(Cout, device=DEV) * 0.1
+
+    def ref_conv(xx, ww):  # fp64, NCHW
+        return F.conv2d(xx.double().permute(0, 3, 1, 2), ww.double().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), bias.double(), padding=1).permute(0, 2, 3, 1)
+
+    x16, w16 = x32.bfloat16(), w32.bfloat16()
+    ref = ref_conv(x16, w16)
+    for dt, tol in ((torch.bfloat16, 8e-3), (torch.float32, 2e-6)):
+        st = ops.gn_stats_buffer(N, H * W, Cout, DEV)
+        st.fill_(float('nan'))
+        y = ops.conv2d_nhwc(x16, w16, bias, 0, out_dtype=dt, gn_stats=st)
+        close(y, ref, tol, f'conv_in {dt}')
+        part = st[N * 2 * Cout:][:N * H * 32 * 2].view(N, H, 32, 2).double()
+        v = y.double().view(N, H, W, 32, 4)
+        close(part[..., 0], v.sum((2, 4)), 1e-5, 'GroupNorm partial sums')
+        close(part[..., 1], (v * v).sum((2, 4)), 1e-5, 'GroupNorm partial sums of squares')
+    # the pair operator: x = hi + lo, w = hi + lo, three products; partial sums on the fp32 values
+    planes, w3 = ops.split_planes(x32), ops.split_weights(w32)
+    st = ops.gn_stats_buffer(N, H * W, Cout, DEV)
+    y = torch.empty(N, H, W, Cout, device=DEV)
+    call('mmvid_conv2d_nhwc_split3', 0, _p(planes), N, H, W, Cin, _p(w3), _p(bias), Cout, None, 0, _p(y),
+         ctypes.c_void_p(st.data_ptr() + N * Cout * 2 * 4), 1, None, _stream())
+    xs, ws = planes[0].double() + planes[1].double(), w3[:, 0].double() + w3[:, 2].double()
+    close(y, ref_conv(xs, ws), 2e-5, 'conv_in, pair operator')
+    part = st[N * 2 * Cout:][:N * H * 32 * 2].view(N, H, 32, 2).double()
+    close(part[..., 0], y.double().view(N, H, W, 32, 4).sum((2, 4)), 1e-5, 'GroupNorm partial sums (pair operator)')
