@@ -218,10 +218,16 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
         for (int j = 0; j < 4; ++j) mfma_settle(acc[i][j]);
     __syncthreads();  // every wave is done reading the stages
     float* slab = reinterpret_cast<float*>(smem) + wave * (32 * SLAB_PITCH);
-    const int cg = lane & 31, n = cout0 + 4 * cg;
+    // Round 6: a lane finishes EIGHT channels of a row (two float4 of the slab) instead of four: 16-byte bf16 stores and residual loads,
+    // half the vector-memory instructions of the epilogue (a store costs the CU ~30 ns of issue time whatever it moves: 256 of them per
+    // block were ~8 us of a 47-us block).  Lane = (row quarter rq, channel octet c8): rows rq, rq + 4, ..., rq + 28 of the pass.
+    const int c8 = lane & 15, rq = lane >> 4, n = cout0 + 8 * c8;
     const bool n_ok = n < p.Cout;
-    const float4 bias4 = (p.bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float gs = 0.f, gq = 0.f;
+    float4 bias4[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        bias4[e] = (p.bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};  // per channel quad of the octet
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -232,58 +238,88 @@ __global__ __launch_bounds__(512, 1) void conv_strip_kernel(StripParams p) {
                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS write -> read
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {  // 8 rows at a time: every load of a batch is issued before any is consumed
-            float4 v4[8], rf[8];
-            uint2 rb[8];
+        for (int half = 0; half < 2; ++half) {  // 4 rows at a time: every load of a batch is issued before any is consumed
+        float4 v4[4][2], rf[4][2];
+        uint4 rb[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = h8 + 2 * (half * 8 + k);
-                const long m = m0 + wave * 64 + i * 32 + r;
-                const bool ok = n_ok && m < p.M;
-                const long o = m * p.Cout + n;
-                v4[k] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + 4 * cg);
-                rf[k] = (p.res_f32 && ok) ? *reinterpret_cast<const float4*>(p.res_f32 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[k] = (p.res_bf16 && ok) ? *reinterpret_cast<const uint2*>(p.res_bf16 + o) : make_uint2(0u, 0u);
+        for (int k = 0; k < 4; ++k) {
+            const int r = rq + 4 * (half * 4 + k);
+            const long m = m0 + wave * 64 + i * 32 + r;
+            const bool ok = n_ok && m < p.M;
+            const long o = m * p.Cout + n;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v4[k][e] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + 8 * c8 + 4 * e);
+                rf[k][e] = (p.res_f32 && ok) ? *reinterpret_cast<const float4*>(p.res_f32 + o + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            rb[k] = (p.res_bf16 && ok) ? *reinterpret_cast<const uint4*>(p.res_bf16 + o) : make_uint4(0u, 0u, 0u, 0u);
+        }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = h8 + 2 * (half * 8 + k);
-                const long m = m0 + wave * 64 + i * 32 + r;
-                if (!n_ok || m >= p.M) continue;
-                const float v[4] = {v4[k].x + bias4.x + rf[k].x + bf_lo(rb[k].x), v4[k].y + bias4.y + rf[k].y + bf_hi(rb[k].x),
-                                    v4[k].z + bias4.z + rf[k].z + bf_lo(rb[k].y), v4[k].w + bias4.w + rf[k].w + bf_hi(rb[k].y)};
-                const long o = m * p.Cout + n;
-                if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
-                const uint2 packed = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                if (p.out_bf16) *reinterpret_cast<uint2*>(p.out_bf16 + o) = packed;
-                if (p.out_planes) {  // hi = bf16(v), lo = bf16(v - hi): what mmvid_split_f32_bf16x2 would make of the fp32 result
-                    *reinterpret_cast<uint2*>(p.out_planes + o) = packed;
-                    *reinterpret_cast<uint2*>(p.out_planes + p.out_plane + o) =
-                        make_uint2(pack_bf2(v[0] - bf_lo(packed.x), v[1] - bf_hi(packed.x)), pack_bf2(v[2] - bf_lo(packed.y), v[3] - bf_hi(packed.y)));
-                }
-                if (p.gn_partial) {  // statistics of the values the GroupNorm will read (bf16-rounded unless fp32 is stored)
-                    const float u[4] = {p.out_f32 ? v[0] : bf_lo(packed.x), p.out_f32 ? v[1] : bf_hi(packed.x),
-                                        p.out_f32 ? v[2] : bf_lo(packed.y), p.out_f32 ? v[3] : bf_hi(packed.y)};
+        for (int k = 0; k < 4; ++k) {
+            const int r = rq + 4 * (half * 4 + k);
+            const long m = m0 + wave * 64 + i * 32 + r;
+            if (!n_ok || m >= p.M) continue;
+            const uint32_t rbw[4] = {rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+            float v[8];
+            uint32_t pk[4], lo[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) gs += u[e], gq += u[e] * u[e];
+            for (int e = 0; e < 2; ++e) {
+                v[4 * e] = v4[k][e].x + bias4[e].x + rf[k][e].x + bf_lo(rbw[2 * e]);
+                v[4 * e + 1] = v4[k][e].y + bias4[e].y + rf[k][e].y + bf_hi(rbw[2 * e]);
+                v[4 * e + 2] = v4[k][e].z + bias4[e].z + rf[k][e].z + bf_lo(rbw[2 * e + 1]);
+                v[4 * e + 3] = v4[k][e].w + bias4[e].w + rf[k][e].w + bf_hi(rbw[2 * e + 1]);
+                pk[2 * e] = pack_bf2(v[4 * e], v[4 * e + 1]), pk[2 * e + 1] = pack_bf2(v[4 * e + 2], v[4 * e + 3]);
+            }
+            const long o = m * p.Cout + n;
+            if (p.out_f32) {
+                *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(p.out_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (p.out_bf16) *reinterpret_cast<uint4*>(p.out_bf16 + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (p.out_planes) {  // hi = bf16(v), lo = bf16(v - hi): what mmvid_split_f32_bf16x2 would make of the fp32 result
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lo[e] = pack_bf2(v[2 * e] - bf_lo(pk[e]), v[2 * e + 1] - bf_hi(pk[e]));
+                *reinterpret_cast<uint4*>(p.out_planes + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                *reinterpret_cast<uint4*>(p.out_planes + p.out_plane + o) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            }
+            if (p.gn_partial) {  // statistics of the values the GroupNorm will read (bf16-rounded unless fp32 is stored)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float u[4] = {p.out_f32 ? v[4 * e] : bf_lo(pk[2 * e]), p.out_f32 ? v[4 * e + 1] : bf_hi(pk[2 * e]),
+                                        p.out_f32 ? v[4 * e + 2] : bf_lo(pk[2 * e + 1]), p.out_f32 ? v[4 * e + 3] : bf_hi(pk[2 * e + 1])};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gs[e] += u[c], gq[e] += u[c] * u[c];
                 }
             }
         }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab reads done before the next pass overwrites it
     }
-    // ---- GroupNorm partial sums of this wave's 64 pixels (one image: H*W % 64 == 0), fixed order: lane -> half-wave pair ->
-    // the lanes of a group.  cpg = Cout/32 channels per group = cpg/4 adjacent lanes.
+    // ---- GroupNorm partial sums of this wave's 64 pixels (one image: H*W % 64 == 0), fixed order: the lane's rows -> the four row
+    // quarters -> the lanes of a group.  cpg = Cout / 32 channels per group: 4 (a channel quad each), 8 (the lane's octet) or a
+    // multiple of 8 (cpg / 8 adjacent lanes).
     if (p.gn_partial) {
-        gs += __shfl_xor(gs, 32, 64), gq += __shfl_xor(gq, 32, 64);
-        const int lpg = (p.Cout >> 5) >> 2;  // lanes per group: 1, 2, 4
-        for (int o = 1; o < lpg; o <<= 1) gs += __shfl_xor(gs, o, 64), gq += __shfl_xor(gq, o, 64);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            gs[e] += __shfl_xor(gs[e], 16, 64), gq[e] += __shfl_xor(gq[e], 16, 64);
+            gs[e] += __shfl_xor(gs[e], 32, 64), gq[e] += __shfl_xor(gq[e], 32, 64);
+        }
+        const int cpg = p.Cout >> 5;
         const long mw = m0 + wave * 64;
-        if (lane < 32 && (cg & (lpg - 1)) == 0 && n_ok && mw < p.M) {
-            const long hw = (long)H * W;
-            const long img = mw / hw;
-            const int blk = (int)((mw - img * hw) >> 6);
-            const int grp = n / (p.Cout >> 5);
-            *reinterpret_cast<float2*>(p.gn_partial + ((img * (hw >> 6) + blk) * 32 + grp) * 2) = make_float2(gs, gq);
+        const long hw = (long)H * W;
+        const long img = mw / hw;
+        const int blk = (int)((mw - img * hw) >> 6);
+        float* dst = p.gn_partial + ((img * (hw >> 6) + blk) * 32) * 2;
+        if (cpg == 4) {
+            if (rq == 0 && n_ok && mw < p.M) {
+                *reinterpret_cast<float2*>(dst + (n / 4) * 2) = make_float2(gs[0], gq[0]);
+                *reinterpret_cast<float2*>(dst + (n / 4 + 1) * 2) = make_float2(gs[1], gq[1]);
+            }
+        } else {
+            float a = gs[0] + gs[1], q = gq[0] + gq[1];
+            const int lpg = cpg >> 3;  // lanes per group: 1, 2, ...
+            for (int o = 1; o < lpg; o <<= 1) a += __shfl_xor(a, o, 64), q += __shfl_xor(q, o, 64);
+            if (rq == 0 && (c8 & (lpg - 1)) == 0 && n_ok && mw < p.M) *reinterpret_cast<float2*>(dst + (n / cpg) * 2) = make_float2(a, q);
         }
     }
 }
