@@ -212,60 +212,81 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
             b0 = b1, b1 = b2, b2 = tmp;
         }
     }
-    // epilogue through LDS (row-contiguous global traffic; see gemm.hip)
+    // epilogue through LDS (row-contiguous global traffic; see gemm.hip).  Round 6: a thread finishes EIGHT channels of a row (two float4
+    // of the slab): 16-byte bf16 stores / residual loads, half the vector-memory instructions (as conv_strip.hip)
     mfma_settle(acc[0][0]), mfma_settle(acc[0][1]), mfma_settle(acc[1][0]), mfma_settle(acc[1][1]);
     float* slab = reinterpret_cast<float*>(smem);
-    const int n = bn0 + 4 * (tid & 31);
-    const bool n_ok = n < p.Cout;
-    const float4 bias4 = (p.bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n = bn0 + 8 * (tid & 15);
+    const bool n_ok = n < p.Cout;  // (Cout % 8 == 0)
+    float4 bias4[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        bias4[e] = (p.bias && n_ok) ? *reinterpret_cast<const float4*>(p.bias + n + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int HALVES = WM / 2;  // 128-row blocks of the tile = GroupNorm partial blocks
-    float gs[HALVES][4], gq[HALVES][4];
+    float gs[HALVES][8], gq[HALVES][8];
 #pragma unroll
     for (int hf = 0; hf < HALVES; ++hf)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gs[hf][e] = gq[hf][e] = 0.f;
+        for (int e = 0; e < 8; ++e) gs[hf][e] = gq[hf][e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         __syncthreads();
         slab_write(acc, i, slab, wm, wn, lane);
         __syncthreads();
-        float4 v4[8], rf[8];
-        uint2 rb[8];
-        long mrow[8];
+        float4 v4[4][2], rf[4][2];
+        uint4 rb[4];
+        long mrow[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            int r, ml, c;
-            slab_piece<S::THREADS>(tid, k, i, r, ml, c);
-            mrow[k] = bm0 + ml;
+        for (int k = 0; k < 4; ++k) {  // piece k: slab row r = (tid + THREADS k) / 16, channels [8 (tid & 15), + 8)
+            const int r = (tid + S::THREADS * k) >> 4;
+            mrow[k] = bm0 + (r >> 5) * 64 + i * 32 + (r & 31);
             const bool ok = n_ok && mrow[k] < p.M;
             const long o = mrow[k] * p.Cout + n;
-            v4[k] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + c);
-            rf[k] = (p.res_f32 && ok) ? *reinterpret_cast<const float4*>(p.res_f32 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[k] = (p.res_bf16 && ok) ? *reinterpret_cast<const uint2*>(p.res_bf16 + o) : make_uint2(0u, 0u);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v4[k][e] = *reinterpret_cast<const float4*>(slab + r * SLAB_PITCH + 8 * (tid & 15) + 4 * e);
+                rf[k][e] = (p.res_f32 && ok) ? *reinterpret_cast<const float4*>(p.res_f32 + o + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            rb[k] = (p.res_bf16 && ok) ? *reinterpret_cast<const uint4*>(p.res_bf16 + o) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 4; ++k) {
             if (!n_ok || mrow[k] >= p.M) continue;
             if (p.partial) {  // split-K: the raw partial sums; bias, residual and stores happen in the fixed-order reduce
-                *reinterpret_cast<float4*>(p.partial + ((long)blockIdx.z * p.M + mrow[k]) * p.Cout + n) = v4[k];
+                float* dst = p.partial + ((long)blockIdx.z * p.M + mrow[k]) * p.Cout + n;
+                *reinterpret_cast<float4*>(dst) = v4[k][0];
+                *reinterpret_cast<float4*>(dst + 4) = v4[k][1];
                 continue;
             }
-            float v[4] = {v4[k].x + bias4.x + rf[k].x + bf_lo(rb[k].x), v4[k].y + bias4.y + rf[k].y + bf_hi(rb[k].x),
-                          v4[k].z + bias4.z + rf[k].z + bf_lo(rb[k].y), v4[k].w + bias4.w + rf[k].w + bf_hi(rb[k].y)};
+            const uint32_t rbw[4] = {rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+            float v[8];
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v[4 * e] = v4[k][e].x + bias4[e].x + rf[k][e].x + bf_lo(rbw[2 * e]);
+                v[4 * e + 1] = v4[k][e].y + bias4[e].y + rf[k][e].y + bf_hi(rbw[2 * e]);
+                v[4 * e + 2] = v4[k][e].z + bias4[e].z + rf[k][e].z + bf_lo(rbw[2 * e + 1]);
+                v[4 * e + 3] = v4[k][e].w + bias4[e].w + rf[k][e].w + bf_hi(rbw[2 * e + 1]);
+            }
             if (p.clamp01) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (fminf(fmaxf(v[e], -1.f), 1.f) + 1.f) * 0.5f;
+                for (int e = 0; e < 8; ++e) v[e] = (fminf(fmaxf(v[e], -1.f), 1.f) + 1.f) * 0.5f;
             }
-            const long o = mrow[k] * p.Cout + n;
-            if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
-            const uint2 packed = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            if (p.out_bf16) *reinterpret_cast<uint2*>(p.out_bf16 + o) = packed;
-            if (p.gn_partial) {  // statistics of the values the GroupNorm will read (bf16-rounded unless fp32 is stored)
-                const int hf = (WM == 4) ? (k >> 2) : 0;  // pieces 0..3 -> rows 0..127, 4..7 -> 128..255 (slab_piece)
-                const float u[4] = {p.out_f32 ? v[0] : bf_lo(packed.x), p.out_f32 ? v[1] : bf_hi(packed.x),
-                                    p.out_f32 ? v[2] : bf_lo(packed.y), p.out_f32 ? v[3] : bf_hi(packed.y)};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gs[hf][e] += u[e], gq[hf][e] += u[e] * u[e];
+            for (int e = 0; e < 4; ++e) pk[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+            const long o = mrow[k] * p.Cout + n;
+            if (p.out_f32) {
+                *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(p.out_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (p.out_bf16) *reinterpret_cast<uint4*>(p.out_bf16 + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (p.gn_partial) {  // statistics of the values the GroupNorm will read (bf16-rounded unless fp32 is stored)
+                const int hf = (WM == 4) ? (k >> 1) : 0;  // pieces 0, 1 -> rows 0..127, 2, 3 -> 128..255
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float u = p.out_f32 ? v[e] : ((e & 1) ? bf_hi(pk[e >> 1]) : bf_lo(pk[e >> 1]));
+                    gs[hf][e] += u, gq[hf][e] += u * u;
+                }
             }
         }
     }
@@ -273,16 +294,16 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void conv_igemm_kernel(C
     // thread -> LDS [half][row group][channel][2] -> per channel over row groups -> per group over its channels ->
     // partial[n][128-row block][group][2]; groupnorm finalisation adds the blocks in order.
     if (p.gn_partial) {
-        constexpr int RG = S::THREADS / 32;
+        constexpr int RG = S::THREADS / 16;
         float* red = reinterpret_cast<float*>(smem);             // [HALVES][RG][128][2]
         float* chs = red + HALVES * RG * 256;                     // [HALVES][128][2]
         __syncthreads();
-        const int rg = tid >> 5, c4 = (tid & 31) * 4;
+        const int rg = tid >> 4, c8 = (tid & 15) * 8;
 #pragma unroll
         for (int hf = 0; hf < HALVES; ++hf)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                *reinterpret_cast<float2*>(red + ((hf * RG + rg) * 128 + c4 + e) * 2) = make_float2(gs[hf][e], gq[hf][e]);
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<float2*>(red + ((hf * RG + rg) * 128 + c8 + e) * 2) = make_float2(gs[hf][e], gq[hf][e]);
         __syncthreads();
         for (int idx = tid; idx < HALVES * 256; idx += S::THREADS) {
             const int hf = idx >> 8, cw = idx & 255;

@@ -531,6 +531,9 @@ __global__ __launch_bounds__(512) void gemv16_mfma_kernel(Gemv16Args a) {
         a.kv_cache[((long)eb * a.Lmax + epos) * a.kv_width + (en - a.kv_lo)] = f2bf(v);
 }
 
+// from 3 rows on the matrix-pipe form is the faster one (batch 4: 315 -> 270 us per tower step, 8: 390 -> 307, 16: 568 -> 348; same box,
+// profiles/r06_decode_step_vector_alu_vs_mfma_gemv.log); 1-2 rows stay on gemv_rows_kernel (the persistent step's fall-back form)
+constexpr int GV16_MIN_ROWS = 3;
 bool gemv16_supported(int NB, int N, int K) {
     const int S = K / 256;
     return NB >= 1 && NB <= 16 && N % 16 == 0 && K % 256 == 0 && (S == 2 || S == 3 || S == 8 || S == 12);
@@ -789,8 +792,7 @@ extern "C" int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const
     a.x = x, a.ldx = ldx, a.ln_w = ln_w, a.ln_b = ln_b, a.eps = eps, a.W = (const bf16_t*)W, a.bias = bias;
     a.residual = residual, a.ldr = ldr, a.out = out, a.ldo = ldo, a.NB = NB, a.N = N, a.K = K, a.act = act;
     a.round_in = round_in, a.round_out = round_out;
-    static const int g16_min = getenv("MMVID_GEMV16_MIN") ? atoi(getenv("MMVID_GEMV16_MIN")) : 3;
-    if (round_in && NB >= g16_min && K <= 1024 && ldx % 8 == 0 && gemv16_supported(NB, N, K)) {  // 3..16 bf16-exact rows: the matrix-pipe form
+    if (round_in && NB >= GV16_MIN_ROWS && K <= 1024 && ldx % 8 == 0 && gemv16_supported(NB, N, K)) {  // 3..16 bf16-exact rows: the matrix-pipe form
         Gemv16Args g = {};
         g.x = x, g.ldx = ldx, g.ln_w = ln_w, g.ln_b = ln_b, g.eps = eps, g.W = (const bf16_t*)W, g.bias = bias, g.residual = residual, g.ldr = ldr;
         g.out = out, g.ldo = ldo, g.NB = NB, g.N = N, g.K = K, g.act = act, g.round_out = round_out;
@@ -858,8 +860,7 @@ extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, cons
     float* xb = p;
     const float* x = x_in;
     // 3..16 sequences: the linear layers on the matrix pipe (gemv16_mfma_kernel); 1-2: the vector-ALU form (what the persistent step falls back to)
-    static const int g16_min = getenv("MMVID_GEMV16_MIN") ? atoi(getenv("MMVID_GEMV16_MIN")) : 3;
-    const bool mfma = B >= g16_min && gemv16_supported(B, 3 * E, E) && gemv16_supported(B, E, F) && gemv16_supported(B, F, E);
+    const bool mfma = B >= GV16_MIN_ROWS && gemv16_supported(B, 3 * E, E) && gemv16_supported(B, E, F) && gemv16_supported(B, F, E);
     bf16_t* o_bf = (bf16_t*)o;      // (MFMA form: the attention output and the activation travel as bf16 -- the operand the next layer
     bf16_t* act_bf = (bf16_t*)act;  //  would round them to anyway)
     for (int i = 0; i < cfg->layers; ++i) {

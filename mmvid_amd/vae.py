@@ -477,15 +477,17 @@ class VQGanVAE1024(nn.Module):
         self.num_layers = 4
         self.image_size = 256
         self.num_tokens = 1024
-        # strict = True: fp32-accurate encoder / decoder (csrc/strict.hip) -- token indices equal the reference's; the
-        # default bf16 MFMA path is ~6x faster and differs on near-ties of the codebook distances.
-        # strict = 'split': the middle path -- bf16-pair convolutions on the bf16 matrix pipe (3 products per convolution,
-        # fp32 accumulate; ~1e-5 of the fp32 result), fp32 residual stream / GroupNorm / attention
-        # strict = 'mixed' (round 5): 'split', except that the ENCODER's 3x3 residual-block convolutions on maps of at least
-        # mixed_f16_side pixels a side (the 128x128, 64x64 and 32x32 levels: 82 % of the multiply-adds) are ONE product of fp16 operands
-        # -- 1.35x the plain bf16 work instead of 3x; the indices still equal the reference's on every golden and the reference's top-2
-        # distance gap stays above 8x the error of that gap (tests/test_round3_gpu.py::test_split_index_safety_margin; the per-layer
-        # sweep behind the choice: tests/sweep_exact_layers.py, profiles/r05_exact_index_layer_sensitivity_sweep.log)
+        # Arithmetic modes of the encoder / decoder, and what each means for the token indices (measured: the flip census of 40,960 fresh
+        # full-size tokens per mode, profiles/r06_flip_census.log, and 2 x 1,024 reference tokens, tests/test_round6_gpu.py):
+        #   strict = False   bf16 MFMA operands (training speed): 97.7 % of the reference's tokens; every flip a near-tie of its distances
+        #   strict = 'mixed' the ENCODER's 3x3 residual-block convolutions on maps of at least mixed_f16_side pixels a side (the 128x128,
+        #                    64x64 and 32x32 levels: 82 % of the multiply-adds) as ONE product of fp16 operands, the rest as 'split':
+        #                    99.87 % of the tokens at 1.11x the step -- NOT an exact mode (rounds 4-5 called it one on 448 golden tokens)
+        #   strict = 'split' bf16-pair convolutions (3 products per convolution, fp32 accumulate; ~1e-5 of the fp32 result), fp32 residual
+        #                    stream / GroupNorm / attention: the reference's tokens except ties at its OWN fp32 resolution (1 in 40,960
+        #                    against the fp32 mode; the one golden flip has a top-2 gap of 17 fp32 spacings of the distance); 1.28x
+        #   strict = True    fp32 operator (csrc/strict.hip: f32 MFMA, fp64 GroupNorm statistics): every token seen equal; 2.3x
+        # (per-layer sensitivity behind 'mixed': tests/sweep_exact_layers.py, profiles/r05_exact_index_layer_sensitivity_sweep.log)
         self.strict = False
         self.mixed_f16_side = 32  # (the error comes from the 128x128 level: 64 -> 32 adds 3 % to max |dz|, the sweep's rows A / B)
         # default (bf16) operator only: 'bf16' = the ENCODER's residual stream between blocks is bf16 too (round 5: the fp32 stream
