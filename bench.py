@@ -116,7 +116,7 @@ PMC_KERNELS = {  # bench kernel family -> kernel-name prefixes in the rocprofv3 
     'gemm_bf16_kernel<A.B^T> (forward)': ('gemm_bf16_kernel<false, false', 'gemm_bf16_lw_kernel<false, false'),
     'gemm_bf16_kernel<dX>': ('gemm_bf16_kernel<false, true', 'gemm_bf16_lw_kernel<false, true'),
     'gemm_bf16_kernel<dW>': ('gemm_bf16_kernel<true, true', 'gemm_bf16_lw_kernel<true, true', 'gemm_bf16_lw_grouped_kernel'),
-    'conv_igemm_kernel (VQGAN)': ('conv_igemm_kernel', 'conv_strip_kernel'),
+    'conv_igemm_kernel (VQGAN)': ('conv_igemm_kernel', 'conv_strip_kernel', 'conv_in_kernel'),
     'attn_fwd_kernel': ('attn_fwd_kernel', ),
     'attn_bwd (dq+dkv)': ('attn_bwd_', ),
 }
@@ -131,7 +131,7 @@ def pmc_traffic(family):
     instance per GEMM layout)."""
     import csv
     prefixes = PMC_KERNELS.get(family, (family.split('<')[0].split(' ')[0], ))
-    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
         tot, disp = 0.0, {}
         try:
             for name, mult in (('fetch', 2.0), ('write', 1.0)):
@@ -582,18 +582,18 @@ def main():
     # census of 40,960 fresh tokens per mode, tools/flip_census.py -> profiles/r06_flip_census.log; 2 x 1,024 reference tokens in
     # tests/test_round6_gpu.py): the headline's bf16 tokeniser agrees with the reference on 97.7 % of the tokens; 'mixed' on 99.87 % --
     # NOT an exact mode, rounds 4-5 called it one on 64 + 384 golden tokens; 'split' on all but ties at the reference's own fp32
-    # resolution (1 token in 40,960 against the fp32 mode, 1 in 2,048 golden tokens: a top-2 gap of 17 fp32 spacings of the distance);
+    # resolution (2 tokens in 40,960 against the fp32 mode, 1 in 2,048 golden tokens: a top-2 gap of 17 fp32 spacings of the distance);
     # the fp32 mode (vae.strict = True, `--strict fp32`) on every token seen.  `exact_index_step` is therefore the 'split' step.
     exact = None
     if world == 1 and not args.strict and not args.eager and not args.no_exact:
-        what = {'mixed': "NOT index-exact: 99.87 % of the reference's tokens (flip census: 56 of 40,960 against the fp32 mode; 5 of 2,048 "
+        what = {'mixed': "NOT index-exact: 99.87 % of the reference's tokens (flip census: 57 of 40,960 against the fp32 mode; 5 of 2,048 "
                          "golden tokens).  The pair operator of 'split' except the 3x3 residual-block convolutions of the 128x128, 64x64 and "
                          '32x32 levels (82 % of the multiply-adds), which are ONE product of fp16 operands, fp32 accumulate',
                 'split': 'every VQGAN convolution as three bf16 products of hi/lo pairs (fp32 accumulate), fp32 GroupNorm / attention / residual '
-                         "stream: token indices equal the reference's except ties at its own fp32 resolution (flip census: 1 of 40,960 against "
+                         "stream: token indices equal the reference's except ties at its own fp32 resolution (flip census: 2 of 40,960 against "
                          'the fp32 mode, 0 of 4,096 against the CPU oracle; 1 of 2,048 golden tokens, top-2 gap = 17 fp32 spacings of the distance)'}
-        census = {'mixed': {'flips_vs_fp32_mode': 56, 'tokens': 40960, 'flips_vs_reference_goldens': 5, 'golden_tokens': 2048},
-                  'split': {'flips_vs_fp32_mode': 1, 'tokens': 40960, 'flips_vs_reference_goldens': 1, 'golden_tokens': 2048}}
+        census = {'mixed': {'flips_vs_fp32_mode': 57, 'tokens': 40960, 'flips_vs_reference_goldens': 5, 'golden_tokens': 2048},
+                  'split': {'flips_vs_fp32_mode': 2, 'tokens': 40960, 'flips_vs_reference_goldens': 1, 'golden_tokens': 2048}}
         try:
             for mode in ('split', 'mixed'):
                 model.vae.strict = mode

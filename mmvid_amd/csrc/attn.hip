@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
                                         : max((mask.r0 >= q_wave0 && mask.r0 < q_wave0 + 32) ? mask.c0 : 0,
                                               (mask.r1 >= q_wave0 && mask.r1 < q_wave0 + 32) ? mask.c1 : 0);
     // No padding mask here: the K rows of positions >= L are zero-filled by the descriptor's range check, so whatever dS holds for a
-    // padded key is multiplied by zero in dQ^T += K^T dS^T (S = 0 there, P = 2^(-lse2) is finite).  Mask-free body: no causal /
+    // padded key is multiplied by zero in dQ^T += K^T dS^T (S = 0 there; the sub-tile that straddles L sets P = 0, see below).  Mask-free body: no causal /
     // restricted pair possible and a further tile follows.
     // (tile ranges as in the forward kernel: [lo, hi) = whole pairs of mask-free tiles)
     int lo = (row_kmax + 63) >> 6, hi = min(t_end - 1, L >> 6);
@@ -582,6 +582,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const bf16_t* __res
                 if ((mask.mode == 1 && key0 + 31 > q_wave0) || key0 < row_kmax) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[r] = is_masked(mask, q, key0 + acc_row(r, h), L) ? -INFINITY : s[r];
+                }
+                // the one sub-tile that straddles L: a padded key has S = 0, i.e. P = 2^(-lse2) -- finite unless EVERY score
+                // of the row lies below -128 in the log2 domain, where it overflows and 0 x inf would put NaN into dQ; P = 0 there instead
+                if (key0 + 32 > L) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = (key0 + acc_row(r, h) >= L) ? -INFINITY : s[r];
                 }
             }
             (void)exp2_affine_sum(s, scale_log2, neg_lse);  // P

@@ -484,7 +484,7 @@ class VQGanVAE1024(nn.Module):
         #                    64x64 and 32x32 levels: 82 % of the multiply-adds) as ONE product of fp16 operands, the rest as 'split':
         #                    99.87 % of the tokens at 1.11x the step -- NOT an exact mode (rounds 4-5 called it one on 448 golden tokens)
         #   strict = 'split' bf16-pair convolutions (3 products per convolution, fp32 accumulate; ~1e-5 of the fp32 result), fp32 residual
-        #                    stream / GroupNorm / attention: the reference's tokens except ties at its OWN fp32 resolution (1 in 40,960
+        #                    stream / GroupNorm / attention: the reference's tokens except ties at its OWN fp32 resolution (2 in 40,960
         #                    against the fp32 mode; the one golden flip has a top-2 gap of 17 fp32 spacings of the distance); 1.28x
         #   strict = True    fp32 operator (csrc/strict.hip: f32 MFMA, fp64 GroupNorm statistics): every token seen equal; 2.3x
         # (per-layer sensitivity behind 'mixed': tests/sweep_exact_layers.py, profiles/r05_exact_index_layer_sensitivity_sweep.log)

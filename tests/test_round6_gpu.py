@@ -1,6 +1,6 @@
 """Round 6: the token-index contract on evidence wider than one frame, the MFMA decode layer (item 2) and the
 advisor's round-5 findings.  Stated flip-rate bounds come from the census of 40,960 fresh tokens per mode
-(tools/flip_census.py -> profiles/r06_flip_census.log): bf16 2.1-2.4 %, 'mixed' 0.06-0.25 %, 'split' 1 token in 40,960, fp32 0 of
+(tools/flip_census.py -> profiles/r06_flip_census.log): bf16 2.1-2.4 %, 'mixed' 0.06-0.25 %, 'split' 2 tokens in 40,960, fp32 0 of
 4,096 against the CPU oracle."""
 import numpy as np
 import pytest
@@ -199,3 +199,32 @@ def test_conv_in_kernel_vs_torch(N, H):
     close(y, ref_conv(xs, ws), 2e-5, 'conv_in, pair operator')
     part = st[N * 2 * Cout:][:N * H * 32 * 2].view(N, H, 32, 2).double()
     close(part[..., 0], y.double().view(N, H, W, 32, 4).sum((2, 4)), 1e-5, 'GroupNorm partial sums (pair operator)')
+
+
+@pytest.mark.parametrize('L,spec', [(33, None), (97, ('rows', [(70, 70), (71, 71)])), (579, ('rows', [(65, 65), (66, 66)]))])
+def test_attention_backward_rows_with_hugely_negative_scores(L, spec):
+    """ADVICE r5 (attn.hip, dQ kernel): a padded key of the sub-tile that straddles L has S = 0, i.e. P = 2^(-lse2); when EVERY score of a
+    row is hugely negative (here q.k / 8 = -128 for all keys: lse2 ~ -180) that overflows, and 0 x inf put NaN into dQ wherever L is
+    not a multiple of 32.  The straddling sub-tile now masks its padded keys.  All three kernels against fp32 torch."""
+    from mmvid_amd import ops
+    from test_models_gpu import close
+    from test_round5_gpu import _attn_ref, _mask_tensor
+    B, H = 1, 2
+    E = H * 64
+    torch.manual_seed(L)
+    qkv = torch.empty(B * L, 3 * E, device=DEV)
+    qkv[:, :E] = 4.0
+    qkv[:, E:2 * E] = -4.0 + 0.25 * torch.randn(B * L, E, device=DEV).round()
+    qkv[:, 2 * E:] = torch.randn(B * L, E, device=DEV) * 0.7
+    qkv = qkv.bfloat16()
+    dO = (torch.randn(B * L, E, device=DEV) * 0.2).bfloat16()
+    qr = qkv.float().requires_grad_(True)
+    ref = _attn_ref(qr, B, L, H, _mask_tensor(L, spec))
+    ref.backward(dO.float())
+    out, lse2 = ops.attention_fwd(qkv, B, L, H, spec)
+    assert float(lse2.max()) < -128, 'the case must drive 2^(-lse2) out of the fp32 range'
+    dqkv = ops.attention_bwd(qkv, out, dO, lse2, B, L, H, spec)
+    assert torch.isfinite(dqkv.float()).all(), 'non-finite gradient (0 x inf on a padded key)'
+    close(out, ref, 1e-2, f'fwd L={L}')
+    for nm, sl in (('dQ', slice(0, E)), ('dK', slice(E, 2 * E)), ('dV', slice(2 * E, 3 * E))):
+        close(dqkv[:, sl], qr.grad[:, sl], 5e-2, f'{nm} L={L}')  # (bf16 dS of rows whose 579 probabilities are all ~1/579)
