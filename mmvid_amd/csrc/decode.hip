@@ -570,7 +570,9 @@ int gemv16_launch(const Gemv16Args& a, hipStream_t s) {
 // ... (NG = 8 NW key groups): a key's row is read by 8 adjacent lanes, its score is the sum over them (three DPP steps), 8 loads per
 // thread are in flight in both passes.  NW = 16 waves for long caches: the kernel is a chain of memory round trips (1,100 keys took
 // three for K and five for V with 256 threads: 16 us of a 48-us layer at batch 8), and one block is all a (head, sequence) gets.
-template <int NW>
+// NB: key / value batches (of 8 keys per thread = 64 NW keys per batch) held in registers: NB * 64 * NW positions are covered without a
+// dependent round trip (NW = 8, NB = 3: 1,536)
+template <int NW, int NB = 2>
 __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __restrict__ q, long ldq, const bf16_t* __restrict__ cache,
                                                                int Lmax, int E, const int* __restrict__ pos_dev, int pos0,
                                                                float scale_log2, float* __restrict__ out, long ldo,
@@ -592,13 +594,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
     const bf16_t* kv = cache + (long)b * Lmax * 2 * E + h * 64 + dc * 8;
     // Round 6: the kernel is a chain of memory round trips (K batch -> scores -> V batch -> ...), 11 us on average at batch 16 for 31 MB.
     // Neither the keys nor the values depend on q or on the scores, so the first TWO key batches (2 x 8 NG keys: 2,048 with 16 waves) and the
-    // first value batch are requested before anything else (96 registers), the second value batch as soon as the key registers are free --
-    // i.e. before the softmax statistics and their two barriers: one round trip for a cache of up to 1,024 positions, two up to 2,048.
+    // first value batch are requested before anything else, the other value batches as soon as the key registers are free -- i.e. before
+    // the softmax statistics and their two barriers: one round trip for the keys and one for the values of up to NB * 64 NW positions.
+    // Eight waves with three batches (1,536 positions) instead of sixteen with two: 460 -> 450 us per token at batch 16 (same box).
     // (What is left is the fixed chain: 7.2 us at 129 keys, 4.8 TB/s marginal from there to 1,100; a head-major cache layout changes 3-6 %:
     // profiles/r06_decode_attention_cache_layout_experiment.log.)
-    uint4 uk[2][8], uv[2][8];
+    uint4 uk[NB][8], uv[NB][8];
 #pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
+    for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = kg + NG * (j + 8 * bt);
@@ -630,9 +633,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
             }
         }
     };
-    scores(uk[0], kg);
-    if (kg + NG * 8 < n) scores(uk[1], kg + NG * 8);
-    for (int k0 = kg + NG * 16; k0 < n; k0 += NG * 8) {  // caches beyond two batches (Lmax > 2,048 with 16 waves)
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt)
+        if (bt == 0 || kg + NG * 8 * bt < n) scores(uk[bt], kg + NG * 8 * bt);
+    for (int k0 = kg + NG * 8 * NB; k0 < n; k0 += NG * 8) {  // caches beyond the register batches
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + NG * j;
@@ -640,12 +644,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
         }
         scores(uk[0], k0);
     }
-    // the second value batch, under the softmax statistics
+    // the other value batches, under the softmax statistics (the key registers are free now)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = kg + NG * (j + 8);
-        uv[1][j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * rs + vo) : make_uint4(0u, 0u, 0u, 0u);
-    }
+    for (int bt = 1; bt < NB; ++bt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kg + NG * (j + 8 * bt);
+            uv[bt][j] = k < n ? *reinterpret_cast<const uint4*>(kv + (long)k * rs + vo) : make_uint4(0u, 0u, 0u, 0u);
+        }
     mx = wave_max_fast(mx);
     if (lane == 0) stat[0][wave] = mx;
     __syncthreads();
@@ -672,9 +678,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode2_kernel(const float* __re
             acc[4] += p * bf_lo(u[j].z), acc[5] += p * bf_hi(u[j].z), acc[6] += p * bf_lo(u[j].w), acc[7] += p * bf_hi(u[j].w);
         }
     };
-    values(uv[0], kg);
-    if (kg + NG * 8 < n) values(uv[1], kg + NG * 8);
-    for (int k0 = kg + NG * 16; k0 < n; k0 += NG * 8) {
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt)
+        if (bt == 0 || kg + NG * 8 * bt < n) values(uv[bt], kg + NG * 8 * bt);
+    for (int k0 = kg + NG * 8 * NB; k0 < n; k0 += NG * 8) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + NG * j;
@@ -875,7 +882,7 @@ extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, cons
             int rc = gemv16_launch(g, s);
             if (rc) return rc;
             if (Lmax > 512)
-                hipLaunchKernelGGL(attn_decode2_kernel<16>, dim3(H, B), dim3(1024), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
+                hipLaunchKernelGGL((attn_decode2_kernel<8, 3>), dim3(H, B), dim3(512), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
                                    0.125f * 1.4426950408889634f, (float*)nullptr, (long)E, o_bf);
             else
                 hipLaunchKernelGGL(attn_decode2_kernel<4>, dim3(H, B), dim3(256), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
@@ -908,7 +915,7 @@ extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, cons
         int rc = gemv_launch(g, s);
         if (rc) return rc;
         if (Lmax > 512)
-            hipLaunchKernelGGL(attn_decode2_kernel<16>, dim3(H, B), dim3(1024), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
+            hipLaunchKernelGGL((attn_decode2_kernel<8, 3>), dim3(H, B), dim3(512), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
                                0.125f * 1.4426950408889634f, o, (long)E);
         else
             hipLaunchKernelGGL(attn_decode2_kernel<4>, dim3(H, B), dim3(256), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
