@@ -431,9 +431,10 @@ __global__ __launch_bounds__(512) void gemv16_mfma_kernel(Gemv16Args a) {
     const int r16 = lane & 15, g = lane >> 4;
     const int rf = HALF ? (r16 & 7) : r16;            // this lane's feature (B operand) / row (A operand) inside the block's tile
     const int kw = wave * (S * 32) + g * 8;  // k of this lane's chunk in MFMA step 0; step s is 32 further (the four lanes of a row read 64 contiguous bytes)
-    // ---- 1. weights -> registers (do not depend on the rows: requested first)
+    // ---- 1. weights -> registers (do not depend on the rows: requested first).  HALF: both operands are staged through LDS instead
+    // (below): 12 fragment loads per lane, each touching sixteen 64-byte segments, kept the texture addresser busier than HBM.
     bf16x8_t wf[S];
-    {
+    if constexpr (!HALF) {
         const bf16_t* wp = a.W + (long)(n0 + rf) * K + kw;
 #pragma unroll
         for (int s = 0; s < S; ++s) wf[s] = *reinterpret_cast<const bf16x8_t*>(wp + s * 32);
@@ -445,7 +446,33 @@ __global__ __launch_bounds__(512) void gemv16_mfma_kernel(Gemv16Args a) {
     const float eres = (elane && a.residual) ? a.residual[(long)eb * a.ldr + en] : 0.f;
     const int epos = a.kv_cache ? (a.pos_dev ? *a.pos_dev : a.pos0) : 0;
     bf16x8_t af[S];
-    if constexpr (DIRECT) {
+    if constexpr (HALF) {
+        // 8 weight rows + 8 input rows of K bf16 each, fetched as whole rows (a wave instruction = 1 KiB contiguous), parked in LDS at a
+        // padded pitch, read back as MFMA fragments
+        static_assert(DIRECT, "the 8 x 8 tile takes bf16 rows");
+        const int ldsk = K + 8, cpr = K >> 3;         // 16-byte chunks per row
+        bf16_t* wsm = xs + 8 * ldsk;
+        constexpr int NCH = S / 2;                    // chunks per thread and operand: 8 rows x K / 8 chunks / 512 threads = K / 512
+        uint4 wv[NCH], xv[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 512 * i, row = c / cpr, col = (c - row * cpr) * 8;
+            wv[i] = *reinterpret_cast<const uint4*>(a.W + (long)(n0 + row) * K + col);
+            xv[i] = rb0 + row < NB ? *reinterpret_cast<const uint4*>(a.xb + (long)(rb0 + row) * a.ldx + col) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 512 * i, row = c / cpr, col = (c - row * cpr) * 8;
+            *reinterpret_cast<uint4*>(wsm + row * ldsk + col) = wv[i];
+            *reinterpret_cast<uint4*>(xs + row * ldsk + col) = xv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            wf[s] = *reinterpret_cast<const bf16x8_t*>(wsm + rf * ldsk + kw + s * 32);
+            af[s] = *reinterpret_cast<const bf16x8_t*>(xs + rf * ldsk + kw + s * 32);
+        }
+    } else if constexpr (DIRECT) {
         const int xrow = rb0 + rf;
         const bf16_t* xp = a.xb + (long)(xrow < NB ? xrow : 0) * a.ldx + kw;
 #pragma unroll
@@ -547,7 +574,7 @@ int gemv16_launch(const Gemv16Args& a, hipStream_t s) {
     const bool direct = a.xb != nullptr;
     const bool half = direct && a.N <= 1024 && a.K >= 2048;  // (narrow and long: see HALF)
     const dim3 grid(half ? a.N / 8 : a.N / 16, (half && a.NB > 8) ? 2 : 1);
-    const size_t lds = 8 * 256 * 4 + (direct ? 0 : (size_t)16 * (a.K + 8) * 2);
+    const size_t lds = 8 * 256 * 4 + ((direct && !half) ? 0 : (size_t)16 * (a.K + 8) * 2);  // (half: 8 weight + 8 input rows)
     auto go = [&](auto kern) {
         static bool attr = false;  // (per instantiation)
         if (!attr) {
