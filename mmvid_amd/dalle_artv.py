@@ -340,6 +340,7 @@ class DALLE(nn.Module):
             # through the tower; advances sess.pos
             ops.decode_embed(tok, iemb, pos_rows, sess.pos, sess.x, record=out, record_pos0=first_pos)
             sess._enqueue()
+            sess.host_pos += 1  # (the host mirror of the device position: DecodeSession keeps it for step() / token_step() itself)
             hid[0] = sess.y
 
         graph = None
@@ -367,6 +368,7 @@ class DALLE(nn.Module):
             while step < steps - 1:
                 if graph is not None:
                     graph.replay()
+                    sess.host_pos += 1
                 else:
                     sess.token_step(tk)
                     if step == 1 and not direct:
@@ -376,6 +378,7 @@ class DALLE(nn.Module):
                         with torch.cuda.stream(side):
                             with torch.cuda.graph(graph, stream=side):
                                 sess.token_step(tk)
+                        sess.host_pos -= 1  # (the capture enqueued nothing)
                         torch.cuda.current_stream().wait_stream(side)
                 step += 1
                 if hook is not None:
@@ -402,6 +405,7 @@ class DALLE(nn.Module):
         for step in range(steps - 1):  # every token but the last: draw it, then run it through the tower
             if graph is not None:
                 graph.replay()
+                sess.host_pos += 1
                 continue
             draw(step)
             advance()
@@ -414,6 +418,7 @@ class DALLE(nn.Module):
                     with torch.cuda.graph(graph, stream=side):
                         draw(-1)
                         advance()
+                sess.host_pos -= 1  # (the capture enqueued nothing)
                 torch.cuda.current_stream().wait_stream(side)
         draw(steps - 1)
         out[:, steps - 1].copy_(tok)

@@ -149,6 +149,7 @@ def test_artv_sampler_recovers_from_a_failed_persistent_launch(golden):
     a_img = run(fail_at_13)
     sess = seen['sess']
     assert sess.fell_back == 1 and not sess.persistent, 'the hook must have driven the sampler into its recovery branch'
+    assert sess.host_pos == int(sess.pos), 'the host mirror of the position follows the device through fall-back and replays'
     os.environ['MMVID_DECODE_TOKEN'] = '0'
     try:
         b_img = run(None)
