@@ -378,7 +378,10 @@ int mmvid_attention_decode(const void* qkv, int64_t ldq, const void* cache, int 
  * out = conv + bias (+ residual bf16/f32 NHWC) [-> (clamp(.,-1,1)+1)/2 when clamp01, vae.py:55]
  *     -> bf16 and/or fp32 NHWC [N, Hout, Wout, Cout].
  * gn_partial (optional; needs Hout*Wout % 128 == 0 and Cout % 128 == 0): GroupNorm(32) partial sums of the output,
- * [N][Hout*Wout/128][32][sum, sumsq] -- the partial-sum area of mmvid_groupnorm_swish_nhwc's stats_scratch. */
+ * [N][Hout*Wout/128][32][sum, sumsq] -- the partial-sum area of mmvid_groupnorm_swish_nhwc's stats_scratch.
+ * The full-size encoder's first layer (model.py:382-386: mode 0, Cin = 8 (3 stored as 8), Cout = 128, Win = 128, even Hin, no residual,
+ * one output precision) runs a kernel of its own built around its stores (csrc/conv.hip::conv_in_kernel, round 6); the choice is
+ * made from the layer's geometry only, like every kernel choice of the encoder (a frame's tokens may not depend on its batch). */
 int mmvid_conv2d_nhwc(int mode, const void* x, int N, int Hin, int Win, int Cin, const void* w, const float* bias,
                       int Cout, const void* residual_bf16, const float* residual_f32, int clamp01, void* out_bf16,
                       float* out_f32, float* gn_partial, void* stream);
