@@ -420,16 +420,21 @@ struct Gemv16Args {
 // HALF: a block = 8 features x 8 rows (grid (N/8, 2)): the tile of the narrow, long-K layer (c_proj: N = 768, K = 3,072).  With 16 x 16 tiles
 // that layer is 48 blocks which each pull 96 KiB of weights + the 96 KiB of all 16 rows through ONE CU's memory path (8.3 us against 4.8 for
 // the K = 768 layers); 8 x 8 tiles are 192 blocks of 48 + 48 KiB.  The MFMA runs a quarter full, which costs nothing here.
-template <int S, bool DIRECT, bool HALF = false>
+// RB: 16-row blocks per launch (1, 2, 4: up to 64 rows -- the weights are streamed ONCE for all of them; a wave runs RB MFMA chains
+// against the same weight fragments).  HALF keeps RB = 1 and covers more rows through grid.y.
+// HR (HALF only): input rows per block, 8 or 16 -- more than 16 rows in all: a block keeps its 8 staged weight rows for 16 input rows.
+template <int S, bool DIRECT, bool HALF = false, int RB = 1, int HR = 8>
 __global__ __launch_bounds__(512) void gemv16_mfma_kernel(Gemv16Args a) {
+    static_assert(!HALF || RB == 1, "the 8-feature tile covers rows through grid.y");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-    float* red = reinterpret_cast<float*>(smem16);                  // [8 waves][16 rows][16 features]
-    bf16_t* xs = reinterpret_cast<bf16_t*>(smem16 + 8 * 256 * 4);   // [16][K + 8] (LayerNorm path only)
+    float* red = reinterpret_cast<float*>(smem16);                       // [8 waves][16 RB rows][16 features]
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem16 + 8 * RB * 256 * 4);   // [16 RB][K + 8] (LayerNorm path); HALF: 8 input + 8 weight rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int FT = HALF ? 8 : 16;                 // features / rows per block
-    const int K = a.K, NB = a.NB, n0 = blockIdx.x * FT, rb0 = HALF ? blockIdx.y * 8 : 0;
+    constexpr int FT = HALF ? 8 : 16;                 // features per block
+    const int K = a.K, NB = a.NB, n0 = blockIdx.x * FT, rb0 = HALF ? blockIdx.y * HR : 0;
     const int r16 = lane & 15, g = lane >> 4;
-    const int rf = HALF ? (r16 & 7) : r16;            // this lane's feature (B operand) / row (A operand) inside the block's tile
+    const int rf = HALF ? (r16 & 7) : r16;            // this lane's feature (B operand) inside the tile
+    const int ra = (HALF && HR == 8) ? (r16 & 7) : r16;  // ... and its row (A operand)
     const int kw = wave * (S * 32) + g * 8;  // k of this lane's chunk in MFMA step 0; step s is 32 further (the four lanes of a row read 64 contiguous bytes)
     // ---- 1. weights -> registers (do not depend on the rows: requested first).  HALF: both operands are staged through LDS instead
     // (below): 12 fragment loads per lane, each touching sixteen 64-byte segments, kept the texture addresser busier than HBM.
@@ -439,70 +444,95 @@ __global__ __launch_bounds__(512) void gemv16_mfma_kernel(Gemv16Args a) {
 #pragma unroll
         for (int s = 0; s < S; ++s) wf[s] = *reinterpret_cast<const bf16x8_t*>(wp + s * 32);
     }
-    // epilogue operands of thread t < 256: output (row eb, feature en)
-    const int eb = rb0 + (HALF ? tid >> 3 : tid >> 4), en = n0 + (HALF ? tid & 7 : tid & 15);
-    const bool elane = tid < FT * FT && eb < NB;
-    const float ebias = (elane && a.bias) ? a.bias[en] : 0.f;
-    const float eres = (elane && a.residual) ? a.residual[(long)eb * a.ldr + en] : 0.f;
+    // epilogue operands: thread t finishes outputs o = t + 512 e of the block's (16 RB rows) x 16 features (HALF: 8 x 8)
+    constexpr int NE = HALF ? 1 : (RB * 256 + 511) / 512;
+    int eb[NE], en[NE];
+    bool elane[NE];
+    float ebias[NE], eres[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int o = tid + 512 * e;
+        eb[e] = rb0 + (HALF ? o >> 3 : o >> 4), en[e] = n0 + (HALF ? o & 7 : o & 15);
+        elane[e] = o < (HALF ? HR * 8 : RB * 256) && eb[e] < NB;
+        ebias[e] = (elane[e] && a.bias) ? a.bias[en[e]] : 0.f;
+        eres[e] = (elane[e] && a.residual) ? a.residual[(long)eb[e] * a.ldr + en[e]] : 0.f;
+    }
     const int epos = a.kv_cache ? (a.pos_dev ? *a.pos_dev : a.pos0) : 0;
-    bf16x8_t af[S];
+    bf16x8_t af[RB][S];
     if constexpr (HALF) {
         // 8 weight rows + 8 input rows of K bf16 each, fetched as whole rows (a wave instruction = 1 KiB contiguous), parked in LDS at a
         // padded pitch, read back as MFMA fragments
         static_assert(DIRECT, "the 8 x 8 tile takes bf16 rows");
         const int ldsk = K + 8, cpr = K >> 3;         // 16-byte chunks per row
-        bf16_t* wsm = xs + 8 * ldsk;
-        constexpr int NCH = S / 2;                    // chunks per thread and operand: 8 rows x K / 8 chunks / 512 threads = K / 512
-        uint4 wv[NCH], xv[NCH];
+        bf16_t* wsm = xs + HR * ldsk;
+        constexpr int NCH = S / 2;                    // chunks per thread for 8 rows: 8 rows x K / 8 chunks / 512 threads = K / 512
+        constexpr int XM = HR / 8;                    // input rows are HR / 8 times the weight rows
+        uint4 wv[NCH], xv[NCH * XM];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
+        for (int i = 0; i < NCH; ++i) {  // (weight and input requests interleaved, as are the LDS stores below: the order measured fastest)
             const int c = tid + 512 * i, row = c / cpr, col = (c - row * cpr) * 8;
             wv[i] = *reinterpret_cast<const uint4*>(a.W + (long)(n0 + row) * K + col);
-            xv[i] = rb0 + row < NB ? *reinterpret_cast<const uint4*>(a.xb + (long)(rb0 + row) * a.ldx + col) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int m = 0; m < XM; ++m) {
+                const int cx = tid + 512 * (i * XM + m), rx = cx / cpr, colx = (cx - rx * cpr) * 8;
+                xv[i * XM + m] = rb0 + rx < NB ? *reinterpret_cast<const uint4*>(a.xb + (long)(rb0 + rx) * a.ldx + colx) : make_uint4(0u, 0u, 0u, 0u);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + 512 * i, row = c / cpr, col = (c - row * cpr) * 8;
             *reinterpret_cast<uint4*>(wsm + row * ldsk + col) = wv[i];
-            *reinterpret_cast<uint4*>(xs + row * ldsk + col) = xv[i];
+#pragma unroll
+            for (int m = 0; m < XM; ++m) {
+                const int cx = tid + 512 * (i * XM + m), rx = cx / cpr, colx = (cx - rx * cpr) * 8;
+                *reinterpret_cast<uint4*>(xs + rx * ldsk + colx) = xv[i * XM + m];
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             wf[s] = *reinterpret_cast<const bf16x8_t*>(wsm + rf * ldsk + kw + s * 32);
-            af[s] = *reinterpret_cast<const bf16x8_t*>(xs + rf * ldsk + kw + s * 32);
+            af[0][s] = *reinterpret_cast<const bf16x8_t*>(xs + ra * ldsk + kw + s * 32);
         }
     } else if constexpr (DIRECT) {
-        const int xrow = rb0 + rf;
-        const bf16_t* xp = a.xb + (long)(xrow < NB ? xrow : 0) * a.ldx + kw;
 #pragma unroll
-        for (int s = 0; s < S; ++s) af[s] = *reinterpret_cast<const bf16x8_t*>(xp + s * 32);
+        for (int rbk = 0; rbk < RB; ++rbk) {
+            const int xrow = rbk * 16 + rf;
+            const bf16_t* xp = a.xb + (long)(xrow < NB ? xrow : 0) * a.ldx + kw;
+#pragma unroll
+            for (int s = 0; s < S; ++s) af[rbk][s] = *reinterpret_cast<const bf16x8_t*>(xp + s * 32);
+        }
         // every request of the block is in flight before the first MFMA waits (hipcc sinks the row loads between the MFMAs otherwise,
         // three at a time: four dependent L2 round trips in the K = 3,072 instance, 9.8 us against 4.9 for K = 768)
         __builtin_amdgcn_sched_barrier(0);
-        if (xrow >= NB) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) af[s] = bf16x8_t{};
-        }
+        for (int rbk = 0; rbk < RB; ++rbk)
+            if (rbk * 16 + rf >= NB) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) af[rbk][s] = bf16x8_t{};
+            }
     } else {
-        // ---- 2. rows: wave w owns rows w and w + 8; LayerNorm statistics are in-wave reductions; the normalised row goes to LDS as bf16
+        // ---- 2. rows: wave w owns rows w, w + 8, ... (two per 16-row block); LayerNorm statistics are in-wave reductions; the
+        // normalised row goes to LDS as bf16.
         const int ldsk = K + 8;
-        float4 xr[2][S], lg[S], lb[S];
+        float4 xr[2 * RB][S];  // every row of this wave is requested before the first is reduced (RB = 4: 24 requests in flight, not 4 x 6)
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int rr = 0; rr < 2 * RB; ++rr) {
             const int r = wave + 8 * rr;
 #pragma unroll
             for (int jj = 0; jj < S; ++jj)
                 xr[rr][jj] = r < NB ? *reinterpret_cast<const float4*>(a.x + (long)r * a.ldx + (jj * 64 + lane) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        float4 lg[S], lb[S];
 #pragma unroll
         for (int jj = 0; jj < S; ++jj) {
             const int k = (jj * 64 + lane) * 4;
             lg[jj] = a.ln_w ? *reinterpret_cast<const float4*>(a.ln_w + k) : make_float4(1.f, 1.f, 1.f, 1.f);
             lb[jj] = a.ln_w ? *reinterpret_cast<const float4*>(a.ln_b + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if constexpr (RB > 1) __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise sinks the later rows' requests behind the first rows' reductions)
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int rr = 0; rr < 2 * RB; ++rr) {
             const int r = wave + 8 * rr;
             float mu = 0.f, rs = 1.f;
             if (a.ln_w && r < NB) {
@@ -532,62 +562,92 @@ __global__ __launch_bounds__(512) void gemv16_mfma_kernel(Gemv16Args a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < S; ++s) af[s] = *reinterpret_cast<const bf16x8_t*>(xs + (long)r16 * ldsk + kw + s * 32);
+        for (int rbk = 0; rbk < RB; ++rbk)
+#pragma unroll
+            for (int s = 0; s < S; ++s) af[rbk][s] = *reinterpret_cast<const bf16x8_t*>(xs + (long)(rbk * 16 + r16) * ldsk + kw + s * 32);
     }
-    // ---- 3. S MFMAs: C[row = 4 g + i][feature = r16] over this wave's K slice
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // ---- 3. S MFMAs per row block: C[row = 16 rbk + 4 g + i][feature = r16] over this wave's K slice
 #pragma unroll
-    for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], wf[s], acc, 0, 0, 0);
-    mfma_settle(acc);
+    for (int rbk = 0; rbk < RB; ++rbk) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[wave * 256 + (g * 4 + i) * 16 + r16] = acc[i];
+        for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rbk][s], wf[s], acc, 0, 0, 0);
+        mfma_settle(acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave * (RB * 256) + (rbk * 16 + g * 4 + i) * 16 + r16] = acc[i];
+    }
     __syncthreads();
     // (no block of this launch reads the position when pos_inc is set: the key/value append belongs to the in-projection)
     if (a.pos_inc && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *a.pos_inc += 1;
-    if (!elane) return;
-    float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) v += red[w * 256 + (HALF ? (tid >> 3) * 16 + (tid & 7) : tid)];
-    v += ebias;
-    if (a.act == 1) v = v * sigmoidf_(1.702f * v);  // QuickGELU (clip_model.py:196-198)
-    v += eres;
-    if (a.round_out) v = round_bf16(v);
-    if (a.out) a.out[(long)eb * a.ldo + en] = v;
-    if (a.out_bf) a.out_bf[(long)eb * a.ldo + en] = f2bf(v);
-    if (a.kv_cache && en >= a.kv_lo && en < a.kv_lo + a.kv_width && epos < a.Lmax)
-        a.kv_cache[((long)eb * a.Lmax + epos) * a.kv_width + (en - a.kv_lo)] = f2bf(v);
+    for (int e = 0; e < NE; ++e) {
+        if (!elane[e]) continue;
+        const int o = tid + 512 * e;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[w * (RB * 256) + (HALF ? (o >> 3) * 16 + (o & 7) : o)];
+        v += ebias[e];
+        if (a.act == 1) v = v * sigmoidf_(1.702f * v);  // QuickGELU (clip_model.py:196-198)
+        v += eres[e];
+        if (a.round_out) v = round_bf16(v);
+        if (a.out) a.out[(long)eb[e] * a.ldo + en[e]] = v;
+        if (a.out_bf) a.out_bf[(long)eb[e] * a.ldo + en[e]] = f2bf(v);
+        if (a.kv_cache && en[e] >= a.kv_lo && en[e] < a.kv_lo + a.kv_width && epos < a.Lmax)
+            a.kv_cache[((long)eb[e] * a.Lmax + epos) * a.kv_width + (en[e] - a.kv_lo)] = f2bf(v);
+    }
 }
 
 // from 3 rows on the matrix-pipe form is the faster one (batch 4: 315 -> 270 us per tower step, 8: 390 -> 307, 16: 568 -> 348; same box,
 // profiles/r06_decode_step_vector_alu_vs_mfma_gemv.log); 1-2 rows stay on gemv_rows_kernel (the persistent step's fall-back form)
 constexpr int GV16_MIN_ROWS = 3;
+constexpr int GV16_MAXB = 64;  // rows per launch: four 16-row blocks
 bool gemv16_supported(int NB, int N, int K) {
     const int S = K / 256;
-    return NB >= 1 && NB <= 16 && N % 16 == 0 && K % 256 == 0 && (S == 2 || S == 3 || S == 8 || S == 12);
+    return NB >= 1 && NB <= GV16_MAXB && N % 16 == 0 && K % 256 == 0 && (S == 2 || S == 3 || ((S == 8 || S == 12) && N <= 1024));
 }
 
 int gemv16_launch(const Gemv16Args& a, hipStream_t s) {
     if (!gemv16_supported(a.NB, a.N, a.K) || a.ldx % 8 != 0 || (!a.x && !a.xb) || (!a.xb && a.K > 1024)) {  // (fp32 rows: K <= 1024)
-        mmvid_set_error("decode gemv (MFMA form): NB=%d (<= 16), N=%d (multiple of 16), K=%d (512 / 768 / 2048 / 3072), ldx %% 8 == 0", a.NB, a.N, a.K);
+        mmvid_set_error("decode gemv (MFMA form): NB=%d (<= %d), N=%d (multiple of 16), K=%d (512 / 768 / 2048 / 3072), ldx %% 8 == 0", a.NB, GV16_MAXB, a.N, a.K);
         return MMVID_ERR_ARG;
     }
     const bool direct = a.xb != nullptr;
     const bool half = direct && a.N <= 1024 && a.K >= 2048;  // (narrow and long: see HALF)
-    const dim3 grid(half ? a.N / 8 : a.N / 16, (half && a.NB > 8) ? 2 : 1);
-    const size_t lds = 8 * 256 * 4 + ((direct && !half) ? 0 : (size_t)16 * (a.K + 8) * 2);  // (half: 8 weight + 8 input rows)
+    if (!half && a.K > 1024) {
+        mmvid_set_error("decode gemv (MFMA form): K=%d > 1024 needs N <= 1024 (the 8 x 8 tile)", a.K);
+        return MMVID_ERR_ARG;
+    }
+    const int rb = half ? 1 : (a.NB <= 16 ? 1 : (a.NB <= 32 ? 2 : 4));
+    const int hr = a.NB > 16 ? 16 : 8;  // (HALF: input rows per block)
+    const dim3 grid(half ? a.N / 8 : a.N / 16, half ? cdiv(a.NB, hr) : 1);
+    const size_t lds = half ? 8 * 256 * 4 + (size_t)(8 + hr) * (a.K + 8) * 2 : (size_t)8 * rb * 256 * 4 + (direct ? 0 : (size_t)16 * rb * (a.K + 8) * 2);
     auto go = [&](auto kern) {
         static bool attr = false;  // (per instantiation)
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 256 * 4 + 16 * (3072 + 8) * 2);
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 256 * 4 + 24 * (3072 + 8) * 2);  // (152 KiB: 8 weight + 16 input rows at K = 3,072; four row blocks at K = 768 need 129 KiB)
             attr = true;
         }
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
     };
+    auto full = [&](auto s_c, auto d_c) {  // the 16 x 16-tile instances by row-block count
+        constexpr int SC = decltype(s_c)::value;
+        constexpr bool DC = decltype(d_c)::value != 0;
+        if (rb == 1)
+            go(gemv16_mfma_kernel<SC, DC, false, 1>);
+        else if (rb == 2)
+            go(gemv16_mfma_kernel<SC, DC, false, 2>);
+        else
+            go(gemv16_mfma_kernel<SC, DC, false, 4>);
+    };
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using T1 = std::integral_constant<int, 1>;
+    using T0 = std::integral_constant<int, 0>;
     switch (a.K / 256) {
-        case 2: direct ? go(gemv16_mfma_kernel<2, true>) : go(gemv16_mfma_kernel<2, false>); break;
-        case 3: direct ? go(gemv16_mfma_kernel<3, true>) : go(gemv16_mfma_kernel<3, false>); break;
-        case 8: half ? go(gemv16_mfma_kernel<8, true, true>) : go(gemv16_mfma_kernel<8, true>); break;
-        default: half ? go(gemv16_mfma_kernel<12, true, true>) : go(gemv16_mfma_kernel<12, true>); break;
+        case 2: direct ? full(I2{}, T1{}) : full(I2{}, T0{}); break;
+        case 3: direct ? full(I3{}, T1{}) : full(I3{}, T0{}); break;
+        case 8: hr == 16 ? go(gemv16_mfma_kernel<8, true, true, 1, 16>) : go(gemv16_mfma_kernel<8, true, true>); break;
+        default: hr == 16 ? go(gemv16_mfma_kernel<12, true, true, 1, 16>) : go(gemv16_mfma_kernel<12, true, true>); break;
     }
     return MMVID_OK;
 }
@@ -826,7 +886,7 @@ extern "C" int mmvid_gemv_rows(const float* x, int64_t ldx, int NB, int K, const
     a.x = x, a.ldx = ldx, a.ln_w = ln_w, a.ln_b = ln_b, a.eps = eps, a.W = (const bf16_t*)W, a.bias = bias;
     a.residual = residual, a.ldr = ldr, a.out = out, a.ldo = ldo, a.NB = NB, a.N = N, a.K = K, a.act = act;
     a.round_in = round_in, a.round_out = round_out;
-    if (round_in && NB >= GV16_MIN_ROWS && K <= 1024 && ldx % 8 == 0 && gemv16_supported(NB, N, K)) {  // 3..16 bf16-exact rows: the matrix-pipe form
+    if (round_in && NB >= GV16_MIN_ROWS && K <= 1024 && ldx % 8 == 0 && gemv16_supported(NB, N, K)) {  // 3..64 bf16-exact rows: the matrix-pipe form
         Gemv16Args g = {};
         g.x = x, g.ldx = ldx, g.ln_w = ln_w, g.ln_b = ln_b, g.eps = eps, g.W = (const bf16_t*)W, g.bias = bias, g.residual = residual, g.ldr = ldr;
         g.out = out, g.ldo = ldo, g.NB = NB, g.N = N, g.K = K, g.act = act, g.round_out = round_out;
@@ -876,8 +936,8 @@ extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, cons
     MMVID_REQUIRE(!advance_pos || pos_dev, "tower_decode_fused: advance_pos needs the device position");
     MMVID_REQUIRE(cfg && layers && x_in && x_out && kv_cache && scratch, "tower_decode_fused: null pointer");
     MMVID_REQUIRE(cache_batch >= cfg->B, "tower_decode_fused: cache_batch %d < batch %d", cache_batch, cfg->B);
-    MMVID_REQUIRE(cfg->mask_mode == 1 && cfg->E == cfg->H * 64 && cfg->B <= GV_MAXB && Lmax <= DEC_MAXL,
-                  "tower_decode_fused: causal tower, head_dim 64, batch <= %d, Lmax <= %d", GV_MAXB, DEC_MAXL);
+    MMVID_REQUIRE(cfg->mask_mode == 1 && cfg->E == cfg->H * 64 && cfg->B <= GV16_MAXB && Lmax <= DEC_MAXL,
+                  "tower_decode_fused: causal tower, head_dim 64, batch <= %d, Lmax <= %d", GV16_MAXB, DEC_MAXL);
     const int B = cfg->B, E = cfg->E, F = cfg->F, H = cfg->H;
     hipStream_t s = (hipStream_t)stream;
     float* p = (float*)scratch;
@@ -893,8 +953,10 @@ extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, cons
     p += (long)B * E;
     float* xb = p;
     const float* x = x_in;
-    // 3..16 sequences: the linear layers on the matrix pipe (gemv16_mfma_kernel); 1-2: the vector-ALU form (what the persistent step falls back to)
+    // 3..64 sequences: the linear layers on the matrix pipe (gemv16_mfma_kernel: the weights are streamed once for all of them); 1-2: the
+    // vector-ALU form (what the persistent step falls back to)
     const bool mfma = B >= GV16_MIN_ROWS && gemv16_supported(B, 3 * E, E) && gemv16_supported(B, E, F) && gemv16_supported(B, F, E);
+    MMVID_REQUIRE(mfma || B <= GV_MAXB, "tower_decode_fused: batch %d > %d needs the matrix-pipe form (widths 512 / 768, F = 4 E)", B, GV_MAXB);
     bf16_t* o_bf = (bf16_t*)o;      // (MFMA form: the attention output and the activation travel as bf16 -- the operand the next layer
     bf16_t* act_bf = (bf16_t*)act;  //  would round them to anyway)
     for (int i = 0; i < cfg->layers; ++i) {
@@ -908,7 +970,10 @@ extern "C" int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, cons
             g.pos_dev = pos_dev, g.pos0 = pos;
             int rc = gemv16_launch(g, s);
             if (rc) return rc;
-            if (Lmax > 512)
+            if (Lmax > 512 && H * B > 512)  // more blocks than two rounds of the chip: two blocks per CU (124 registers) hide each other's chain
+                hipLaunchKernelGGL((attn_decode2_kernel<8, 2>), dim3(H, B), dim3(512), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
+                                   0.125f * 1.4426950408889634f, (float*)nullptr, (long)E, o_bf);
+            else if (Lmax > 512)
                 hipLaunchKernelGGL((attn_decode2_kernel<8, 3>), dim3(H, B), dim3(512), 0, s, qkv, (long)3 * E, cache, Lmax, E, pos_dev, pos,
                                    0.125f * 1.4426950408889634f, (float*)nullptr, (long)E, o_bf);
             else

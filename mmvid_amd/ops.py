@@ -596,7 +596,7 @@ def gemv_rows(x, W, bias=None, ln=None, act=0, residual=None, round_in=False, ro
     if out is None:
         out = torch.empty(NB, N, device=x.device, dtype=f32)
     lw, lb, eps = (ln[0], ln[1], ln[2]) if ln is not None else (None, None, 0.0)
-    step = 16 if round_in else 8  # rows per launch: 16 bf16-exact rows (3..16: the MFMA form), 8 fp32 rows; larger batches in slices
+    step = 64 if (round_in and K <= 1024 and K % 256 == 0 and N % 16 == 0) else (16 if round_in else 8)  # rows per launch: 64 bf16-exact rows on the MFMA form, 16 / 8 on the vector-ALU kernel; larger batches in slices
     for r0 in range(0, NB, step):
         nb = min(step, NB - r0)
         res = residual[r0:r0 + nb] if residual is not None else None

@@ -675,18 +675,31 @@ class VQGanVAE1024(nn.Module):
     @torch.no_grad()
     def encode_z(self, img):
         """img [N,3,S,S] fp32 in [0,1] -> pre-quantisation z [N, h, w, embed_dim] fp32 (NHWC; a copy)."""
-        idx, plan = self._encode(img)
-        off, shape = plan.kept['z']
-        nbytes = int(torch.tensor(shape).prod()) * 4
-        return plan.arena[off:off + nbytes].view(torch.float32).view(shape).clone()
+        step, outs = self._max_frames(img.shape[-1]), []
+        for i in range(0, max(img.shape[0], 1), step):  # (z lives in the plan's arena: read it back slice by slice)
+            _, plan = self._encode(img[i:i + step])
+            off, shape = plan.kept['z']
+            nbytes = int(torch.tensor(shape).prod()) * 4
+            outs.append(plan.arena[off:off + nbytes].view(torch.float32).view(shape).clone())
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+    def _max_frames(self, s):
+        """Frames per planned call: the kernels address an operand through 32-bit byte offsets (< 2 GiB per tensor), and the largest operand
+        of a plan is a pair of bf16 planes at the full resolution with `ch` channels."""
+        ch = self.model.ddconfig['ch']
+        return max(1, ((1 << 31) - 1) // (s * s * max(ch, 8) * 4))
 
     def _encode(self, img):
         img = ops._chk(img.contiguous().float(), f32, 'img')
         n, c, s, s2 = img.shape
         assert c == 3 and s == s2
         idx = torch.empty(n, (s // 16)**2, device=img.device, dtype=torch.int64)
-        plan = self._plan('enc', n, s)
-        plan.run(ext_in={'img': img}, ext_out={'idx': idx})
+        step = self._max_frames(s)
+        plan = None
+        for i in range(0, max(n, 1), step):  # (one call for every batch the drivers use; more than 255 full-size frames go in slices)
+            m = min(step, n - i)
+            plan = self._plan('enc', m, s)
+            plan.run(ext_in={'img': img[i:i + m]}, ext_out={'idx': idx[i:i + m]})
         return idx, plan
 
     @torch.no_grad()
@@ -700,9 +713,11 @@ class VQGanVAE1024(nn.Module):
             img_seq = ops._chk(img_seq.contiguous(), torch.int64, 'img_seq')
             b, n = img_seq.shape
             hw = int(sqrt(n))
-            plan = self._plan('dec', b, hw)
             out = torch.empty(b, 3, hw * 16, hw * 16, device=img_seq.device, dtype=f32)
-            plan.run(ext_in={'idx': img_seq}, ext_out={'img': out})
+            step = self._max_frames(hw * 16)
+            for i in range(0, b, step):  # (slices of at most 255 full-size frames: 32-bit operand offsets)
+                m = min(step, b - i)
+                self._plan('dec', m, hw).run(ext_in={'idx': img_seq[i:i + m]}, ext_out={'img': out[i:i + m]})
             return out
 
     def decode_train(self, probs):

@@ -368,10 +368,11 @@ def test_artv_kv_cache_decode_matches_full_recompute(golden):
         close(cache3[:, :, :prompt.shape[1] + 31], cache2[:, :, :prompt.shape[1] + 31], 1e-2, 'key/value cache')
 
 
-@pytest.mark.parametrize('B', [1, 4, 5, 8, 9, 16, 19])
+@pytest.mark.parametrize('B', [1, 4, 5, 8, 9, 16, 19, 33, 64, 70])
 def test_decode_session_every_batch_size(B):
-    """The decode session picks the persistent single-launch step (B <= 2), the matrix-vector kernels (B <= 16; above 8 their wide
-    instance) or slices of 16 sequences through them (above: the cache is shared, a slice addresses its sequences inside it); all must agree with the full-prefix forward.  (B = 5..8 used to select the fused kernels
+    """The decode session picks the persistent single-launch step (B <= 2), the matrix-pipe linear layers (3..64 sequences in one pass: one,
+    two or four 16-row blocks per wave) or slices of 64 sequences through them (above: the cache is shared, a slice addresses its sequences
+    inside it); all must agree with the full-prefix forward.  (B = 5..8 used to select the fused kernels
     and fail with their argument check: bench.py --config 5 --batch 8.)"""
     from mmvid_amd.clip_tower import OpenAICLIPTransformer
     torch.manual_seed(0)

@@ -90,14 +90,16 @@ def test_flip_census_2048_fresh_tokens(golden):
 def test_gemv_rows_mfma_form_vs_torch():
     """csrc/decode.hip::gemv16_mfma_kernel (3..16 bf16-exact rows on v_mfma_f32_16x16x32_bf16, K split over 8 waves): LayerNorm + weights
     streamed once + bias + QuickGELU + residual + output rounding, against torch on the same bf16-rounded operands.  Tower shapes of
-    both widths (768 / 3,072 and 512 / 2,048), ragged row counts, and 16 + 3 rows through two launches."""
+    both widths (768 / 3,072 and 512 / 2,048), ragged row counts, one / two / four 16-row blocks per launch (19, 33, 64 rows) and 64 + 6 rows
+    through two launches."""
     import torch.nn.functional as F
     from mmvid_amd import ops
     from test_models_gpu import close
     torch.manual_seed(1)
     for NB, K, N, act, ln, res in ((16, 768, 2304, 0, True, False), (16, 768, 3072, 1, True, False), (3, 768, 768, 0, False, True),
                                    (9, 768, 1024, 0, True, False), (12, 512, 1536, 0, True, True), (7, 512, 2048, 1, True, False),
-                                   (19, 768, 768, 0, True, True)):
+                                   (19, 768, 768, 0, True, True), (33, 768, 2304, 0, True, False), (64, 768, 3072, 1, True, False),
+                                   (70, 512, 512, 0, False, True)):
         x = torch.randn(NB, K, device=DEV)
         W = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
         b = torch.randn(N, device=DEV) * 0.1
@@ -229,3 +231,22 @@ def test_attention_backward_rows_with_hugely_negative_scores(L, spec):
     close(out, ref, 1e-2, f'fwd L={L}')
     for nm, sl in (('dQ', slice(0, E)), ('dK', slice(E, 2 * E)), ('dV', slice(2 * E, 3 * E))):
         close(dqkv[:, sl], qr.grad[:, sl], 5e-2, f'{nm} L={L}')  # (bf16 dS of rows whose 579 probabilities are all ~1/579)
+
+
+def test_vqgan_more_frames_than_one_planned_call_holds():
+    """The kernels address an operand through 32-bit byte offsets, so a planned VQGAN call holds at most 255 full-size frames (ART-V sampling
+    at batch 32 decodes 512): encode / decode slice larger batches, and a frame's tokens / pixels do not depend on the slicing."""
+    from mmvid_amd.vae import VQGanVAE1024
+    torch.manual_seed(0)
+    vae = VQGanVAE1024(None, 128).to(DEV)
+    vae.image_size = 128
+    with torch.no_grad():
+        vae.model.quantize.embedding.weight.normal_(0, 0.5)
+    assert vae._max_frames(128) == 255
+    img = torch.rand(300, 3, 128, 128, device=DEV)
+    idx = vae.get_codebook_indices(img)
+    assert idx.shape == (300, 64)
+    assert torch.equal(idx[250:260], vae.get_codebook_indices(img[250:260]))
+    out = vae.decode(idx)
+    assert out.shape == (300, 3, 128, 128) and torch.isfinite(out).all()
+    assert torch.equal(out[250:260], vae.decode(idx[250:260]))
