@@ -311,10 +311,11 @@ def run_artv_sampling(args, device, rank, world):
         step_form = 'one persistent launch (256 co-resident blocks, tagged-word hand-over)'
     elif b <= 2:
         step_form = 'five launches per layer (vector-ALU matrix-vector kernels)'
-    elif b <= 16:
-        step_form = 'five launches per layer: linear layers on the matrix pipe (16 rows = one v_mfma_f32_16x16x32_bf16 row block), cached attention'
+    elif b <= 64:
+        step_form = ('five launches per layer: linear layers on the matrix pipe (%d row block%s of v_mfma_f32_16x16x32_bf16 per wave, weights '
+                     'streamed once), cached attention' % ((b + 15) // 16 if b > 16 else 1, 's' if b > 16 else ''))
     else:
-        step_form = 'five launches per layer (matrix-pipe linear layers), slices of 16 sequences'
+        step_form = 'five launches per layer (matrix-pipe linear layers), slices of 64 sequences'
     # a decode step streams every tower weight once -- 12 layers x 7.08 M matrix params x 2 B (bf16) + the image block of the head -- and,
     # per SEQUENCE, the keys and values cached so far: at the loop's mean position (the 129-token prompt + half of the 1,024 sampled
     # tokens) layers x 2 (K, V) x 768 x 2 B each.  (Round 4 priced the batch-4 / batch-16 lines against the weights alone.)

@@ -305,16 +305,17 @@ int mmvid_tower_prefill(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t*
 int mmvid_tower_decode(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in, float* x_out,
                        void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch, void* stream);
 /* The same step as five matrix-vector launches per layer (weights streamed once, rows in LDS, 256 CUs busy) instead of
- * the M = B corner of the training GEMM: ~10x less time per token.  B <= 16.  scratch: B * (7E + F) floats.
+ * the M = B corner of the training GEMM: ~10x less time per token.  B <= 64 (widths 512 / 768; other towers: B <= 16).  scratch: B * (7E + F) floats.
  * mmvid_gemv_rows is the building block (y = act(LN?(x) W^T + b) (+ residual), x / y fp32 [NB, *], W bf16 [N, K]);
  * mmvid_decode_embed writes the embedding row of the token just sampled (table[tok] + pos_rows[*pos_dev + pos_off]). */
 int mmvid_tower_decode_fused(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,
                              float* x_out, void* kv_cache, int Lmax, const int32_t* pos_dev, int pos, void* scratch,
                              void* stream);
 /* ... for cfg->B consecutive sequences of a cache of cache_batch sequences (kv_cache = the first of them in layer 0; x_in / x_out = their
- * rows): how batches above 16 run, as slices of 16.  Round 6: with 3..16 sequences the four linear layers run on the matrix pipe
- * (csrc/decode.hip::gemv16_mfma_kernel: 16 rows = one v_mfma_f32_16x16x32_bf16 row block, weights streamed once straight into registers,
- * K split over the block's eight waves; the attention output and the activation travel as bf16); 1-2 sequences keep the vector-ALU
+ * rows): how batches above 64 run, as slices of 64.  Round 6: with 3..64 sequences the four linear layers run on the matrix pipe
+ * (csrc/decode.hip::gemv16_mfma_kernel: 16 rows = one v_mfma_f32_16x16x32_bf16 row block, up to four of them per wave against the same
+ * weight fragments -- the weights are streamed once per pass --, K split over the block's eight waves; the attention output and the
+ * activation travel as bf16); 1-2 sequences keep the vector-ALU
  * kernels (the form the persistent step falls back to).  advance_pos != 0: *pos_dev += 1 when the step is done (by the last layer's
  * last launch: no separate launch per token). */
 int mmvid_tower_decode_fused_slice(const mmvid_tower_cfg_t* cfg, const mmvid_tower_layer_t* layers, const float* x_in,

@@ -1,3 +1,5 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_round6_gpu.py tests/test_models_gpu.py tests/test_parity_gpu.py tests/test_round4_gpu.py tests/test_round5_gpu.py -m gpu -q -x -p no:cacheprovider -k "gemv or decode or artv or kv_cache or sampler or more_frames" 2>&1 | grep -v -i "warn\|amdgpu.ids" | tail -3
-for b in 4 16 32 64; do python bench.py --config 5 --batch $b --steps 2 --warmup 1 2>/dev/null | tail -1 > gpurun_out/bench_c5_b$b.json; python -c "import json,sys; d=json.loads(open('gpurun_out/bench_c5_b$b.json').read()); print('batch $b', round(d['value']), 'sampled tokens/s', round(d['roofline']['ms_per_token_step']*1e3,1), 'us per token', round(d['roofline']['frac'],3), 'of HBM')"; done
+export TMPDIR=/tmp
+rm -rf /tmp/p64
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p64 -o dec -- python /root/repo/bench.py --config 5 --batch 64 --steps 1 --warmup 1 > /tmp/p64.log 2>&1; echo "rocprof rc=$?")
+f=$(find /tmp/p64 -name "*kernel_stats*" | head -1); cp $f gpurun_out/dec64_kernel_stats.csv

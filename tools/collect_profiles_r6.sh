@@ -6,7 +6,7 @@ c() { [ -s "$1" ] && cp "$1" "$2"; }
 c $g/bench.log $p/${r}_bench_n1.json; c $g/bench.err $p/${r}_bench_n1.stderr.log
 c $g/bench_split.log $p/${r}_bench_strict_split.json; c $g/bench_mixed.log $p/${r}_bench_strict_mixed.json
 c $g/bench_c4.log $p/${r}_bench_config4.json
-for b in 1 4 8 16; do c $g/bench_c5_b$b.json $p/${r}_bench_config5_b$b.json; done
+for b in 1 4 8 16 32 64; do c $g/bench_c5_b$b.json $p/${r}_bench_config5_b$b.json; done
 c $g/bench_ddp1.log $p/${r}_bench_launcher_forced_exchange.json
 c $g/bench_bert_sampling.log $p/${r}_bench_bert_sampling.json
 c $g/smoke.log $p/${r}_smoke.log; c $g/pytest_gpu.log $p/${r}_gpu_tests.log

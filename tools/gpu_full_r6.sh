@@ -24,7 +24,7 @@ fi
 if has lines; then
   for m in split mixed; do echo "== strict $m"; timeout 600 python bench.py --strict $m --steps 20 --no-cpu-baseline --no-exact > $o/bench_$m.log 2> $o/bench_$m.err; grep "bench\]" $o/bench_$m.err | cut -c1-200; done
   echo "== config 4"; timeout 600 python bench.py --config 4 --steps 20 --warmup 3 --no-cpu-baseline --no-exact > $o/bench_c4.log 2> $o/bench_c4.err; grep "bench\]" $o/bench_c4.err | cut -c1-200
-  for b in 1 4 8 16; do echo "== config 5, batch $b"; timeout 600 python bench.py --config 5 --batch $b --steps 2 --warmup 1 2>$o/bench_c5_b$b.err | tail -1 > $o/bench_c5_b$b.json; grep "bench\]" $o/bench_c5_b$b.err | cut -c1-200; done
+  for b in 1 4 8 16 32 64; do echo "== config 5, batch $b"; timeout 600 python bench.py --config 5 --batch $b --steps 2 --warmup 1 2>$o/bench_c5_b$b.err | tail -1 > $o/bench_c5_b$b.json; grep "bench\]" $o/bench_c5_b$b.err | cut -c1-200; done
   echo "== BERT sampling (mask-predict)"; timeout 900 python bench.py --sample --steps 3 --warmup 1 > $o/bench_bert_sampling.log 2> $o/bench_bert_sampling.err; grep "bench\]" $o/bench_bert_sampling.err | cut -c1-200
   echo "== launcher, forced exchange"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-exact --force-exchange > $o/bench_ddp1.log 2> $o/bench_ddp1.err; grep "bench\]" $o/bench_ddp1.err | cut -c1-200
 fi
