@@ -114,11 +114,12 @@ class DecodeSession:
             # slices of up to 64 sequences through the decode kernels of csrc/decode.hip (3..64 rows: the linear layers on the matrix pipe,
             # the weights streamed once per slice; the M = B corner of the training GEMM took 2.2 ms per token at batch 16); the last
             # slice's last launch advances the position
-            for b0 in range(0, B, 64):
-                nb = min(64, B - b0)
+            per = 64 if E in (512, 768) else 16  # (the matrix-pipe linear layers are instantiated for the CLIP widths; others: 16 rows)
+            for b0 in range(0, B, per):
+                nb = min(per, B - b0)
                 cfg = self.cfg if nb == B else self._slice_cfgs.setdefault(nb, self.tower._cfg(nb, Lmax))
                 _lib.call('mmvid_tower_decode_fused_slice', ctypes.byref(cfg), self.layers, self.x[b0:].data_ptr(), self.y[b0:].data_ptr(),
-                          self.cache[0, b0].data_ptr(), Lmax, B, ops._p(self.pos), 0, int(b0 + 64 >= B), ops._p(self.scratch), ops._stream())
+                          self.cache[0, b0].data_ptr(), Lmax, B, ops._p(self.pos), 0, int(b0 + per >= B), ops._p(self.scratch), ops._stream())
             return
         _lib.call('mmvid_tower_decode', ctypes.byref(self.cfg), self.layers, ops._p(self.x), ops._p(self.y),
                   ops._p(self.cache), Lmax, ops._p(self.pos), 0, ops._p(self.scratch), ops._stream())
